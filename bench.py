@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the telomere scan hot path on MI355X.
+
+A "step" is ONE pass of the hot path (step-1 TRC + sliding-window k-mer counts + single-split
+change-point) over ONE resident batch of synthetic reads, through the C ABI of
+libtopsicle_hip.so.  Workload at N=1 = BASELINE.json configs[1]: 10k synthetic ONT-like reads
+x 15 kb, --pattern CCCTAA (k=4, 12 patterns), window=100 slide=6.  Several copies of the batch
+are kept resident at distinct HBM addresses and scanned in turn so that no step is served from
+the 256 MiB Infinity Cache (the batch alone is only 150 MB).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: one process per GPU, each scanning its own batch (weak scaling, no data-path collective);
+torch.distributed (gloo) is used only for the barrier and the max-over-ranks time.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+# the HIP library is loaded BEFORE torch so that its libamdhip64 (ROCm 7.2, /opt/rocm) is the one
+# in the process; torch is only imported for the multi-process barrier and never touches a GPU here.
+from topsicle_amd import hiplib, synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ~6290
+
+CONFIGS = {
+    # name: (n_reads, read_len, motif, k, window, slide, errors, seed index)
+    "config2": dict(n_reads=10000, read_len=15000, motif="CCCTAA", k=4, window=100, slide=6,
+                    errors=synth.ONT, seed=20250919 + 1,
+                    desc="BASELINE configs[1]: 10k synthetic ONT reads x 15 kb, --pattern CCCTAA, window=100 slide=6"),
+    "config3_per_gpu": dict(n_reads=25000, read_len=20000, motif="AAACCCT", k=5, window=100, slide=7,
+                            errors=synth.HIFI, seed=20250919 + 2,
+                            desc="BASELINE configs[2] shard: 25k synthetic HiFi reads x 20 kb per GPU, --pattern AAACCCT"),
+}
+
+
+def kmer_table(motif, k):
+    """Reference-order pattern list (host logic of the product, topsicle_amd.allsteps)."""
+    from topsicle_amd import allsteps
+    return allsteps.patterns_to_search(motif, k)
+
+
+def min_count_for_cutoff(cutoff, no_bp, motif_len):
+    ratio = no_bp / motif_len
+    return max([c for c in range(no_bp + 1) if not (c / ratio > cutoff)] or [-1])
+
+
+def algorithmic_bytes(lens, passed, n_win, P, prm):
+    """fixed formula, independent of implementation choices."""
+    lens = np.asarray(lens, dtype=np.int64)
+    step1 = (2 * np.minimum(lens, prm.no_bp) + 2 * P * 4).sum()
+    n_s = np.maximum(np.minimum(lens, prm.maxlen) - prm.trimfirst, 0)
+    step2 = (n_s[passed] + 4 * n_win[passed]).sum()
+    step3 = (4 * n_win[passed] + 12).sum()
+    return int(step1 + step2 + step3), int(step1), int(step2), int(step3)
+
+
+def cpu_baseline(seqs, motif, k, prm, budget_s=15.0):
+    """The oracle (a port of the reference algorithm) timed on host cores on a bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    try:
+        import oracle_c
+        have_c = oracle_c.available()
+    except Exception:
+        have_c = False
+    import topsicle_oracle as orc
+    pats = orc.kmer_table(motif, k)
+    if have_c:
+        return oracle_c.timed_baseline(seqs, pats, len(motif), prm, budget_s)
+    t0 = time.perf_counter()
+    done = bases = 0
+    for seq in seqs:
+        cs, ce = orc.trc_counts(seq, pats, prm.no_bp)
+        call = orc.trc_call(cs, ce, pats, len(motif), 0.7, prm.no_bp)
+        if call is not None and len(seq) > prm.min_len:
+            sums = {}
+            for tail in ("forward", "reverse"):        # the reference scans both tails (allsteps.py:279-291)
+                _, counts = orc.window_count_matrix(seq, tail, pats, prm.window, prm.slide, prm.trimfirst, prm.maxlen)
+                sums[tail] = orc.window_sums(counts)
+            orc.boundary_from_sums(sums[call[1]], len(pats), prm.slide, prm.trimfirst, prm.maxlen)
+        done += 1
+        bases += len(seq)
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return dict(value=bases / dt, unit="bases/s", cores=1, kind="port",
+                sample=f"{done} reads of the same batch, pure-Python oracle (re-free restatement of allsteps.py), "
+                       f"single pass, both tails scanned like the reference; {dt:.1f} s",
+                reads_per_s=done / dt)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="config2", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-store-sums", action="store_true", help="do not write S_w to HBM (boundary-only run)")
+    ap.add_argument("--resident-copies", type=int, default=0, help="copies of the batch kept in HBM (0 = enough for >1 GB)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    cfg = CONFIGS[args.workload]
+    motif, k = cfg["motif"], cfg["k"]
+    pats = kmer_table(motif, k)
+    P = len(pats)
+    # every rank scans its own, differently seeded batch of the same shape (weak scaling)
+    bases, offsets, truth = synth.make_reads(cfg["n_reads"], cfg["read_len"], motif, seed=cfg["seed"] + 1000 * rank,
+                                             errors=cfg["errors"])
+    n_reads = cfg["n_reads"]
+    batch_bases = int(offsets[-1])
+    prm = hiplib.make_params(no_bp=1000, min_len=9000, min_count=min_count_for_cutoff(0.7, 1000, len(motif)),
+                             window=cfg["window"], slide=cfg["slide"], trimfirst=100, maxlen=20000, jump=5, min_size=2,
+                             flags=hiplib.F_STEP1 | hiplib.F_WINDOWS | hiplib.F_BINSEG |
+                             (0 if args.no_store_sums else hiplib.F_STORE_SUMS))
+
+    sc = hiplib.HipScanner(local_rank)
+    sc.set_patterns(pats)
+    copies = args.resident_copies or max(2, min(hiplib.MAX_SLOTS, -(-(1 << 30) // max(batch_bases, 1))))
+    for s in range(copies):
+        sc.upload(s, bases, offsets)
+
+    def barrier():
+        sc.sync()
+        if dist is not None:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        sc.scan(i % copies, prm)
+    barrier()
+    sc.kernel_time_reset()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        sc.scan(i % copies, prm)
+    sc.sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        dist.barrier()
+    n_launch, k_total_ms, k_mean_ms = sc.kernel_time_ms()
+
+    res = sc.results((args.steps - 1) % copies)
+    passed = res["pass"].astype(bool)
+    n_win = res["n_win"].astype(np.int64)
+    lens = np.diff(offsets)
+    alg_total, alg1, alg2, alg3 = algorithmic_bytes(lens, passed, n_win, P, prm)
+    scanned = int((2 * np.minimum(lens, prm.no_bp)).sum() + np.maximum(np.minimum(lens, prm.maxlen) - prm.trimfirst, 0)[passed].sum())
+
+    if rank == 0:
+        total_bases = batch_bases * world * args.steps
+        value = total_bases / dt
+        achieved = alg_total / (k_mean_ms * 1e-3) / 1e9 if k_mean_ms > 0 else 0.0
+        out = {
+            "metric": "bases_scanned_per_sec",
+            "value": value,
+            "unit": "bases/s",
+            "reads_per_sec": n_reads * world * args.steps / dt,
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {
+                "workload": cfg["desc"],
+                "reads_per_step_per_gpu": n_reads,
+                "read_len": cfg["read_len"],
+                "pattern": motif, "k": k, "n_patterns": P,
+                "window": cfg["window"], "slide": cfg["slide"], "trimfirst": 100, "maxlengthtelo": 20000, "cutoff": 0.7,
+                "resident_copies": copies,
+                "store_window_sums": not args.no_store_sums,
+                "telomeric_reads_passing": int(passed.sum()),
+                "scanned_bases_per_step_per_gpu": scanned,
+                "sharding": "reads sharded across GPUs, one process per GPU, no collective" if world > 1 else "single GPU",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "tps_scan_kernel",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": alg_total,
+                "algorithmic_bytes_split": {"step1": alg1, "windows": alg2, "binseg": alg3},
+                "kernel_ms_mean": k_mean_ms,
+                "kernel_launches_timed": n_launch,
+            },
+        }
+        if not args.no_cpu_baseline:
+            seqs = synth.split_reads(bases[: offsets[min(n_reads, 4096)]], offsets[: min(n_reads, 4096) + 1])
+            out["cpu_baseline"] = cpu_baseline(seqs, motif, k, prm)
+            out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    sc.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

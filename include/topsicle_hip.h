@@ -1,0 +1,158 @@
+/*
+ * topsicle_hip.h -- C ABI of libtopsicle_hip.so: the MI355X (gfx950) implementation of
+ * Topsicle's per-read hot path.
+ *
+ * The reference (jaeyoungchoilab/Topsicle) has NO plugin / FFI seam: the path is a chain of
+ * plain Python calls inside Topsicle/allsteps.py, driven by Topsicle/main.py:52-154.  This
+ * header is therefore the boundary a maintainer would bind (ctypes stub in INTEGRATION.md);
+ * each entry point names the reference code it replaces (file:line relative to the reference
+ * root).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only; no exceptions cross the boundary.
+ *   - every function returns 0 on success or a negative TPS_E_* code; tps_last_error() gives
+ *     the message of the last failure on the calling thread.
+ *   - the caller allocates and owns every host buffer; the library keeps no host pointer
+ *     after a call returns.  Device memory is owned by the context.
+ *   - one context per (host thread, device); a context is not thread-safe, distinct contexts
+ *     are independent.  There is NO CPU fallback: creating a context without a usable GPU
+ *     fails with TPS_E_NO_DEVICE.
+ *   - reads are passed as ONE concatenated ASCII byte string plus n+1 offsets (any case,
+ *     any IUPAC letter; only A/C/G/T in either case can match, exactly like the reference's
+ *     .upper() + literal regex).
+ */
+#ifndef TOPSICLE_HIP_H
+#define TOPSICLE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TPS_ABI_VERSION 1
+
+/* error codes */
+#define TPS_OK            0
+#define TPS_E_NO_DEVICE  -1   /* no HIP device / device index out of range              */
+#define TPS_E_HIP        -2   /* a HIP runtime call failed (message has the HIP error)  */
+#define TPS_E_ARG        -3   /* invalid argument                                        */
+#define TPS_E_PATTERN    -4   /* pattern table not set / unsupported (non-ACGT, k>7, P>31) */
+#define TPS_E_CAPACITY   -5   /* parameter combination does not fit the kernel's LDS plan */
+#define TPS_E_STATE      -6   /* call order (e.g. scan before upload)                    */
+
+/* limits of this build */
+#define TPS_MAX_K         7   /* k-mer length handled by the LDS lookup table (4^k entries) */
+#define TPS_MAX_PATTERNS 31   /* patterns in one table (bit 31 of the mask is a flag)       */
+
+/* flags for tps_params.flags */
+#define TPS_F_STEP1      1u   /* run the TRC step (a3) and choose tail / pass per read       */
+#define TPS_F_WINDOWS    2u   /* run the sliding-window count step (a5) on passing reads     */
+#define TPS_F_BINSEG     4u   /* run the single-split change-point step (a6) in the same launch */
+#define TPS_F_STORE_SUMS 8u   /* keep S_w (int32 per window) in device memory for download   */
+#define TPS_F_STORE_RAW 16u   /* keep c'_p per window and pattern (u8) -- rawCountPattern (a7) */
+#define TPS_F_TAILS_IN  32u   /* without STEP1: tails[] and pass come from the caller         */
+
+typedef struct tps_ctx tps_ctx;
+
+/* Parameters of one scan.  Names follow the reference CLI (Topsicle/main.py:319-334). */
+typedef struct tps_params {
+    int32_t no_bp;        /* step-1 tail length; reference hard-codes 1000 (main.py:57)        */
+    int32_t min_len;      /* --minSeqLength: keep reads with L >  min_len (allsteps.py:175)    */
+    int32_t min_count;    /* keep reads whose best count > min_count; the host derives it from
+                             --cutoff so that count/(no_bp/len(pattern)) > cutoff in float64  */
+    int32_t window;       /* --windowSize W (window text is W-1 chars, allsteps.py:221-224)    */
+    int32_t slide;        /* --slide s                                                         */
+    int32_t trimfirst;    /* --trimfirst t                                                     */
+    int32_t maxlen;       /* --maxlengthtelo M                                                 */
+    int32_t jump;         /* ruptures Binseg jump (5)                                          */
+    int32_t min_size;     /* ruptures Binseg min_size (2)                                      */
+    uint32_t flags;       /* TPS_F_*                                                           */
+} tps_params;
+
+/* Per-read result of a scan (40 bytes). */
+typedef struct tps_read_result {
+    int32_t best_start;      /* max_p count in the first no_bp bases                (a3)      */
+    int32_t best_start_idx;  /* first pattern index reaching it (allsteps.py:190)             */
+    int32_t best_end;        /* max_p count in the reversed last no_bp bases                  */
+    int32_t best_end_idx;    /* first pattern index reaching it (allsteps.py:191)             */
+    int32_t tail;            /* 0 = forward, 1 = reverse (allsteps.py:193-198)                */
+    int32_t pass;            /* 1 if L > min_len and best count > min_count                   */
+    int32_t n_win;           /* windows of the chosen tail (0 if not scanned)                 */
+    int32_t bkp;             /* best split index, -1 if none admissible / not run   (a6)      */
+    double  gain;            /* l2 gain of that split on y = S/P (float64, informational)     */
+} tps_read_result;
+
+/* ---- context ------------------------------------------------------------------------- */
+int  tps_abi_version(void);
+int  tps_device_count(int* n);
+int  tps_ctx_create(int device, tps_ctx** out);
+int  tps_ctx_destroy(tps_ctx* ctx);
+const char* tps_last_error(void);
+
+/* Replaces patterns_to_search's consumer side (allsteps.py:167-168, 249-250, 378-379): the
+ * compiled regex list.  `pats` holds P strings of k ASCII letters back to back, in reference
+ * order (sorted k-mers then their complements, allsteps.py:104-120); order defines pattern
+ * indices (first-max tie-break, raw count column order). */
+int  tps_set_patterns(tps_ctx* ctx, const char* pats, int32_t n_patterns, int32_t k);
+
+/* ---- resident batch (throughput path) ------------------------------------------------ */
+/* Copy a batch of reads into HBM.  `slot` (0..TPS_MAX_SLOTS-1) names one resident batch so
+ * several can be kept and scanned in turn.  Replaces the per-call file parse of
+ * unzip_file/SeqIO.parse (allsteps.py:127-149, 174, 257) with one upload per batch. */
+#define TPS_MAX_SLOTS 16
+int  tps_batch_upload(tps_ctx* ctx, int32_t slot, const uint8_t* bases, const int64_t* offsets,
+                      int64_t n_reads);
+/* Optional per-read tails (0/1) and pass flags for scans without TPS_F_STEP1. */
+int  tps_batch_set_tails(tps_ctx* ctx, int32_t slot, const uint8_t* tails);
+
+/* One pass of the hot path over a resident batch: patternTRC_count (allsteps.py:152-204) +
+ * bound_detect's window loop (allsteps.py:257-297) + process_mean/Binseg
+ * (allsteps.py:300-333), one workgroup per read, one launch.  Asynchronous on the
+ * context's stream; results land in context-owned pinned memory. */
+int  tps_batch_scan(tps_ctx* ctx, int32_t slot, const tps_params* prm);
+/* Wait for everything enqueued on the context's stream. */
+int  tps_sync(tps_ctx* ctx);
+/* Copy the per-read results of the last scan of `slot` (after tps_sync). */
+int  tps_batch_results(tps_ctx* ctx, int32_t slot, tps_read_result* out, int64_t n_reads);
+/* Window layout of the last scan: win_off[n+1] (prefix of n_win over ALL reads of the batch,
+ * scanned or not, computed from lengths and params only). */
+int  tps_batch_window_offsets(tps_ctx* ctx, int32_t slot, int64_t* win_off, int64_t n_plus_1);
+/* Download S_w (needs TPS_F_STORE_SUMS) / c'_p (needs TPS_F_STORE_RAW) of the last scan. */
+int  tps_batch_window_sums(tps_ctx* ctx, int32_t slot, int32_t* sums, int64_t n_windows);
+int  tps_batch_window_raw(tps_ctx* ctx, int32_t slot, uint8_t* raw, int64_t n_windows_times_p);
+/* Step-1 per-pattern counts of the last scan: c_start[n*P], c_end[n*P] (int32). */
+int  tps_batch_trc_counts(tps_ctx* ctx, int32_t slot, int32_t* c_start, int32_t* c_end, int64_t n_reads);
+
+/* ---- one-shot host-pointer calls (parity tests, per-read API) -------------------------- */
+/* patternTRC_count's counting loop (allsteps.py:176-184): integer counts only; the float64
+ * TRC, arg-max and cutoff stay in the host language so they are bit-identical. */
+int  tps_trc_counts(tps_ctx* ctx, const uint8_t* bases, const int64_t* offsets, int64_t n_reads,
+                    int32_t no_bp, int32_t* c_start, int32_t* c_end);
+/* bound_detect / rawCountPattern window loops (allsteps.py:275-291, 398-411) for the given
+ * tail per read.  win_off[n+1] must be the prefix of tps_window_count() over the reads.
+ * sums: int32[win_off[n]]; raw: u8[win_off[n]*P] or NULL. */
+int  tps_window_counts(tps_ctx* ctx, const uint8_t* bases, const int64_t* offsets,
+                       const uint8_t* tails, int64_t n_reads, int32_t window, int32_t slide,
+                       int32_t trimfirst, int32_t maxlen, const int64_t* win_off,
+                       int32_t* sums, uint8_t* raw);
+/* rpt.Binseg(model="l2").fit(y).predict(n_bkps=1) (allsteps.py:310-311) on integer window
+ * sums: bkp[n] (-1 = no admissible split), gain[n] (may be NULL). */
+int  tps_binseg_l2(tps_ctx* ctx, const int32_t* sums, const int64_t* win_off, int64_t n_reads,
+                   int32_t n_patterns, int32_t jump, int32_t min_size, int32_t* bkp, double* gain);
+
+/* Number of windows seq_cut_windows yields for a read of length L (allsteps.py:219, 263-271). */
+int64_t tps_window_count(int64_t read_len, int32_t window, int32_t slide, int32_t trimfirst, int32_t maxlen);
+
+/* ---- measurement ----------------------------------------------------------------------- */
+/* hipEvent timings of the scan kernel launches since the last reset: number of launches,
+ * total and mean milliseconds (events are recorded on the stream the kernel runs on). */
+int  tps_kernel_time_ms(tps_ctx* ctx, int32_t* n_launches, double* total_ms, double* mean_ms);
+int  tps_kernel_time_reset(tps_ctx* ctx);
+/* Name of the device and a few properties, as a NUL-terminated string. */
+int  tps_device_info(tps_ctx* ctx, char* buf, int32_t buf_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TOPSICLE_HIP_H */

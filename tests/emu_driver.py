@@ -1,0 +1,75 @@
+"""Test helper: builds and drives tests/emu (host emulation of the HIP kernel source)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from topsicle_amd import hiplib
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "emu", "emu_scan.cpp")
+DEPS = [SRC] + [os.path.join(HERE, "..", "topsicle_amd", "csrc", f) for f in ("tps_device.h", "tps_plan.h")] + \
+       [os.path.join(HERE, "..", "include", "topsicle_hip.h")]
+
+
+def build(asan=False):
+    out = os.path.join(HERE, "emu", "_build", "libtps_emu_asan.so" if asan else "libtps_emu.so")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in DEPS):
+        return out
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas", "-shared", "-fPIC"]
+    if asan:
+        cmd += ["-g", "-fsanitize=address,undefined"]
+    subprocess.check_call(cmd + ["-o", out, SRC])
+    return out
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.emu_last_error.restype = C.c_char_p
+        _lib.emu_scan.restype = C.c_int
+        _lib.emu_binseg.restype = C.c_int
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def scan(patterns, seqs, prm, tails=None, spans_pref=0, lds_budget=160 * 1024, base_shift=0):
+    """Returns dict(results, c_start, c_end, win_off, sums, raw)."""
+    L = lib()
+    bases, offsets = hiplib.pack_reads(seqs)
+    n, P, k = len(seqs), len(patterns), len(patterns[0])
+    res = np.zeros(n, dtype=hiplib.RESULT_DTYPE)
+    cs = np.zeros((n, P), np.int32)
+    ce = np.zeros((n, P), np.int32)
+    lens = np.diff(offsets)
+    nw = [hiplib.window_count(int(x), prm.window, prm.slide, prm.trimfirst, prm.maxlen) for x in lens]
+    tot = int(sum(nw))
+    win_off = np.zeros(n + 1, np.int64)
+    sums = np.zeros(max(tot, 1), np.int32)
+    raw = np.zeros(max(tot * P, 1), np.uint8)
+    t = None if tails is None else np.ascontiguousarray(tails, dtype=np.uint8)
+    rc = L.emu_scan("".join(patterns).encode(), P, k, _p(bases), _p(offsets), C.c_int64(n), _p(t), C.byref(prm),
+                    spans_pref, lds_budget, base_shift, _p(res), _p(cs), _p(ce), _p(win_off), _p(sums), _p(raw))
+    if rc != 0:
+        raise RuntimeError(f"emu_scan rc={rc}: {L.emu_last_error().decode()}")
+    return dict(results=res, c_start=cs, c_end=ce, win_off=win_off, sums=sums[:tot], raw=raw[:tot * P].reshape(-1, P))
+
+
+def binseg(sums, win_off, n_patterns, jump=5, min_size=2):
+    L = lib()
+    sums = np.ascontiguousarray(sums, np.int32)
+    win_off = np.ascontiguousarray(win_off, np.int64)
+    n = len(win_off) - 1
+    bkp = np.zeros(n, np.int32)
+    gain = np.zeros(n, np.float64)
+    L.emu_binseg(_p(sums), _p(win_off), C.c_int64(n), n_patterns, jump, min_size, _p(bkp), _p(gain))
+    return bkp, gain

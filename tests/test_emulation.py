@@ -1,0 +1,165 @@
+"""Kernel LOGIC checks without a GPU: the HIP kernel source compiled as a sequential host
+emulation (tests/emu) must reproduce the reference-generated goldens and the oracle bit for
+bit.  The same comparisons run against the real kernels in tests/test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+import emu_driver as emu
+import topsicle_oracle as orc
+from topsicle_amd import hiplib
+
+TAILV = {"forward": 0, "reverse": 1}
+
+
+def check_case(c, arrs, ci, **emu_kw):
+    pats = c["patterns"]
+    k = c["k"]
+    if k > hiplib.MAX_K or len(pats) > hiplib.MAX_PATTERNS:
+        return False
+    # step 1
+    prm = hiplib.make_params(no_bp=c["no_bp"], min_len=0, min_count=-1, window=c["W"], slide=c["s"],
+                             trimfirst=c["t"], maxlen=c["M"], flags=hiplib.F_STEP1)
+    out = emu.scan(pats, [c["seq"]], prm, **emu_kw)
+    cs, ce = orc.trc_counts(c["seq"], pats, c["no_bp"])
+    assert out["c_start"][0].tolist() == cs, c["name"]
+    assert out["c_end"][0].tolist() == ce, c["name"]
+    r = out["results"][0]
+    if c["step1"] is not None:
+        pat, tail, trc = c["step1"]
+        assert TAILV[tail] == r["tail"], c["name"]
+        best, idx = (r["best_start"], r["best_start_idx"]) if r["tail"] == 0 else (r["best_end"], r["best_end_idx"])
+        assert pats[idx] == pat and best / (c["no_bp"] / len(c["motif"])) == trc, c["name"]
+    # step 2 + 3 for every pinned tail
+    for tail in c["tails"]:
+        want = arrs[f"counts_{ci}_{tail}"].astype(np.int64)
+        prm = hiplib.make_params(window=c["W"], slide=c["s"], trimfirst=c["t"], maxlen=c["M"],
+                                 flags=hiplib.F_WINDOWS | hiplib.F_BINSEG | hiplib.F_TAILS_IN | hiplib.F_STORE_SUMS | hiplib.F_STORE_RAW)
+        out = emu.scan(pats, [c["seq"]], prm, tails=[TAILV[tail]], **emu_kw)
+        assert out["raw"].shape[0] == want.shape[0], c["name"]
+        if want.shape[0]:
+            assert np.array_equal(out["raw"], want), (c["name"], tail)
+            assert np.array_equal(out["sums"], want.sum(axis=1)), (c["name"], tail)
+        # sums-only fast path must agree with the exact path
+        prm.flags = hiplib.F_WINDOWS | hiplib.F_BINSEG | hiplib.F_TAILS_IN | hiplib.F_STORE_SUMS
+        out2 = emu.scan(pats, [c["seq"]], prm, tails=[TAILV[tail]], **emu_kw)
+        assert np.array_equal(out2["sums"], want.sum(axis=1) if want.shape[0] else np.zeros(0)), (c["name"], tail)
+        r = out2["results"][0]
+        assert r["n_win"] == want.shape[0]
+        b = c["boundary"][tail]
+        if b is None:
+            assert r["bkp"] == -1, c["name"]
+        else:
+            exact = orc.binseg_l2_exact(want.sum(axis=1))
+            assert r["bkp"] == exact, c["name"]
+            if r["bkp"] * c["s"] + c["t"] != b:      # only legal where float64 cannot resolve a tie
+                assert c["name"] in ("polyC",), c["name"]
+    return True
+
+
+def test_emulation_synthetic_goldens(synth_cases):
+    meta, arrs = synth_cases
+    done = sum(check_case(c, arrs, ci) for ci, c in enumerate(meta))
+    assert done >= 50
+
+
+def test_emulation_small_tiles_and_misalignment(synth_cases):
+    """Force many tiles per read (2..8 spans) and every 16-byte misalignment class."""
+    meta, arrs = synth_cases
+    rng = np.random.default_rng(3)
+    for ci, c in enumerate(meta):
+        if ci % 3 == 0:
+            check_case(c, arrs, ci, spans_pref=int(rng.integers(1, 9)), base_shift=int(rng.integers(0, 16)))
+
+
+def test_emulation_demo_reads(demo_windows, demo_records):
+    meta, arrs = demo_windows
+    seqs = dict(demo_records)
+    pats = meta["patterns"]
+    reads = [r for r in meta["reads"] if "key" not in r]
+    prm = hiplib.make_params(min_len=9000, min_count=int(0.7 * (1000 / 7)), window=100, slide=6, trimfirst=100,
+                             maxlen=20000, flags=hiplib.F_STEP1 | hiplib.F_WINDOWS | hiplib.F_BINSEG | hiplib.F_STORE_SUMS)
+    out = emu.scan(pats, [seqs[r["id"]] for r in reads], prm)
+    for i, r in enumerate(reads):
+        res = out["results"][i]
+        assert res["pass"] == 1 and res["tail"] == TAILV[r["tail"]]
+        best = res["best_start"] if res["tail"] == 0 else res["best_end"]
+        assert best / (1000 / 7) == r["trc"]
+        lo, hi = out["win_off"][i], out["win_off"][i + 1]
+        assert np.array_equal(out["sums"][lo:hi], arrs[f"counts_{i}"].astype(np.int64).sum(axis=1))
+        assert res["bkp"] * 6 + 100 == r["boundary"]
+
+
+def test_emulation_whole_demo_file_filter(demo_records, gold_dir):
+    """All 44 demo reads in one batch: exactly the 17 golden reads pass the filter."""
+    import csv, os
+    pats = orc.kmer_table("CCCTAAA", 5)
+    ratio = 1000 / 7
+    min_count = max(c for c in range(0, 1001) if not (c / ratio > 0.7))
+    prm = hiplib.make_params(min_len=9000, min_count=min_count, flags=hiplib.F_STEP1 | hiplib.F_WINDOWS | hiplib.F_BINSEG)
+    out = emu.scan(pats, [s for _, s in demo_records], prm, base_shift=5)
+    gold = list(csv.reader(open(os.path.join(gold_dir, "demo_telolengths_all.csv"))))[1:]
+    got = [(demo_records[i][0], int(r["bkp"]) * 6 + 100) for i, r in enumerate(out["results"]) if r["pass"]]
+    assert got == [(g[3], int(g[4])) for g in gold]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_emulation_random_vs_oracle(seed):
+    """Seeded random reads / parameters against the Python oracle (counts bit-exact)."""
+    rng = np.random.default_rng(100 + seed)
+    motif, k = [("CCCTAA", 4), ("CCCTAA", 5), ("AAACCCT", 5), ("CCCTAA", 6), ("TTAGGG", 3), ("AAACCCT", 7)][seed]
+    pats = orc.kmer_table(motif, k)
+    W = int(rng.choice([100, 64, 23, 100]))
+    s = int(rng.choice([6, 7, 1, 4, 16, 11]))
+    t = int(rng.choice([100, 0, 17]))
+    M = int(rng.choice([20000, 900, 1500]))
+    seqs, tails = [], []
+    for i in range(6):
+        L = int(rng.integers(0, 2600))
+        tract = int(rng.integers(0, max(1, L // 2)))
+        ph = int(rng.integers(len(motif)))
+        body = (motif * (tract // len(motif) + 2))[ph:ph + tract] + "".join("ACGT"[x] for x in rng.integers(0, 4, max(0, L - tract)))
+        body = list(body[:L])
+        for p in rng.integers(0, max(1, len(body)), len(body) // 25):      # errors, N, lower case
+            if len(body):
+                body[p] = "ACGTNacgtn"[int(rng.integers(10))]
+        seq = "".join(body)
+        if rng.random() < 0.5:
+            seq = seq[::-1].translate(str.maketrans("ACGTacgt", "TGCAtgca"))
+        seqs.append(seq)
+        tails.append(int(rng.integers(2)))
+    prm = hiplib.make_params(window=W, slide=s, trimfirst=t, maxlen=M,
+                             flags=hiplib.F_WINDOWS | hiplib.F_BINSEG | hiplib.F_TAILS_IN | hiplib.F_STORE_SUMS | hiplib.F_STORE_RAW)
+    out = emu.scan(pats, seqs, prm, tails=tails, spans_pref=int(rng.integers(0, 6)), base_shift=int(rng.integers(16)))
+    prm1 = hiplib.make_params(no_bp=1000, flags=hiplib.F_STEP1)
+    out1 = emu.scan(pats, seqs, prm1)
+    for i, seq in enumerate(seqs):
+        cs, ce = orc.trc_counts(seq, pats)
+        assert out1["c_start"][i].tolist() == cs and out1["c_end"][i].tolist() == ce
+        _, counts = orc.window_count_matrix(seq, ["forward", "reverse"][tails[i]], pats, W, s, t, M)
+        lo, hi = out["win_off"][i], out["win_off"][i + 1]
+        assert hi - lo == counts.shape[0]
+        assert np.array_equal(out["raw"][lo:hi], counts.reshape(-1, len(pats)))
+        assert np.array_equal(out["sums"][lo:hi], counts.sum(axis=1))
+        want = orc.binseg_l2_exact(counts.sum(axis=1)) if counts.shape[0] else None
+        assert out["results"][i]["bkp"] == (-1 if want is None else want)
+
+
+def test_emulation_binseg_standalone():
+    rng = np.random.default_rng(5)
+    sums, off = [], [0]
+    for n in [0, 3, 6, 7, 8, 12, 50, 255, 256, 257, 1000, 3301]:
+        v = rng.integers(12, 200, n)
+        if n > 20:
+            v[: n // 3] += 150
+        sums.append(v)
+        off.append(off[-1] + n)
+    allv = np.concatenate(sums).astype(np.int32)
+    bkp, gain = emu.binseg(allv, np.array(off, np.int64), 12)
+    for i, v in enumerate(sums):
+        want = orc.binseg_l2_exact(v)
+        assert bkp[i] == (-1 if want is None else want)
+        if want is not None:
+            _, g = orc.binseg_l2_numpy(v / 12)
+            bf, _ = orc.binseg_l2_numpy(v / 12)
+            if bf == want:
+                assert abs(gain[i] - g) <= 1e-9 * max(1.0, abs(g))

@@ -1,0 +1,201 @@
+"""Parity of the HIP kernels (through the C ABI, on a real MI355X) with the reference-generated
+goldens and the CPU oracle.  Integer work: every comparison is bit-exact."""
+import csv
+import os
+
+import numpy as np
+import pytest
+
+import topsicle_oracle as orc
+from topsicle_amd import hiplib, synth
+
+pytestmark = pytest.mark.gpu
+TAILV = {"forward": 0, "reverse": 1}
+WIN_FLAGS = hiplib.F_WINDOWS | hiplib.F_BINSEG | hiplib.F_TAILS_IN | hiplib.F_STORE_SUMS
+
+
+@pytest.fixture(scope="module")
+def sc():
+    s = hiplib.HipScanner(0)
+    yield s
+    s.close()
+
+
+def test_library_reports_gfx950(sc):
+    info = sc.device_info()
+    assert "gfx950" in info, info
+
+
+def test_synthetic_goldens(sc, synth_cases):
+    meta, arrs = synth_cases
+    done = 0
+    for ci, c in enumerate(meta):
+        pats = c["patterns"]
+        if c["k"] > hiplib.MAX_K or len(pats) > hiplib.MAX_PATTERNS:
+            continue
+        sc.set_patterns(pats)
+        bases, offsets = hiplib.pack_reads([c["seq"]])
+        cs, ce = sc.trc_counts(bases, offsets, c["no_bp"])
+        ws, we = orc.trc_counts(c["seq"], pats, c["no_bp"])
+        assert cs[0].tolist() == ws and ce[0].tolist() == we, c["name"]
+        for tail in c["tails"]:
+            want = arrs[f"counts_{ci}_{tail}"].astype(np.int64)
+            sums, win_off, raw = sc.window_counts(bases, offsets, [TAILV[tail]], c["W"], c["s"], c["t"], c["M"], raw=True)
+            assert raw.shape[0] == want.shape[0], c["name"]
+            if want.shape[0]:
+                assert np.array_equal(raw, want), (c["name"], tail)
+                assert np.array_equal(sums, want.sum(axis=1)), (c["name"], tail)
+            sums2, _, _ = sc.window_counts(bases, offsets, [TAILV[tail]], c["W"], c["s"], c["t"], c["M"], raw=False)
+            assert np.array_equal(sums2, sums), (c["name"], tail)
+            bkp, gain = sc.binseg_l2(sums, win_off, len(pats))
+            b = c["boundary"][tail]
+            if b is None:
+                assert bkp[0] == -1, c["name"]
+            else:
+                assert bkp[0] == orc.binseg_l2_exact(want.sum(axis=1)), c["name"]
+                if bkp[0] * c["s"] + c["t"] != b:
+                    assert c["name"] == "polyC"      # exact tie, float64 noise decides upstream
+        done += 1
+    assert done >= 50
+
+
+def test_demo_file_end_to_end(sc, demo_records, demo_windows, gold_dir):
+    """44 demo reads in one launch: the 17 golden reads pass, TRC to 3 dp, boundaries equal,
+    per-window sums equal the reference's rawCountPattern sums."""
+    meta, arrs = demo_windows
+    pats = meta["patterns"]
+    sc.set_patterns(pats)
+    bases, offsets = hiplib.pack_reads([s for _, s in demo_records])
+    sc.upload(0, bases, offsets)
+    ratio = 1000 / 7
+    min_count = max(c for c in range(1001) if not (c / ratio > 0.7))
+    prm = hiplib.make_params(min_len=9000, min_count=min_count, window=100, slide=6, trimfirst=100, maxlen=20000,
+                             flags=hiplib.F_STEP1 | hiplib.F_WINDOWS | hiplib.F_BINSEG | hiplib.F_STORE_SUMS)
+    sc.scan(0, prm)
+    sc.sync()
+    res = sc.results(0)
+    sums, win_off = sc.window_sums(0)
+    gold = list(csv.reader(open(os.path.join(gold_dir, "demo_telolengths_all.csv"))))[1:]
+    passing = [i for i in range(len(demo_records)) if res["pass"][i]]
+    assert [demo_records[i][0] for i in passing] == [g[3] for g in gold]
+    for j, i in enumerate(passing):
+        best = res["best_start"][i] if res["tail"][i] == 0 else res["best_end"][i]
+        assert f"{best / ratio:.3f}" == gold[j][2]
+        assert int(res["bkp"][i]) * 6 + 100 == int(gold[j][4])
+        assert np.array_equal(sums[win_off[i]:win_off[i + 1]], arrs[f"counts_{j}"].astype(np.int64).sum(axis=1))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_vs_oracle(sc, seed):
+    rng = np.random.default_rng(500 + seed)
+    motif, k = [("CCCTAA", 4), ("CCCTAA", 5), ("AAACCCT", 5), ("CCCTAA", 6), ("TTAGGG", 3), ("AAACCCT", 7),
+                ("CCCTAA", 4), ("TTTAGGG", 5)][seed]
+    pats = orc.kmer_table(motif, k)
+    sc.set_patterns(pats)
+    W = int(rng.choice([100, 64, 23, 100]))
+    s = int(rng.choice([6, 7, 1, 4, 16, 11]))
+    t = int(rng.choice([100, 0, 17]))
+    M = int(rng.choice([20000, 900, 1500]))
+    seqs, tails = [], []
+    for i in range(12):
+        L = int(rng.integers(0, 4000))
+        tract = int(rng.integers(0, max(1, L // 2)))
+        ph = int(rng.integers(len(motif)))
+        body = list(((motif * (tract // len(motif) + 2))[ph:ph + tract] +
+                     "".join("ACGT"[x] for x in rng.integers(0, 4, max(0, L - tract))))[:L])
+        for p in rng.integers(0, max(1, len(body)), len(body) // 25):
+            if body:
+                body[p] = "ACGTNacgtn"[int(rng.integers(10))]
+        seq = "".join(body)
+        if rng.random() < 0.5:
+            seq = seq[::-1].translate(str.maketrans("ACGTacgt", "TGCAtgca"))
+        seqs.append(seq)
+        tails.append(int(rng.integers(2)))
+    bases, offsets = hiplib.pack_reads(seqs)
+    cs, ce = sc.trc_counts(bases, offsets)
+    sums, win_off, raw = sc.window_counts(bases, offsets, tails, W, s, t, M, raw=True)
+    bkp, _ = sc.binseg_l2(sums, win_off, len(pats))
+    for i, seq in enumerate(seqs):
+        ws, we = orc.trc_counts(seq, pats)
+        assert cs[i].tolist() == ws and ce[i].tolist() == we
+        _, counts = orc.window_count_matrix(seq, ["forward", "reverse"][tails[i]], pats, W, s, t, M)
+        lo, hi = win_off[i], win_off[i + 1]
+        assert hi - lo == counts.shape[0]
+        assert np.array_equal(raw[lo:hi], counts.reshape(-1, len(pats)))
+        assert np.array_equal(sums[lo:hi], counts.sum(axis=1))
+        want = orc.binseg_l2_exact(counts.sum(axis=1)) if counts.shape[0] else None
+        assert bkp[i] == (-1 if want is None else want)
+
+
+def test_config2_batch_sample_vs_oracle(sc):
+    """BASELINE config 2 shape (15 kb ONT-like reads, CCCTAA, k=4, W=100, s=6) at a size the
+    oracle finishes in seconds; full fused pipeline in one launch."""
+    motif, k = "CCCTAA", 4
+    pats = orc.kmer_table(motif, k)
+    sc.set_patterns(pats)
+    bases, offsets, truth = synth.make_reads(64, 15000, motif, seed=20250920)
+    sc.upload(1, bases, offsets)
+    ratio = 1000 / 6
+    min_count = max(c for c in range(1001) if not (c / ratio > 0.7))
+    prm = hiplib.make_params(min_len=9000, min_count=min_count,
+                             flags=hiplib.F_STEP1 | hiplib.F_WINDOWS | hiplib.F_BINSEG | hiplib.F_STORE_SUMS)
+    sc.scan(1, prm)
+    sc.sync()
+    res = sc.results(1)
+    sums, win_off = sc.window_sums(1)
+    seqs = synth.split_reads(bases, offsets)
+    for i in range(0, 64, 4):
+        cs, ce = orc.trc_counts(seqs[i], pats)
+        call = orc.trc_call(cs, ce, pats, 6, 0.7)
+        assert bool(res["pass"][i]) == (call is not None)
+        if call is None:
+            continue
+        assert res["tail"][i] == TAILV[call[1]] == int(truth["reverse"][i])
+        _, counts = orc.window_count_matrix(seqs[i], call[1], pats, 100, 6, 100, 20000)
+        assert np.array_equal(sums[win_off[i]:win_off[i + 1]], counts.sum(axis=1))
+        assert res["bkp"][i] == orc.binseg_l2_exact(counts.sum(axis=1))
+
+
+def test_full_size_properties(sc):
+    """Size-independent properties at BASELINE config-2 scale (10k x 15 kb), no oracle:
+      * reverse-complementing every read and swapping forward/reverse gives the same S_w
+        when the complement k-mers are in the table (they always are, allsteps.py:115-119);
+      * duplicating the batch gives identical per-read results (independence of reads);
+      * boundaries land near the planted tract end for clean reads."""
+    motif, k = "CCCTAA", 4
+    pats = orc.kmer_table(motif, k)
+    sc.set_patterns(pats)
+    n = 10000
+    bases, offsets, truth = synth.make_reads(n, 15000, motif, seed=20250920)
+    comp = np.zeros(256, np.uint8)
+    comp[list(b"ACGT")] = list(b"TGCA")
+    rc = comp[bases.reshape(n, -1)[:, ::-1]].reshape(-1)
+    prm = hiplib.make_params(min_len=9000, min_count=-1,
+                             flags=hiplib.F_STEP1 | hiplib.F_WINDOWS | hiplib.F_BINSEG | hiplib.F_STORE_SUMS)
+    sc.upload(2, bases, offsets)
+    sc.scan(2, prm)
+    sc.sync()
+    res = sc.results(2).copy()
+    sums, win_off = sc.window_sums(2)
+    sc.upload(3, rc, offsets)
+    sc.scan(3, prm)
+    sc.sync()
+    res_rc = sc.results(3)
+    sums_rc, _ = sc.window_sums(3)
+    nw = 2467
+    assert np.array_equal(res["n_win"], res_rc["n_win"]) and res["n_win"].min() == nw == res["n_win"].max()
+    strict = res["best_start"] != res["best_end"]          # ties go to 'reverse' on both strands
+    assert strict.mean() > 0.99
+    assert np.array_equal(res["tail"][strict], 1 - res_rc["tail"][strict])
+    assert np.array_equal(res["best_start"], res_rc["best_end"]) and np.array_equal(res["best_end"], res_rc["best_start"])
+    # the table holds every k-mer and its complement, so S_w is strand-symmetric window by window
+    S, S_rc = sums.reshape(n, nw), sums_rc.reshape(n, nw)
+    assert np.array_equal(S[strict], S_rc[strict])
+    assert np.array_equal(res["bkp"][strict], res_rc["bkp"][strict])
+    assert (res["tail"] == truth["reverse"]).mean() > 0.999
+    # planted tract end vs called boundary (ONT-like errors)
+    called = res["bkp"].astype(np.int64) * 6 + 100
+    err = np.abs(called - truth["tract"])
+    assert np.median(err) <= 60, np.median(err)
+    # S_w range: P <= S_w <= P * floor(99 / k)
+    assert sums.min() >= len(pats) and sums.max() <= len(pats) * (99 // k)

@@ -1,0 +1,527 @@
+// topsicle_hip.hip -- libtopsicle_hip.so: kernels + C ABI (include/topsicle_hip.h).
+// Build: hipcc --offload-arch=gfx950 -O3 -shared -fPIC  (see __graft_entry__.build()).
+// gfx950 only; there is no CPU fallback in this library.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "tps_device.h"
+#include "tps_plan.h"
+
+// ======================================================================== kernels
+extern "C" __global__ void __launch_bounds__(tps::NT) tps_scan_kernel(tps::ScanArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    tps::scan_read(a, (int64_t)blockIdx.x, lds);
+}
+
+extern "C" __global__ void __launch_bounds__(tps::NT) tps_binseg_kernel(tps::BinsegArgs a) {
+    __shared__ uint32_t misc[tps::MISC_DW];
+    tps::binseg_read(a, (int64_t)blockIdx.x, misc);
+}
+
+// ======================================================================== host side
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) return fail(TPS_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+constexpr int64_t PAD = 64;          // readable bytes before / after the concatenated bases
+constexpr int INTERNAL_SLOT = TPS_MAX_SLOTS;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return TPS_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        HIP_TRY(hipMalloc(&p, want));
+        cap = want;
+        return TPS_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct Slot {
+    DevBuf bases, offsets, tails, results, c_start, c_end, win_off, sums, raw;
+    std::vector<int64_t> h_offsets;      // host copy of offsets (n+1)
+    std::vector<int64_t> h_win_off;      // window layout of the last plan
+    tps_read_result* h_results = nullptr;   // pinned
+    size_t h_results_cap = 0;
+    int64_t n = -1;
+    bool has_tails = false;
+    // cached plan
+    bool planned = false;
+    tps_params plan_prm{};
+    int plan_k = 0, plan_p = 0;
+    tps::ScanArgs args{};
+    size_t lds_bytes = 0;
+    bool scanned = false;
+    uint32_t last_flags = 0;
+};
+
+struct EventPair { hipEvent_t a, b; };
+
+}  // namespace
+
+struct tps_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipDeviceProp_t prop{};
+    DevBuf lut;
+    tps::PatInfo pat{};
+    bool have_pat = false;
+    Slot slots[TPS_MAX_SLOTS + 1];
+    std::vector<EventPair> ev_pool;
+    size_t ev_used = 0;
+    size_t lds_set = 0;
+    int spans_override = 0;
+};
+
+namespace {
+
+int bind(tps_ctx* c) {
+    if (!c) return fail(TPS_E_ARG, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    return TPS_OK;
+}
+
+using tps::window_count;
+
+int plan_lds(tps_ctx* c, Slot& sl, const tps_params& prm, int64_t max_nwin) {
+    const size_t lds_max = c->prop.sharedMemPerBlock > 0 ? std::min<size_t>(c->prop.sharedMemPerBlock, 160 * 1024) : 64 * 1024;
+    std::string err = tps::plan_geometry(sl.args, prm, c->pat.k, max_nwin, (int64_t)lds_max / 4, c->spans_override);
+    if (!err.empty()) return fail(TPS_E_CAPACITY, "%s", err.c_str());
+    sl.lds_bytes = (size_t)tps::lds_dwords(sl.args) * 4;
+    return TPS_OK;
+}
+
+int check_params(const tps_params& p) {
+    if (p.window < 1 || p.slide < 1 || p.trimfirst < 0 || p.maxlen < 0 || p.no_bp < 0)
+        return fail(TPS_E_ARG, "bad window/slide/trimfirst/maxlen/no_bp");
+    if ((p.flags & TPS_F_BINSEG) && (p.jump < 1 || p.min_size < 1))
+        return fail(TPS_E_ARG, "bad jump/min_size");
+    if (p.slide > 4096 || p.window > 65536) return fail(TPS_E_CAPACITY, "window/slide too large");
+    return TPS_OK;
+}
+
+int do_upload(tps_ctx* c, Slot& sl, const uint8_t* bases, const int64_t* offsets, int64_t n) {
+    if (n < 0 || !offsets || (n > 0 && !bases)) return fail(TPS_E_ARG, "bad batch pointers");
+    if (offsets[0] != 0) return fail(TPS_E_ARG, "offsets[0] must be 0");
+    for (int64_t i = 0; i < n; ++i)
+        if (offsets[i + 1] < offsets[i]) return fail(TPS_E_ARG, "offsets not monotone at %lld", (long long)i);
+    const int64_t total = offsets[n];
+    int rc;
+    if ((rc = sl.bases.ensure((size_t)(total + 2 * PAD + 32)))) return rc;
+    if ((rc = sl.offsets.ensure((size_t)(n + 1) * 8))) return rc;
+    uint8_t* d = (uint8_t*)sl.bases.p;
+    HIP_TRY(hipMemsetAsync(d, 'A', PAD, c->stream));
+    HIP_TRY(hipMemsetAsync(d + PAD + total, 'A', PAD + 32, c->stream));
+    if (total) HIP_TRY(hipMemcpyAsync(d + PAD, bases, (size_t)total, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(sl.offsets.p, offsets, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    sl.h_offsets.assign(offsets, offsets + n + 1);
+    sl.n = n;
+    sl.has_tails = false;
+    sl.planned = false;
+    sl.scanned = false;
+    return TPS_OK;
+}
+
+bool same_params(const tps_params& x, const tps_params& y) { return memcmp(&x, &y, sizeof x) == 0; }
+
+int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm) {
+    int rc;
+    if (!c->have_pat) return fail(TPS_E_PATTERN, "tps_set_patterns has not been called");
+    if (sl.n < 0) return fail(TPS_E_STATE, "no batch uploaded in this slot");
+    if ((rc = check_params(prm))) return rc;
+    if (!(prm.flags & TPS_F_STEP1) && (prm.flags & TPS_F_TAILS_IN) && !sl.has_tails)
+        return fail(TPS_E_STATE, "TPS_F_TAILS_IN without tps_batch_set_tails");
+    const int64_t n = sl.n;
+    const int P = c->pat.P;
+    if (!sl.planned || !same_params(prm, sl.plan_prm) || sl.plan_k != c->pat.k || sl.plan_p != P) {
+        sl.h_win_off.resize((size_t)n + 1);
+        int64_t acc = 0, mx = 0;
+        for (int64_t i = 0; i < n; ++i) {
+            sl.h_win_off[(size_t)i] = acc;
+            int64_t nw = window_count(sl.h_offsets[i + 1] - sl.h_offsets[i], prm.window, prm.slide, prm.trimfirst, prm.maxlen);
+            mx = std::max(mx, nw);
+            acc += nw;
+        }
+        sl.h_win_off[(size_t)n] = acc;
+        sl.args = tps::ScanArgs{};
+        if ((rc = plan_lds(c, sl, prm, mx))) return rc;
+        if ((rc = sl.win_off.ensure((size_t)(n + 1) * 8))) return rc;
+        HIP_TRY(hipMemcpyAsync(sl.win_off.p, sl.h_win_off.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));       // h_win_off may be reused by the caller's next plan
+        sl.plan_prm = prm;
+        sl.plan_k = c->pat.k;
+        sl.plan_p = P;
+        sl.planned = true;
+    }
+    const int64_t total_win = sl.h_win_off[(size_t)n];
+    if ((rc = sl.results.ensure((size_t)std::max<int64_t>(n, 1) * sizeof(tps_read_result)))) return rc;
+    if (sl.h_results_cap < (size_t)n) {
+        if (sl.h_results) (void)hipHostFree(sl.h_results);
+        sl.h_results = nullptr;
+        size_t want = (size_t)n + (size_t)n / 8 + 16;
+        HIP_TRY(hipHostMalloc((void**)&sl.h_results, want * sizeof(tps_read_result), hipHostMallocDefault));
+        sl.h_results_cap = want;
+    }
+    tps::ScanArgs& a = sl.args;
+    a.bases = (const uint8_t*)sl.bases.p + PAD;
+    a.offsets = (const int64_t*)sl.offsets.p;
+    a.tails_in = ((prm.flags & TPS_F_TAILS_IN) && !(prm.flags & TPS_F_STEP1)) ? (const uint8_t*)sl.tails.p : nullptr;
+    a.lut = (const uint32_t*)c->lut.p;
+    a.results = (tps_read_result*)sl.results.p;
+    a.c_start = a.c_end = nullptr;
+    if (prm.flags & TPS_F_STEP1) {
+        if ((rc = sl.c_start.ensure((size_t)std::max<int64_t>(n * P, 1) * 4))) return rc;
+        if ((rc = sl.c_end.ensure((size_t)std::max<int64_t>(n * P, 1) * 4))) return rc;
+        a.c_start = (int32_t*)sl.c_start.p;
+        a.c_end = (int32_t*)sl.c_end.p;
+    }
+    a.win_off = (const int64_t*)sl.win_off.p;
+    a.sums = nullptr;
+    a.raw = nullptr;
+    if (prm.flags & TPS_F_STORE_SUMS) {
+        if ((rc = sl.sums.ensure((size_t)std::max<int64_t>(total_win, 1) * 4))) return rc;
+        a.sums = (int32_t*)sl.sums.p;
+    }
+    if (prm.flags & TPS_F_STORE_RAW) {
+        if ((rc = sl.raw.ensure((size_t)std::max<int64_t>(total_win * P, 1)))) return rc;
+        a.raw = (uint8_t*)sl.raw.p;
+    }
+    a.n_reads = n;
+    a.pat = c->pat;
+    a.prm = prm;
+    sl.last_flags = prm.flags;
+    if (n == 0) { sl.scanned = true; return TPS_OK; }
+
+    if (sl.lds_bytes > c->lds_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)tps_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sl.lds_bytes));
+        c->lds_set = sl.lds_bytes;
+    }
+    if (c->ev_used == c->ev_pool.size()) {
+        if (c->ev_pool.size() >= 8192) {
+            c->ev_used = 0;                               // wrap: oldest timings are dropped
+        } else {
+            EventPair ep;
+            HIP_TRY(hipEventCreate(&ep.a));
+            HIP_TRY(hipEventCreate(&ep.b));
+            c->ev_pool.push_back(ep);
+        }
+    }
+    EventPair& ep = c->ev_pool[c->ev_used++];
+    HIP_TRY(hipEventRecord(ep.a, c->stream));
+    hipLaunchKernelGGL(tps_scan_kernel, dim3((unsigned)n), dim3(tps::NT), sl.lds_bytes, c->stream, a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ep.b, c->stream));
+    HIP_TRY(hipMemcpyAsync(sl.h_results, sl.results.p, (size_t)n * sizeof(tps_read_result), hipMemcpyDeviceToHost, c->stream));
+    sl.scanned = true;
+    return TPS_OK;
+}
+
+Slot* get_slot(tps_ctx* c, int slot) {
+    if (!c || slot < 0 || slot >= TPS_MAX_SLOTS) { fail(TPS_E_ARG, "slot out of range"); return nullptr; }
+    return &c->slots[slot];
+}
+
+}  // namespace
+
+// ======================================================================== C ABI
+extern "C" {
+
+int tps_abi_version(void) { return TPS_ABI_VERSION; }
+
+const char* tps_last_error(void) { return g_err.c_str(); }
+
+int tps_device_count(int* n) {
+    if (!n) return fail(TPS_E_ARG, "null pointer");
+    int cnt = 0;
+    hipError_t e = hipGetDeviceCount(&cnt);
+    if (e != hipSuccess) { *n = 0; return fail(TPS_E_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *n = cnt;
+    return TPS_OK;
+}
+
+int tps_ctx_create(int device, tps_ctx** out) {
+    if (!out) return fail(TPS_E_ARG, "null pointer");
+    *out = nullptr;
+    int cnt = 0;
+    hipError_t e = hipGetDeviceCount(&cnt);
+    if (e != hipSuccess || cnt <= 0)
+        return fail(TPS_E_NO_DEVICE, "no HIP device available (%s); this library has no CPU fallback",
+                    e == hipSuccess ? "count is 0" : hipGetErrorString(e));
+    if (device < 0 || device >= cnt) return fail(TPS_E_NO_DEVICE, "device %d out of range (0..%d)", device, cnt - 1);
+    tps_ctx* c = new tps_ctx();
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&c->prop, device) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return fail(TPS_E_HIP, "cannot initialise device %d", device);
+    }
+    if (const char* s = getenv("TPS_SPANS_PER_TILE")) c->spans_override = atoi(s);
+    *out = c;
+    return TPS_OK;
+}
+
+int tps_ctx_destroy(tps_ctx* c) {
+    if (!c) return TPS_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& sl : c->slots) {
+        sl.bases.release(); sl.offsets.release(); sl.tails.release(); sl.results.release();
+        sl.c_start.release(); sl.c_end.release(); sl.win_off.release(); sl.sums.release(); sl.raw.release();
+        if (sl.h_results) (void)hipHostFree(sl.h_results);
+    }
+    c->lut.release();
+    for (auto& ep : c->ev_pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return TPS_OK;
+}
+
+int tps_device_info(tps_ctx* c, char* buf, int32_t buf_len) {
+    if (!c || !buf || buf_len < 1) return fail(TPS_E_ARG, "bad arguments");
+    snprintf(buf, (size_t)buf_len, "%s arch=%s CUs=%d LDS/block=%zu clock=%dkHz", c->prop.name, c->prop.gcnArchName,
+             c->prop.multiProcessorCount, c->prop.sharedMemPerBlock, c->prop.clockRate);
+    return TPS_OK;
+}
+
+int tps_set_patterns(tps_ctx* c, const char* pats, int32_t P, int32_t k) {
+    int rc;
+    if ((rc = bind(c))) return rc;
+    if (!pats) return fail(TPS_E_ARG, "null pattern table");
+    std::vector<uint32_t> lut;
+    tps::PatInfo pi{};
+    std::string err = tps::build_patterns(pats, P, k, lut, pi);
+    if (!err.empty()) return fail(TPS_E_PATTERN, "%s", err.c_str());
+    if ((rc = c->lut.ensure(lut.size() * 4))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->lut.p, lut.data(), lut.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->pat = pi;
+    c->have_pat = true;
+    return TPS_OK;
+}
+
+int tps_batch_upload(tps_ctx* c, int32_t slot, const uint8_t* bases, const int64_t* offsets, int64_t n) {
+    int rc;
+    if ((rc = bind(c))) return rc;
+    Slot* sl = get_slot(c, slot);
+    if (!sl) return TPS_E_ARG;
+    return do_upload(c, *sl, bases, offsets, n);
+}
+
+int tps_batch_set_tails(tps_ctx* c, int32_t slot, const uint8_t* tails) {
+    int rc;
+    if ((rc = bind(c))) return rc;
+    Slot* sl = get_slot(c, slot);
+    if (!sl) return TPS_E_ARG;
+    if (sl->n < 0) return fail(TPS_E_STATE, "no batch uploaded in this slot");
+    if (!tails && sl->n > 0) return fail(TPS_E_ARG, "null tails");
+    if ((rc = sl->tails.ensure((size_t)std::max<int64_t>(sl->n, 1)))) return rc;
+    if (sl->n) HIP_TRY(hipMemcpyAsync(sl->tails.p, tails, (size_t)sl->n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    sl->has_tails = true;
+    return TPS_OK;
+}
+
+int tps_batch_scan(tps_ctx* c, int32_t slot, const tps_params* prm) {
+    int rc;
+    if ((rc = bind(c))) return rc;
+    Slot* sl = get_slot(c, slot);
+    if (!sl) return TPS_E_ARG;
+    if (!prm) return fail(TPS_E_ARG, "null params");
+    return do_scan(c, *sl, *prm);
+}
+
+int tps_sync(tps_ctx* c) {
+    int rc;
+    if ((rc = bind(c))) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return TPS_OK;
+}
+
+static int need_scanned(tps_ctx* c, int slot, Slot** out) {
+    int rc;
+    if ((rc = bind(c))) return rc;
+    Slot* sl = (slot == INTERNAL_SLOT) ? &c->slots[INTERNAL_SLOT] : get_slot(c, slot);
+    if (!sl) return TPS_E_ARG;
+    if (!sl->scanned) return fail(TPS_E_STATE, "slot has not been scanned");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *out = sl;
+    return TPS_OK;
+}
+
+int tps_batch_results(tps_ctx* c, int32_t slot, tps_read_result* out, int64_t n) {
+    Slot* sl;
+    int rc;
+    if ((rc = need_scanned(c, slot, &sl))) return rc;
+    if (n != sl->n || (n > 0 && !out)) return fail(TPS_E_ARG, "result buffer must hold %lld reads", (long long)sl->n);
+    if (n) memcpy(out, sl->h_results, (size_t)n * sizeof(tps_read_result));
+    return TPS_OK;
+}
+
+int tps_batch_window_offsets(tps_ctx* c, int32_t slot, int64_t* win_off, int64_t n1) {
+    Slot* sl;
+    int rc;
+    if ((rc = need_scanned(c, slot, &sl))) return rc;
+    if (n1 != sl->n + 1 || !win_off) return fail(TPS_E_ARG, "win_off must hold n+1 entries");
+    memcpy(win_off, sl->h_win_off.data(), (size_t)n1 * 8);
+    return TPS_OK;
+}
+
+int tps_batch_window_sums(tps_ctx* c, int32_t slot, int32_t* sums, int64_t nw) {
+    Slot* sl;
+    int rc;
+    if ((rc = need_scanned(c, slot, &sl))) return rc;
+    if (!(sl->last_flags & TPS_F_STORE_SUMS)) return fail(TPS_E_STATE, "last scan did not store window sums");
+    if (nw != sl->h_win_off[(size_t)sl->n] || (nw > 0 && !sums)) return fail(TPS_E_ARG, "sums must hold %lld windows", (long long)sl->h_win_off[(size_t)sl->n]);
+    if (nw) HIP_TRY(hipMemcpy(sums, sl->sums.p, (size_t)nw * 4, hipMemcpyDeviceToHost));
+    return TPS_OK;
+}
+
+int tps_batch_window_raw(tps_ctx* c, int32_t slot, uint8_t* raw, int64_t nwp) {
+    Slot* sl;
+    int rc;
+    if ((rc = need_scanned(c, slot, &sl))) return rc;
+    if (!(sl->last_flags & TPS_F_STORE_RAW)) return fail(TPS_E_STATE, "last scan did not store raw counts");
+    int64_t want = sl->h_win_off[(size_t)sl->n] * sl->plan_p;
+    if (nwp != want || (nwp > 0 && !raw)) return fail(TPS_E_ARG, "raw must hold %lld bytes", (long long)want);
+    if (nwp) HIP_TRY(hipMemcpy(raw, sl->raw.p, (size_t)nwp, hipMemcpyDeviceToHost));
+    return TPS_OK;
+}
+
+int tps_batch_trc_counts(tps_ctx* c, int32_t slot, int32_t* c_start, int32_t* c_end, int64_t n) {
+    Slot* sl;
+    int rc;
+    if ((rc = need_scanned(c, slot, &sl))) return rc;
+    if (!(sl->last_flags & TPS_F_STEP1)) return fail(TPS_E_STATE, "last scan did not run step 1");
+    if (n != sl->n || (n > 0 && (!c_start || !c_end))) return fail(TPS_E_ARG, "count buffers must hold n*P entries");
+    size_t bytes = (size_t)n * (size_t)sl->plan_p * 4;
+    if (bytes) {
+        HIP_TRY(hipMemcpy(c_start, sl->c_start.p, bytes, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(c_end, sl->c_end.p, bytes, hipMemcpyDeviceToHost));
+    }
+    return TPS_OK;
+}
+
+int64_t tps_window_count(int64_t L, int32_t W, int32_t s, int32_t t, int32_t M) { return window_count(L, W, s, t, M); }
+
+int tps_trc_counts(tps_ctx* c, const uint8_t* bases, const int64_t* offsets, int64_t n, int32_t no_bp,
+                   int32_t* c_start, int32_t* c_end) {
+    int rc;
+    if ((rc = bind(c))) return rc;
+    Slot& sl = c->slots[INTERNAL_SLOT];
+    if ((rc = do_upload(c, sl, bases, offsets, n))) return rc;
+    tps_params p{};
+    p.no_bp = no_bp; p.min_len = 0; p.min_count = 0; p.window = 100; p.slide = 6; p.trimfirst = 0; p.maxlen = 0;
+    p.jump = 5; p.min_size = 2; p.flags = TPS_F_STEP1;
+    if ((rc = do_scan(c, sl, p))) return rc;
+    return tps_batch_trc_counts(c, INTERNAL_SLOT, c_start, c_end, n);
+}
+
+int tps_window_counts(tps_ctx* c, const uint8_t* bases, const int64_t* offsets, const uint8_t* tails, int64_t n,
+                      int32_t W, int32_t s, int32_t t, int32_t M, const int64_t* win_off, int32_t* sums, uint8_t* raw) {
+    int rc;
+    if ((rc = bind(c))) return rc;
+    if (!win_off || (n > 0 && !tails)) return fail(TPS_E_ARG, "null win_off / tails");
+    Slot& sl = c->slots[INTERNAL_SLOT];
+    if ((rc = do_upload(c, sl, bases, offsets, n))) return rc;
+    if ((rc = sl.tails.ensure((size_t)std::max<int64_t>(n, 1)))) return rc;
+    if (n) HIP_TRY(hipMemcpy(sl.tails.p, tails, (size_t)n, hipMemcpyHostToDevice));
+    sl.has_tails = true;
+    tps_params p{};
+    p.no_bp = 0; p.window = W; p.slide = s; p.trimfirst = t; p.maxlen = M; p.jump = 5; p.min_size = 2;
+    p.flags = TPS_F_WINDOWS | TPS_F_TAILS_IN | TPS_F_STORE_SUMS | (raw ? TPS_F_STORE_RAW : 0u);
+    if ((rc = do_scan(c, sl, p))) return rc;
+    for (int64_t i = 0; i <= n; ++i)
+        if (win_off[i] != sl.h_win_off[(size_t)i])
+            return fail(TPS_E_ARG, "win_off[%lld]=%lld does not match the window layout (%lld)", (long long)i,
+                        (long long)win_off[i], (long long)sl.h_win_off[(size_t)i]);
+    int64_t nw = sl.h_win_off[(size_t)n];
+    if ((rc = tps_batch_window_sums(c, INTERNAL_SLOT, sums, nw))) return rc;
+    if (raw && (rc = tps_batch_window_raw(c, INTERNAL_SLOT, raw, nw * c->pat.P))) return rc;
+    return TPS_OK;
+}
+
+int tps_binseg_l2(tps_ctx* c, const int32_t* sums, const int64_t* win_off, int64_t n, int32_t n_patterns,
+                  int32_t jump, int32_t min_size, int32_t* bkp, double* gain) {
+    int rc;
+    if ((rc = bind(c))) return rc;
+    if (n < 0 || !win_off || !bkp || jump < 1 || min_size < 1 || n_patterns < 1) return fail(TPS_E_ARG, "bad arguments");
+    if (n == 0) return TPS_OK;
+    const int64_t nw = win_off[n];
+    if (nw > 0 && !sums) return fail(TPS_E_ARG, "null sums");
+    Slot& sl = c->slots[INTERNAL_SLOT];
+    if ((rc = sl.sums.ensure((size_t)std::max<int64_t>(nw, 1) * 4))) return rc;
+    if ((rc = sl.win_off.ensure((size_t)(n + 1) * 8))) return rc;
+    if ((rc = sl.results.ensure((size_t)n * 16))) return rc;          // bkp (4n) + gain (8n), gain first for alignment
+    sl.planned = false;                                                // the slot's plan buffers were overwritten
+    sl.scanned = false;
+    if (nw) HIP_TRY(hipMemcpyAsync(sl.sums.p, sums, (size_t)nw * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(sl.win_off.p, win_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    tps::BinsegArgs a{};
+    a.sums = (const int32_t*)sl.sums.p;
+    a.win_off = (const int64_t*)sl.win_off.p;
+    a.gain = (double*)sl.results.p;
+    a.bkp = (int32_t*)((char*)sl.results.p + (size_t)n * 8);
+    a.n_reads = n;
+    a.n_patterns = n_patterns;
+    a.jump = jump;
+    a.min_size = min_size;
+    hipLaunchKernelGGL(tps_binseg_kernel, dim3((unsigned)n), dim3(tps::NT), 0, c->stream, a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(bkp, a.bkp, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (gain) HIP_TRY(hipMemcpyAsync(gain, a.gain, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return TPS_OK;
+}
+
+int tps_kernel_time_ms(tps_ctx* c, int32_t* n_launches, double* total_ms, double* mean_ms) {
+    int rc;
+    if ((rc = bind(c))) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    double tot = 0.0;
+    for (size_t i = 0; i < c->ev_used; ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev_pool[i].a, c->ev_pool[i].b));
+        tot += ms;
+    }
+    if (n_launches) *n_launches = (int32_t)c->ev_used;
+    if (total_ms) *total_ms = tot;
+    if (mean_ms) *mean_ms = c->ev_used ? tot / (double)c->ev_used : 0.0;
+    return TPS_OK;
+}
+
+int tps_kernel_time_reset(tps_ctx* c) {
+    int rc;
+    if ((rc = bind(c))) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->ev_used = 0;
+    return TPS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,103 @@
+// tps_plan.h -- host-side planning shared by the library (topsicle_hip.hip) and the test
+// emulation (tests/emu): pattern table -> lookup table + self-overlap info, and the LDS
+// geometry of one scan.  Plain C++, no HIP calls.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "tps_device.h"
+
+namespace tps {
+
+inline int64_t window_count(int64_t L, int W, int s, int t, int M) {
+    // seq_cut_windows over seq[t:min(L,M)]: range(0, n_s - W + 1, s)   (allsteps.py:219, 263-271)
+    int64_t m = std::min<int64_t>(L, M);
+    int64_t ns = m - t;
+    if (W < 1 || s < 1 || ns < W) return 0;
+    return (ns - W) / s + 1;
+}
+
+inline int gcd_i(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
+
+// Pattern list (P strings of k letters, reference order) -> 4^k lookup table of list masks and
+// the self-overlap (period) information.  Returns "" or an error message.
+inline std::string build_patterns(const char* pats, int P, int k, std::vector<uint32_t>& lut, PatInfo& pi) {
+    if (k < 1 || k > TPS_MAX_K) return "k=" + std::to_string(k) + " not supported (1.." + std::to_string(TPS_MAX_K) + ")";
+    if (P < 1 || P > TPS_MAX_PATTERNS) return std::to_string(P) + " patterns not supported (1.." + std::to_string(TPS_MAX_PATTERNS) + ")";
+    lut.assign((size_t)1 << (2 * k), 0u);
+    pi = PatInfo{};
+    pi.P = P;
+    pi.k = k;
+    pi.kmask = (1u << (2 * k)) - 1u;
+    pi.all_mask = (1u << P) - 1u;
+    uint32_t per_pat[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int p = 0; p < P; ++p) {
+        uint32_t code = 0;
+        char up[16];
+        for (int i = 0; i < k; ++i) {
+            char ch = pats[p * k + i];
+            if (ch >= 'a' && ch <= 'z') ch = (char)(ch - 32);
+            up[i] = ch;
+            uint32_t v;
+            switch (ch) {          // the 2-bit code the kernel derives from ASCII: (c >> 1) & 3
+                case 'A': v = 0; break;
+                case 'C': v = 1; break;
+                case 'T': v = 2; break;
+                case 'G': v = 3; break;
+                default: return "pattern " + std::to_string(p) + " has a non-ACGT letter";
+            }
+            code |= v << (2 * i);
+        }
+        lut[code] |= 1u << p;
+        for (int d = 1; d < k; ++d) {             // proper periods -> the k-mer can overlap itself
+            bool periodic = true;
+            for (int i = 0; i + d < k; ++i) periodic = periodic && (up[i] == up[i + d]);
+            if (periodic) { per_pat[d] |= 1u << p; pi.so_mask |= 1u << p; }
+        }
+    }
+    for (int d = 1; d < k; ++d)
+        if (per_pat[d]) {
+            pi.period[pi.n_periods] = d;
+            pi.period_pat[pi.n_periods] = per_pat[d];
+            ++pi.n_periods;
+        }
+    return "";
+}
+
+// Geometry of one scan: fills lut_n, lw/q/r, span_dw, blk_log2, spans_per_tile, nblk_cap,
+// seq_dw, s_cap.  budget_dw = LDS dwords available to one workgroup.
+inline std::string plan_geometry(ScanArgs& a, const tps_params& prm, int k, int64_t max_nwin, int64_t budget_dw,
+                                 int spans_pref) {
+    a.lut_n = 1 << (2 * k);
+    a.lw = std::max(0, prm.window - k);            // k-mer start positions in a (W-1)-char window
+    a.q = a.lw / prm.slide;
+    a.r = a.lw % prm.slide;
+    const int g = gcd_i(prm.slide, 16);
+    a.span_dw = prm.slide / g;
+    const int bps = 16 / g;
+    a.blk_log2 = 0;
+    while ((1 << a.blk_log2) < bps) ++a.blk_log2;
+    if (max_nwin > 500000) return "too many windows per read (" + std::to_string(max_nwin) + ")";
+    a.s_cap = (int)std::max<int64_t>(max_nwin, 1);
+    const int min_spans = (a.q + 2 + bps - 1) / bps;        // a tile must hold >= 1 window
+    int spans = spans_pref > 0 ? spans_pref : 128;
+    const int64_t need_blk = max_nwin + a.q + 1;            // no more spans than the longest read uses
+    const int need_spans = (int)std::min<int64_t>((need_blk + bps - 1) / bps, NT);
+    spans = std::max(min_spans, std::min(spans, std::max(need_spans, 1)));
+    if (spans > NT) return "window/slide combination needs " + std::to_string(spans) + " spans per tile (max " + std::to_string(NT) + ")";
+    for (;;) {
+        a.spans_per_tile = spans;
+        a.nblk_cap = spans * bps;
+        a.seq_dw = std::max(spans * a.span_dw + 4, (prm.no_bp + 31) / 16 + 4);
+        if (lds_dwords(a) <= budget_dw) break;
+        if (spans <= min_spans)
+            return "LDS plan does not fit: window=" + std::to_string(prm.window) + " slide=" + std::to_string(prm.slide) +
+                   " k=" + std::to_string(k) + " windows/read=" + std::to_string(max_nwin);
+        spans = std::max(min_spans, spans / 2);
+    }
+    return "";
+}
+
+}  // namespace tps

@@ -1,0 +1,277 @@
+"""ctypes binding of libtopsicle_hip.so (C ABI: include/topsicle_hip.h).
+
+This is the only way the package reaches the GPU.  There is deliberately NO CPU fallback:
+if the shared library is missing, cannot be loaded, or no MI355X is visible, every entry
+point raises `TopsicleHipError` -- results never silently come from anywhere else.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+LIB_NAME = "libtopsicle_hip.so"
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+
+# flags (TPS_F_*)
+F_STEP1, F_WINDOWS, F_BINSEG, F_STORE_SUMS, F_STORE_RAW, F_TAILS_IN = 1, 2, 4, 8, 16, 32
+MAX_K, MAX_PATTERNS, MAX_SLOTS = 7, 31, 16
+
+EXPORTS = [
+    "tps_abi_version", "tps_device_count", "tps_ctx_create", "tps_ctx_destroy", "tps_last_error",
+    "tps_set_patterns", "tps_batch_upload", "tps_batch_set_tails", "tps_batch_scan", "tps_sync",
+    "tps_batch_results", "tps_batch_window_offsets", "tps_batch_window_sums", "tps_batch_window_raw",
+    "tps_batch_trc_counts", "tps_trc_counts", "tps_window_counts", "tps_binseg_l2", "tps_window_count",
+    "tps_kernel_time_ms", "tps_kernel_time_reset", "tps_device_info",
+]
+
+
+class TopsicleHipError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    """struct tps_params -- names follow the reference CLI (Topsicle/main.py:319-334)."""
+    _fields_ = [("no_bp", C.c_int32), ("min_len", C.c_int32), ("min_count", C.c_int32),
+                ("window", C.c_int32), ("slide", C.c_int32), ("trimfirst", C.c_int32),
+                ("maxlen", C.c_int32), ("jump", C.c_int32), ("min_size", C.c_int32),
+                ("flags", C.c_uint32)]
+
+
+RESULT_DTYPE = np.dtype([("best_start", "<i4"), ("best_start_idx", "<i4"), ("best_end", "<i4"),
+                         ("best_end_idx", "<i4"), ("tail", "<i4"), ("pass", "<i4"), ("n_win", "<i4"),
+                         ("bkp", "<i4"), ("gain", "<f8")], align=True)
+assert RESULT_DTYPE.itemsize == 40
+
+
+def make_params(no_bp=1000, min_len=0, min_count=-1, window=100, slide=6, trimfirst=100, maxlen=20000,
+                jump=5, min_size=2, flags=F_STEP1 | F_WINDOWS | F_BINSEG) -> Params:
+    return Params(no_bp, min_len, min_count, window, slide, trimfirst, maxlen, jump, min_size, flags)
+
+
+_lib = None
+
+
+def load_library(path: str | None = None) -> C.CDLL:
+    """Load libtopsicle_hip.so (built in-tree by `__graft_entry__.build()` / `make`)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise TopsicleHipError(f"{p} not found: build the HIP library first (python -c 'import __graft_entry__ as g; g.build()'). "
+                               "topsicle_amd has no CPU fallback.")
+    try:
+        lib = C.CDLL(p)
+    except OSError as e:
+        raise TopsicleHipError(f"cannot load {p}: {e}") from e
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    proto = {
+        "tps_abi_version": (C.c_int, []),
+        "tps_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+        "tps_ctx_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
+        "tps_ctx_destroy": (C.c_int, [vp]),
+        "tps_last_error": (C.c_char_p, []),
+        "tps_set_patterns": (C.c_int, [vp, C.c_char_p, i32, i32]),
+        "tps_batch_upload": (C.c_int, [vp, i32, vp, vp, i64]),
+        "tps_batch_set_tails": (C.c_int, [vp, i32, vp]),
+        "tps_batch_scan": (C.c_int, [vp, i32, C.POINTER(Params)]),
+        "tps_sync": (C.c_int, [vp]),
+        "tps_batch_results": (C.c_int, [vp, i32, vp, i64]),
+        "tps_batch_window_offsets": (C.c_int, [vp, i32, vp, i64]),
+        "tps_batch_window_sums": (C.c_int, [vp, i32, vp, i64]),
+        "tps_batch_window_raw": (C.c_int, [vp, i32, vp, i64]),
+        "tps_batch_trc_counts": (C.c_int, [vp, i32, vp, vp, i64]),
+        "tps_trc_counts": (C.c_int, [vp, vp, vp, i64, i32, vp, vp]),
+        "tps_window_counts": (C.c_int, [vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, vp, vp]),
+        "tps_binseg_l2": (C.c_int, [vp, vp, vp, i64, i32, i32, i32, vp, vp]),
+        "tps_window_count": (i64, [i64, i32, i32, i32, i32]),
+        "tps_kernel_time_ms": (C.c_int, [vp, C.POINTER(i32), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+        "tps_kernel_time_reset": (C.c_int, [vp]),
+        "tps_device_info": (C.c_int, [vp, C.c_char_p, i32]),
+    }
+    for name, (res, args) in proto.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise TopsicleHipError(f"{p} does not export {name}") from e
+        fn.restype, fn.argtypes = res, args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def pack_reads(seqs) -> tuple[np.ndarray, np.ndarray]:
+    """Concatenate read strings/bytes into (bases u8, offsets i64[n+1])."""
+    bs = [s.encode("ascii", "replace") if isinstance(s, str) else bytes(s) for s in seqs]
+    offsets = np.zeros(len(bs) + 1, dtype=np.int64)
+    if bs:
+        np.cumsum([len(b) for b in bs], out=offsets[1:])
+    bases = np.frombuffer(b"".join(bs), dtype=np.uint8) if bs else np.zeros(0, np.uint8)
+    return np.ascontiguousarray(bases), offsets
+
+
+def window_count(read_len: int, window: int, slide: int, trimfirst: int, maxlen: int) -> int:
+    """Windows seq_cut_windows yields for one read (allsteps.py:219, 263-271)."""
+    ns = min(read_len, maxlen) - trimfirst
+    if window < 1 or slide < 1 or ns < window:
+        return 0
+    return (ns - window) // slide + 1
+
+
+class HipScanner:
+    """One context on one MI355X.  Not thread-safe; use one per host thread and device."""
+
+    def __init__(self, device: int = 0, lib_path: str | None = None):
+        self.lib = load_library(lib_path)
+        n = C.c_int(0)
+        rc = self.lib.tps_device_count(C.byref(n))
+        if rc != 0 or n.value <= 0:
+            raise TopsicleHipError("no MI355X / HIP device visible: " + self._err() + " (topsicle_amd has no CPU fallback)")
+        h = C.c_void_p()
+        self._check(self.lib.tps_ctx_create(int(device), C.byref(h)))
+        self._h = h
+        self.device = int(device)
+        self.patterns: list[str] = []
+        self._n = {}
+
+    # -- plumbing
+    def _err(self) -> str:
+        m = self.lib.tps_last_error()
+        return m.decode("utf-8", "replace") if m else ""
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise TopsicleHipError(f"libtopsicle_hip error {rc}: {self._err()}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.tps_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def device_info(self) -> str:
+        buf = C.create_string_buffer(256)
+        self._check(self.lib.tps_device_info(self._h, buf, 256))
+        return buf.value.decode()
+
+    # -- pattern table
+    def set_patterns(self, patterns: list[str]):
+        if not patterns:
+            raise TopsicleHipError("empty pattern list")
+        k = len(patterns[0])
+        if any(len(p) != k for p in patterns):
+            raise TopsicleHipError("all patterns of one table must have the same length")
+        blob = "".join(patterns).encode("ascii")
+        self._check(self.lib.tps_set_patterns(self._h, blob, len(patterns), k))
+        self.patterns = list(patterns)
+
+    # -- resident batches
+    def upload(self, slot: int, bases: np.ndarray, offsets: np.ndarray):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        n = len(offsets) - 1
+        self._check(self.lib.tps_batch_upload(self._h, slot, _ptr(bases), _ptr(offsets), n))
+        self._n[slot] = n
+
+    def set_tails(self, slot: int, tails: np.ndarray):
+        tails = np.ascontiguousarray(tails, dtype=np.uint8)
+        assert len(tails) == self._n[slot]
+        self._check(self.lib.tps_batch_set_tails(self._h, slot, _ptr(tails)))
+
+    def scan(self, slot: int, prm: Params):
+        self._check(self.lib.tps_batch_scan(self._h, slot, C.byref(prm)))
+
+    def sync(self):
+        self._check(self.lib.tps_sync(self._h))
+
+    def results(self, slot: int) -> np.ndarray:
+        n = self._n[slot]
+        out = np.zeros(n, dtype=RESULT_DTYPE)
+        self._check(self.lib.tps_batch_results(self._h, slot, _ptr(out), n))
+        return out
+
+    def window_offsets(self, slot: int) -> np.ndarray:
+        n = self._n[slot]
+        out = np.zeros(n + 1, dtype=np.int64)
+        self._check(self.lib.tps_batch_window_offsets(self._h, slot, _ptr(out), n + 1))
+        return out
+
+    def window_sums(self, slot: int) -> tuple[np.ndarray, np.ndarray]:
+        off = self.window_offsets(slot)
+        out = np.zeros(int(off[-1]), dtype=np.int32)
+        self._check(self.lib.tps_batch_window_sums(self._h, slot, _ptr(out), len(out)))
+        return out, off
+
+    def window_raw(self, slot: int) -> tuple[np.ndarray, np.ndarray]:
+        off = self.window_offsets(slot)
+        p = len(self.patterns)
+        out = np.zeros(int(off[-1]) * p, dtype=np.uint8)
+        self._check(self.lib.tps_batch_window_raw(self._h, slot, _ptr(out), len(out)))
+        return out.reshape(-1, p), off
+
+    def batch_trc_counts(self, slot: int) -> tuple[np.ndarray, np.ndarray]:
+        n, p = self._n[slot], len(self.patterns)
+        cs = np.zeros((n, p), dtype=np.int32)
+        ce = np.zeros((n, p), dtype=np.int32)
+        self._check(self.lib.tps_batch_trc_counts(self._h, slot, _ptr(cs), _ptr(ce), n))
+        return cs, ce
+
+    # -- one-shot calls
+    def trc_counts(self, bases, offsets, no_bp: int = 1000):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        n, p = len(offsets) - 1, len(self.patterns)
+        cs = np.zeros((n, p), dtype=np.int32)
+        ce = np.zeros((n, p), dtype=np.int32)
+        self._check(self.lib.tps_trc_counts(self._h, _ptr(bases), _ptr(offsets), n, no_bp, _ptr(cs), _ptr(ce)))
+        return cs, ce
+
+    def window_counts(self, bases, offsets, tails, window, slide, trimfirst, maxlen, raw=False):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        tails = np.ascontiguousarray(tails, dtype=np.uint8)
+        n, p = len(offsets) - 1, len(self.patterns)
+        lens = np.diff(offsets)
+        nw = np.array([window_count(int(x), window, slide, trimfirst, maxlen) for x in lens], dtype=np.int64)
+        win_off = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(nw, out=win_off[1:])
+        sums = np.zeros(int(win_off[-1]), dtype=np.int32)
+        rawbuf = np.zeros(int(win_off[-1]) * p, dtype=np.uint8) if raw else None
+        self._check(self.lib.tps_window_counts(self._h, _ptr(bases), _ptr(offsets), _ptr(tails), n, window, slide,
+                                               trimfirst, maxlen, _ptr(win_off), _ptr(sums), _ptr(rawbuf)))
+        return sums, win_off, (rawbuf.reshape(-1, p) if raw else None)
+
+    def binseg_l2(self, sums, win_off, n_patterns, jump=5, min_size=2):
+        sums = np.ascontiguousarray(sums, dtype=np.int32)
+        win_off = np.ascontiguousarray(win_off, dtype=np.int64)
+        n = len(win_off) - 1
+        bkp = np.full(n, -1, dtype=np.int32)
+        gain = np.zeros(n, dtype=np.float64)
+        self._check(self.lib.tps_binseg_l2(self._h, _ptr(sums), _ptr(win_off), n, n_patterns, jump, min_size, _ptr(bkp), _ptr(gain)))
+        return bkp, gain
+
+    # -- measurement
+    def kernel_time_ms(self) -> tuple[int, float, float]:
+        n, tot, mean = C.c_int32(0), C.c_double(0), C.c_double(0)
+        self._check(self.lib.tps_kernel_time_ms(self._h, C.byref(n), C.byref(tot), C.byref(mean)))
+        return n.value, tot.value, mean.value
+
+    def kernel_time_reset(self):
+        self._check(self.lib.tps_kernel_time_reset(self._h))
