@@ -51,8 +51,8 @@ def kmer_table(motif, k):
 
 
 def min_count_for_cutoff(cutoff, no_bp, motif_len):
-    ratio = no_bp / motif_len
-    return max([c for c in range(no_bp + 1) if not (c / ratio > cutoff)] or [-1])
+    from topsicle_amd import allsteps
+    return allsteps.min_count_for_cutoff(cutoff, no_bp / motif_len, no_bp)
 
 
 def algorithmic_bytes(lens, passed, n_win, P, prm):
@@ -110,16 +110,11 @@ def main():
     ap.add_argument("--resident-copies", type=int, default=0, help="copies of the batch kept in HBM (0 = enough for >1 GB)")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from topsicle_amd import dist
+    grp = dist.Group()
+    rank, world, local_rank = grp.rank, grp.world, grp.local_rank
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_mod
-        dist = dist_mod
-        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     cfg = CONFIGS[args.workload]
     motif, k = cfg["motif"], cfg["k"]
@@ -143,8 +138,7 @@ def main():
 
     def barrier():
         sc.sync()
-        if dist is not None:
-            dist.barrier()
+        grp.barrier()
 
     for i in range(args.warmup):
         sc.scan(i % copies, prm)
@@ -153,14 +147,9 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         sc.scan(i % copies, prm)
-    sc.sync()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        dist.barrier()
+    sc.sync()                      # device idle: every step's kernel and result copy has finished
+    dt = grp.max(time.perf_counter() - t0)
+    grp.barrier()
     n_launch, k_total_ms, k_mean_ms = sc.kernel_time_ms()
 
     res = sc.results((args.steps - 1) % copies)
@@ -220,8 +209,7 @@ def main():
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     sc.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    grp.close()
 
 
 if __name__ == "__main__":

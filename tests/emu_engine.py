@@ -1,0 +1,81 @@
+"""Test helper: an engine with HipScanner's interface backed by the host emulation of the kernel
+source (tests/emu).  Lets the host-side logic (allsteps mirror, batch driver, CLI) be tested in a
+container without a GPU.  Never used by the product."""
+import numpy as np
+
+import emu_driver as emu
+from topsicle_amd import hiplib
+
+
+class EmuEngine:
+    device = -1
+
+    def __init__(self):
+        self.patterns = []
+        self.slots = {}
+
+    def device_info(self):
+        return "host emulation of tps_device.h (tests only)"
+
+    def close(self):
+        pass
+
+    def set_patterns(self, patterns):
+        k = len(patterns[0])
+        if k > hiplib.MAX_K or len(patterns) > hiplib.MAX_PATTERNS or any(set(p.upper()) - set("ACGT") for p in patterns):
+            raise hiplib.TopsicleHipError("pattern table not supported")
+        self.patterns = list(patterns)
+
+    def upload(self, slot, bases, offsets):
+        self.slots[slot] = dict(bases=np.array(bases, np.uint8), offsets=np.array(offsets, np.int64), tails=None, out=None)
+
+    def set_tails(self, slot, tails):
+        self.slots[slot]["tails"] = np.array(tails, np.uint8)
+
+    def _seqs(self, s):
+        raw = s["bases"].tobytes()
+        o = s["offsets"]
+        return [raw[o[i]:o[i + 1]].decode("latin1") for i in range(len(o) - 1)]
+
+    def scan(self, slot, prm):
+        s = self.slots[slot]
+        p = hiplib.Params.from_buffer_copy(prm)
+        s["out"] = emu.scan(self.patterns, self._seqs(s), p, tails=s["tails"])
+        s["flags"] = p.flags
+
+    def sync(self):
+        pass
+
+    def results(self, slot):
+        return self.slots[slot]["out"]["results"]
+
+    def window_offsets(self, slot):
+        return self.slots[slot]["out"]["win_off"]
+
+    def window_sums(self, slot):
+        o = self.slots[slot]["out"]
+        return o["sums"], o["win_off"]
+
+    def window_raw(self, slot):
+        o = self.slots[slot]["out"]
+        return o["raw"], o["win_off"]
+
+    def batch_trc_counts(self, slot):
+        o = self.slots[slot]["out"]
+        return o["c_start"], o["c_end"]
+
+    def trc_counts(self, bases, offsets, no_bp=1000):
+        self.upload(99, bases, offsets)
+        self.scan(99, hiplib.make_params(no_bp=no_bp, flags=hiplib.F_STEP1))
+        return self.batch_trc_counts(99)
+
+    def window_counts(self, bases, offsets, tails, window, slide, trimfirst, maxlen, raw=False):
+        self.upload(99, bases, offsets)
+        self.set_tails(99, tails)
+        flags = hiplib.F_WINDOWS | hiplib.F_TAILS_IN | hiplib.F_STORE_SUMS | (hiplib.F_STORE_RAW if raw else 0)
+        self.scan(99, hiplib.make_params(no_bp=0, window=window, slide=slide, trimfirst=trimfirst, maxlen=maxlen, flags=flags))
+        o = self.slots[99]["out"]
+        return o["sums"], o["win_off"], (o["raw"] if raw else None)
+
+    def binseg_l2(self, sums, win_off, n_patterns, jump=5, min_size=2):
+        return emu.binseg(sums, win_off, n_patterns, jump, min_size)

@@ -1,0 +1,49 @@
+"""The C-ABI library loads on a machine without a GPU, exports every symbol include/*.h
+declares, and refuses to create a context (there is no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from topsicle_amd import hiplib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "topsicle_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tps_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    assert declared_symbols() == sorted(hiplib.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = C.CDLL(hiplib.LIB_PATH)
+    for name in declared_symbols():
+        assert hasattr(lib, name), name
+    assert hiplib.load_library().tps_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(hiplib.Params) == 40
+    assert hiplib.RESULT_DTYPE.itemsize == 40
+    assert hiplib.RESULT_DTYPE.fields["gain"][1] == 32
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="GPU present: context creation is expected to work")
+def test_no_gpu_means_loud_failure():
+    with pytest.raises(hiplib.TopsicleHipError) as e:
+        hiplib.HipScanner(0)
+    assert "no CPU fallback" in str(e.value)
+
+
+def test_window_count_helper_matches_reference_formula():
+    lib = hiplib.load_library()
+    for L, W, s, t, M in [(15000, 100, 6, 100, 20000), (30000, 100, 6, 100, 20000), (199, 100, 6, 100, 20000),
+                          (200, 100, 6, 100, 20000), (206, 100, 6, 100, 20000), (0, 100, 6, 100, 20000), (500, 37, 1, 0, 300)]:
+        want = len(range(0, max(min(L, M) - t, 0) - W + 1, s)) if min(L, M) - t >= W else 0
+        assert lib.tps_window_count(L, W, s, t, M) == want == hiplib.window_count(L, W, s, t, M)

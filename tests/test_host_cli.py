@@ -1,0 +1,153 @@
+"""Host-side logic without a GPU: the allsteps mirror, the batched driver and the `topsicle`
+CLI run on the demo data with the emulated engine and must reproduce the reference's shipped
+results (Topsicle_demo/telolengths_all.csv, log lines) and the reference-generated goldens."""
+import csv
+import gzip
+import json
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from emu_engine import EmuEngine
+from topsicle_amd import allsteps, main as cli, seqio
+
+
+@pytest.fixture()
+def engine():
+    e = EmuEngine()
+    allsteps.set_engine(e)
+    yield e
+    allsteps.set_engine(None)
+
+
+@pytest.fixture()
+def demo_fastq(tmp_path, gold_dir):
+    d = tmp_path / "in"
+    d.mkdir()
+    dst = d / "Col-0-6909_GWHBDNP00000001.1_nano_right.fastq.gz"
+    shutil.copyfile(os.path.join(gold_dir, "demo_col0.fastq.gz"), dst)
+    return str(dst)
+
+
+def run_cli(engine, argv):
+    args = cli.build_parser().parse_args(argv)
+    cli.tprint.logfile = cli.get_log_path(args)
+    cli.analysis_run(args, engines=[engine])
+    return args
+
+
+def test_pattern_functions(gold_dir):
+    for c in json.load(open(os.path.join(gold_dir, "patterns.json"))):
+        if c["scramble"] is not None:
+            assert allsteps.pattern_scramble_telo(c["motif"], c["k"]) == c["scramble"]
+        assert allsteps.patterns_to_search(c["motif"], c["k"]) == c["search"]
+
+
+def test_seq_cut_windows():
+    w = allsteps.seq_cut_windows("ACGTACGTACGT", 5, 3)
+    assert w == [(0, "ACGT"), (3, "TACG"), (6, "GTAC")]
+
+
+def test_min_count_for_cutoff_matches_float_test():
+    for motif_len in (5, 6, 7, 12):
+        ratio = 1000 / motif_len
+        for cutoff in (-1.0, 0.0, 0.3, 0.5, 0.7, 0.7000000001, 0.8, 1.0, 5.0):
+            mc = allsteps.min_count_for_cutoff(cutoff, ratio, 1000)
+            for c in range(0, 1002):
+                assert (c > mc) == (c / ratio > cutoff), (motif_len, cutoff, c)
+
+
+def test_patternTRC_count_demo(engine, demo_fastq, gold_dir):
+    for case in json.load(open(os.path.join(gold_dir, "demo_step1.json"))):
+        rows = allsteps.patternTRC_count(demo_fastq, case["motif"], read_length=case["min_len"], kmer=case["k"],
+                                         no_bp=1000, cutoff=case["cutoff"])
+        assert rows == case["rows"], (case["motif"], case["k"], case["cutoff"])
+
+
+def test_bound_detect_and_rawcount_demo(engine, demo_fastq, demo_windows):
+    meta, arrs = demo_windows
+    pats = meta["patterns"]
+    for i, r in enumerate(meta["reads"][:17:4]):
+        i = i * 4
+        b = allsteps.bound_detect(demo_fastq, r["id"], pats, 100, 6, 100, 20000, 5, tail=r["tail"])
+        assert b == [[r["id"], r["boundary"]]]
+        df = allsteps.rawCountPattern(demo_fastq, r["id"], pats, 100, 6, 100, 5, 9000, 20000, tail=r["tail"])
+        want = arrs[f"counts_{i}"]
+        assert list(df.columns) == ["tail", "position", "pattern", "count"]
+        assert np.array_equal(df["count"].to_numpy().reshape(-1, len(pats)), want)
+        assert df["pattern"].tolist()[: len(pats)] == pats and set(df["tail"]) == {r["tail"]}
+        assert df["position"].tolist()[len(pats)] == 6
+    # tail=None: reverse boundary first, then forward (allsteps.py:335-336)
+    rid = meta["reads"][0]["id"]
+    both = allsteps.bound_detect(demo_fastq, rid, pats, 100, 7, 100, 20000, 5)
+    s7 = {m["tail"]: m["boundary"] for m in meta["reads"] if m.get("key", "").startswith("s7_0")}
+    assert both == [[rid, s7["reverse"]], [rid, s7["forward"]]]
+
+
+def test_cli_demo_reproduces_reference_outputs(engine, demo_fastq, tmp_path, gold_dir, capsys):
+    out = tmp_path / "out"
+    run_cli(engine, ["--inputDir", os.path.dirname(demo_fastq), "--outputDir", str(out), "--pattern", "CCCTAAA", "--slide", "6"])
+    got = open(out / "telolengths_all.csv").read().splitlines()
+    want = open(os.path.join(gold_dir, "demo_telolengths_all.csv")).read().splitlines()
+    assert got == want
+    log = open(out / "topsicle_run.log").read()
+    g = json.load(open(os.path.join(gold_dir, "demo_run_log.json")))
+    for key in ("patterns_line", "median_line", "asymptotic_line", "filtered_line"):
+        assert g[key] in log, key
+    assert "All telomere found, have a nice day." in log
+    # filtered fastq: the 17 passing records, byte-identical to the input records
+    filt = out / "Col-0-6909_GWHBDNP00000001.1_nano_right.fastq_trc_over_0.7.fastq"
+    recs = list(seqio.read_records(str(filt)))
+    src = {r.id: r for r in seqio.read_records(demo_fastq)}
+    assert [r.id for r in recs] == [w.split(",")[3] for w in want[1:]]
+    assert all(r.seq == src[r.id].seq and r.qual == src[r.id].qual and r.description == src[r.id].description for r in recs)
+    assert os.path.exists(out / "quadfit_5mer_CCCTAAA.png")
+    # second run without --override refuses (main.py:181-187)
+    with pytest.raises(SystemExit):
+        run_cli(engine, ["--inputDir", os.path.dirname(demo_fastq), "--outputDir", str(out), "--pattern", "CCCTAAA", "--slide", "6"])
+    run_cli(engine, ["-i", os.path.dirname(demo_fastq), "-o", str(out), "--pattern", "CCCTAAA", "--slide", "6", "--override"])
+    assert open(out / "telolengths_all.csv").read().splitlines() == want
+
+
+def test_cli_rawcount_plot_readcheck_and_multik(engine, demo_fastq, tmp_path, demo_windows):
+    meta, arrs = demo_windows
+    out = tmp_path / "out2"
+    rid = meta["reads"][2]["id"]
+    run_cli(engine, ["-i", demo_fastq, "-o", str(out), "--pattern", "CCCTAAA", "--slide", "6", "--rawcountpattern",
+                     "--plot", "--read_check", rid, "--telophrase", "5", "4"])
+    rows = list(csv.reader(open(out / "telolengths_all.csv")))
+    assert rows[0] == ["file_number", "phrase", "trc", "readID", "telo_length"]
+    assert [r[1] for r in rows[1:]] == ["5", "4"] and all(r[3] == rid for r in rows[1:])
+    assert rows[1][4] == str(meta["reads"][2]["boundary"])
+    raw = list(csv.reader(open(out / "rawcount_5_1.csv")))
+    assert raw[0] == ["", "tail", "position", "pattern", "count"]
+    counts = np.array([int(r[4]) for r in raw[1:]]).reshape(-1, 14)
+    assert np.array_equal(counts, arrs["counts_2"])
+    assert os.path.exists(out / "plot_5_1.png") and os.path.exists(out / "plot_4_1.png")
+
+
+def test_cli_fasta_gz_input_and_default_slide(engine, tmp_path, demo_records):
+    """FASTA input (wrapped lines, gz), default slide = len(pattern) (main.py:212-215)."""
+    fa = tmp_path / "reads.fa.gz"
+    with gzip.open(fa, "wt") as h:
+        for rid, seq in demo_records[:12]:
+            h.write(f">{rid} some description\n")
+            for i in range(0, len(seq), 80):
+                h.write(seq[i:i + 80] + "\n")
+    out = tmp_path / "o"
+    run_cli(engine, ["-i", str(fa), "-o", str(out), "--pattern", "AAACCCT", "--cutoff", "0.7", "0.5"])
+    rows = list(csv.reader(open(out / "telolengths_all.csv")))[1:]
+    assert rows and all(r[0] == "reads.fa" for r in rows)
+    # filtered at min(cutoff)=0.5, reported with cutoff[0]=0.7 (main.py:56, 254-257)
+    assert os.path.exists(out / "reads.fa_trc_over_0.5.fasta")
+    assert "with TRC >= 0.7" in open(out / "topsicle_run.log").read()
+    import topsicle_oracle as orc
+    pats = orc.kmer_table("AAACCCT", 5)
+    seqs = dict(demo_records)
+    for r in rows:
+        cs, ce = orc.trc_counts(seqs[r[3]], pats)
+        call = orc.trc_call(cs, ce, pats, 7, 0.5)
+        assert f"{call[2]:.3f}" == r[2]
+        assert orc.step2(seqs[r[3]], call[1], pats, 100, 7, 100, 20000) == int(r[4])

@@ -43,3 +43,45 @@ def scan_records(engine, recs, prm: hiplib.Params, slot: int = 0, want_sums=Fals
     if want_raw:
         raw, win_off = engine.window_raw(slot)
     return res, sums, raw, win_off
+
+
+class EnginePool:
+    """Read-sharding over the GPUs of one node: one engine (context) per
+    GPU, each driven by its own host thread; batches of ~equal bases are dealt round-robin and
+    results are handed back in input order.  No collective, no device-to-device traffic."""
+
+    def __init__(self, engines, patterns):
+        self.engines = list(engines)
+        if not self.engines:
+            raise ValueError("no engines")
+        for e in self.engines:
+            e.set_patterns(patterns)
+
+    def scan_stream(self, records, prm, want_sums=False, want_raw=False, max_bases=None):
+        n = len(self.engines)
+        if max_bases is None:
+            max_bases = BATCH_BASES if n == 1 else BATCH_BASES // 4
+        batches = record_batches(records, max_bases=max_bases)
+        if n == 1:
+            for recs in batches:
+                res, sums, raw, win_off = scan_records(self.engines[0], recs, prm, 0, want_sums, want_raw)
+                yield recs, res, sums, raw, win_off
+            return
+        from collections import deque
+        from concurrent.futures import ThreadPoolExecutor
+        workers = [ThreadPoolExecutor(max_workers=1) for _ in range(n)]
+        pending = deque()
+        try:
+            for i, recs in enumerate(batches):
+                eng = self.engines[i % n]
+                fut = workers[i % n].submit(scan_records, eng, recs, prm, 0, want_sums, want_raw)
+                pending.append((recs, fut))
+                while len(pending) >= 2 * n:
+                    r, f = pending.popleft()
+                    yield (r,) + f.result()
+            while pending:
+                r, f = pending.popleft()
+                yield (r,) + f.result()
+        finally:
+            for w in workers:
+                w.shutdown(wait=True)

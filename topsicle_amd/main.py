@@ -1,0 +1,279 @@
+"""`topsicle` command line on MI355X: same flags, output files and log lines as the reference's
+Topsicle/main.py (flags main.py:319-334; CSV header :200, rows :138; log lines :266, 293, 302,
+309), with the per-read work done in batched HIP launches instead of the reference's
+one-process-per-file pool and per-read file re-parsing (main.py:125-152, 232-235).
+
+Extra flags (not in the reference): --gpus N shards batches of reads over N GPUs of the node
+(one host thread + one context per GPU, no collective); --device picks the first GPU.
+"""
+from __future__ import annotations
+
+import argparse
+import csv
+import datetime
+import os
+import sys
+import time
+from collections import defaultdict
+
+import numpy as np
+
+from . import allsteps, batch, hiplib, seqio
+
+version_number = "1.0.0"
+Topsicle_output_prefix = "Topsicle"
+
+
+def get_log_path(args):
+    log_dir = getattr(args, "outputDir", ".")
+    os.makedirs(log_dir, exist_ok=True)
+    return os.path.join(log_dir, "topsicle_run.log")
+
+
+def tprint(*args, **kwargs):
+    """Timestamped print, mirrored into <outputDir>/topsicle_run.log (main.py:37-45)."""
+    msg = " ".join(str(a) for a in args)
+    now = datetime.datetime.now().strftime("%Y-%m-%d %H:%M:%S")
+    line = f"[{now}] {msg}"
+    print(line)
+    if hasattr(tprint, "logfile"):
+        with open(tprint.logfile, "a") as f:
+            f.write(line + "\n")
+
+
+def _formats(seq_loc: str):
+    """(input format, filtered-file extension) by file name, as main.py:68-81 decides it."""
+    if seq_loc.endswith(".gz"):
+        fq = seq_loc.endswith(".fastq.gz") or seq_loc.endswith(".fq.gz")
+    else:
+        fq = seq_loc.endswith(".fastq") or seq_loc.endswith(".fq")
+    return "fastq" if fq else "fasta"
+
+
+def process_file(args, seq_loc, telo_phrase, pattern, sliding_val, engines):
+    """One input file: step 1 + filtered file + step 2 rows (main.py:52-154), batched.
+    Returns [(file_name, telo_phrase, [[readID, telolen]], trc), ...] in read order."""
+    tprint("subsetting raw dataset based on TRC cutoff")
+    base_name = os.path.basename(seq_loc)
+    file_name = os.path.splitext(base_name)[0]
+    min_cutoff = min(args.cutoff) if isinstance(args.cutoff, (list, tuple)) else args.cutoff
+    no_bp = 1000
+    ratio = no_bp / len(args.pattern)
+    prm = hiplib.make_params(
+        no_bp=no_bp, min_len=args.minSeqLength, min_count=allsteps.min_count_for_cutoff(min_cutoff, ratio, no_bp),
+        window=args.windowSize, slide=sliding_val, trimfirst=args.trimfirst, maxlen=args.maxlengthtelo,
+        flags=hiplib.F_STEP1 | hiplib.F_WINDOWS | hiplib.F_BINSEG)
+    want_sums = bool(args.plot)
+    want_raw = bool(args.rawcountpattern)
+
+    fmt = _formats(seq_loc)
+    fasta_temp = os.path.join(args.outputDir, f"{file_name}_trc_over_{min_cutoff}.fasta")
+    out_handle = None
+    if os.path.exists(fasta_temp):
+        tprint(f"Temporary fasta file already exists: {fasta_temp}. Using existing file.")
+    else:
+        fasta_temp = os.path.join(args.outputDir, f"{file_name}_trc_over_{min_cutoff}.{fmt}")
+        out_handle = open(fasta_temp, "w")
+
+    rows = []
+    image_num = 1
+    csv_path = f"{args.outputDir}/telolengths_all.csv"
+    pool = batch.EnginePool(engines, pattern)
+    try:
+        for recs, res, sums, raw, win_off in pool.scan_stream(seqio.read_records(seq_loc), prm, want_sums, want_raw):
+            with open(csv_path, mode="a", newline="") as fh:
+                writer = csv.writer(fh)
+                for i, rec in enumerate(recs):
+                    r = res[i]
+                    if not r["pass"]:
+                        continue
+                    if out_handle is not None:
+                        seqio.write_record(out_handle, rec, fmt)
+                    if args.read_check and rec.id != args.read_check:
+                        continue
+                    fwd = r["tail"] == 0
+                    trc_val = int(r["best_start"] if fwd else r["best_end"]) / ratio
+                    m = min(args.maxlengthtelo, len(rec.seq))
+                    point = int(r["bkp"]) * sliding_val + args.trimfirst if r["bkp"] >= 0 else 0
+                    telolen = point if (point <= m and point != 0) else 0
+                    if r["bkp"] < 0:
+                        tprint(f"read {rec.id}: {int(r['n_win'])} windows, no admissible change point; reporting 0")
+                    writer.writerow([file_name, telo_phrase, f"{trc_val:.3f}", rec.id, telolen])
+                    rows.append((file_name, telo_phrase, [[rec.id, telolen]], trc_val))
+                    if args.plot and r["n_win"] > 0:
+                        import matplotlib.pyplot as plt
+                        y = sums[win_off[i]:win_off[i + 1]] / len(pattern)
+                        allsteps._plot_changepoint(rec.id, y, sliding_val, args.trimfirst, point, args.rangecp or m)
+                        plt.savefig(f"{args.outputDir}/plot_{telo_phrase}_{image_num}.png", format="png", dpi=300)
+                        plt.close()
+                    if args.rawcountpattern:
+                        _write_rawcount(args, telo_phrase, image_num, pattern, sliding_val,
+                                        raw[win_off[i]:win_off[i + 1]], "forward" if fwd else "reverse")
+                    image_num += 1
+    finally:
+        if out_handle is not None:
+            out_handle.close()
+    if out_handle is not None:
+        tprint(f"Temporary fasta file with TRC more than {min_cutoff}:", fasta_temp)
+    return rows
+
+
+def _write_rawcount(args, telo_phrase, image_num, pattern, slide, block, tail):
+    """rawcount_{k}_{i}.csv in the layout DataFrame.to_csv gives upstream (main.py:146-150)."""
+    import pandas as pd
+    n_win = block.shape[0]
+    df = pd.DataFrame({
+        "tail": tail,
+        "position": np.repeat(np.arange(n_win, dtype=np.int64) * slide, len(pattern)),
+        "pattern": np.tile(np.array(pattern, dtype=object), n_win),
+        "count": block.reshape(-1).astype(np.int64),
+    })
+    df.to_csv(f"{args.outputDir}/rawcount_{telo_phrase}_{image_num}.csv")
+
+
+def analysis_run(args, engines=None):
+    print("---- Topsicle run parameters ---")
+    for k, v in vars(args).items():
+        tprint(f"{k}: {v}")
+    print("---------------------")
+    tprint("Starting Topsicle analysis")
+    os.makedirs(args.outputDir, exist_ok=True)
+
+    if args.threads is not None:
+        num_cores = args.threads
+        tprint(f"Specified number of cores are/is: {num_cores}")
+    else:
+        num_cores = len(os.sched_getaffinity(0))
+        tprint(f"By default, Topsicle allocates nmber of cores: {num_cores}")
+
+    output_csv = f"{args.outputDir}/telolengths_all.csv"
+    tprint(f"Output will be here: {output_csv}")
+    if os.path.exists(output_csv) and os.path.getsize(output_csv) > 0:
+        if args.override:
+            tprint(f"Output file {output_csv} already exists and will be overridden becuz having --override flag.")
+            os.remove(output_csv)
+        else:
+            tprint(f"Output file {output_csv} already exists and is not empty. Exiting to avoid overwrite. Use --override to force overwrite.")
+            sys.exit(1)
+
+    if args.telophrase is None:
+        telo_phrases = [len(args.pattern) - 2]
+        tprint(f"No telophrase provided, use kmer: {telo_phrases}")
+    else:
+        telo_phrases = args.telophrase if isinstance(args.telophrase, list) else [args.telophrase]
+    print("---------------------")
+
+    with open(output_csv, mode="w", newline="") as fh:
+        csv.writer(fh).writerow(["file_number", "phrase", "trc", "readID", "telo_length"])
+
+    if engines is None:
+        n_gpus = max(1, getattr(args, "gpus", 1) or 1)
+        first = getattr(args, "device", 0) or 0
+        engines = [hiplib.HipScanner(first + i) for i in range(n_gpus)]
+        tprint(f"GPU engines: {[e.device_info() for e in engines]}")
+
+    phrase_to_telo = defaultdict(list)
+    phrase_to_trc = defaultdict(list)
+    for telo_phrase in telo_phrases:
+        if telo_phrase > len(args.pattern):
+            tprint("Cannot have length of subset larger than length of pattern")
+            tprint(f"Cannot get {telo_phrase}-bp cut from {len(args.pattern)}-bp pattern")
+            sys.exit()
+        sliding_val = args.slide if args.slide else len(args.pattern)
+        pattern = allsteps.patterns_to_search(telopattern=args.pattern, cut_length=telo_phrase)
+        tprint("patterns to search:", pattern)
+
+        filenames = []
+        if os.path.isdir(args.inputDir):
+            for root, _dirs, files in os.walk(args.inputDir):
+                for filename in files:
+                    filenames.append(os.path.join(root, filename))
+        else:
+            filenames.append(args.inputDir)
+
+        tprint("begin processing reads")
+        results = [process_file(args, seq_loc, telo_phrase, pattern, sliding_val, engines) for seq_loc in filenames]
+        tprint("finished processing all reads")
+        print("---------------------")
+        for file_result in results:
+            for entry in file_result:
+                phrase_to_telo[entry[1]].append(float(entry[2][0][1]))
+                phrase_to_trc[entry[1]].append(float(entry[3]))
+
+    summarize(args, phrase_to_telo, phrase_to_trc)
+    return tprint("All telomere found, have a nice day.")
+
+
+def summarize(args, phrase_to_telo, phrase_to_trc):
+    """Per-k medians and the quadratic-fit cutoff advice (main.py:248-306)."""
+    inputtrc = args.cutoff[0] if isinstance(args.cutoff, (list, tuple)) else args.cutoff
+    for phrase in sorted(phrase_to_telo):
+        median_telo = np.median(phrase_to_telo[phrase])
+        median_trc = np.median(phrase_to_trc[phrase])
+        tprint(f"k-mer: {phrase}, with TRC >= {inputtrc}, median telomere length is {median_telo:.2f} bp")
+        if len(phrase_to_telo[phrase]) >= 3:
+            max_trc = max(phrase_to_trc[phrase])
+            plot_path = os.path.join(args.outputDir, f"quadfit_{phrase}mer_{args.pattern}.png")
+            vertex_x, _vertex_y, _coeffs = allsteps.fit_quadratic_and_find_vertex(
+                phrase_to_trc[phrase], phrase_to_telo[phrase], inputtrc=inputtrc, median_trc=median_trc,
+                save_path=plot_path)
+            if vertex_x > max_trc:
+                tprint(f"Asymptotic TRC {vertex_x:.3f} is greater than max TRC, which is not expected. See plot.")
+                if median_trc < 1.0:
+                    tprint(f"Using median TRC value ({median_trc:.3f}) as asymptotic TRC instead.")
+                    vertex_x = median_trc
+                else:
+                    tprint("Using 0.9 as asymptotic TRC instead, since asymptotic is greater than 1.0.")
+                    vertex_x = 0.9
+            if vertex_x < 0.4:
+                tprint("Quadratic fit suggests asymptotic TRC less than 0.4. See plot with fit line")
+                if max_trc < 0.4:
+                    tprint(f"Maximum TRC value in data is {max_trc:.3f}, which is less than 0.4, indicating low confidence in telomere detection.")
+                if vertex_x < inputtrc:
+                    tprint(f"Asymptotic TRC {vertex_x:.3f} is less than input cutoff {inputtrc:.3f}. Topsicle declares input TRC (={inputtrc}) as asymptotic TRC.")
+                    vertex_x = inputtrc
+            tprint(f"asymptotic TRC, or recommended cutoff: {vertex_x:.3f}")
+            kept = [t for c, t in zip(phrase_to_trc[phrase], phrase_to_telo[phrase]) if c >= vertex_x]
+            if kept:
+                tprint(f"Median telomere length for reads with TRC cutoff >= {vertex_x:.3f}: {np.median(kept):.2f} bp")
+            else:
+                tprint(f"No read has TRC >= {vertex_x:.3f}, please double check the data or submit log to GitHub.")
+        else:
+            tprint("Not enough data points to recommend TRC cutoff.")
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(description="Topsicle - Telomere length estimation from long reads (MI355X build)",
+                                     formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    parser.add_argument("--inputDir", "-i", type=str, metavar="FILE/FOLDER", help="Required, Path to the input file or directory", required=True)
+    parser.add_argument("--outputDir", "-o", type=str, metavar="FOLDER", help="Required, Path to the output directory", required=True)
+    parser.add_argument("--pattern", metavar="CHAR", type=str, help="Required, Telomere repeat sequence (in 5' to 3' orientation). For e.g., in human use CCCTAA", required=True)
+    parser.add_argument("--minSeqLength", metavar="INT", type=int, help="Minimum length of a long read sequence that will be analyzed", default=9000)
+    parser.add_argument("--rawcountpattern", action="store_true", help="Output raw count of the k-mer for each window")
+    parser.add_argument("--telophrase", nargs="+", metavar="INT", type=int, help="Length of telomere k-mer to search. By default will use telomere k-mer length minus 2")
+    parser.add_argument("--cutoff", nargs="+", metavar="FLOAT", type=float, help="TRC statistics threshold", default=0.7)
+    parser.add_argument("--windowSize", metavar="INT", type=int, help="Sliding window size", default=100)
+    parser.add_argument("--slide", metavar="INT", type=int, help="Window sliding step. Default is telomere k-mer length")
+    parser.add_argument("--trimfirst", metavar="INT", type=int, help="Length of intial number of base pairs to trim", default=100)
+    parser.add_argument("--maxlengthtelo", metavar="INT", type=int, help="Longest possible length of telomere for any given read", default=20000)
+    parser.add_argument("--plot", action="store_true", help="Optional, generate plot showing for each telomere read the abundance across the sequencing reead and the changepoint")
+    parser.add_argument("--rangecp", metavar="INT", type=int, help="Optional, set range of changepoint plot for visualization, default is maxlengthtelo")
+    parser.add_argument("--read_check", metavar="STR", type=str, help="Optional, get telomere of a specific read")
+    parser.add_argument("--override", "-ov", action="store_true", help="Override telolengths_all.csv file but keep subset fastq")
+    parser.add_argument("--threads", "-t", metavar="INT", type=int, help="Number of CPU cores to use (by default, all available cores)", default=None)
+    # MI355X build only
+    parser.add_argument("--gpus", metavar="INT", type=int, default=1, help="GPUs of this node to shard reads over")
+    parser.add_argument("--device", metavar="INT", type=int, default=0, help="index of the first GPU to use")
+    return parser
+
+
+def main(argv=None):
+    start_time = time.time()
+    args = build_parser().parse_args(argv)
+    tprint.logfile = get_log_path(args)
+    analysis_run(args)
+    print(f"Elapsed time(s): {time.time() - start_time:.2f} seconds")
+
+
+if __name__ == "__main__":
+    main()
