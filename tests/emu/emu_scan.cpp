@@ -15,6 +15,8 @@
 #include "../../topsicle_amd/csrc/tps_plan.h"
 
 static std::string g_err;
+static int g_variant_calls[9] = {0};
+extern "C" int emu_variant_calls(int v) { return (v >= 0 && v < 9) ? g_variant_calls[v] : -1; }
 
 extern "C" const char* emu_last_error() { return g_err.c_str(); }
 
@@ -25,7 +27,7 @@ extern "C" int64_t emu_window_count(int64_t L, int W, int s, int t, int M) { ret
 // concatenated bases relative to the 16-byte load grid.
 extern "C" int emu_scan(const char* pats, int P, int k, const uint8_t* bases, const int64_t* offsets, int64_t n,
                         const uint8_t* tails, const tps_params* prm, int spans_pref, int lds_budget_bytes,
-                        int base_shift, tps_read_result* results, int32_t* c_start, int32_t* c_end,
+                        int base_shift, int force_generic, tps_read_result* results, int32_t* c_start, int32_t* c_end,
                         int64_t* win_off_out, int32_t* sums, uint8_t* raw) {
     std::vector<uint32_t> lut;
     tps::ScanArgs a{};
@@ -41,7 +43,7 @@ extern "C" int emu_scan(const char* pats, int P, int k, const uint8_t* bases, co
     }
     win_off[(size_t)n] = acc;
     if (win_off_out) memcpy(win_off_out, win_off.data(), (size_t)(n + 1) * 8);
-    err = tps::plan_geometry(a, *prm, k, mx, lds_budget_bytes / 4, spans_pref);
+    err = tps::plan_geometry(a, *prm, k, P, mx, lds_budget_bytes / 4, spans_pref, force_generic);
     if (!err.empty()) { g_err = err; return TPS_E_CAPACITY; }
 
     const int64_t total = offsets[n];
@@ -66,10 +68,20 @@ extern "C" int emu_scan(const char* pats, int P, int k, const uint8_t* bases, co
     a.raw = (prm->flags & TPS_F_STORE_RAW) ? raw : nullptr;
     a.n_reads = n;
     a.prm = *prm;
-    std::vector<uint32_t> lds((size_t)tps::lds_dwords(a) + 8);
+    std::vector<uint32_t> ldsbuf((size_t)tps::lds_dwords(a) + 16);
+    uint32_t* lds_al = (uint32_t*)(((uintptr_t)ldsbuf.data() + 15) & ~(uintptr_t)15);
+    struct { uint32_t* p; size_t n; uint32_t* data() { return p; } uint32_t* begin() { return p; } uint32_t* end() { return p + n; } } lds{lds_al, (size_t)tps::lds_dwords(a)};
+    g_variant_calls[a.variant] += (int)n;
     for (int64_t r = 0; r < n; ++r) {
         for (auto& w : lds) w = 0xDEADBEEFu;          // LDS content is undefined at workgroup start
-        tps::scan_read(a, r, lds.data());
+        const bool so = a.pat.so_mask != 0;
+        switch (a.variant) {
+            case 5: so ? tps::scan_read<5, true>(a, r, lds.data()) : tps::scan_read<5, false>(a, r, lds.data()); break;
+            case 6: so ? tps::scan_read<6, true>(a, r, lds.data()) : tps::scan_read<6, false>(a, r, lds.data()); break;
+            case 7: so ? tps::scan_read<7, true>(a, r, lds.data()) : tps::scan_read<7, false>(a, r, lds.data()); break;
+            case 8: so ? tps::scan_read<8, true>(a, r, lds.data()) : tps::scan_read<8, false>(a, r, lds.data()); break;
+            default: tps::scan_read<0, false>(a, r, lds.data()); break;
+        }
     }
     return TPS_OK;
 }
@@ -77,7 +89,8 @@ extern "C" int emu_scan(const char* pats, int P, int k, const uint8_t* bases, co
 extern "C" int emu_binseg(const int32_t* sums, const int64_t* win_off, int64_t n, int n_patterns, int jump,
                           int min_size, int32_t* bkp, double* gain) {
     tps::BinsegArgs a{sums, win_off, bkp, gain, n, n_patterns, jump, min_size};
-    std::vector<uint32_t> misc(tps::MISC_DW);
+    std::vector<uint32_t> miscbuf(tps::BINSEG_SMEM_DW + 8);
+    struct { uint32_t* p; size_t n; uint32_t* data() { return p; } uint32_t* begin() { return p; } uint32_t* end() { return p + n; } } misc{(uint32_t*)(((uintptr_t)miscbuf.data() + 15) & ~(uintptr_t)15), (size_t)tps::BINSEG_SMEM_DW};
     for (int64_t r = 0; r < n; ++r) {
         for (auto& w : misc) w = 0xDEADBEEFu;
         tps::binseg_read(a, r, misc.data());
@@ -85,11 +98,11 @@ extern "C" int emu_binseg(const int32_t* sums, const int64_t* win_off, int64_t n
     return TPS_OK;
 }
 
-extern "C" int emu_plan(int k, const tps_params* prm, int64_t max_nwin, int spans_pref, int lds_budget_bytes, int32_t* out8) {
+extern "C" int emu_plan(int k, int P, const tps_params* prm, int64_t max_nwin, int spans_pref, int lds_budget_bytes, int force_generic, int32_t* out10) {
     tps::ScanArgs a{};
-    std::string err = tps::plan_geometry(a, *prm, k, max_nwin, lds_budget_bytes / 4, spans_pref);
+    std::string err = tps::plan_geometry(a, *prm, k, P, max_nwin, lds_budget_bytes / 4, spans_pref, force_generic);
     if (!err.empty()) { g_err = err; return TPS_E_CAPACITY; }
-    out8[0] = a.spans_per_tile; out8[1] = a.span_dw; out8[2] = a.blk_log2; out8[3] = a.q; out8[4] = a.r;
-    out8[5] = a.lw; out8[6] = a.seq_dw; out8[7] = (int32_t)(tps::lds_dwords(a) * 4);
+    out10[0] = a.spans_per_tile; out10[1] = a.span_dw; out10[2] = a.blk_log2; out10[3] = a.q; out10[4] = a.r;
+    out10[5] = a.lw; out10[6] = a.seq_dw; out10[7] = (int32_t)(tps::lds_dwords(a) * 4); out10[8] = a.variant; out10[9] = a.rec_rs;
     return TPS_OK;
 }

@@ -42,7 +42,7 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
-def scan(patterns, seqs, prm, tails=None, spans_pref=0, lds_budget=160 * 1024, base_shift=0):
+def scan(patterns, seqs, prm, tails=None, spans_pref=0, lds_budget=160 * 1024, base_shift=0, force_generic=0):
     """Returns dict(results, c_start, c_end, win_off, sums, raw)."""
     L = lib()
     bases, offsets = hiplib.pack_reads(seqs)
@@ -58,7 +58,7 @@ def scan(patterns, seqs, prm, tails=None, spans_pref=0, lds_budget=160 * 1024, b
     raw = np.zeros(max(tot * P, 1), np.uint8)
     t = None if tails is None else np.ascontiguousarray(tails, dtype=np.uint8)
     rc = L.emu_scan("".join(patterns).encode(), P, k, _p(bases), _p(offsets), C.c_int64(n), _p(t), C.byref(prm),
-                    spans_pref, lds_budget, base_shift, _p(res), _p(cs), _p(ce), _p(win_off), _p(sums), _p(raw))
+                    spans_pref, lds_budget, base_shift, force_generic, _p(res), _p(cs), _p(ce), _p(win_off), _p(sums), _p(raw))
     if rc != 0:
         raise RuntimeError(f"emu_scan rc={rc}: {L.emu_last_error().decode()}")
     return dict(results=res, c_start=cs, c_end=ce, win_off=win_off, sums=sums[:tot], raw=raw[:tot * P].reshape(-1, P))
@@ -73,3 +73,12 @@ def binseg(sums, win_off, n_patterns, jump=5, min_size=2):
     gain = np.zeros(n, np.float64)
     L.emu_binseg(_p(sums), _p(win_off), C.c_int64(n), n_patterns, jump, min_size, _p(bkp), _p(gain))
     return bkp, gain
+
+
+def plan(k, P, prm, max_nwin, spans_pref=0, lds_budget=160 * 1024, force_generic=0):
+    out = (C.c_int32 * 10)()
+    rc = lib().emu_plan(k, P, C.byref(prm), C.c_int64(max_nwin), spans_pref, lds_budget, force_generic, out)
+    if rc != 0:
+        raise RuntimeError(lib().emu_last_error().decode())
+    keys = ["spans_per_tile", "span_dw", "blk_log2", "q", "r", "lw", "seq_dw", "lds_bytes", "variant", "rec_rs"]
+    return dict(zip(keys, list(out)))

@@ -56,10 +56,20 @@ def check_case(c, arrs, ci, **emu_kw):
     return True
 
 
-def test_emulation_synthetic_goldens(synth_cases):
+@pytest.mark.parametrize("force_generic", [0, 1])
+def test_emulation_synthetic_goldens(synth_cases, force_generic):
     meta, arrs = synth_cases
-    done = sum(check_case(c, arrs, ci) for ci, c in enumerate(meta))
+    done = sum(check_case(c, arrs, ci, force_generic=force_generic) for ci, c in enumerate(meta))
     assert done >= 50
+
+
+def test_plan_picks_specialised_kernels_for_the_baseline_configs():
+    for k, P, slide, nwin, variant in [(4, 12, 6, 2467, 6), (5, 14, 7, 2829, 7), (4, 12, 6, 3301, 6), (5, 12, 6, 3301, 6),
+                                       (6, 12, 6, 3301, 6), (3, 10, 5, 3000, 5), (6, 16, 8, 2400, 0), (4, 12, 11, 1000, 0)]:
+        pl = emu.plan(k, P, hiplib.make_params(slide=slide), nwin)
+        assert pl["variant"] == variant, (k, P, slide, pl)
+        assert pl["lds_bytes"] <= 160 * 1024
+    assert emu.plan(4, 12, hiplib.make_params(slide=6), 2467, force_generic=1)["variant"] == 0
 
 
 def test_emulation_small_tiles_and_misalignment(synth_cases):
@@ -102,14 +112,16 @@ def test_emulation_whole_demo_file_filter(demo_records, gold_dir):
     assert got == [(g[3], int(g[4])) for g in gold]
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(18))
 def test_emulation_random_vs_oracle(seed):
-    """Seeded random reads / parameters against the Python oracle (counts bit-exact)."""
+    """Seeded random reads / parameters against the Python oracle (counts bit-exact).  Covers the
+    specialised slides (5..8) with and without self-overlapping k-mers and invalid bases, and
+    the generic path."""
     rng = np.random.default_rng(100 + seed)
-    motif, k = [("CCCTAA", 4), ("CCCTAA", 5), ("AAACCCT", 5), ("CCCTAA", 6), ("TTAGGG", 3), ("AAACCCT", 7)][seed]
+    motif, k = [("CCCTAA", 4), ("CCCTAA", 5), ("AAACCCT", 5), ("CCCTAA", 6), ("TTAGGG", 3), ("AAACCCT", 7)][seed % 6]
     pats = orc.kmer_table(motif, k)
     W = int(rng.choice([100, 64, 23, 100]))
-    s = int(rng.choice([6, 7, 1, 4, 16, 11]))
+    s = [6, 7, 5, 8, 6, 7, 1, 4, 16, 11, 8, 5, 6, 7, 5, 8, 3, 12][seed]
     t = int(rng.choice([100, 0, 17]))
     M = int(rng.choice([20000, 900, 1500]))
     seqs, tails = [], []
@@ -163,3 +175,10 @@ def test_emulation_binseg_standalone():
             bf, _ = orc.binseg_l2_numpy(v / 12)
             if bf == want:
                 assert abs(gain[i] - g) <= 1e-9 * max(1.0, abs(g))
+
+
+def test_zz_specialised_paths_were_exercised():
+    """Bookkeeping: the runs above went through every specialised instantiation and the generic one."""
+    L = emu.lib()
+    calls = {v: L.emu_variant_calls(v) for v in (0, 5, 6, 7, 8)}
+    assert all(c > 0 for c in calls.values()), calls

@@ -15,14 +15,24 @@
 #include "tps_plan.h"
 
 // ======================================================================== kernels
-extern "C" __global__ void __launch_bounds__(tps::NT) tps_scan_kernel(tps::ScanArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    tps::scan_read(a, (int64_t)blockIdx.x, lds);
-}
+#define TPS_SCAN_KERNEL(NAME, SV, SO)                                                      \
+    extern "C" __global__ void __launch_bounds__(tps::NT, (SO) ? 2 : 4) NAME(tps::ScanArgs a) { \
+        extern __shared__ __attribute__((aligned(16))) uint32_t lds[];                     \
+        tps::scan_read<SV, SO>(a, (int64_t)blockIdx.x, lds);                               \
+    }
+TPS_SCAN_KERNEL(tps_scan_kernel, 0, false)          // generic: any slide, up to 31 patterns
+TPS_SCAN_KERNEL(tps_scan_kernel_s5, 5, false)       // specialised: compile-time slide, <= 15 patterns
+TPS_SCAN_KERNEL(tps_scan_kernel_s6, 6, false)
+TPS_SCAN_KERNEL(tps_scan_kernel_s7, 7, false)
+TPS_SCAN_KERNEL(tps_scan_kernel_s8, 8, false)
+TPS_SCAN_KERNEL(tps_scan_kernel_s5so, 5, true)      // ... with self-overlapping k-mers in the table
+TPS_SCAN_KERNEL(tps_scan_kernel_s6so, 6, true)
+TPS_SCAN_KERNEL(tps_scan_kernel_s7so, 7, true)
+TPS_SCAN_KERNEL(tps_scan_kernel_s8so, 8, true)
 
 extern "C" __global__ void __launch_bounds__(tps::NT) tps_binseg_kernel(tps::BinsegArgs a) {
-    __shared__ uint32_t misc[tps::MISC_DW];
-    tps::binseg_read(a, (int64_t)blockIdx.x, misc);
+    __shared__ __attribute__((aligned(16))) uint32_t smem[tps::BINSEG_SMEM_DW];
+    tps::binseg_read(a, (int64_t)blockIdx.x, smem);
 }
 
 // ======================================================================== host side
@@ -95,8 +105,10 @@ struct tps_ctx {
     Slot slots[TPS_MAX_SLOTS + 1];
     std::vector<EventPair> ev_pool;
     size_t ev_used = 0;
-    size_t lds_set = 0;
     int spans_override = 0;
+    int force_generic = 0;
+    int64_t lds_target_dw = 10 * 1024;
+    size_t lds_set_v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 namespace {
@@ -111,7 +123,8 @@ using tps::window_count;
 
 int plan_lds(tps_ctx* c, Slot& sl, const tps_params& prm, int64_t max_nwin) {
     const size_t lds_max = c->prop.sharedMemPerBlock > 0 ? std::min<size_t>(c->prop.sharedMemPerBlock, 160 * 1024) : 64 * 1024;
-    std::string err = tps::plan_geometry(sl.args, prm, c->pat.k, max_nwin, (int64_t)lds_max / 4, c->spans_override);
+    std::string err = tps::plan_geometry(sl.args, prm, c->pat.k, c->pat.P, max_nwin, (int64_t)lds_max / 4, c->spans_override,
+                                         c->force_generic, c->lds_target_dw);
     if (!err.empty()) return fail(TPS_E_CAPACITY, "%s", err.c_str());
     sl.lds_bytes = (size_t)tps::lds_dwords(sl.args) * 4;
     return TPS_OK;
@@ -219,9 +232,19 @@ int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm) {
     sl.last_flags = prm.flags;
     if (n == 0) { sl.scanned = true; return TPS_OK; }
 
-    if (sl.lds_bytes > c->lds_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)tps_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sl.lds_bytes));
-        c->lds_set = sl.lds_bytes;
+    const void* kfn;
+    int kidx;
+    const bool so = a.pat.so_mask != 0;
+    switch (a.variant) {
+        case 5: kfn = so ? (const void*)tps_scan_kernel_s5so : (const void*)tps_scan_kernel_s5; kidx = so ? 5 : 1; break;
+        case 6: kfn = so ? (const void*)tps_scan_kernel_s6so : (const void*)tps_scan_kernel_s6; kidx = so ? 6 : 2; break;
+        case 7: kfn = so ? (const void*)tps_scan_kernel_s7so : (const void*)tps_scan_kernel_s7; kidx = so ? 7 : 3; break;
+        case 8: kfn = so ? (const void*)tps_scan_kernel_s8so : (const void*)tps_scan_kernel_s8; kidx = so ? 8 : 4; break;
+        default: kfn = (const void*)tps_scan_kernel; kidx = 0; break;
+    }
+    if (sl.lds_bytes > c->lds_set_v[kidx]) {
+        HIP_TRY(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sl.lds_bytes));
+        c->lds_set_v[kidx] = sl.lds_bytes;
     }
     if (c->ev_used == c->ev_pool.size()) {
         if (c->ev_pool.size() >= 8192) {
@@ -235,8 +258,10 @@ int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm) {
     }
     EventPair& ep = c->ev_pool[c->ev_used++];
     HIP_TRY(hipEventRecord(ep.a, c->stream));
-    hipLaunchKernelGGL(tps_scan_kernel, dim3((unsigned)n), dim3(tps::NT), sl.lds_bytes, c->stream, a);
-    HIP_TRY(hipGetLastError());
+    {
+        void* kargs[] = {(void*)&a};
+        HIP_TRY(hipLaunchKernel(kfn, dim3((unsigned)n), dim3(tps::NT), kargs, sl.lds_bytes, c->stream));
+    }
     HIP_TRY(hipEventRecord(ep.b, c->stream));
     HIP_TRY(hipMemcpyAsync(sl.h_results, sl.results.p, (size_t)n * sizeof(tps_read_result), hipMemcpyDeviceToHost, c->stream));
     sl.scanned = true;
@@ -283,6 +308,8 @@ int tps_ctx_create(int device, tps_ctx** out) {
         return fail(TPS_E_HIP, "cannot initialise device %d", device);
     }
     if (const char* s = getenv("TPS_SPANS_PER_TILE")) c->spans_override = atoi(s);
+    if (const char* s = getenv("TPS_FORCE_GENERIC")) c->force_generic = atoi(s);
+    if (const char* s = getenv("TPS_LDS_TARGET_KB")) c->lds_target_dw = (int64_t)atoi(s) * 256;
     *out = c;
     return TPS_OK;
 }

@@ -8,9 +8,16 @@
 // Data flow inside the workgroup (everything between HBM and the result lives in LDS):
 //   HBM ASCII bases --16 B/lane coalesced loads--> 2-bit packed tile in LDS (seq2)
 //   seq2 --k-mer code per position--> LDS lookup table (4^k masks over the pattern list)
-//   per block of `slide` positions: OR of masks (G), OR over the first r positions (Gp),
-//   running match counts (C0/C1)  -->  per window: S_w = matches + #patterns absent
-//   S_w (u16, LDS) --prefix sums--> exact integer arg-max of the split gain.
+//   per block of `slide` positions: ORs of masks + running match counts
+//   per window: S_w = matches + #patterns absent  (OR over the window's blocks, count differences)
+//   S_w (u16, LDS) --prefix sums--> arg-max of the split gain (f64 scores, exact-integer tie-break).
+//
+// Two block/window code paths share everything else:
+//   * specialised (template <S>): slide S known at compile time, <= 15 patterns.  A thread keeps
+//     its span of the packed read in registers, every shift is an immediate, block results are
+//     8-byte records {suffix-OR, prefix-OR, count, count} laid out bank-conflict-free, and a
+//     window's OR needs 3-4 LDS reads (chunked prefix/suffix ORs) instead of q+1.
+//   * generic: any slide / up to 31 patterns; simple per-block masks, q+1 reads per window.
 //
 // The file is written against a tiny portability layer so that the SAME source also builds
 // as a sequential host emulation (tests/emu, -DTPS_EMU) for logic tests without a GPU.
@@ -24,17 +31,23 @@
 #define TPS_HD static inline
 #define TPS_PHASE for (int tid = 0; tid < tps::NT; ++tid)
 #define TPS_SYNC() ((void)0)
+#define TPS_UNROLL
+#define TPS_SCHED_BARRIER() ((void)0)
 #else
 #define TPS_DEV __device__ __forceinline__
 #define TPS_HD __host__ __device__ inline
 #define TPS_PHASE for (int tid = (int)threadIdx.x, once_ = 1; once_; once_ = 0)
 #define TPS_SYNC() __syncthreads()
+#define TPS_UNROLL _Pragma("unroll")
+#define TPS_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #endif
 
 namespace tps {
 
-constexpr int NT = 256;                 // threads per workgroup (4 waves of 64)
-constexpr uint32_t FLAG_CONFLICT = 0x80000000u;   // bit 31 of a block mask
+constexpr int NT = 256;                           // threads per workgroup (4 waves of 64)
+constexpr uint32_t FLAG_CONFLICT = 0x80000000u;   // generic path: bit 31 of a block mask
+constexpr uint32_t FLAG16 = 0x8000u;              // specialised path: bit 15 of a 16-bit mask
+constexpr int HIST_COPIES = 16;                   // private step-1 histograms (lane % 16)
 
 typedef unsigned __int128 u128;
 
@@ -63,7 +76,10 @@ TPS_DEV int popc(uint32_t x) { return __builtin_popcount(x); }
 TPS_DEV int ffs0(uint32_t x) { return __builtin_ctz(x); }
 TPS_DEV void lds_add(uint32_t* p, uint32_t v) { *p += v; }
 TPS_DEV void lds_or(uint32_t* p, uint32_t v) { *p |= v; }
+TPS_DEV void lds_max_u64(uint64_t* p, uint64_t v) { if (v > *p) *p = v; }
+TPS_DEV void lds_max_i32(int32_t* p, int32_t v) { if (v > *p) *p = v; }
 struct u32x4 { uint32_t x, y, z, w; };
+struct u32x2 { uint32_t x, y; };
 TPS_DEV u32x4 load16(const uint8_t* p) { return *(const u32x4*)p; }
 #else
 TPS_DEV uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
@@ -73,9 +89,15 @@ TPS_DEV int popc(uint32_t x) { return __builtin_popcount(x); }
 TPS_DEV int ffs0(uint32_t x) { return __builtin_ctz(x); }
 TPS_DEV void lds_add(uint32_t* p, uint32_t v) { atomicAdd(p, v); }
 TPS_DEV void lds_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
+TPS_DEV void lds_max_u64(uint64_t* p, uint64_t v) { atomicMax((unsigned long long*)p, (unsigned long long)v); }
+TPS_DEV void lds_max_i32(int32_t* p, int32_t v) { atomicMax(p, v); }
 typedef uint4 u32x4;
+typedef uint2 u32x2;
 TPS_DEV u32x4 load16(const uint8_t* p) { return *reinterpret_cast<const uint4*>(p); }
 #endif
+
+constexpr int cgcd(int a, int b) { return b == 0 ? a : cgcd(b, a % b); }
+constexpr int clog2(int x) { return x <= 1 ? 0 : 1 + clog2(x / 2); }
 
 // ------------------------------------------------------------------ kernel arguments
 struct PatInfo {
@@ -83,6 +105,7 @@ struct PatInfo {
     uint32_t kmask;          // (1 << 2k) - 1
     uint32_t all_mask;       // (1 << P) - 1
     uint32_t so_mask;        // list patterns that can overlap themselves (have a period < k)
+    uint32_t dup_mask;       // list patterns whose k-mer appears more than once in the list
     int32_t n_periods;
     int32_t period[8];       // union of those periods d (1 <= d < k)
     uint32_t period_pat[8];  // list patterns having period d
@@ -102,13 +125,18 @@ struct ScanArgs {
     int64_t n_reads;
     PatInfo pat;
     tps_params prm;
-    // LDS plan (host-computed, see plan_lds() in topsicle_hip.hip)
+    // LDS plan (host-computed: plan_geometry() in tps_plan.h)
+    int32_t variant;             // 0 = generic path, otherwise the compile-time slide of the kernel
     int32_t lut_n;               // 4^k
     int32_t seq_dw;              // dwords of seq2 (and of val)
+    int32_t head_dw;             // dwords reserved per step-1 head inside seq2
     int32_t nblk_cap;            // blocks per tile = spans_per_tile << blk_log2
     int32_t spans_per_tile;
     int32_t span_dw;             // dwords (16 positions each) one span covers = slide / gcd(slide,16)
     int32_t blk_log2;            // log2(blocks per span), blocks per span = 16 / gcd(slide,16)
+    int32_t rec_rs;              // specialised path: row stride (records) of the block-record table
+    int32_t tot_dw;              // dwords of the Tot array (>= spans_per_tile + 1 and >= NT, even)
+    int32_t blk_dw;              // dwords of the block region (also step-1 histograms, Binseg scratch)
     int32_t s_cap;               // capacity of the S array (u16 entries)
     int32_t q, r, lw;            // window = q full blocks + r positions; lw = W - k start positions
 };
@@ -123,50 +151,113 @@ struct BinsegArgs {
 };
 
 // ------------------------------------------------------------------ LDS carve
-constexpr int MISC_DW = 2560;
+constexpr int MISC_DW = 96;
+constexpr int XS_DW = 1728;             // scratch of the exact Binseg tournament (aliases the block region)
+constexpr int HIST_DW = 2 * HIST_COPIES * 32;   // step-1 private histograms (alias the block region)
 struct Lds {
     uint32_t* lut;
     uint32_t* seq2;    // 2-bit packed bases, 16 per dword
     uint32_t* val;     // bit j of val[c] set = position 16c+j is NOT one of acgtACGT
+    uint32_t* blk;     // block region
+    // generic path views of blk
     uint32_t* G;       // per block: OR of masks over its `slide` positions (+FLAG_CONFLICT)
     uint32_t* Gp;      // per block: OR over its first r positions
     uint16_t* C0;      // per block: matches before the block (span-local running count)
     uint16_t* C1;      // per block: matches before position r of the block
+    // specialised path views of blk
+    u32x2* rec;        // per block {suf | preP << 16, C0 | C1 << 16}, index (blk % B) * rec_rs + blk / B
+    uint16_t* full;    // per chunk of C blocks: OR of all its block masks
     uint32_t* Tot;     // per span: matches in the span, then exclusive prefix over spans
     uint16_t* S;       // window sums of the whole read
-    uint32_t* misc;    // hist[32], cmask, flags, scan/reduction scratch
+    uint32_t* misc;
 };
+TPS_HD int64_t blk_region_dw(const ScanArgs& a) {
+    int64_t need;
+    if (a.variant == 0) {
+        need = 2ll * a.nblk_cap + 2ll * ((a.nblk_cap + 1) / 2);
+    } else {
+        int bps = 1 << a.blk_log2;
+        need = 2ll * bps * a.rec_rs + (a.nblk_cap + 1) / 2 + 2;
+    }
+    if (need < XS_DW) need = XS_DW;
+    if (need < HIST_DW) need = HIST_DW;
+    return (need + 3) & ~3ll;
+}
 TPS_DEV Lds carve(uint32_t* base, const ScanArgs& a) {
     Lds l;
     uint32_t* p = base;
+    l.blk = p;  p += a.blk_dw;                 // first: 16-byte aligned for the 8-byte records
     l.lut = p;  p += a.lut_n;
     l.seq2 = p; p += a.seq_dw;
     l.val = p;  p += a.seq_dw;
-    l.G = p;    p += a.nblk_cap;
-    l.Gp = p;   p += a.nblk_cap;
-    l.C0 = (uint16_t*)p; p += (a.nblk_cap + 1) / 2;
-    l.C1 = (uint16_t*)p; p += (a.nblk_cap + 1) / 2;
-    l.Tot = p;  p += a.spans_per_tile + 1;
-    l.S = (uint16_t*)p;  p += (a.s_cap + 1) / 2;
+    l.Tot = p;  p += a.tot_dw;
+    l.S = (uint16_t*)p;  p += ((a.s_cap + 3) / 4) * 2;   // even dword count keeps misc 8-byte aligned
     l.misc = p;
+    l.G = l.blk;
+    l.Gp = l.G + a.nblk_cap;
+    l.C0 = (uint16_t*)(l.Gp + a.nblk_cap);
+    l.C1 = l.C0 + ((a.nblk_cap + 1) / 2) * 2;
+    l.rec = (u32x2*)l.blk;
+    l.full = (uint16_t*)(l.blk + 2 * (1 << a.blk_log2) * a.rec_rs);
     return l;
 }
 TPS_HD int64_t lds_dwords(const ScanArgs& a) {
-    return (int64_t)a.lut_n + 2ll * a.seq_dw + 2ll * a.nblk_cap + 2ll * ((a.nblk_cap + 1) / 2) +
-           a.spans_per_tile + 1 + (a.s_cap + 1) / 2 + MISC_DW;
+    return (int64_t)a.blk_dw + a.lut_n + 2ll * a.seq_dw + a.tot_dw + ((a.s_cap + 3) / 4) * 2 + MISC_DW;
 }
 // misc layout (dwords)
-constexpr int M_HIST = 0;        // 32
-constexpr int M_CMASK = 32;      // conflict mask of step 1
-constexpr int M_INVALID = 33;    // any non-ACGT base in the staged range
-constexpr int M_BEST = 34;       // best_start, idx, best_end, idx  (4)
-constexpr int M_TAIL = 38;       // tail, pass
-constexpr int M_Q = 64;          // 64 dwords: scan partials
-constexpr int M_BS = 128;        // NT dwords: binseg chunk sums
-constexpr int M_CD = 384;        // NT x u64 : candidate |D|      (512 dwords)
-constexpr int M_CDEN = 896;      // NT x u64 : candidate b(n-b)   (512 dwords)
-constexpr int M_CB = 1408;       // NT x i32 : candidate b
-constexpr int M_R = 1664;        // 16 x (u64,u64,i32) second-level reduction (reserve 128)
+constexpr int M_FIN = 0;         // 2 x 32: final step-1 counts (start side, end side)
+constexpr int M_CMASK = 64;      // 2: conflict masks of step 1 (start, end)
+constexpr int M_INVALID = 66;    // any non-ACGT base in the staged range
+constexpr int M_SCAN = 68;       // 8: workgroup scan scratch (wave totals, grand total)
+constexpr int M_MAXSC = 76;      // u64 (8-byte aligned): best f64 score bits
+constexpr int M_BESTB = 78;      // i32: largest b among the candidates with the best score
+constexpr int M_NTIE = 79;       // candidates within float noise of the best score
+// exact Binseg tournament scratch (dwords, relative to its base)
+constexpr int X_Q = 0;           // 64: scan partials
+constexpr int X_BS = 64;         // NT: chunk sums
+constexpr int X_CD = 320;        // NT x u64: candidate |D|
+constexpr int X_CDEN = 832;      // NT x u64: candidate b(n-b)
+constexpr int X_CB = 1344;       // NT x i32: candidate b
+constexpr int X_R = 1600;        // 16 x (u64, u64, i32)
+
+// ------------------------------------------------------------------ workgroup exclusive scan (in place)
+// arr[0..n) in LDS -> exclusive prefix sums; returns the grand total.  Called by every thread of
+// the workgroup outside TPS_PHASE.  scratch: 8 dwords.
+#ifdef TPS_EMU
+TPS_DEV uint32_t wg_exclusive_scan(uint32_t* arr, int n, uint32_t* scratch) {
+    (void)scratch;
+    uint32_t run = 0;
+    for (int i = 0; i < n; ++i) { uint32_t t = arr[i]; arr[i] = run; run += t; }
+    return run;
+}
+#else
+TPS_DEV uint32_t wg_exclusive_scan(uint32_t* arr, int n, uint32_t* scratch) {
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (n + NT - 1) / NT;
+    const int lo = tid * per, hi = (lo + per < n) ? lo + per : n;
+    uint32_t s = 0;
+    for (int i = lo; i < hi; ++i) s += arr[i];
+    uint32_t inc = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(inc, d);
+        if (lane >= d) inc += t;
+    }
+    if (lane == 63) scratch[wave] = inc;
+    __syncthreads();
+    uint32_t woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) {
+        uint32_t t = scratch[w];
+        if (w < wave) woff += t;
+        total += t;
+    }
+    uint32_t run = woff + inc - s;
+    for (int i = lo; i < hi; ++i) { uint32_t t = arr[i]; arr[i] = run; run += t; }
+    __syncthreads();
+    return total;
+}
+#endif
 
 // ------------------------------------------------------------------ staging: HBM ASCII -> LDS 2-bit
 // Stages s-indices [i0, i0+n) of a tail string into LDS.  Forward tail: s[i] = seq[t + i];
@@ -212,58 +303,64 @@ TPS_DEV uint32_t bad_bits16(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, 
     return m;
 }
 
-// one thread stages chunks tid, tid+NT, ...
-TPS_DEV void stage_thread(const Stage& st, const Lds& l, int seq_dw, int tid) {
-    const uint32_t wfwd = 0x40100401u, wrev = 0x01041040u;
-    const uint32_t w = st.reverse ? wrev : wfwd;
-    for (int c = tid; c < seq_dw; c += NT) {
-        uint32_t packed = 0, bad = 0;
-        if (c < st.nch) {
-            const uint8_t* p = st.reverse ? st.chunk0 - 16 * (intptr_t)c : st.chunk0 + 16 * (intptr_t)c;
-            u32x4 v = load16(p);
-            uint32_t y0 = v.x & 0x06060606u, y1 = v.y & 0x06060606u, y2 = v.z & 0x06060606u, y3 = v.w & 0x06060606u;
-            uint32_t d0 = udot4(y0, w), d1 = udot4(y1, w), d2 = udot4(y2, w), d3 = udot4(y3, w);
-            // d_i = 2 * (8-bit packed codes of 4 bases); halve per 16-bit half so bit 32 is never needed
-            uint32_t lo2 = st.reverse ? (d3 + (d2 << 8)) : (d0 + (d1 << 8));
-            uint32_t hi2 = st.reverse ? (d1 + (d0 << 8)) : (d2 + (d3 << 8));
-            packed = (lo2 >> 1) | ((hi2 >> 1) << 16);
-            // expected lower-case letter for each 2-bit code: selector 0,2,4,6 -> a,c,t,g
-            const uint32_t s1 = 0x00630061u, s0 = 0x00670074u;
-            uint32_t b0 = (v.x | 0x20202020u) ^ perm(s0, s1, y0);
-            uint32_t b1 = (v.y | 0x20202020u) ^ perm(s0, s1, y1);
-            uint32_t b2 = (v.z | 0x20202020u) ^ perm(s0, s1, y2);
-            uint32_t b3 = (v.w | 0x20202020u) ^ perm(s0, s1, y3);
-            if (b0 | b1 | b2 | b3) {
-                bad = bad_bits16(b0, b1, b2, b3, st.reverse);
-                // keep only positions inside the staged range [delta, delta+n)
-                int lo = st.delta - 16 * c, hi = st.delta + st.n - 16 * c;
-                uint32_t keep = 0xFFFFu;
-                if (lo > 0) keep &= (lo >= 16) ? 0u : (0xFFFFu << lo);
-                if (hi < 16) keep &= (hi <= 0) ? 0u : ((1u << hi) - 1u);
-                bad &= keep & 0xFFFFu;
-                if (bad) l.misc[M_INVALID] = 1u;      // benign race: every writer stores 1
-            }
-        }
-        l.seq2[c] = packed;
-        l.val[c] = bad;
+// chunk c of a staged range -> (packed 16 bases, 16 invalid bits); zero beyond the staged chunks
+TPS_DEV void stage_chunk(const Stage& st, int c, uint32_t& packed, uint32_t& bad) {
+    packed = 0;
+    bad = 0;
+    if (c >= st.nch) return;
+    const uint32_t w = st.reverse ? 0x01041040u : 0x40100401u;
+    const uint8_t* p = st.reverse ? st.chunk0 - 16 * (intptr_t)c : st.chunk0 + 16 * (intptr_t)c;
+    u32x4 v = load16(p);
+    // bits 1-2 of an ASCII letter: A,C,T,G (either case) -> 0,1,2,3; one dot product packs 4 bases
+    uint32_t y0 = v.x & 0x06060606u, y1 = v.y & 0x06060606u, y2 = v.z & 0x06060606u, y3 = v.w & 0x06060606u;
+    uint32_t d0 = udot4(y0, w), d1 = udot4(y1, w), d2 = udot4(y2, w), d3 = udot4(y3, w);
+    // d_i = 2 * (8-bit packed codes of 4 bases); halve per 16-bit half so bit 32 is never needed
+    uint32_t lo2 = st.reverse ? (d3 + (d2 << 8)) : (d0 + (d1 << 8));
+    uint32_t hi2 = st.reverse ? (d1 + (d0 << 8)) : (d2 + (d3 << 8));
+    packed = (lo2 >> 1) | ((hi2 >> 1) << 16);
+    // expected lower-case letter for each 2-bit code: selector 0,2,4,6 -> a,c,t,g
+    const uint32_t s1 = 0x00630061u, s0 = 0x00670074u;
+    uint32_t b0 = (v.x | 0x20202020u) ^ perm(s0, s1, y0);
+    uint32_t b1 = (v.y | 0x20202020u) ^ perm(s0, s1, y1);
+    uint32_t b2 = (v.z | 0x20202020u) ^ perm(s0, s1, y2);
+    uint32_t b3 = (v.w | 0x20202020u) ^ perm(s0, s1, y3);
+    if (b0 | b1 | b2 | b3) {
+        bad = bad_bits16(b0, b1, b2, b3, st.reverse);
+        // keep only positions inside the staged range [delta, delta+n)
+        int lo = st.delta - 16 * c, hi = st.delta + st.n - 16 * c;
+        uint32_t keep = 0xFFFFu;
+        if (lo > 0) keep &= (lo >= 16) ? 0u : (0xFFFFu << lo);
+        if (hi < 16) keep &= (hi <= 0) ? 0u : ((1u << hi) - 1u);
+        bad &= keep & 0xFFFFu;
     }
 }
 
-// 32-bit window (16 bases) starting at LDS position q
-TPS_DEV uint32_t v_at(const Lds& l, int q) {
+// one thread stages chunks tid, tid+NT, ... of `ndw` dwords at seq2/val
+TPS_DEV void stage_thread(const Stage& st, uint32_t* seq2, uint32_t* val, int ndw, uint32_t* invalid_flag, int tid) {
+    for (int c = tid; c < ndw; c += NT) {
+        uint32_t packed, bad;
+        stage_chunk(st, c, packed, bad);
+        if (bad) *invalid_flag = 1u;               // benign race: every writer stores 1
+        seq2[c] = packed;
+        val[c] = bad;
+    }
+}
+
+// 32-bit window (16 bases) starting at position q of a packed array
+TPS_DEV uint32_t v_at(const uint32_t* seq2, int q) {
     int idx = q >> 4;
-    return alignbit(l.seq2[idx + 1], l.seq2[idx], (uint32_t)(q & 15) * 2u);
+    return alignbit(seq2[idx + 1], seq2[idx], (uint32_t)(q & 15) * 2u);
 }
 // 1 if any of the k positions q..q+k-1 is not ACGT
-TPS_DEV bool invalid_at(const Lds& l, int q, int k) {
+TPS_DEV bool invalid_at(const uint32_t* val, int q, int k) {
     int idx = q >> 4;
-    uint64_t v = (uint64_t)l.val[idx] | ((uint64_t)l.val[idx + 1] << 16) | ((uint64_t)l.val[idx + 2] << 32);
+    uint64_t v = (uint64_t)val[idx] | ((uint64_t)val[idx + 1] << 16) | ((uint64_t)val[idx + 2] << 32);
     return ((v >> (q & 15)) & ((1ull << k) - 1ull)) != 0;
 }
-// mask of list patterns whose k-mer starts at LDS position q
-TPS_DEV uint32_t h_at(const Lds& l, const PatInfo& pat, int q, bool any_invalid) {
-    uint32_t h = l.lut[v_at(l, q) & pat.kmask];
-    if (any_invalid && h && invalid_at(l, q, pat.k)) h = 0;
+// mask of list patterns whose k-mer starts at position q
+TPS_DEV uint32_t h_at(const uint32_t* lut, const uint32_t* seq2, const uint32_t* val, const PatInfo& pat, int q, bool any_invalid) {
+    uint32_t h = lut[v_at(seq2, q) & pat.kmask];
+    if (any_invalid && h && invalid_at(val, q, pat.k)) h = 0;
     return h;
 }
 // patterns p (subset of `h`) that occur again d < k positions later (d a period of p)
@@ -276,14 +373,14 @@ TPS_DEV uint32_t conflict_bits(const PatInfo& pat, uint32_t v, uint32_t h) {
     return c;
 }
 
-// Leftmost non-overlapping count of list pattern `bit` over `npos` start positions from LDS
+// Leftmost non-overlapping count of list pattern `bit` over `npos` start positions from
 // position q0 -- exactly what len(list(re.finditer(p, text))) gives (allsteps.py:182, 281).
-TPS_DEV void greedy_count(const Lds& l, const PatInfo& pat, int q0, int npos, int bit, bool any_invalid,
-                          int& occ, int& greedy) {
+TPS_DEV void greedy_count(const uint32_t* lut, const uint32_t* seq2, const uint32_t* val, const PatInfo& pat, int q0,
+                          int npos, int bit, bool any_invalid, int& occ, int& greedy) {
     occ = 0; greedy = 0;
     int cursor = 0;
     for (int p = 0; p < npos; ++p) {
-        uint32_t h = h_at(l, pat, q0 + p, any_invalid);
+        uint32_t h = h_at(lut, seq2, val, pat, q0 + p, any_invalid);
         if ((h >> bit) & 1u) {
             ++occ;
             if (p >= cursor) { ++greedy; cursor = p + pat.k; }
@@ -291,39 +388,60 @@ TPS_DEV void greedy_count(const Lds& l, const PatInfo& pat, int q0, int npos, in
     }
 }
 
-// ------------------------------------------------------------------ step 1: TRC counts of one tail
-// Counts every list pattern over the staged string of n1 bases (LDS positions delta..).
-// hist[] must be zeroed; phases are separated by the caller's TPS_SYNC().
-TPS_DEV void trc_count_thread(const Lds& l, const PatInfo& pat, const Stage& st, int tid) {
+// ------------------------------------------------------------------ step 1: TRC counts of both tails
+// Thread `tid`: side = tid / 128, a run of `ppt` consecutive start positions of that side's staged
+// head.  Matches go to one of 16 private histograms (lane % 16) so that LDS atomics rarely collide.
+TPS_DEV void trc_count_thread(const ScanArgs& a, const Lds& l, const Stage& st_s, const Stage& st_e, int tid) {
+    const PatInfo& pat = a.pat;
+    const int side = tid >> 7, t = tid & 127;
+    Stage s;
+    s.delta = side ? st_e.delta : st_s.delta;
+    s.n = st_s.n;
+    const uint32_t* seq2 = l.seq2 + side * a.head_dw;
+    const uint32_t* val = l.val + side * a.head_dw;
     const bool inv = l.misc[M_INVALID] != 0;
-    const int npos = st.n - pat.k + 1;
-    for (int p = tid; p < npos; p += NT) {
-        uint32_t v = v_at(l, st.delta + p);
+    const int npos = s.n - pat.k + 1;
+    const int ppt = (npos + 127) / 128;
+    uint32_t* hist = l.blk + (side * HIST_COPIES + (tid & (HIST_COPIES - 1))) * 32;
+    uint32_t cm = 0;
+    for (int j = 0; j < ppt; ++j) {
+        const int p = t * ppt + j;
+        if (p >= npos) break;
+        uint32_t v = v_at(seq2, s.delta + p);
         uint32_t h = l.lut[v & pat.kmask];
         if (!h) continue;
-        if (inv && invalid_at(l, st.delta + p, pat.k)) continue;
-        if (h & pat.so_mask) {
-            uint32_t c = conflict_bits(pat, v, h);
-            if (c) lds_or(&l.misc[M_CMASK], c);
-        }
-        while (h) {
+        if (inv && invalid_at(val, s.delta + p, pat.k)) continue;
+        if (h & pat.so_mask) cm |= conflict_bits(pat, v, h);
+        do {
             int b = ffs0(h);
             h &= h - 1;
-            lds_add(&l.misc[M_HIST + b], 1u);
-        }
+            lds_add(&hist[b], 1u);
+        } while (h);
+    }
+    if (cm) lds_or(&l.misc[M_CMASK + side], cm);
+}
+// sum the private histograms: thread (side, p) -> misc[M_FIN + 32*side + p]
+TPS_DEV void trc_sum_thread(const ScanArgs& a, const Lds& l, int tid) {
+    const int side = tid >> 7, p = tid & 127;
+    if (p < a.pat.P) {
+        uint32_t s = 0;
+        for (int c = 0; c < HIST_COPIES; ++c) s += l.blk[(side * HIST_COPIES + c) * 32 + p];
+        l.misc[M_FIN + 32 * side + p] = s;
     }
 }
-TPS_DEV void trc_fix_thread(const Lds& l, const PatInfo& pat, const Stage& st, int tid) {
-    // patterns with overlapping occurrences: recount leftmost-non-overlapping, sequentially
-    if (tid < pat.P && ((l.misc[M_CMASK] >> tid) & 1u)) {
+// patterns with overlapping occurrences: recount leftmost-non-overlapping, sequentially
+TPS_DEV void trc_fix_thread(const ScanArgs& a, const Lds& l, const Stage& st_s, const Stage& st_e, int tid) {
+    const int side = tid >> 7, p = tid & 127;
+    if (p < a.pat.P && ((l.misc[M_CMASK + side] >> p) & 1u)) {
         int occ, g;
-        greedy_count(l, pat, st.delta, st.n - pat.k + 1, tid, l.misc[M_INVALID] != 0, occ, g);
-        l.misc[M_HIST + tid] = (uint32_t)g;
+        greedy_count(l.lut, l.seq2 + side * a.head_dw, l.val + side * a.head_dw, a.pat, side ? st_e.delta : st_s.delta,
+                     st_s.n - a.pat.k + 1, p, l.misc[M_INVALID] != 0, occ, g);
+        l.misc[M_FIN + 32 * side + p] = (uint32_t)g;
     }
 }
 
-// ------------------------------------------------------------------ step 2, phase B: blocks
-// Thread `tid` owns span `span` of the tile: span_dw dwords = (1<<blk_log2) blocks of `slide`
+// ------------------------------------------------------------------ step 2 (generic path), phase B: blocks
+// Thread owns span `span` of the tile: span_dw dwords = (1<<blk_log2) blocks of `slide`
 // positions, starting at a dword boundary + (delta & 15).
 TPS_DEV void blocks_span(const ScanArgs& a, const Lds& l, int delta, int span) {
     const PatInfo& pat = a.pat;
@@ -341,24 +459,24 @@ TPS_DEV void blocks_span(const ScanArgs& a, const Lds& l, int delta, int span) {
         uint32_t nx2 = l.seq2[d0 + dw + 2];
         uint32_t nxt = alignbit(nx2, hi, sh2);
         uint32_t v[16], h[16];
-#pragma unroll
+        TPS_UNROLL
         for (int i = 0; i < 16; ++i) {
             v[i] = i ? alignbit(nxt, cur, 2u * i) : cur;
             h[i] = l.lut[v[i] & pat.kmask];
         }
         if (inv) {
             int q = ((d0 + dw) << 4) + (delta & 15);
-#pragma unroll
+            TPS_UNROLL
             for (int i = 0; i < 16; ++i)
-                if (h[i] && invalid_at(l, q + i, k)) h[i] = 0;
+                if (h[i] && invalid_at(l.val, q + i, k)) h[i] = 0;
         }
         uint32_t cf = 0;                          // bit i: position i starts an overlapping pair
         if (so) {
-#pragma unroll
+            TPS_UNROLL
             for (int i = 0; i < 16; ++i)
                 if ((h[i] & pat.so_mask) && conflict_bits(pat, v[i], h[i])) cf |= 1u << i;
         }
-#pragma unroll
+        TPS_UNROLL
         for (int i = 0; i < 16; ++i) {
             if (pib == 0) {
                 g = 0;
@@ -378,11 +496,10 @@ TPS_DEV void blocks_span(const ScanArgs& a, const Lds& l, int delta, int span) {
     l.Tot[span] = cnt;
 }
 
-// ------------------------------------------------------------------ step 2, phase C: windows
+// ------------------------------------------------------------------ step 2, exact window recount
 // Exact count of every pattern in tile-local window wl (slow path: overlapping occurrences of a
 // self-overlapping k-mer inside the window, or raw output requested).
-TPS_DEV uint32_t window_exact(const ScanArgs& a, const Lds& l, int delta, int wl, uint32_t present,
-                              uint8_t* raw_row) {
+TPS_DEV uint32_t window_exact(const ScanArgs& a, const Lds& l, int delta, int wl, uint32_t present, uint8_t* raw_row) {
     const PatInfo& pat = a.pat;
     const bool inv = l.misc[M_INVALID] != 0;
     uint32_t sum = 0;
@@ -390,7 +507,7 @@ TPS_DEV uint32_t window_exact(const ScanArgs& a, const Lds& l, int delta, int wl
         int c = 0;
         if ((present >> b) & 1u) {
             int occ;
-            greedy_count(l, pat, delta + wl * a.prm.slide, a.lw, b, inv, occ, c);
+            greedy_count(l.lut, l.seq2, l.val, pat, delta + wl * a.prm.slide, a.lw, b, inv, occ, c);
         }
         if (c == 0) c = 1;                         // `matches or 1` (allsteps.py:281, 288)
         if (raw_row) raw_row[b] = (uint8_t)c;
@@ -399,8 +516,7 @@ TPS_DEV uint32_t window_exact(const ScanArgs& a, const Lds& l, int delta, int wl
     return sum;
 }
 
-TPS_DEV void windows_thread(const ScanArgs& a, const Lds& l, int delta, int w0, int nw_tile,
-                            int64_t out_base, int tid) {
+TPS_DEV void windows_thread(const ScanArgs& a, const Lds& l, int delta, int w0, int nw_tile, int64_t out_base, int tid) {
     const PatInfo& pat = a.pat;
     const int q = a.q;
     for (int wl = tid; wl < nw_tile; wl += NT) {
@@ -417,11 +533,170 @@ TPS_DEV void windows_thread(const ScanArgs& a, const Lds& l, int delta, int w0, 
     }
 }
 
+// ------------------------------------------------------------------ step 2 (specialised path)
+// Compile-time slide S: a span is SPAN = S/gcd(S,16) dwords = B = 16/gcd(S,16) blocks, kept in
+// registers with immediate shifts.  Blocks are grouped in aligned chunks of C = min(B, 8): per
+// block the record holds the OR over the rest of its chunk (suffix) and the OR over the chunk's
+// earlier blocks plus this block's first r positions (prefix), so a window's presence mask is
+// suffix[first block] | full chunks in between | prefix[partial block].
+template <int S>
+struct Geo {
+    static constexpr int G = cgcd(S, 16);
+    static constexpr int SPAN = S / G;
+    static constexpr int B = 16 / G;
+    static constexpr int LOG2B = clog2(B);
+    static constexpr int C = B < 8 ? B : 8;
+    static constexpr int LOG2C = clog2(C);
+};
+
+template <int S, bool SO>
+TPS_DEV void blocks_span_s(const ScanArgs& a, const Lds& l, int delta, int span) {
+    typedef Geo<S> g_;
+    constexpr int SPAN = g_::SPAN, B = g_::B, C = g_::C;
+    const PatInfo& pat = a.pat;
+    const int r = a.r;
+    const uint32_t kmask = pat.kmask;
+    const uint32_t sh2 = (uint32_t)(delta & 15) * 2u;
+    const int d0 = (delta >> 4) + span * SPAN;
+    uint32_t w[SPAN + 1];
+    {
+        uint32_t prev = l.seq2[d0];
+        TPS_UNROLL
+        for (int i = 0; i <= SPAN; ++i) {
+            uint32_t nx = l.seq2[d0 + i + 1];
+            w[i] = alignbit(nx, prev, sh2);
+            prev = nx;
+        }
+    }
+    uint32_t cnt = 0, run_or = 0;
+    uint32_t pg[C], cc[C];                        // per block of the current chunk: gm | pp << 16, c0 | c1 << 16
+    // table lookups run one block ahead of their use (software pipeline, 2 S values in flight)
+    uint32_t hc[S], vc[S], hn[S], vn[S];
+    auto fetch = [&](int blk, uint32_t* hh, uint32_t* vv) {
+        TPS_UNROLL
+        for (int i = 0; i < S; ++i) {
+            const int p = blk * S + i;            // constant after unrolling
+            const int dw = p >> 4, bit = p & 15;
+            uint32_t v = bit ? alignbit(w[dw + 1], w[dw], 2u * bit) : w[dw];
+            uint32_t h = l.lut[v & kmask];
+            hh[i] = h;
+            vv[i] = v;
+        }
+    };
+    fetch(0, hc, vc);
+    TPS_UNROLL
+    for (int blk = 0; blk < B; ++blk) {
+        const int bc = blk % C;
+        if (blk + 1 < B) fetch(blk + 1, hn, vn);
+        if (bc == 0) run_or = 0;
+        uint32_t g = 0;
+        uint32_t c0 = cnt, c1 = cnt, pp = run_or;
+        TPS_UNROLL
+        for (int i = 0; i < S; ++i) {
+            const uint32_t h = hc[i];
+            if (SO) {
+                if ((h & pat.so_mask) && conflict_bits(pat, vc[i], h)) g |= FLAG16;
+            }
+            g |= h;
+            cnt += (uint32_t)popc(h);
+            if (i + 1 == r) { c1 = cnt; pp = run_or | g; }
+        }
+        pg[bc] = (g & 0xFFFFu) | (pp << 16);
+        cc[bc] = (c0 & 0xFFFFu) | (c1 << 16);
+        run_or |= g;
+        if (bc == C - 1) {                        // chunk complete: suffix ORs, records, chunk total
+            uint32_t sfx = 0;
+            TPS_UNROLL
+            for (int j = C - 1; j >= 0; --j) {
+                const int b = blk - (C - 1) + j;
+                sfx |= pg[j] & 0xFFFFu;
+                u32x2 rec;
+                rec.x = sfx | (pg[j] & 0xFFFF0000u);
+                rec.y = cc[j];
+                l.rec[b * a.rec_rs + span] = rec;
+            }
+            l.full[span * (B / C) + blk / C] = (uint16_t)sfx;
+        }
+        TPS_UNROLL
+        for (int i = 0; i < S; ++i) { hc[i] = hn[i]; vc[i] = vn[i]; }
+        TPS_SCHED_BARRIER();
+    }
+    l.Tot[span] = cnt;
+}
+
+// Same records as blocks_span_s, written by plain loops with per-position validity checks: used
+// for tiles that hold non-ACGT letters (rare), so the fast path carries no validity logic.
+template <int S>
+TPS_DEV void blocks_span_slow(const ScanArgs& a, const Lds& l, int delta, int span) {
+    typedef Geo<S> g_;
+    constexpr int B = g_::B, C = g_::C;
+    const PatInfo& pat = a.pat;
+    const int r = a.r;
+    const int q0 = delta + span * B * S;          // LDS position of the span's first base
+    uint32_t cnt = 0;
+    for (int ch = 0; ch < B / C; ++ch) {
+        uint32_t run_or = 0;
+        for (int bc = 0; bc < C; ++bc) {
+            const int blk = ch * C + bc;
+            uint32_t g = 0, c0 = cnt, c1 = cnt, pp = run_or;
+            for (int i = 0; i < S; ++i) {
+                const int q = q0 + blk * S + i;
+                const uint32_t v = v_at(l.seq2, q);
+                uint32_t h = l.lut[v & pat.kmask];
+                if (h && invalid_at(l.val, q, pat.k)) h = 0;
+                if ((h & pat.so_mask) && conflict_bits(pat, v, h)) g |= FLAG16;
+                g |= h;
+                cnt += (uint32_t)popc(h);
+                if (i + 1 == r) { c1 = cnt; pp = run_or | g; }
+            }
+            u32x2 rec;
+            rec.x = (g & 0xFFFFu) | (pp << 16);
+            rec.y = (c0 & 0xFFFFu) | (c1 << 16);
+            l.rec[blk * a.rec_rs + span] = rec;
+            run_or |= g;
+        }
+        uint32_t sfx = 0;
+        for (int bc = C - 1; bc >= 0; --bc) {     // suffix ORs over the chunk (re-reads this thread's own records)
+            const int blk = ch * C + bc;
+            u32x2 rec = l.rec[blk * a.rec_rs + span];
+            sfx |= rec.x & 0xFFFFu;
+            rec.x = sfx | (rec.x & 0xFFFF0000u);
+            l.rec[blk * a.rec_rs + span] = rec;
+        }
+        l.full[span * (B / C) + ch] = (uint16_t)sfx;
+    }
+    l.Tot[span] = cnt;
+}
+
+template <int S>
+TPS_DEV void windows_thread_s(const ScanArgs& a, const Lds& l, int delta, int w0, int nw_tile, int64_t out_base, int tid) {
+    typedef Geo<S> g_;
+    constexpr int B = g_::B, LOG2B = g_::LOG2B, LOG2C = g_::LOG2C;
+    const PatInfo& pat = a.pat;
+    const int q = a.q;
+    for (int wl = tid; wl < nw_tile; wl += NT) {
+        const int e = wl + q;
+        const u32x2 rw = l.rec[(wl & (B - 1)) * a.rec_rs + (wl >> LOG2B)];
+        const u32x2 re = l.rec[(e & (B - 1)) * a.rec_rs + (e >> LOG2B)];
+        uint32_t m = (rw.x & 0xFFFFu) | (re.x >> 16);
+        for (int c = (wl >> LOG2C) + 1; c < (e >> LOG2C); ++c) m |= l.full[c];
+        uint32_t cnt = ((re.y >> 16) + l.Tot[e >> LOG2B]) - ((rw.y & 0xFFFFu) + l.Tot[wl >> LOG2B]);
+        uint32_t present = m & pat.all_mask;
+        uint32_t sw = cnt + (uint32_t)(pat.P - popc(present));
+        uint8_t* raw_row = a.raw ? a.raw + (out_base + w0 + wl) * (int64_t)pat.P : nullptr;
+        if ((m & FLAG16) || raw_row) sw = window_exact(a, l, delta, wl, present, raw_row);
+        l.S[w0 + wl] = (uint16_t)sw;
+        if (a.sums) a.sums[out_base + w0 + wl] = (int32_t)sw;
+    }
+}
+
 // ------------------------------------------------------------------ step 3: single-split Binseg (l2)
 // gain(b) = cost(0,n) - cost(0,b) - cost(b,n) = (n L_b - T b)^2 / (n b (n-b))   [y = S / P]
-// so the arg-max over b in {0, jump, 2 jump, ...}, b >= min_size, n-b >= min_size is decided in
-// exact integer arithmetic on D_b = n L_b - T b (ties -> larger b, as max() over (gain, bkp)
-// tuples does in ruptures' Binseg._single_bkp).
+// so the arg-max over b in {0, jump, 2 jump, ...}, b >= min_size, n-b >= min_size is that of
+// D_b^2 / (b (n-b)), D_b = n L_b - T b (an exact integer).  Scores are compared in float64; if
+// more than one candidate lies within float noise of the best score, an exact 128-bit integer
+// tournament decides (ties -> larger b, as max() over (gain, bkp) tuples does in ruptures'
+// Binseg._single_bkp).
 struct Cand { uint64_t d; uint64_t den; int32_t b; };
 TPS_DEV bool cand_better(const Cand& x, const Cand& y) {
     if (x.b < 0) return false;
@@ -450,47 +725,50 @@ TPS_DEV Cand binseg_chunk(const ST* S, int n, int jump, int min_size, int lo, in
     }
     return best;
 }
-TPS_DEV double cand_gain(const Cand& c, int n, int n_patterns) {
-    if (c.b < 0) return 0.0;
-    double d = (double)c.d;
-    return d * d / ((double)n * (double)c.den) / ((double)n_patterns * (double)n_patterns);
+TPS_DEV double score_f64(int64_t d, uint64_t den) {
+    double x = (double)d;
+    return x * x / (double)den;
+}
+TPS_DEV double gain_from(int64_t d, uint64_t den, int n, int n_patterns) {
+    double x = (double)d;
+    return x * x / ((double)n * (double)den) / ((double)n_patterns * (double)n_patterns);
 }
 
-// Workgroup-wide Binseg over S[0..n): phases separated by TPS_SYNC(); scratch in misc.
-#define TPS_BINSEG_BODY(S, n, jump, min_size, misc, RESULT)                                        \
+// Exact tournament over all candidates (slow path), scratch xs (XS_DW dwords).
+#define TPS_BINSEG_EXACT(S, n, jump, min_size, xs, RESULT)                                         \
     {                                                                                              \
         const int cl_ = ((n) + tps::NT - 1) / tps::NT;                                             \
         TPS_PHASE {                                                                                \
             int lo_ = tid * cl_, hi_ = lo_ + cl_ < (n) ? lo_ + cl_ : (n);                          \
             uint32_t s_ = 0;                                                                       \
             for (int i_ = lo_; i_ < hi_; ++i_) s_ += (uint32_t)(S)[i_];                            \
-            (misc)[tps::M_BS + tid] = s_;                                                          \
+            (xs)[tps::X_BS + tid] = s_;                                                            \
         }                                                                                          \
         TPS_SYNC();                                                                                \
         TPS_PHASE {                                                                                \
             if (tid < 16) {                                                                        \
                 uint32_t s_ = 0;                                                                   \
-                for (int i_ = 0; i_ < 16; ++i_) s_ += (misc)[tps::M_BS + tid * 16 + i_];           \
-                (misc)[tps::M_Q + tid] = s_;                                                       \
+                for (int i_ = 0; i_ < 16; ++i_) s_ += (xs)[tps::X_BS + tid * 16 + i_];             \
+                (xs)[tps::X_Q + tid] = s_;                                                         \
             }                                                                                      \
         }                                                                                          \
         TPS_SYNC();                                                                                \
         TPS_PHASE {                                                                                \
             if (tid == 0) {                                                                        \
                 uint32_t run_ = 0;                                                                 \
-                for (int i_ = 0; i_ < 16; ++i_) { uint32_t t_ = (misc)[tps::M_Q + i_]; (misc)[tps::M_Q + i_] = run_; run_ += t_; } \
-                (misc)[tps::M_Q + 16] = run_;                                                      \
+                for (int i_ = 0; i_ < 16; ++i_) { uint32_t t_ = (xs)[tps::X_Q + i_]; (xs)[tps::X_Q + i_] = run_; run_ += t_; } \
+                (xs)[tps::X_Q + 16] = run_;                                                        \
             }                                                                                      \
         }                                                                                          \
         TPS_SYNC();                                                                                \
         TPS_PHASE {                                                                                \
-            uint64_t pre_ = (misc)[tps::M_Q + (tid >> 4)];                                         \
-            for (int i_ = (tid & ~15); i_ < tid; ++i_) pre_ += (misc)[tps::M_BS + i_];             \
+            uint64_t pre_ = (xs)[tps::X_Q + (tid >> 4)];                                           \
+            for (int i_ = (tid & ~15); i_ < tid; ++i_) pre_ += (xs)[tps::X_BS + i_];               \
             int lo_ = tid * cl_, hi_ = lo_ + cl_ < (n) ? lo_ + cl_ : (n);                          \
-            tps::Cand c_ = tps::binseg_chunk((S), (n), (jump), (min_size), lo_, hi_, pre_, (uint64_t)(misc)[tps::M_Q + 16]); \
-            ((uint64_t*)&(misc)[tps::M_CD])[tid] = c_.d;                                           \
-            ((uint64_t*)&(misc)[tps::M_CDEN])[tid] = c_.den;                                       \
-            ((int32_t*)&(misc)[tps::M_CB])[tid] = c_.b;                                            \
+            tps::Cand c_ = tps::binseg_chunk((S), (n), (jump), (min_size), lo_, hi_, pre_, (uint64_t)(xs)[tps::X_Q + 16]); \
+            ((uint64_t*)&(xs)[tps::X_CD])[tid] = c_.d;                                             \
+            ((uint64_t*)&(xs)[tps::X_CDEN])[tid] = c_.den;                                         \
+            ((int32_t*)&(xs)[tps::X_CB])[tid] = c_.b;                                              \
         }                                                                                          \
         TPS_SYNC();                                                                                \
         TPS_PHASE {                                                                                \
@@ -498,19 +776,19 @@ TPS_DEV double cand_gain(const Cand& c, int n, int n_patterns) {
                 tps::Cand b_{0, 1, -1};                                                            \
                 for (int i_ = 0; i_ < 16; ++i_) {                                                  \
                     int t_ = tid * 16 + i_;                                                        \
-                    tps::Cand c_{((uint64_t*)&(misc)[tps::M_CD])[t_], ((uint64_t*)&(misc)[tps::M_CDEN])[t_], ((int32_t*)&(misc)[tps::M_CB])[t_]}; \
+                    tps::Cand c_{((uint64_t*)&(xs)[tps::X_CD])[t_], ((uint64_t*)&(xs)[tps::X_CDEN])[t_], ((int32_t*)&(xs)[tps::X_CB])[t_]}; \
                     if (tps::cand_better(c_, b_)) b_ = c_;                                         \
                 }                                                                                  \
-                ((uint64_t*)&(misc)[tps::M_R])[tid] = b_.d;                                        \
-                ((uint64_t*)&(misc)[tps::M_R + 32])[tid] = b_.den;                                 \
-                ((int32_t*)&(misc)[tps::M_R + 64])[tid] = b_.b;                                    \
+                ((uint64_t*)&(xs)[tps::X_R])[tid] = b_.d;                                          \
+                ((uint64_t*)&(xs)[tps::X_R + 32])[tid] = b_.den;                                   \
+                ((int32_t*)&(xs)[tps::X_R + 64])[tid] = b_.b;                                      \
             }                                                                                      \
         }                                                                                          \
         TPS_SYNC();                                                                                \
         {                                                                                          \
             tps::Cand b_{0, 1, -1};                                                                \
             for (int i_ = 0; i_ < 16; ++i_) {                                                      \
-                tps::Cand c_{((uint64_t*)&(misc)[tps::M_R])[i_], ((uint64_t*)&(misc)[tps::M_R + 32])[i_], ((int32_t*)&(misc)[tps::M_R + 64])[i_]}; \
+                tps::Cand c_{((uint64_t*)&(xs)[tps::X_R])[i_], ((uint64_t*)&(xs)[tps::X_R + 32])[i_], ((int32_t*)&(xs)[tps::X_R + 64])[i_]}; \
                 if (tps::cand_better(c_, b_)) b_ = c_;                                             \
             }                                                                                      \
             RESULT = b_;                                                                           \
@@ -518,11 +796,84 @@ TPS_DEV double cand_gain(const Cand& c, int n, int n_patterns) {
         TPS_SYNC();                                                                                \
     }
 
+// Workgroup-wide Binseg over S[0..n): fast float64 pass + exact fallback.
+//   bs: NT dwords (chunk sums -> prefixes), misc: MISC_DW region, xs: XS_DW scratch.
+//   Sets bkp_ (int) and gain_ (double).
+#define TPS_BINSEG(S, n, jump, min_size, n_patterns, bs, misc, xs, bkp_, gain_)                    \
+    {                                                                                              \
+        const int per_ = ((n) + (jump) * tps::NT - 1) / ((jump) * tps::NT);                        \
+        const int cl_ = per_ * (jump);             /* chunk length, a multiple of jump */          \
+        TPS_PHASE {                                                                                \
+            int lo_ = tid * cl_, hi_ = lo_ + cl_ < (n) ? lo_ + cl_ : (n);                          \
+            uint32_t s_ = 0;                                                                       \
+            for (int i_ = lo_; i_ < hi_; ++i_) s_ += (uint32_t)(S)[i_];                            \
+            (bs)[tid] = s_;                                                                        \
+            if (tid == 0) { *(uint64_t*)&(misc)[tps::M_MAXSC] = 0ull; (misc)[tps::M_BESTB] = (uint32_t)-1; (misc)[tps::M_NTIE] = 0u; } \
+        }                                                                                          \
+        TPS_SYNC();                                                                                \
+        const uint64_t tot_ = tps::wg_exclusive_scan((bs), tps::NT, &(misc)[tps::M_SCAN]);         \
+        TPS_PHASE {                                                                                \
+            int lo_ = tid * cl_, hi_ = lo_ + cl_ < (n) ? lo_ + cl_ : (n);                          \
+            uint64_t run_ = (bs)[tid];                                                             \
+            double best_ = -1.0;                                                                   \
+            for (int b_ = lo_, j_ = 0; b_ < hi_; ++b_) {                                           \
+                if (j_ == 0 && b_ >= (min_size) && (n) - b_ >= (min_size)) {                       \
+                    int64_t d_ = (int64_t)(n) * (int64_t)run_ - (int64_t)tot_ * (int64_t)b_;       \
+                    double sc_ = tps::score_f64(d_, (uint64_t)b_ * (uint64_t)((n) - b_));          \
+                    if (sc_ > best_) best_ = sc_;                                                  \
+                }                                                                                  \
+                run_ += (uint64_t)(S)[b_];                                                         \
+                if (++j_ == (jump)) j_ = 0;                                                        \
+            }                                                                                      \
+            if (best_ >= 0.0) {                                                                    \
+                uint64_t bits_;                                                                    \
+                __builtin_memcpy(&bits_, &best_, 8);   /* non-negative doubles order like integers */ \
+                tps::lds_max_u64((uint64_t*)&(misc)[tps::M_MAXSC], bits_);                         \
+            }                                                                                      \
+        }                                                                                          \
+        TPS_SYNC();                                                                                \
+        TPS_PHASE {                                                                                \
+            double m_;                                                                             \
+            __builtin_memcpy(&m_, &(misc)[tps::M_MAXSC], 8);                                       \
+            const double thr_ = m_ * (1.0 - 1e-14);                                                \
+            int lo_ = tid * cl_, hi_ = lo_ + cl_ < (n) ? lo_ + cl_ : (n);                          \
+            uint64_t run_ = (bs)[tid];                                                             \
+            for (int b_ = lo_, j_ = 0; b_ < hi_; ++b_) {                                           \
+                if (j_ == 0 && b_ >= (min_size) && (n) - b_ >= (min_size)) {                       \
+                    int64_t d_ = (int64_t)(n) * (int64_t)run_ - (int64_t)tot_ * (int64_t)b_;       \
+                    double sc_ = tps::score_f64(d_, (uint64_t)b_ * (uint64_t)((n) - b_));          \
+                    if (sc_ >= thr_) {                                                             \
+                        tps::lds_add(&(misc)[tps::M_NTIE], 1u);                                    \
+                        if (sc_ == m_) tps::lds_max_i32((int32_t*)&(misc)[tps::M_BESTB], b_);      \
+                    }                                                                              \
+                }                                                                                  \
+                run_ += (uint64_t)(S)[b_];                                                         \
+                if (++j_ == (jump)) j_ = 0;                                                        \
+            }                                                                                      \
+        }                                                                                          \
+        TPS_SYNC();                                                                                \
+        if ((misc)[tps::M_NTIE] > 1u) {            /* float noise cannot separate them: exact */   \
+            tps::Cand ex_;                                                                         \
+            TPS_BINSEG_EXACT(S, n, jump, min_size, xs, ex_);                                       \
+            bkp_ = ex_.b;                                                                          \
+            gain_ = ex_.b < 0 ? 0.0 : tps::gain_from((int64_t)ex_.d, ex_.den, (n), (n_patterns));  \
+        } else {                                                                                   \
+            bkp_ = (int32_t)(misc)[tps::M_BESTB];                                                  \
+            double m_;                                                                             \
+            __builtin_memcpy(&m_, &(misc)[tps::M_MAXSC], 8);                                       \
+            gain_ = bkp_ < 0 ? 0.0 : m_ / (double)(n) / ((double)(n_patterns) * (double)(n_patterns)); \
+        }                                                                                          \
+        TPS_SYNC();                                                                                \
+    }
+
 // ------------------------------------------------------------------ the per-read program
-// `lds_base` is the workgroup's LDS (dynamic shared memory); `r` the read index.
+// `lds_base` is the workgroup's LDS (dynamic shared memory); `r` the read index.  SV = 0 runs the
+// generic block/window path, SV > 0 the path specialised for slide == SV; SO = the pattern table
+// holds self-overlapping k-mers (only meaningful for SV > 0; the generic path tests it at run time).
 // In the device build every thread of the workgroup executes this function; TPS_PHASE bodies
 // run once per thread and TPS_SYNC() is __syncthreads().  In the emulation TPS_PHASE loops
 // over the 256 thread ids, so phases run in program order.
+template <int SV, bool SO>
 TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base) {
     const Lds l = carve(lds_base, a);
     const PatInfo& pat = a.pat;
@@ -530,12 +881,35 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base) {
     const int64_t off = a.offsets[r];
     const int64_t L = a.offsets[r + 1] - off;
     const uint8_t* seq = a.bases + off;
+    const bool step1 = (prm.flags & TPS_F_STEP1) != 0;
+
+    const int n1 = (int)(L < prm.no_bp ? L : prm.no_bp);
+    const Stage st_s = stage_plan(seq, L, false, 0, 0, n1);     // first n1 bases
+    const Stage st_e = stage_plan(seq, L, true, 0, 0, n1);      // last n1 bases, reversed
 
     TPS_PHASE {
         for (int i = tid; i < a.lut_n; i += NT) l.lut[i] = a.lut[i];
-        if (tid < 64) l.misc[tid] = 0;
+        if (tid < MISC_DW) l.misc[tid] = 0;
+        if (step1)
+            for (int i = tid; i < HIST_DW; i += NT) l.blk[i] = 0;
     }
     TPS_SYNC();
+    if (step1) {
+        TPS_PHASE {
+            // both heads are staged side by side: [0, head_dw) and [head_dw, 2 head_dw)
+            for (int c = tid; c < 2 * a.head_dw; c += NT) {
+                const int side = c >= a.head_dw;
+                const int cc = c - side * a.head_dw;
+                uint32_t packed, bad;
+                if (side) stage_chunk(st_e, cc, packed, bad);
+                else stage_chunk(st_s, cc, packed, bad);
+                if (bad) l.misc[M_INVALID] = 1u;
+                l.seq2[c] = packed;
+                l.val[c] = bad;
+            }
+        }
+        TPS_SYNC();
+    }
 
     int tail = 0, pass = 1;
     tps_read_result res;
@@ -543,41 +917,32 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base) {
     res.best_start_idx = res.best_end_idx = 0;
     res.n_win = 0; res.bkp = -1; res.gain = 0.0;
 
-    if (prm.flags & TPS_F_STEP1) {
-        const int n1 = (int)(L < prm.no_bp ? L : prm.no_bp);
-        for (int side = 0; side < 2; ++side) {
-            const Stage st = stage_plan(seq, L, side == 1, 0, 0, n1);
-            TPS_PHASE {
-                if (tid < 34) l.misc[tid] = 0;           // hist, cmask, invalid
-            }
-            TPS_SYNC();
-            TPS_PHASE { stage_thread(st, l, a.seq_dw, tid); }
-            TPS_SYNC();
-            TPS_PHASE { trc_count_thread(l, pat, st, tid); }
-            TPS_SYNC();
-            if (l.misc[M_CMASK]) {
-                TPS_PHASE { trc_fix_thread(l, pat, st, tid); }
-                TPS_SYNC();
-            }
-            TPS_PHASE {
-                if (tid < pat.P) {
-                    int32_t* dst = side ? a.c_end : a.c_start;
-                    if (dst) dst[r * pat.P + tid] = (int32_t)l.misc[M_HIST + tid];
-                }
-                if (tid == 0) {
-                    uint32_t best = 0; int idx = 0;
-                    for (int p = 0; p < pat.P; ++p)
-                        if (l.misc[M_HIST + p] > best) { best = l.misc[M_HIST + p]; idx = p; }
-                    l.misc[M_BEST + 2 * side] = best;
-                    l.misc[M_BEST + 2 * side + 1] = (uint32_t)idx;
-                }
-            }
+    if (step1) {
+        TPS_PHASE { trc_count_thread(a, l, st_s, st_e, tid); }
+        TPS_SYNC();
+        TPS_PHASE { trc_sum_thread(a, l, tid); }
+        TPS_SYNC();
+        if (l.misc[M_CMASK] | l.misc[M_CMASK + 1]) {
+            TPS_PHASE { trc_fix_thread(a, l, st_s, st_e, tid); }
             TPS_SYNC();
         }
-        res.best_start = (int32_t)l.misc[M_BEST];
-        res.best_start_idx = (int32_t)l.misc[M_BEST + 1];
-        res.best_end = (int32_t)l.misc[M_BEST + 2];
-        res.best_end_idx = (int32_t)l.misc[M_BEST + 3];
+        TPS_PHASE {
+            const int side = tid >> 7, p = tid & 127;
+            if (p < pat.P) {
+                int32_t* dst = side ? a.c_end : a.c_start;
+                if (dst) dst[r * pat.P + p] = (int32_t)l.misc[M_FIN + 32 * side + p];
+            }
+        }
+        // every thread derives the (uniform) decision from the final counts: first maximum wins
+        uint32_t bs = 0, be = 0;
+        int is = 0, ie = 0;
+        for (int p = 0; p < pat.P; ++p) {
+            uint32_t cs = l.misc[M_FIN + p], ce = l.misc[M_FIN + 32 + p];
+            if (cs > bs) { bs = cs; is = p; }
+            if (ce > be) { be = ce; ie = p; }
+        }
+        res.best_start = (int32_t)bs; res.best_start_idx = is;
+        res.best_end = (int32_t)be; res.best_end_idx = ie;
         // forward only if strictly larger (allsteps.py:193); strict cutoff and length tests
         tail = res.best_start > res.best_end ? 0 : 1;
         int best = tail ? res.best_end : res.best_start;
@@ -585,7 +950,7 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base) {
     } else if (a.tails_in) {
         uint8_t tv = a.tails_in[r];
         tail = tv & 1;
-        pass = (tv & 2) ? 0 : 1;                          // bit 1 set = skip this read
+        pass = (tv & 2) ? 0 : 1;                   // bit 1 set = skip this read
     }
     res.tail = tail;
     res.pass = pass;
@@ -595,9 +960,9 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base) {
         const int64_t m = L < prm.maxlen ? L : prm.maxlen;
         const int64_t n_s = m - prm.trimfirst;
         if (n_s >= prm.window) n_win = (int)((n_s - prm.window) / prm.slide) + 1;
-        if (n_win > a.s_cap) n_win = 0;                   // host plans s_cap >= max n_win
+        if (n_win > a.s_cap) n_win = 0;            // host plans s_cap >= max n_win
         const int blk_per_tile = a.spans_per_tile << a.blk_log2;
-        const int tw = blk_per_tile - a.q - 1;            // windows per tile
+        const int tw = blk_per_tile - a.q - 1;     // windows per tile
         const int64_t out_base = a.win_off ? a.win_off[r] : 0;
         for (int w0 = 0; w0 < n_win; w0 += tw) {
             const int nw_tile = (n_win - w0) < tw ? (n_win - w0) : tw;
@@ -606,69 +971,65 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base) {
             const int64_t cap = (int64_t)blk_per_tile * prm.slide + 32;
             if (n_stage > cap) n_stage = cap;
             const Stage st = stage_plan(seq, L, tail == 1, prm.trimfirst, i0, (int)n_stage);
-            TPS_PHASE { if (tid == 0) l.misc[M_INVALID] = 0; }
-            TPS_SYNC();
-            TPS_PHASE { stage_thread(st, l, a.seq_dw, tid); }
-            TPS_SYNC();
             // spans needed for this tile's blocks 0 .. nw_tile-1+q (+ the partial block)
             const int blk_need = nw_tile + a.q + 1;
             const int spans = (blk_need + (1 << a.blk_log2) - 1) >> a.blk_log2;
-            TPS_PHASE {
-                for (int sp = tid; sp < spans; sp += NT) blocks_span(a, l, st.delta, sp);
-            }
+            const int ndw = spans * a.span_dw + 4 < a.seq_dw ? spans * a.span_dw + 4 : a.seq_dw;
+            TPS_PHASE { if (tid == 0) l.misc[M_INVALID] = 0; }
             TPS_SYNC();
-            // exclusive prefix of Tot over spans (two-level; spans <= NT)
-            const int per = (spans + 63) / 64;
+            TPS_PHASE { stage_thread(st, l.seq2, l.val, ndw, &l.misc[M_INVALID], tid); }
+            TPS_SYNC();
+            const bool inv = l.misc[M_INVALID] != 0;
             TPS_PHASE {
-                if (tid < 64) {
-                    uint32_t s_ = 0;
-                    for (int i = tid * per; i < (tid + 1) * per && i < spans; ++i) s_ += l.Tot[i];
-                    l.misc[M_Q + tid] = s_;
+                for (int sp = tid; sp < spans; sp += NT) {
+                    if constexpr (SV == 0) {
+                        blocks_span(a, l, st.delta, sp);
+                    } else {
+                        if (inv) blocks_span_slow<SV>(a, l, st.delta, sp);
+                        else blocks_span_s<SV, SO>(a, l, st.delta, sp);
+                    }
                 }
             }
             TPS_SYNC();
+            wg_exclusive_scan(l.Tot, spans, &l.misc[M_SCAN]);
             TPS_PHASE {
-                if (tid == 0) {
-                    uint32_t run = 0;
-                    for (int i = 0; i < 64; ++i) { uint32_t t_ = l.misc[M_Q + i]; l.misc[M_Q + i] = run; run += t_; }
-                }
+                if constexpr (SV == 0) windows_thread(a, l, st.delta, w0, nw_tile, out_base, tid);
+                else windows_thread_s<SV>(a, l, st.delta, w0, nw_tile, out_base, tid);
             }
-            TPS_SYNC();
-            TPS_PHASE {
-                if (tid < 64) {
-                    uint32_t run = l.misc[M_Q + tid];
-                    for (int i = tid * per; i < (tid + 1) * per && i < spans; ++i) { uint32_t t_ = l.Tot[i]; l.Tot[i] = run; run += t_; }
-                }
-            }
-            TPS_SYNC();
-            TPS_PHASE { windows_thread(a, l, st.delta, w0, nw_tile, out_base, tid); }
             TPS_SYNC();
         }
     }
     res.n_win = n_win;
 
     if (n_win > 0 && (prm.flags & TPS_F_BINSEG) && binseg_admissible(n_win, prm.jump, prm.min_size)) {
-        Cand best;
-        TPS_BINSEG_BODY(l.S, n_win, prm.jump, prm.min_size, l.misc, best);
-        res.bkp = best.b;
-        res.gain = cand_gain(best, n_win, pat.P);
+        int bkp;
+        double gain;
+        uint32_t* bs = l.Tot;                      // tot_dw >= NT
+        TPS_BINSEG(l.S, n_win, prm.jump, prm.min_size, pat.P, bs, l.misc, l.blk, bkp, gain);
+        res.bkp = bkp;
+        res.gain = gain;
     }
     TPS_PHASE { if (tid == 0) a.results[r] = res; }
 }
 
 // standalone Binseg over window sums in global memory (tps_binseg_l2)
-TPS_DEV void binseg_read(const BinsegArgs& a, int64_t r, uint32_t* misc) {
+constexpr int BINSEG_SMEM_DW = XS_DW + MISC_DW + NT;
+TPS_DEV void binseg_read(const BinsegArgs& a, int64_t r, uint32_t* smem) {
     const int64_t lo = a.win_off[r];
     const int n = (int)(a.win_off[r + 1] - lo);
     const int32_t* S = a.sums + lo;
-    Cand best{0, 1, -1};
+    uint32_t* xs = smem;
+    uint32_t* misc = smem + XS_DW;
+    uint32_t* bs = misc + MISC_DW;
+    int bkp = -1;
+    double gain = 0.0;
     if (binseg_admissible(n, a.jump, a.min_size)) {
-        TPS_BINSEG_BODY(S, n, a.jump, a.min_size, misc, best);
+        TPS_BINSEG(S, n, a.jump, a.min_size, a.n_patterns, bs, misc, xs, bkp, gain);
     }
     TPS_PHASE {
         if (tid == 0) {
-            a.bkp[r] = best.b;
-            if (a.gain) a.gain[r] = cand_gain(best, n, a.n_patterns);
+            a.bkp[r] = bkp;
+            if (a.gain) a.gain[r] = gain;
         }
     }
 }

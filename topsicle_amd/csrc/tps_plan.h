@@ -33,6 +33,7 @@ inline std::string build_patterns(const char* pats, int P, int k, std::vector<ui
     pi.kmask = (1u << (2 * k)) - 1u;
     pi.all_mask = (1u << P) - 1u;
     uint32_t per_pat[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::vector<uint32_t> codes((size_t)P);
     for (int p = 0; p < P; ++p) {
         uint32_t code = 0;
         char up[16];
@@ -51,12 +52,15 @@ inline std::string build_patterns(const char* pats, int P, int k, std::vector<ui
             code |= v << (2 * i);
         }
         lut[code] |= 1u << p;
+        codes[(size_t)p] = code;
         for (int d = 1; d < k; ++d) {             // proper periods -> the k-mer can overlap itself
             bool periodic = true;
             for (int i = 0; i + d < k; ++i) periodic = periodic && (up[i] == up[i + d]);
             if (periodic) { per_pat[d] |= 1u << p; pi.so_mask |= 1u << p; }
         }
     }
+    for (int p = 0; p < P; ++p)
+        if (lut[codes[(size_t)p]] & (lut[codes[(size_t)p]] - 1)) pi.dup_mask |= 1u << p;
     for (int d = 1; d < k; ++d)
         if (per_pat[d]) {
             pi.period[pi.n_periods] = d;
@@ -66,10 +70,14 @@ inline std::string build_patterns(const char* pats, int P, int k, std::vector<ui
     return "";
 }
 
-// Geometry of one scan: fills lut_n, lw/q/r, span_dw, blk_log2, spans_per_tile, nblk_cap,
-// seq_dw, s_cap.  budget_dw = LDS dwords available to one workgroup.
-inline std::string plan_geometry(ScanArgs& a, const tps_params& prm, int k, int64_t max_nwin, int64_t budget_dw,
-                                 int spans_pref) {
+// Slides that have a specialised kernel instantiation (tps_scan_kernel_s<S>).
+inline bool has_specialised_slide(int s) { return s == 5 || s == 6 || s == 7 || s == 8; }
+
+// Geometry of one scan: fills variant, lut_n, lw/q/r, span_dw, blk_log2, spans_per_tile, nblk_cap,
+// rec_rs, seq_dw, head_dw, tot_dw, blk_dw, s_cap.  budget_dw = LDS dwords one workgroup may use;
+// target_dw = preferred LDS size (occupancy), spans_pref > 0 forces the spans per tile.
+inline std::string plan_geometry(ScanArgs& a, const tps_params& prm, int k, int P, int64_t max_nwin, int64_t budget_dw,
+                                 int spans_pref, int force_generic = 0, int64_t target_dw = 10 * 1024) {
     a.lut_n = 1 << (2 * k);
     a.lw = std::max(0, prm.window - k);            // k-mer start positions in a (W-1)-char window
     a.q = a.lw / prm.slide;
@@ -79,23 +87,40 @@ inline std::string plan_geometry(ScanArgs& a, const tps_params& prm, int k, int6
     const int bps = 16 / g;
     a.blk_log2 = 0;
     while ((1 << a.blk_log2) < bps) ++a.blk_log2;
+    const int chunk = bps < 8 ? bps : 8;
+    a.variant = (!force_generic && has_specialised_slide(prm.slide) && P <= 15 && a.q >= chunk) ? prm.slide : 0;
     if (max_nwin > 500000) return "too many windows per read (" + std::to_string(max_nwin) + ")";
     a.s_cap = (int)std::max<int64_t>(max_nwin, 1);
+    a.head_dw = (prm.no_bp + 30) / 16 + 3;
+    const int max_spans = 2 * NT;
     const int min_spans = (a.q + 2 + bps - 1) / bps;        // a tile must hold >= 1 window
-    int spans = spans_pref > 0 ? spans_pref : 128;
     const int64_t need_blk = max_nwin + a.q + 1;            // no more spans than the longest read uses
-    const int need_spans = (int)std::min<int64_t>((need_blk + bps - 1) / bps, NT);
+    const int need_spans = (int)std::min<int64_t>((need_blk + bps - 1) / bps, max_spans);
+    int spans = spans_pref > 0 ? std::min(spans_pref, max_spans) : std::max(need_spans, 1);
     spans = std::max(min_spans, std::min(spans, std::max(need_spans, 1)));
-    if (spans > NT) return "window/slide combination needs " + std::to_string(spans) + " spans per tile (max " + std::to_string(NT) + ")";
+    if (spans > max_spans) return "window/slide combination needs " + std::to_string(spans) + " spans per tile (max " + std::to_string(max_spans) + ")";
+    bool shrink_to_target = spans_pref <= 0;
     for (;;) {
         a.spans_per_tile = spans;
         a.nblk_cap = spans * bps;
-        a.seq_dw = std::max(spans * a.span_dw + 4, (prm.no_bp + 31) / 16 + 4);
-        if (lds_dwords(a) <= budget_dw) break;
-        if (spans <= min_spans)
+        a.rec_rs = ((spans + 31) / 32) * 32 + 32 / bps;
+        a.tot_dw = std::max(((spans + 2) / 2) * 2, (int)NT);
+        a.seq_dw = std::max(spans * a.span_dw + 4, 2 * a.head_dw);
+        a.blk_dw = (int32_t)blk_region_dw(a);
+        const int64_t need = lds_dwords(a);
+        if (need <= (shrink_to_target ? std::min(target_dw, budget_dw) : budget_dw)) break;
+        if (spans <= min_spans) {
+            if (shrink_to_target) { shrink_to_target = false; if (need <= budget_dw) break; }
             return "LDS plan does not fit: window=" + std::to_string(prm.window) + " slide=" + std::to_string(prm.slide) +
                    " k=" + std::to_string(k) + " windows/read=" + std::to_string(max_nwin);
-        spans = std::max(min_spans, spans / 2);
+        }
+        // prefer a tile count that divides the read evenly
+        int tiles = 2;
+        while (true) {
+            int sp = (int)((need_blk + (int64_t)tiles * bps - 1) / ((int64_t)tiles * bps)) + (a.q + 1 + bps - 1) / bps;
+            if (sp < spans) { spans = std::max(min_spans, sp); break; }
+            if (++tiles > 4096) { spans = std::max(min_spans, spans - 1); break; }
+        }
     }
     return "";
 }
