@@ -1,0 +1,25 @@
+"""Diagnostic: per-phase clock shares of the scan kernel (thread-0 stamps per read)."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
+import numpy as np
+from topsicle_amd import hiplib, synth, allsteps
+motif, k, slide = (sys.argv[1], int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else ("CCCTAA", 4, 6)
+pats = allsteps.patterns_to_search(motif, k)
+b, o, _ = synth.make_reads(10000, 15000, motif, 1)
+sc = hiplib.HipScanner(0); sc.set_patterns(pats)
+sc.upload(0, b, o)
+prm = hiplib.make_params(min_len=9000, min_count=100, slide=slide, flags=1 | 2 | 4 | 8)
+sc.scan(0, prm); sc.sync()
+sc.lib.tps_debug_stamps_enable(sc._h, 1)
+sc.scan(0, prm); sc.sync()
+st = np.zeros((10000, 16), np.uint64)
+sc.lib.tps_debug_stamps_get.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
+rc = sc.lib.tps_debug_stamps_get(sc._h, 0, st.ctypes.data_as(C.c_void_p), 10000)
+assert rc == 0
+st = st.astype(np.int64)
+names = ["lut+zero", "stage heads", "trc count", "trc sum+decide", "stage tile0", "blocks tile0", "scan tile0", "windows tile0", "rest tiles", "binseg+result"]
+d = np.diff(st[:, :11], axis=1)
+tot = (st[:, 10] - st[:, 0])
+print("mean total clocks per read:", tot.mean(), " kernel span clocks:", st[:, 10].max() - st[:, 0].min())
+for i, n in enumerate(names):
+    print(f"{n:16s} {d[:, i].mean():10.0f}  {100 * d[:, i].mean() / tot.mean():5.1f}%")

@@ -74,7 +74,7 @@ struct DevBuf {
 };
 
 struct Slot {
-    DevBuf bases, offsets, tails, results, c_start, c_end, win_off, sums, raw;
+    DevBuf bases, offsets, tails, results, c_start, c_end, win_off, sums, raw, stamps;
     std::vector<int64_t> h_offsets;      // host copy of offsets (n+1)
     std::vector<int64_t> h_win_off;      // window layout of the last plan
     tps_read_result* h_results = nullptr;   // pinned
@@ -106,6 +106,7 @@ struct tps_ctx {
     std::vector<EventPair> ev_pool;
     size_t ev_used = 0;
     int spans_override = 0;
+    int want_stamps = 0;
     int force_generic = 0;
     int64_t lds_target_dw = 10 * 1024;
     size_t lds_set_v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -226,6 +227,12 @@ int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm) {
         if ((rc = sl.raw.ensure((size_t)std::max<int64_t>(total_win * P, 1)))) return rc;
         a.raw = (uint8_t*)sl.raw.p;
     }
+    a.stamps = nullptr;
+    if (c->want_stamps) {
+        if ((rc = sl.stamps.ensure((size_t)std::max<int64_t>(n, 1) * 16 * 8))) return rc;
+        HIP_TRY(hipMemsetAsync(sl.stamps.p, 0, (size_t)std::max<int64_t>(n, 1) * 16 * 8, c->stream));
+        a.stamps = (uint64_t*)sl.stamps.p;
+    }
     a.n_reads = n;
     a.pat = c->pat;
     a.prm = prm;
@@ -250,10 +257,14 @@ int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm) {
         if (c->ev_pool.size() >= 8192) {
             c->ev_used = 0;                               // wrap: oldest timings are dropped
         } else {
-            EventPair ep;
-            HIP_TRY(hipEventCreate(&ep.a));
-            HIP_TRY(hipEventCreate(&ep.b));
-            c->ev_pool.push_back(ep);
+            // events are created in batches, never one per launch (hipEventCreate costs ~60 us)
+            const size_t grow = c->ev_pool.empty() ? 256 : c->ev_pool.size();
+            for (size_t i = 0; i < grow; ++i) {
+                EventPair ep;
+                HIP_TRY(hipEventCreate(&ep.a));
+                HIP_TRY(hipEventCreate(&ep.b));
+                c->ev_pool.push_back(ep);
+            }
         }
     }
     EventPair& ep = c->ev_pool[c->ev_used++];
@@ -320,7 +331,7 @@ int tps_ctx_destroy(tps_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto& sl : c->slots) {
         sl.bases.release(); sl.offsets.release(); sl.tails.release(); sl.results.release();
-        sl.c_start.release(); sl.c_end.release(); sl.win_off.release(); sl.sums.release(); sl.raw.release();
+        sl.c_start.release(); sl.c_end.release(); sl.win_off.release(); sl.sums.release(); sl.raw.release(); sl.stamps.release();
         if (sl.h_results) (void)hipHostFree(sl.h_results);
     }
     c->lut.release();
@@ -540,6 +551,17 @@ int tps_kernel_time_ms(tps_ctx* c, int32_t* n_launches, double* total_ms, double
     if (n_launches) *n_launches = (int32_t)c->ev_used;
     if (total_ms) *total_ms = tot;
     if (mean_ms) *mean_ms = c->ev_used ? tot / (double)c->ev_used : 0.0;
+    return TPS_OK;
+}
+
+/* diagnostics (not part of the public header): per-read phase clock stamps of the next scans */
+int tps_debug_stamps_enable(tps_ctx* c, int on) { if (!c) return TPS_E_ARG; c->want_stamps = on; return TPS_OK; }
+int tps_debug_stamps_get(tps_ctx* c, int32_t slot, uint64_t* out, int64_t n) {
+    Slot* sl;
+    int rc;
+    if ((rc = need_scanned(c, slot, &sl))) return rc;
+    if (!sl->stamps.p || n != sl->n) return fail(TPS_E_STATE, "no stamps recorded");
+    HIP_TRY(hipMemcpy(out, sl->stamps.p, (size_t)n * 16 * 8, hipMemcpyDeviceToHost));
     return TPS_OK;
 }
 

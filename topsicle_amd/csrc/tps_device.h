@@ -99,6 +99,13 @@ TPS_DEV u32x4 load16(const uint8_t* p) { return *reinterpret_cast<const uint4*>(
 constexpr int cgcd(int a, int b) { return b == 0 ? a : cgcd(b, a % b); }
 constexpr int clog2(int x) { return x <= 1 ? 0 : 1 + clog2(x / 2); }
 
+// diagnostics: thread 0 stores the shader clock at phase boundaries when ScanArgs::stamps is set
+#ifdef TPS_EMU
+#define TPS_STAMP(i) ((void)0)
+#else
+#define TPS_STAMP(i) do { if (a.stamps && threadIdx.x == 0) a.stamps[r * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#endif
+
 // ------------------------------------------------------------------ kernel arguments
 struct PatInfo {
     int32_t P, k;
@@ -122,6 +129,7 @@ struct ScanArgs {
     const int64_t* win_off;      // n+1 (window layout of sums/raw)
     int32_t* sums;               // or nullptr
     uint8_t* raw;                // or nullptr
+    uint64_t* stamps;            // diagnostics: 16 clock stamps per read, or nullptr
     int64_t n_reads;
     PatInfo pat;
     tps_params prm;
@@ -887,6 +895,7 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base) {
     const Stage st_s = stage_plan(seq, L, false, 0, 0, n1);     // first n1 bases
     const Stage st_e = stage_plan(seq, L, true, 0, 0, n1);      // last n1 bases, reversed
 
+    TPS_STAMP(0);
     TPS_PHASE {
         for (int i = tid; i < a.lut_n; i += NT) l.lut[i] = a.lut[i];
         if (tid < MISC_DW) l.misc[tid] = 0;
@@ -894,6 +903,7 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base) {
             for (int i = tid; i < HIST_DW; i += NT) l.blk[i] = 0;
     }
     TPS_SYNC();
+    TPS_STAMP(1);
     if (step1) {
         TPS_PHASE {
             // both heads are staged side by side: [0, head_dw) and [head_dw, 2 head_dw)
@@ -917,9 +927,11 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base) {
     res.best_start_idx = res.best_end_idx = 0;
     res.n_win = 0; res.bkp = -1; res.gain = 0.0;
 
+    TPS_STAMP(2);
     if (step1) {
         TPS_PHASE { trc_count_thread(a, l, st_s, st_e, tid); }
         TPS_SYNC();
+        TPS_STAMP(3);
         TPS_PHASE { trc_sum_thread(a, l, tid); }
         TPS_SYNC();
         if (l.misc[M_CMASK] | l.misc[M_CMASK + 1]) {
@@ -954,6 +966,7 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base) {
     }
     res.tail = tail;
     res.pass = pass;
+    TPS_STAMP(4);
 
     int n_win = 0;
     if (pass && (prm.flags & TPS_F_WINDOWS)) {
@@ -979,6 +992,7 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base) {
             TPS_SYNC();
             TPS_PHASE { stage_thread(st, l.seq2, l.val, ndw, &l.misc[M_INVALID], tid); }
             TPS_SYNC();
+            if (w0 == 0) TPS_STAMP(5);
             const bool inv = l.misc[M_INVALID] != 0;
             TPS_PHASE {
                 for (int sp = tid; sp < spans; sp += NT) {
@@ -991,15 +1005,19 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base) {
                 }
             }
             TPS_SYNC();
+            if (w0 == 0) TPS_STAMP(6);
             wg_exclusive_scan(l.Tot, spans, &l.misc[M_SCAN]);
+            if (w0 == 0) TPS_STAMP(7);
             TPS_PHASE {
                 if constexpr (SV == 0) windows_thread(a, l, st.delta, w0, nw_tile, out_base, tid);
                 else windows_thread_s<SV>(a, l, st.delta, w0, nw_tile, out_base, tid);
             }
             TPS_SYNC();
+            if (w0 == 0) TPS_STAMP(8);
         }
     }
     res.n_win = n_win;
+    TPS_STAMP(9);
 
     if (n_win > 0 && (prm.flags & TPS_F_BINSEG) && binseg_admissible(n_win, prm.jump, prm.min_size)) {
         int bkp;
@@ -1010,6 +1028,7 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base) {
         res.gain = gain;
     }
     TPS_PHASE { if (tid == 0) a.results[r] = res; }
+    TPS_STAMP(10);
 }
 
 // standalone Binseg over window sums in global memory (tps_binseg_l2)
