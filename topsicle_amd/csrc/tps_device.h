@@ -213,7 +213,7 @@ TPS_HD int64_t lds_dwords(const ScanArgs& a) {
     return (int64_t)a.blk_dw + a.lut_n + 2ll * a.seq_dw + a.tot_dw + ((a.s_cap + 3) / 4) * 2 + MISC_DW;
 }
 // misc layout (dwords)
-constexpr int M_FIN = 0;         // 2 x 32: final step-1 counts (start side, end side)
+constexpr int M_BEST = 0;        // 2: step-1 arg-max keys (count << 5 | 31 - pattern) of the two sides
 constexpr int M_CMASK = 64;      // 2: conflict masks of step 1 (start, end)
 constexpr int M_INVALID = 66;    // any non-ACGT base in the staged range
 constexpr int M_SCAN = 68;       // 8: workgroup scan scratch (wave totals, grand total)
@@ -311,14 +311,13 @@ TPS_DEV uint32_t bad_bits16(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, 
     return m;
 }
 
-// chunk c of a staged range -> (packed 16 bases, 16 invalid bits); zero beyond the staged chunks
-TPS_DEV void stage_chunk(const Stage& st, int c, uint32_t& packed, uint32_t& bad) {
-    packed = 0;
-    bad = 0;
-    if (c >= st.nch) return;
+// address of chunk c of a staged range
+TPS_DEV const uint8_t* stage_addr(const Stage& st, int c) {
+    return st.reverse ? st.chunk0 - 16 * (intptr_t)c : st.chunk0 + 16 * (intptr_t)c;
+}
+// 16 ASCII bytes of chunk c -> (packed 16 bases, 16 invalid bits)
+TPS_DEV void stage_pack(const Stage& st, int c, const u32x4& v, uint32_t& packed, uint32_t& bad) {
     const uint32_t w = st.reverse ? 0x01041040u : 0x40100401u;
-    const uint8_t* p = st.reverse ? st.chunk0 - 16 * (intptr_t)c : st.chunk0 + 16 * (intptr_t)c;
-    u32x4 v = load16(p);
     // bits 1-2 of an ASCII letter: A,C,T,G (either case) -> 0,1,2,3; one dot product packs 4 bases
     uint32_t y0 = v.x & 0x06060606u, y1 = v.y & 0x06060606u, y2 = v.z & 0x06060606u, y3 = v.w & 0x06060606u;
     uint32_t d0 = udot4(y0, w), d1 = udot4(y1, w), d2 = udot4(y2, w), d3 = udot4(y3, w);
@@ -332,6 +331,7 @@ TPS_DEV void stage_chunk(const Stage& st, int c, uint32_t& packed, uint32_t& bad
     uint32_t b1 = (v.y | 0x20202020u) ^ perm(s0, s1, y1);
     uint32_t b2 = (v.z | 0x20202020u) ^ perm(s0, s1, y2);
     uint32_t b3 = (v.w | 0x20202020u) ^ perm(s0, s1, y3);
+    bad = 0;
     if (b0 | b1 | b2 | b3) {
         bad = bad_bits16(b0, b1, b2, b3, st.reverse);
         // keep only positions inside the staged range [delta, delta+n)
@@ -342,15 +342,36 @@ TPS_DEV void stage_chunk(const Stage& st, int c, uint32_t& packed, uint32_t& bad
         bad &= keep & 0xFFFFu;
     }
 }
+// chunk c of a staged range -> (packed 16 bases, 16 invalid bits); zero beyond the staged chunks
+TPS_DEV void stage_chunk(const Stage& st, int c, uint32_t& packed, uint32_t& bad) {
+    packed = 0;
+    bad = 0;
+    if (c >= st.nch) return;
+    stage_pack(st, c, load16(stage_addr(st, c)), packed, bad);
+}
 
-// one thread stages chunks tid, tid+NT, ... of `ndw` dwords at seq2/val
+// one thread stages chunks tid, tid+NT, ... of `ndw` dwords at seq2/val; four 16-byte loads are in
+// flight per lane before the first one is consumed (HBM latency is paid once per four chunks)
 TPS_DEV void stage_thread(const Stage& st, uint32_t* seq2, uint32_t* val, int ndw, uint32_t* invalid_flag, int tid) {
-    for (int c = tid; c < ndw; c += NT) {
-        uint32_t packed, bad;
-        stage_chunk(st, c, packed, bad);
-        if (bad) *invalid_flag = 1u;               // benign race: every writer stores 1
-        seq2[c] = packed;
-        val[c] = bad;
+    for (int base = tid; base < ndw; base += 4 * NT) {
+        u32x4 v[4];
+        TPS_UNROLL
+        for (int u = 0; u < 4; ++u) {
+            const int c = base + u * NT;
+            v[u].x = v[u].y = v[u].z = v[u].w = 0;
+            if (c < ndw && c < st.nch) v[u] = load16(stage_addr(st, c));
+        }
+        TPS_UNROLL
+        for (int u = 0; u < 4; ++u) {
+            const int c = base + u * NT;
+            if (c < ndw) {
+                uint32_t packed = 0, bad = 0;
+                if (c < st.nch) stage_pack(st, c, v[u], packed, bad);
+                if (bad) *invalid_flag = 1u;       // benign race: every writer stores 1
+                seq2[c] = packed;
+                val[c] = bad;
+            }
+        }
     }
 }
 
@@ -397,54 +418,67 @@ TPS_DEV void greedy_count(const uint32_t* lut, const uint32_t* seq2, const uint3
 }
 
 // ------------------------------------------------------------------ step 1: TRC counts of both tails
-// Thread `tid`: side = tid / 128, a run of `ppt` consecutive start positions of that side's staged
-// head.  Matches go to one of 16 private histograms (lane % 16) so that LDS atomics rarely collide.
+// Threads 0-127 take the first-bases head, 128-255 the reversed-last-bases head.  A thread handles
+// groups of 8 consecutive start positions: two LDS reads give the 16 packed bases that hold all
+// eight k-mers (k <= 7), the eight table lookups are independent.  Matches go to one of 16
+// private histograms (lane % 16) so that LDS atomics rarely collide.
 TPS_DEV void trc_count_thread(const ScanArgs& a, const Lds& l, const Stage& st_s, const Stage& st_e, int tid) {
     const PatInfo& pat = a.pat;
     const int side = tid >> 7, t = tid & 127;
-    Stage s;
-    s.delta = side ? st_e.delta : st_s.delta;
-    s.n = st_s.n;
+    const int delta = side ? st_e.delta : st_s.delta;
     const uint32_t* seq2 = l.seq2 + side * a.head_dw;
     const uint32_t* val = l.val + side * a.head_dw;
     const bool inv = l.misc[M_INVALID] != 0;
-    const int npos = s.n - pat.k + 1;
-    const int ppt = (npos + 127) / 128;
+    const bool so = pat.so_mask != 0;
+    const int npos = st_s.n - pat.k + 1;
     uint32_t* hist = l.blk + (side * HIST_COPIES + (tid & (HIST_COPIES - 1))) * 32;
     uint32_t cm = 0;
-    for (int j = 0; j < ppt; ++j) {
-        const int p = t * ppt + j;
-        if (p >= npos) break;
-        uint32_t v = v_at(seq2, s.delta + p);
-        uint32_t h = l.lut[v & pat.kmask];
-        if (!h) continue;
-        if (inv && invalid_at(val, s.delta + p, pat.k)) continue;
-        if (h & pat.so_mask) cm |= conflict_bits(pat, v, h);
-        do {
-            int b = ffs0(h);
-            h &= h - 1;
-            lds_add(&hist[b], 1u);
-        } while (h);
+    for (int p0 = t * 8; p0 < npos; p0 += 128 * 8) {
+        const int q0 = delta + p0, idx = q0 >> 4;
+        const uint32_t sh = (uint32_t)(q0 & 15) * 2u;
+        const uint32_t d0 = seq2[idx], d1 = seq2[idx + 1], d2 = seq2[idx + 2];
+        const uint32_t w0 = alignbit(d1, d0, sh), w1 = alignbit(d2, d1, sh);
+        uint32_t h[8], v[8];
+        TPS_UNROLL
+        for (int j = 0; j < 8; ++j) {
+            v[j] = j ? alignbit(w1, w0, 2u * j) : w0;
+            h[j] = l.lut[v[j] & pat.kmask];
+        }
+        TPS_UNROLL
+        for (int j = 0; j < 8; ++j) {
+            uint32_t hj = h[j];
+            if (p0 + j >= npos) hj = 0;
+            if (hj && inv && invalid_at(val, q0 + j, pat.k)) hj = 0;
+            if (hj) {
+                if (so && (hj & pat.so_mask)) cm |= conflict_bits(pat, v[j], hj);
+                do {
+                    int b = ffs0(hj);
+                    hj &= hj - 1;
+                    lds_add(&hist[b], 1u);
+                } while (hj);
+            }
+        }
     }
     if (cm) lds_or(&l.misc[M_CMASK + side], cm);
 }
-// sum the private histograms: thread (side, p) -> misc[M_FIN + 32*side + p]
-TPS_DEV void trc_sum_thread(const ScanArgs& a, const Lds& l, int tid) {
+// Thread (side, p): sum the private histograms; if pattern p has overlapping occurrences, recount
+// it leftmost-non-overlapping (sequential, rare); publish the count and bid for the side's
+// arg-max with key = count << 5 | (31 - p), so the FIRST pattern with the largest count wins.
+TPS_DEV void trc_sum_thread(const ScanArgs& a, const Lds& l, const Stage& st_s, const Stage& st_e, int64_t r, int tid) {
     const int side = tid >> 7, p = tid & 127;
     if (p < a.pat.P) {
-        uint32_t s = 0;
-        for (int c = 0; c < HIST_COPIES; ++c) s += l.blk[(side * HIST_COPIES + c) * 32 + p];
-        l.misc[M_FIN + 32 * side + p] = s;
-    }
-}
-// patterns with overlapping occurrences: recount leftmost-non-overlapping, sequentially
-TPS_DEV void trc_fix_thread(const ScanArgs& a, const Lds& l, const Stage& st_s, const Stage& st_e, int tid) {
-    const int side = tid >> 7, p = tid & 127;
-    if (p < a.pat.P && ((l.misc[M_CMASK + side] >> p) & 1u)) {
-        int occ, g;
-        greedy_count(l.lut, l.seq2 + side * a.head_dw, l.val + side * a.head_dw, a.pat, side ? st_e.delta : st_s.delta,
-                     st_s.n - a.pat.k + 1, p, l.misc[M_INVALID] != 0, occ, g);
-        l.misc[M_FIN + 32 * side + p] = (uint32_t)g;
+        uint32_t sm = 0;
+        TPS_UNROLL
+        for (int c = 0; c < HIST_COPIES; ++c) sm += l.blk[(side * HIST_COPIES + c) * 32 + p];
+        if ((l.misc[M_CMASK + side] >> p) & 1u) {
+            int occ, g;
+            greedy_count(l.lut, l.seq2 + side * a.head_dw, l.val + side * a.head_dw, a.pat, side ? st_e.delta : st_s.delta,
+                         st_s.n - a.pat.k + 1, p, l.misc[M_INVALID] != 0, occ, g);
+            sm = (uint32_t)g;
+        }
+        int32_t* dst = side ? a.c_end : a.c_start;
+        if (dst) dst[r * a.pat.P + p] = (int32_t)sm;
+        lds_max_i32((int32_t*)&l.misc[M_BEST + side], (int32_t)((sm << 5) | (uint32_t)(31 - p)));
     }
 }
 
@@ -680,21 +714,36 @@ template <int S>
 TPS_DEV void windows_thread_s(const ScanArgs& a, const Lds& l, int delta, int w0, int nw_tile, int64_t out_base, int tid) {
     typedef Geo<S> g_;
     constexpr int B = g_::B, LOG2B = g_::LOG2B, LOG2C = g_::LOG2C;
+    constexpr int U = 4;                           // windows in flight per lane
     const PatInfo& pat = a.pat;
     const int q = a.q;
-    for (int wl = tid; wl < nw_tile; wl += NT) {
-        const int e = wl + q;
-        const u32x2 rw = l.rec[(wl & (B - 1)) * a.rec_rs + (wl >> LOG2B)];
-        const u32x2 re = l.rec[(e & (B - 1)) * a.rec_rs + (e >> LOG2B)];
-        uint32_t m = (rw.x & 0xFFFFu) | (re.x >> 16);
-        for (int c = (wl >> LOG2C) + 1; c < (e >> LOG2C); ++c) m |= l.full[c];
-        uint32_t cnt = ((re.y >> 16) + l.Tot[e >> LOG2B]) - ((rw.y & 0xFFFFu) + l.Tot[wl >> LOG2B]);
-        uint32_t present = m & pat.all_mask;
-        uint32_t sw = cnt + (uint32_t)(pat.P - popc(present));
-        uint8_t* raw_row = a.raw ? a.raw + (out_base + w0 + wl) * (int64_t)pat.P : nullptr;
-        if ((m & FLAG16) || raw_row) sw = window_exact(a, l, delta, wl, present, raw_row);
-        l.S[w0 + wl] = (uint16_t)sw;
-        if (a.sums) a.sums[out_base + w0 + wl] = (int32_t)sw;
+    for (int base = tid; base < nw_tile; base += U * NT) {
+        uint32_t sw[U], mm[U];
+        TPS_UNROLL
+        for (int u = 0; u < U; ++u) {
+            const int wl = base + u * NT;
+            sw[u] = 0; mm[u] = 0;
+            if (wl < nw_tile) {
+                const int e = wl + q;
+                const u32x2 rw = l.rec[(wl & (B - 1)) * a.rec_rs + (wl >> LOG2B)];
+                const u32x2 re = l.rec[(e & (B - 1)) * a.rec_rs + (e >> LOG2B)];
+                uint32_t m = (rw.x & 0xFFFFu) | (re.x >> 16);
+                for (int c = (wl >> LOG2C) + 1; c < (e >> LOG2C); ++c) m |= l.full[c];
+                uint32_t cnt = ((re.y >> 16) + l.Tot[e >> LOG2B]) - ((rw.y & 0xFFFFu) + l.Tot[wl >> LOG2B]);
+                mm[u] = m;
+                sw[u] = cnt + (uint32_t)(pat.P - popc(m & pat.all_mask));
+            }
+        }
+        TPS_UNROLL
+        for (int u = 0; u < U; ++u) {
+            const int wl = base + u * NT;
+            if (wl < nw_tile) {
+                uint8_t* raw_row = a.raw ? a.raw + (out_base + w0 + wl) * (int64_t)pat.P : nullptr;
+                if ((mm[u] & FLAG16) || raw_row) sw[u] = window_exact(a, l, delta, wl, mm[u] & pat.all_mask, raw_row);
+                l.S[w0 + wl] = (uint16_t)sw[u];
+                if (a.sums) a.sums[out_base + w0 + wl] = (int32_t)sw[u];
+            }
+        }
     }
 }
 
@@ -742,137 +791,169 @@ TPS_DEV double gain_from(int64_t d, uint64_t den, int n, int n_patterns) {
     return x * x / ((double)n * (double)den) / ((double)n_patterns * (double)n_patterns);
 }
 
-// Exact tournament over all candidates (slow path), scratch xs (XS_DW dwords).
-#define TPS_BINSEG_EXACT(S, n, jump, min_size, xs, RESULT)                                         \
-    {                                                                                              \
-        const int cl_ = ((n) + tps::NT - 1) / tps::NT;                                             \
-        TPS_PHASE {                                                                                \
-            int lo_ = tid * cl_, hi_ = lo_ + cl_ < (n) ? lo_ + cl_ : (n);                          \
-            uint32_t s_ = 0;                                                                       \
-            for (int i_ = lo_; i_ < hi_; ++i_) s_ += (uint32_t)(S)[i_];                            \
-            (xs)[tps::X_BS + tid] = s_;                                                            \
-        }                                                                                          \
-        TPS_SYNC();                                                                                \
-        TPS_PHASE {                                                                                \
-            if (tid < 16) {                                                                        \
-                uint32_t s_ = 0;                                                                   \
-                for (int i_ = 0; i_ < 16; ++i_) s_ += (xs)[tps::X_BS + tid * 16 + i_];             \
-                (xs)[tps::X_Q + tid] = s_;                                                         \
-            }                                                                                      \
-        }                                                                                          \
-        TPS_SYNC();                                                                                \
-        TPS_PHASE {                                                                                \
-            if (tid == 0) {                                                                        \
-                uint32_t run_ = 0;                                                                 \
-                for (int i_ = 0; i_ < 16; ++i_) { uint32_t t_ = (xs)[tps::X_Q + i_]; (xs)[tps::X_Q + i_] = run_; run_ += t_; } \
-                (xs)[tps::X_Q + 16] = run_;                                                        \
-            }                                                                                      \
-        }                                                                                          \
-        TPS_SYNC();                                                                                \
-        TPS_PHASE {                                                                                \
-            uint64_t pre_ = (xs)[tps::X_Q + (tid >> 4)];                                           \
-            for (int i_ = (tid & ~15); i_ < tid; ++i_) pre_ += (xs)[tps::X_BS + i_];               \
-            int lo_ = tid * cl_, hi_ = lo_ + cl_ < (n) ? lo_ + cl_ : (n);                          \
-            tps::Cand c_ = tps::binseg_chunk((S), (n), (jump), (min_size), lo_, hi_, pre_, (uint64_t)(xs)[tps::X_Q + 16]); \
-            ((uint64_t*)&(xs)[tps::X_CD])[tid] = c_.d;                                             \
-            ((uint64_t*)&(xs)[tps::X_CDEN])[tid] = c_.den;                                         \
-            ((int32_t*)&(xs)[tps::X_CB])[tid] = c_.b;                                              \
-        }                                                                                          \
-        TPS_SYNC();                                                                                \
-        TPS_PHASE {                                                                                \
-            if (tid < 16) {                                                                        \
-                tps::Cand b_{0, 1, -1};                                                            \
-                for (int i_ = 0; i_ < 16; ++i_) {                                                  \
-                    int t_ = tid * 16 + i_;                                                        \
-                    tps::Cand c_{((uint64_t*)&(xs)[tps::X_CD])[t_], ((uint64_t*)&(xs)[tps::X_CDEN])[t_], ((int32_t*)&(xs)[tps::X_CB])[t_]}; \
-                    if (tps::cand_better(c_, b_)) b_ = c_;                                         \
-                }                                                                                  \
-                ((uint64_t*)&(xs)[tps::X_R])[tid] = b_.d;                                          \
-                ((uint64_t*)&(xs)[tps::X_R + 32])[tid] = b_.den;                                   \
-                ((int32_t*)&(xs)[tps::X_R + 64])[tid] = b_.b;                                      \
-            }                                                                                      \
-        }                                                                                          \
-        TPS_SYNC();                                                                                \
-        {                                                                                          \
-            tps::Cand b_{0, 1, -1};                                                                \
-            for (int i_ = 0; i_ < 16; ++i_) {                                                      \
-                tps::Cand c_{((uint64_t*)&(xs)[tps::X_R])[i_], ((uint64_t*)&(xs)[tps::X_R + 32])[i_], ((int32_t*)&(xs)[tps::X_R + 64])[i_]}; \
-                if (tps::cand_better(c_, b_)) b_ = c_;                                             \
-            }                                                                                      \
-            RESULT = b_;                                                                           \
-        }                                                                                          \
-        TPS_SYNC();                                                                                \
+// max of a non-negative f64 (as its bit pattern) over the workgroup into *slot (LDS, pre-zeroed):
+// wave-level butterfly first so that only one LDS atomic per wave is issued.
+TPS_DEV void wg_max_bits(uint64_t bits, uint64_t* slot) {
+#ifndef TPS_EMU
+    TPS_UNROLL
+    for (int d = 32; d >= 1; d >>= 1) {
+        uint32_t lo = __shfl_xor((uint32_t)bits, d), hi = __shfl_xor((uint32_t)(bits >> 32), d);
+        uint64_t o = ((uint64_t)hi << 32) | lo;
+        bits = o > bits ? o : bits;
     }
+    if ((threadIdx.x & 63) != 0) return;
+#endif
+    lds_max_u64(slot, bits);
+}
 
-// Workgroup-wide Binseg over S[0..n): fast float64 pass + exact fallback.
-//   bs: NT dwords (chunk sums -> prefixes), misc: MISC_DW region, xs: XS_DW scratch.
-//   Sets bkp_ (int) and gain_ (double).
-#define TPS_BINSEG(S, n, jump, min_size, n_patterns, bs, misc, xs, bkp_, gain_)                    \
-    {                                                                                              \
-        const int per_ = ((n) + (jump) * tps::NT - 1) / ((jump) * tps::NT);                        \
-        const int cl_ = per_ * (jump);             /* chunk length, a multiple of jump */          \
-        TPS_PHASE {                                                                                \
-            int lo_ = tid * cl_, hi_ = lo_ + cl_ < (n) ? lo_ + cl_ : (n);                          \
-            uint32_t s_ = 0;                                                                       \
-            for (int i_ = lo_; i_ < hi_; ++i_) s_ += (uint32_t)(S)[i_];                            \
-            (bs)[tid] = s_;                                                                        \
-            if (tid == 0) { *(uint64_t*)&(misc)[tps::M_MAXSC] = 0ull; (misc)[tps::M_BESTB] = (uint32_t)-1; (misc)[tps::M_NTIE] = 0u; } \
-        }                                                                                          \
-        TPS_SYNC();                                                                                \
-        const uint64_t tot_ = tps::wg_exclusive_scan((bs), tps::NT, &(misc)[tps::M_SCAN]);         \
-        TPS_PHASE {                                                                                \
-            int lo_ = tid * cl_, hi_ = lo_ + cl_ < (n) ? lo_ + cl_ : (n);                          \
-            uint64_t run_ = (bs)[tid];                                                             \
-            double best_ = -1.0;                                                                   \
-            for (int b_ = lo_, j_ = 0; b_ < hi_; ++b_) {                                           \
-                if (j_ == 0 && b_ >= (min_size) && (n) - b_ >= (min_size)) {                       \
-                    int64_t d_ = (int64_t)(n) * (int64_t)run_ - (int64_t)tot_ * (int64_t)b_;       \
-                    double sc_ = tps::score_f64(d_, (uint64_t)b_ * (uint64_t)((n) - b_));          \
-                    if (sc_ > best_) best_ = sc_;                                                  \
-                }                                                                                  \
-                run_ += (uint64_t)(S)[b_];                                                         \
-                if (++j_ == (jump)) j_ = 0;                                                        \
-            }                                                                                      \
-            if (best_ >= 0.0) {                                                                    \
-                uint64_t bits_;                                                                    \
-                __builtin_memcpy(&bits_, &best_, 8);   /* non-negative doubles order like integers */ \
-                tps::lds_max_u64((uint64_t*)&(misc)[tps::M_MAXSC], bits_);                         \
-            }                                                                                      \
-        }                                                                                          \
-        TPS_SYNC();                                                                                \
-        TPS_PHASE {                                                                                \
-            double m_;                                                                             \
-            __builtin_memcpy(&m_, &(misc)[tps::M_MAXSC], 8);                                       \
-            const double thr_ = m_ * (1.0 - 1e-14);                                                \
-            int lo_ = tid * cl_, hi_ = lo_ + cl_ < (n) ? lo_ + cl_ : (n);                          \
-            uint64_t run_ = (bs)[tid];                                                             \
-            for (int b_ = lo_, j_ = 0; b_ < hi_; ++b_) {                                           \
-                if (j_ == 0 && b_ >= (min_size) && (n) - b_ >= (min_size)) {                       \
-                    int64_t d_ = (int64_t)(n) * (int64_t)run_ - (int64_t)tot_ * (int64_t)b_;       \
-                    double sc_ = tps::score_f64(d_, (uint64_t)b_ * (uint64_t)((n) - b_));          \
-                    if (sc_ >= thr_) {                                                             \
-                        tps::lds_add(&(misc)[tps::M_NTIE], 1u);                                    \
-                        if (sc_ == m_) tps::lds_max_i32((int32_t*)&(misc)[tps::M_BESTB], b_);      \
-                    }                                                                              \
-                }                                                                                  \
-                run_ += (uint64_t)(S)[b_];                                                         \
-                if (++j_ == (jump)) j_ = 0;                                                        \
-            }                                                                                      \
-        }                                                                                          \
-        TPS_SYNC();                                                                                \
-        if ((misc)[tps::M_NTIE] > 1u) {            /* float noise cannot separate them: exact */   \
-            tps::Cand ex_;                                                                         \
-            TPS_BINSEG_EXACT(S, n, jump, min_size, xs, ex_);                                       \
-            bkp_ = ex_.b;                                                                          \
-            gain_ = ex_.b < 0 ? 0.0 : tps::gain_from((int64_t)ex_.d, ex_.den, (n), (n_patterns));  \
-        } else {                                                                                   \
-            bkp_ = (int32_t)(misc)[tps::M_BESTB];                                                  \
-            double m_;                                                                             \
-            __builtin_memcpy(&m_, &(misc)[tps::M_MAXSC], 8);                                       \
-            gain_ = bkp_ < 0 ? 0.0 : m_ / (double)(n) / ((double)(n_patterns) * (double)(n_patterns)); \
-        }                                                                                          \
-        TPS_SYNC();                                                                                \
+// Exact tournament over all candidates (slow path), scratch xs (XS_DW dwords).  Called by the
+// whole workgroup outside TPS_PHASE.
+template <typename ST>
+TPS_DEV Cand binseg_exact_wg(const ST* S, int n, int jump, int min_size, uint32_t* xs) {
+    const int cl = (n + NT - 1) / NT;
+    TPS_PHASE {
+        int lo = tid * cl, hi = lo + cl < n ? lo + cl : n;
+        uint32_t sm = 0;
+        for (int i = lo; i < hi; ++i) sm += (uint32_t)S[i];
+        xs[X_BS + tid] = sm;
     }
+    TPS_SYNC();
+    TPS_PHASE {
+        if (tid < 16) {
+            uint32_t sm = 0;
+            for (int i = 0; i < 16; ++i) sm += xs[X_BS + tid * 16 + i];
+            xs[X_Q + tid] = sm;
+        }
+    }
+    TPS_SYNC();
+    TPS_PHASE {
+        if (tid == 0) {
+            uint32_t run = 0;
+            for (int i = 0; i < 16; ++i) { uint32_t t = xs[X_Q + i]; xs[X_Q + i] = run; run += t; }
+            xs[X_Q + 16] = run;
+        }
+    }
+    TPS_SYNC();
+    TPS_PHASE {
+        uint64_t pre = xs[X_Q + (tid >> 4)];
+        for (int i = (tid & ~15); i < tid; ++i) pre += xs[X_BS + i];
+        int lo = tid * cl, hi = lo + cl < n ? lo + cl : n;
+        Cand c = binseg_chunk(S, n, jump, min_size, lo, hi, pre, (uint64_t)xs[X_Q + 16]);
+        ((uint64_t*)&xs[X_CD])[tid] = c.d;
+        ((uint64_t*)&xs[X_CDEN])[tid] = c.den;
+        ((int32_t*)&xs[X_CB])[tid] = c.b;
+    }
+    TPS_SYNC();
+    TPS_PHASE {
+        if (tid < 16) {
+            Cand best{0, 1, -1};
+            for (int i = 0; i < 16; ++i) {
+                int t = tid * 16 + i;
+                Cand c{((uint64_t*)&xs[X_CD])[t], ((uint64_t*)&xs[X_CDEN])[t], ((int32_t*)&xs[X_CB])[t]};
+                if (cand_better(c, best)) best = c;
+            }
+            ((uint64_t*)&xs[X_R])[tid] = best.d;
+            ((uint64_t*)&xs[X_R + 32])[tid] = best.den;
+            ((int32_t*)&xs[X_R + 64])[tid] = best.b;
+        }
+    }
+    TPS_SYNC();
+    Cand best{0, 1, -1};
+    for (int i = 0; i < 16; ++i) {
+        Cand c{((uint64_t*)&xs[X_R])[i], ((uint64_t*)&xs[X_R + 32])[i], ((int32_t*)&xs[X_R + 64])[i]};
+        if (cand_better(c, best)) best = c;
+    }
+    TPS_SYNC();
+    return best;
+}
+
+// Workgroup-wide Binseg over S[0..n): float64 scores, exact fallback when float noise cannot
+// separate the best candidates.  bs: NT dwords, misc: MISC_DW region, xs: XS_DW scratch.
+// A thread owns a chunk of cl = jump * ceil(n / (jump NT)) consecutive windows; chunks of up to
+// CHUNK_REGS windows are read from LDS/HBM once and kept in registers.
+constexpr int CHUNK_REGS = 16;
+template <typename ST>
+TPS_DEV void binseg_wg(const ST* S, int n, int jump, int min_size, int n_patterns, uint32_t* bs, uint32_t* misc,
+                       uint32_t* xs, int& bkp, double& gain) {
+    const int per = (n + jump * NT - 1) / (jump * NT);
+    const int cl = per * jump;
+    const bool in_regs = cl <= CHUNK_REGS;
+    TPS_PHASE {
+        const int lo = tid * cl, hi = lo + cl < n ? lo + cl : n;
+        uint32_t sm = 0;
+        if (in_regs) {
+            TPS_UNROLL
+            for (int i = 0; i < CHUNK_REGS; ++i)
+                if (lo + i < hi) sm += (uint32_t)S[lo + i];
+        } else {
+            for (int i = lo; i < hi; ++i) sm += (uint32_t)S[i];
+        }
+        bs[tid] = sm;
+        if (tid == 0) { *(uint64_t*)&misc[M_MAXSC] = 0ull; misc[M_BESTB] = (uint32_t)-1; misc[M_NTIE] = 0u; }
+    }
+    TPS_SYNC();
+    const uint64_t tot = wg_exclusive_scan(bs, NT, &misc[M_SCAN]);
+    // per-thread best and runner-up scores over its candidates; they stay in registers on the
+    // device and in bs-adjacent scratch (xs) in the emulation, where phases are separate loops
+#ifdef TPS_EMU
+    double* keep = (double*)xs;                   // 3 doubles per thread: best, second, (double)best_b
+#endif
+    double best = -1.0, second = -1.0;
+    int best_b = -1;
+    TPS_PHASE {
+        const int lo = tid * cl, hi = lo + cl < n ? lo + cl : n;
+        uint64_t run = bs[tid];
+        best = -1.0; second = -1.0; best_b = -1;
+        auto visit = [&](int b, uint32_t sv, int& j) {
+            if (j == 0 && b >= min_size && n - b >= min_size) {
+                int64_t d = (int64_t)n * (int64_t)run - (int64_t)tot * (int64_t)b;
+                double sc = score_f64(d, (uint64_t)b * (uint64_t)(n - b));
+                if (sc >= best) { second = best; best = sc; best_b = b; }
+                else if (sc > second) second = sc;
+            }
+            run += (uint64_t)sv;
+            if (++j == jump) j = 0;
+        };
+        int j = 0;
+        if (in_regs) {
+            TPS_UNROLL
+            for (int i = 0; i < CHUNK_REGS; ++i)
+                if (lo + i < hi) visit(lo + i, (uint32_t)S[lo + i], j);
+        } else {
+            for (int b = lo; b < hi; ++b) visit(b, (uint32_t)S[b], j);
+        }
+        uint64_t bits = 0;
+        if (best >= 0.0) __builtin_memcpy(&bits, &best, 8);   // non-negative doubles order like integers
+        wg_max_bits(bits, (uint64_t*)&misc[M_MAXSC]);
+#ifdef TPS_EMU
+        keep[3 * tid] = best; keep[3 * tid + 1] = second; keep[3 * tid + 2] = (double)best_b;
+#endif
+    }
+    TPS_SYNC();
+    TPS_PHASE {
+#ifdef TPS_EMU
+        best = keep[3 * tid]; second = keep[3 * tid + 1]; best_b = (int)keep[3 * tid + 2];
+#endif
+        double m;
+        __builtin_memcpy(&m, &misc[M_MAXSC], 8);
+        const double thr = m * (1.0 - 1e-14);
+        uint32_t near = (best >= thr && best >= 0.0 ? 1u : 0u) + (second >= thr && second >= 0.0 ? 1u : 0u);
+        if (near) lds_add(&misc[M_NTIE], near);
+        if (best == m && best_b >= 0) lds_max_i32((int32_t*)&misc[M_BESTB], best_b);
+    }
+    TPS_SYNC();
+    if (misc[M_NTIE] > 1u) {                      // float noise cannot separate them: exact integers decide
+        Cand ex = binseg_exact_wg(S, n, jump, min_size, xs);
+        bkp = ex.b;
+        gain = ex.b < 0 ? 0.0 : gain_from((int64_t)ex.d, ex.den, n, n_patterns);
+    } else {
+        bkp = (int32_t)misc[M_BESTB];
+        double m;
+        __builtin_memcpy(&m, &misc[M_MAXSC], 8);
+        gain = bkp < 0 ? 0.0 : m / (double)n / ((double)n_patterns * (double)n_patterns);
+        TPS_SYNC();
+    }
+}
 
 // ------------------------------------------------------------------ the per-read program
 // `lds_base` is the workgroup's LDS (dynamic shared memory); `r` the read index.  SV = 0 runs the
@@ -896,17 +977,16 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base) {
     const Stage st_e = stage_plan(seq, L, true, 0, 0, n1);      // last n1 bases, reversed
 
     TPS_STAMP(0);
-    TPS_PHASE {
-        for (int i = tid; i < a.lut_n; i += NT) l.lut[i] = a.lut[i];
-        if (tid < MISC_DW) l.misc[tid] = 0;
-        if (step1)
-            for (int i = tid; i < HIST_DW; i += NT) l.blk[i] = 0;
-    }
+    TPS_PHASE { if (tid < MISC_DW) l.misc[tid] = 0; }
     TPS_SYNC();
     TPS_STAMP(1);
-    if (step1) {
-        TPS_PHASE {
-            // both heads are staged side by side: [0, head_dw) and [head_dw, 2 head_dw)
+    TPS_PHASE {
+        // table load, histogram reset and the staging of both step-1 heads are independent: one
+        // phase, so their global-memory latencies overlap
+        for (int i = tid; i < a.lut_n; i += NT) l.lut[i] = a.lut[i];
+        if (step1) {
+            for (int i = tid; i < HIST_DW; i += NT) l.blk[i] = 0;
+            // the heads are staged side by side: [0, head_dw) and [head_dw, 2 head_dw)
             for (int c = tid; c < 2 * a.head_dw; c += NT) {
                 const int side = c >= a.head_dw;
                 const int cc = c - side * a.head_dw;
@@ -918,8 +998,8 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base) {
                 l.val[c] = bad;
             }
         }
-        TPS_SYNC();
     }
+    TPS_SYNC();
 
     int tail = 0, pass = 1;
     tps_read_result res;
@@ -932,29 +1012,11 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base) {
         TPS_PHASE { trc_count_thread(a, l, st_s, st_e, tid); }
         TPS_SYNC();
         TPS_STAMP(3);
-        TPS_PHASE { trc_sum_thread(a, l, tid); }
+        TPS_PHASE { trc_sum_thread(a, l, st_s, st_e, r, tid); }
         TPS_SYNC();
-        if (l.misc[M_CMASK] | l.misc[M_CMASK + 1]) {
-            TPS_PHASE { trc_fix_thread(a, l, st_s, st_e, tid); }
-            TPS_SYNC();
-        }
-        TPS_PHASE {
-            const int side = tid >> 7, p = tid & 127;
-            if (p < pat.P) {
-                int32_t* dst = side ? a.c_end : a.c_start;
-                if (dst) dst[r * pat.P + p] = (int32_t)l.misc[M_FIN + 32 * side + p];
-            }
-        }
-        // every thread derives the (uniform) decision from the final counts: first maximum wins
-        uint32_t bs = 0, be = 0;
-        int is = 0, ie = 0;
-        for (int p = 0; p < pat.P; ++p) {
-            uint32_t cs = l.misc[M_FIN + p], ce = l.misc[M_FIN + 32 + p];
-            if (cs > bs) { bs = cs; is = p; }
-            if (ce > be) { be = ce; ie = p; }
-        }
-        res.best_start = (int32_t)bs; res.best_start_idx = is;
-        res.best_end = (int32_t)be; res.best_end_idx = ie;
+        const uint32_t ks = l.misc[M_BEST], ke = l.misc[M_BEST + 1];
+        res.best_start = (int32_t)(ks >> 5); res.best_start_idx = 31 - (int32_t)(ks & 31u);
+        res.best_end = (int32_t)(ke >> 5); res.best_end_idx = 31 - (int32_t)(ke & 31u);
         // forward only if strictly larger (allsteps.py:193); strict cutoff and length tests
         tail = res.best_start > res.best_end ? 0 : 1;
         int best = tail ? res.best_end : res.best_start;
@@ -1022,8 +1084,7 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base) {
     if (n_win > 0 && (prm.flags & TPS_F_BINSEG) && binseg_admissible(n_win, prm.jump, prm.min_size)) {
         int bkp;
         double gain;
-        uint32_t* bs = l.Tot;                      // tot_dw >= NT
-        TPS_BINSEG(l.S, n_win, prm.jump, prm.min_size, pat.P, bs, l.misc, l.blk, bkp, gain);
+        binseg_wg(l.S, n_win, prm.jump, prm.min_size, pat.P, l.Tot /* tot_dw >= NT */, l.misc, l.blk, bkp, gain);
         res.bkp = bkp;
         res.gain = gain;
     }
@@ -1043,7 +1104,7 @@ TPS_DEV void binseg_read(const BinsegArgs& a, int64_t r, uint32_t* smem) {
     int bkp = -1;
     double gain = 0.0;
     if (binseg_admissible(n, a.jump, a.min_size)) {
-        TPS_BINSEG(S, n, a.jump, a.min_size, a.n_patterns, bs, misc, xs, bkp, gain);
+        binseg_wg(S, n, a.jump, a.min_size, a.n_patterns, bs, misc, xs, bkp, gain);
     }
     TPS_PHASE {
         if (tid == 0) {
