@@ -64,10 +64,11 @@ extern "C" int emu_scan(const char* pats, int P, int k, const uint8_t* bases, co
     a.c_start = (prm->flags & TPS_F_STEP1) ? c_start : nullptr;
     a.c_end = (prm->flags & TPS_F_STEP1) ? c_end : nullptr;
     a.win_off = win_off.data();
-    a.sums = (prm->flags & TPS_F_STORE_SUMS) ? sums : nullptr;
+    a.sums = sums;                                 // always present, like the library's device buffer
     a.raw = (prm->flags & TPS_F_STORE_RAW) ? raw : nullptr;
     a.n_reads = n;
     a.prm = *prm;
+    std::vector<uint32_t> lutbuf(lut);            // the workgroup-shared table (read-only for the waves)
     std::vector<uint32_t> ldsbuf((size_t)tps::lds_dwords(a) + 16);
     uint32_t* lds_al = (uint32_t*)(((uintptr_t)ldsbuf.data() + 15) & ~(uintptr_t)15);
     struct { uint32_t* p; size_t n; uint32_t* data() { return p; } uint32_t* begin() { return p; } uint32_t* end() { return p + n; } } lds{lds_al, (size_t)tps::lds_dwords(a)};
@@ -76,11 +77,11 @@ extern "C" int emu_scan(const char* pats, int P, int k, const uint8_t* bases, co
         for (auto& w : lds) w = 0xDEADBEEFu;          // LDS content is undefined at workgroup start
         const bool so = a.pat.so_mask != 0;
         switch (a.variant) {
-            case 5: so ? tps::scan_read<5, true>(a, r, lds.data()) : tps::scan_read<5, false>(a, r, lds.data()); break;
-            case 6: so ? tps::scan_read<6, true>(a, r, lds.data()) : tps::scan_read<6, false>(a, r, lds.data()); break;
-            case 7: so ? tps::scan_read<7, true>(a, r, lds.data()) : tps::scan_read<7, false>(a, r, lds.data()); break;
-            case 8: so ? tps::scan_read<8, true>(a, r, lds.data()) : tps::scan_read<8, false>(a, r, lds.data()); break;
-            default: tps::scan_read<0, false>(a, r, lds.data()); break;
+            case 5: so ? tps::scan_read<5, true>(a, r, lds.data(), lutbuf.data()) : tps::scan_read<5, false>(a, r, lds.data(), lutbuf.data()); break;
+            case 6: so ? tps::scan_read<6, true>(a, r, lds.data(), lutbuf.data()) : tps::scan_read<6, false>(a, r, lds.data(), lutbuf.data()); break;
+            case 7: so ? tps::scan_read<7, true>(a, r, lds.data(), lutbuf.data()) : tps::scan_read<7, false>(a, r, lds.data(), lutbuf.data()); break;
+            case 8: so ? tps::scan_read<8, true>(a, r, lds.data(), lutbuf.data()) : tps::scan_read<8, false>(a, r, lds.data(), lutbuf.data()); break;
+            default: tps::scan_read<0, false>(a, r, lds.data(), lutbuf.data()); break;
         }
     }
     return TPS_OK;
@@ -103,6 +104,6 @@ extern "C" int emu_plan(int k, int P, const tps_params* prm, int64_t max_nwin, i
     std::string err = tps::plan_geometry(a, *prm, k, P, max_nwin, lds_budget_bytes / 4, spans_pref, force_generic);
     if (!err.empty()) { g_err = err; return TPS_E_CAPACITY; }
     out10[0] = a.spans_per_tile; out10[1] = a.span_dw; out10[2] = a.blk_log2; out10[3] = a.q; out10[4] = a.r;
-    out10[5] = a.lw; out10[6] = a.seq_dw; out10[7] = (int32_t)(tps::lds_dwords(a) * 4); out10[8] = a.variant; out10[9] = a.rec_rs;
+    out10[5] = a.lw; out10[6] = a.seq_dw; out10[7] = (int32_t)(tps::wg_lds_dwords(a) * 4); out10[8] = a.variant; out10[9] = a.rec_rs;
     return TPS_OK;
 }

@@ -15,10 +15,20 @@
 #include "tps_plan.h"
 
 // ======================================================================== kernels
-#define TPS_SCAN_KERNEL(NAME, SV, SO)                                                      \
-    extern "C" __global__ void __launch_bounds__(tps::NT, (SO) ? 2 : 4) NAME(tps::ScanArgs a) { \
-        extern __shared__ __attribute__((aligned(16))) uint32_t lds[];                     \
-        tps::scan_read<SV, SO>(a, (int64_t)blockIdx.x, lds);                               \
+// One wave per read, tps::WPG waves per workgroup.  The lookup table is loaded once per workgroup
+// (the only workgroup barrier in the kernel); after that every wave runs its own read with
+// wave-level synchronisation only.
+#define TPS_SCAN_KERNEL(NAME, SV, SO)                                                                     \
+    extern "C" __global__ void __launch_bounds__(tps::NT * tps::WPG, (SO) ? 2 : 3) NAME(tps::ScanArgs a) { \
+        extern __shared__ __attribute__((aligned(16))) uint32_t lds[];                                     \
+        uint32_t* lut = lds;                                                                               \
+        for (int i = (int)threadIdx.x; i < a.lut_n; i += tps::NT * tps::WPG) lut[i] = a.lut[i];            \
+        __syncthreads();                                                                                   \
+        const int wave = (int)(threadIdx.x >> 6);                                                          \
+        const int64_t r = (int64_t)blockIdx.x * tps::WPG + wave;                                           \
+        if (r >= a.n_reads) return;                                                                        \
+        const int64_t wave_dw = (tps::lds_dwords(a) + 3) & ~3ll;                                           \
+        tps::scan_read<SV, SO>(a, r, lds + ((a.lut_n + 3) & ~3) + wave * wave_dw, lut);                    \
     }
 TPS_SCAN_KERNEL(tps_scan_kernel, 0, false)          // generic: any slide, up to 31 patterns
 TPS_SCAN_KERNEL(tps_scan_kernel_s5, 5, false)       // specialised: compile-time slide, <= 15 patterns
@@ -30,9 +40,12 @@ TPS_SCAN_KERNEL(tps_scan_kernel_s6so, 6, true)
 TPS_SCAN_KERNEL(tps_scan_kernel_s7so, 7, true)
 TPS_SCAN_KERNEL(tps_scan_kernel_s8so, 8, true)
 
-extern "C" __global__ void __launch_bounds__(tps::NT) tps_binseg_kernel(tps::BinsegArgs a) {
-    __shared__ __attribute__((aligned(16))) uint32_t smem[tps::BINSEG_SMEM_DW];
-    tps::binseg_read(a, (int64_t)blockIdx.x, smem);
+extern "C" __global__ void __launch_bounds__(tps::NT * tps::WPG) tps_binseg_kernel(tps::BinsegArgs a) {
+    __shared__ __attribute__((aligned(16))) uint32_t smem[tps::WPG * tps::BINSEG_SMEM_DW];
+    const int wave = (int)(threadIdx.x >> 6);
+    const int64_t r = (int64_t)blockIdx.x * tps::WPG + wave;
+    if (r >= a.n_reads) return;
+    tps::binseg_read(a, r, smem + wave * tps::BINSEG_SMEM_DW);
 }
 
 // ======================================================================== host side
@@ -108,7 +121,7 @@ struct tps_ctx {
     int spans_override = 0;
     int want_stamps = 0;
     int force_generic = 0;
-    int64_t lds_target_dw = 10 * 1024;
+    int64_t lds_target_dw = 32 * 256;
     size_t lds_set_v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
 
@@ -127,7 +140,7 @@ int plan_lds(tps_ctx* c, Slot& sl, const tps_params& prm, int64_t max_nwin) {
     std::string err = tps::plan_geometry(sl.args, prm, c->pat.k, c->pat.P, max_nwin, (int64_t)lds_max / 4, c->spans_override,
                                          c->force_generic, c->lds_target_dw);
     if (!err.empty()) return fail(TPS_E_CAPACITY, "%s", err.c_str());
-    sl.lds_bytes = (size_t)tps::lds_dwords(sl.args) * 4;
+    sl.lds_bytes = (size_t)tps::wg_lds_dwords(sl.args) * 4;
     return TPS_OK;
 }
 
@@ -136,7 +149,8 @@ int check_params(const tps_params& p) {
         return fail(TPS_E_ARG, "bad window/slide/trimfirst/maxlen/no_bp");
     if ((p.flags & TPS_F_BINSEG) && (p.jump < 1 || p.min_size < 1))
         return fail(TPS_E_ARG, "bad jump/min_size");
-    if (p.slide > 4096 || p.window > 65536) return fail(TPS_E_CAPACITY, "window/slide too large");
+    if (p.slide > 4096 || p.window > 65536 || p.jump > 4096) return fail(TPS_E_CAPACITY, "window/slide/jump too large");
+    if ((p.flags & TPS_F_WINDOWS) && p.jump < 1) return fail(TPS_E_ARG, "jump must be >= 1");
     return TPS_OK;
 }
 
@@ -219,7 +233,9 @@ int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm) {
     a.win_off = (const int64_t*)sl.win_off.p;
     a.sums = nullptr;
     a.raw = nullptr;
-    if (prm.flags & TPS_F_STORE_SUMS) {
+    if (prm.flags & TPS_F_WINDOWS) {
+        // S_w always goes to HBM (4 B per window): it is the step's output and the only copy the
+        // exact change-point fallback can re-read; TPS_F_STORE_SUMS just makes it downloadable
         if ((rc = sl.sums.ensure((size_t)std::max<int64_t>(total_win, 1) * 4))) return rc;
         a.sums = (int32_t*)sl.sums.p;
     }
@@ -271,7 +287,7 @@ int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm) {
     HIP_TRY(hipEventRecord(ep.a, c->stream));
     {
         void* kargs[] = {(void*)&a};
-        HIP_TRY(hipLaunchKernel(kfn, dim3((unsigned)n), dim3(tps::NT), kargs, sl.lds_bytes, c->stream));
+        HIP_TRY(hipLaunchKernel(kfn, dim3((unsigned)((n + tps::WPG - 1) / tps::WPG)), dim3(tps::NT * tps::WPG), kargs, sl.lds_bytes, c->stream));
     }
     HIP_TRY(hipEventRecord(ep.b, c->stream));
     HIP_TRY(hipMemcpyAsync(sl.h_results, sl.results.p, (size_t)n * sizeof(tps_read_result), hipMemcpyDeviceToHost, c->stream));
@@ -530,7 +546,7 @@ int tps_binseg_l2(tps_ctx* c, const int32_t* sums, const int64_t* win_off, int64
     a.n_patterns = n_patterns;
     a.jump = jump;
     a.min_size = min_size;
-    hipLaunchKernelGGL(tps_binseg_kernel, dim3((unsigned)n), dim3(tps::NT), 0, c->stream, a);
+    hipLaunchKernelGGL(tps_binseg_kernel, dim3((unsigned)((n + tps::WPG - 1) / tps::WPG)), dim3(tps::NT * tps::WPG), 0, c->stream, a);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(bkp, a.bkp, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     if (gain) HIP_TRY(hipMemcpyAsync(gain, a.gain, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));

@@ -1,6 +1,6 @@
 // tps_device.h -- per-read scan logic of the telomere k-mer scanner (MI355X / gfx950).
 //
-// One 256-thread workgroup owns one read and runs, in one launch:
+// One WAVE (64 lanes) owns one read and runs, in one launch (4 independent waves per workgroup):
 //   step 1  TRC counts of the first / reversed-last no_bp bases      (allsteps.py:152-204)
 //   step 2  sliding-window k-mer counts S_w of the chosen tail        (allsteps.py:257-297)
 //   step 3  single-split l2 change-point on S_w                      (allsteps.py:300-333)
@@ -36,18 +36,23 @@
 #else
 #define TPS_DEV __device__ __forceinline__
 #define TPS_HD __host__ __device__ inline
-#define TPS_PHASE for (int tid = (int)threadIdx.x, once_ = 1; once_; once_ = 0)
-#define TPS_SYNC() __syncthreads()
+#define TPS_PHASE for (int tid = (int)(threadIdx.x & 63u), once_ = 1; once_; once_ = 0)
+// wave-level synchronisation: a wave's LDS operations execute in issue order, so making earlier LDS
+// writes visible to the other lanes of the SAME wave only needs the compiler not to reorder / cache
+// across this point (no s_barrier, no cross-wave skew)
+#define TPS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 #define TPS_UNROLL _Pragma("unroll")
 #define TPS_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #endif
 
 namespace tps {
 
-constexpr int NT = 256;                           // threads per workgroup (4 waves of 64)
+constexpr int NT = 64;                            // lanes that cooperate on one read: one wave
+constexpr int WPG = 4;                            // independent waves (reads) per workgroup
 constexpr uint32_t FLAG_CONFLICT = 0x80000000u;   // generic path: bit 31 of a block mask
 constexpr uint32_t FLAG16 = 0x8000u;              // specialised path: bit 15 of a 16-bit mask
 constexpr int HIST_COPIES = 16;                   // private step-1 histograms (lane % 16)
+constexpr int WIN_U = 4;                          // windows per lane and group in the window phase
 
 typedef unsigned __int128 u128;
 
@@ -103,7 +108,7 @@ constexpr int clog2(int x) { return x <= 1 ? 0 : 1 + clog2(x / 2); }
 #ifdef TPS_EMU
 #define TPS_STAMP(i) ((void)0)
 #else
-#define TPS_STAMP(i) do { if (a.stamps && threadIdx.x == 0) a.stamps[r * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#define TPS_STAMP(i) do { if (a.stamps && (threadIdx.x & 63u) == 0) a.stamps[r * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
 #endif
 
 // ------------------------------------------------------------------ kernel arguments
@@ -145,7 +150,8 @@ struct ScanArgs {
     int32_t rec_rs;              // specialised path: row stride (records) of the block-record table
     int32_t tot_dw;              // dwords of the Tot array (>= spans_per_tile + 1 and >= NT, even)
     int32_t blk_dw;              // dwords of the block region (also step-1 histograms, Binseg scratch)
-    int32_t s_cap;               // capacity of the S array (u16 entries)
+    int32_t lc_cap;              // capacity of the candidate-prefix array Lc (u32 entries) = max n_win / jump + 1
+    uint32_t jump_magic;         // ceil(2^32 / jump): w / jump == mulhi(w, jump_magic) for w < 2^20
     int32_t q, r, lw;            // window = q full blocks + r positions; lw = W - k start positions
 };
 
@@ -160,7 +166,7 @@ struct BinsegArgs {
 
 // ------------------------------------------------------------------ LDS carve
 constexpr int MISC_DW = 96;
-constexpr int XS_DW = 1728;             // scratch of the exact Binseg tournament (aliases the block region)
+constexpr int XS_DW = 64 + NT + 4 * NT + NT + 16 * 5 + 8;   // scratch of the exact Binseg tournament (aliases the block region)
 constexpr int HIST_DW = 2 * HIST_COPIES * 32;   // step-1 private histograms (alias the block region)
 struct Lds {
     uint32_t* lut;
@@ -176,7 +182,8 @@ struct Lds {
     u32x2* rec;        // per block {suf | preP << 16, C0 | C1 << 16}, index (blk % B) * rec_rs + blk / B
     uint16_t* full;    // per chunk of C blocks: OR of all its block masks
     uint32_t* Tot;     // per span: matches in the span, then exclusive prefix over spans
-    uint16_t* S;       // window sums of the whole read
+    uint32_t* Lc;      // Lc[c] = sum of S_w over w < c * jump: left sums of the change-point candidates
+    uint32_t* row;     // WIN_U * NT dwords: one group of window sums, scanned in place
     uint32_t* misc;
 };
 TPS_HD int64_t blk_region_dw(const ScanArgs& a) {
@@ -191,15 +198,16 @@ TPS_HD int64_t blk_region_dw(const ScanArgs& a) {
     if (need < HIST_DW) need = HIST_DW;
     return (need + 3) & ~3ll;
 }
-TPS_DEV Lds carve(uint32_t* base, const ScanArgs& a) {
+TPS_DEV Lds carve(uint32_t* base, uint32_t* lut, const ScanArgs& a) {
     Lds l;
     uint32_t* p = base;
     l.blk = p;  p += a.blk_dw;                 // first: 16-byte aligned for the 8-byte records
-    l.lut = p;  p += a.lut_n;
+    l.lut = lut;                               // one table per workgroup, shared by its waves
     l.seq2 = p; p += a.seq_dw;
     l.val = p;  p += a.seq_dw;
     l.Tot = p;  p += a.tot_dw;
-    l.S = (uint16_t*)p;  p += ((a.s_cap + 3) / 4) * 2;   // even dword count keeps misc 8-byte aligned
+    l.Lc = p;   p += ((a.lc_cap + 1) / 2) * 2;   // even dword counts keep misc 8-byte aligned
+    l.row = p;  p += WIN_U * NT;
     l.misc = p;
     l.G = l.blk;
     l.Gp = l.G + a.nblk_cap;
@@ -210,8 +218,10 @@ TPS_DEV Lds carve(uint32_t* base, const ScanArgs& a) {
     return l;
 }
 TPS_HD int64_t lds_dwords(const ScanArgs& a) {
-    return (int64_t)a.blk_dw + a.lut_n + 2ll * a.seq_dw + a.tot_dw + ((a.s_cap + 3) / 4) * 2 + MISC_DW;
+    return (int64_t)a.blk_dw + 2ll * a.seq_dw + a.tot_dw + ((a.lc_cap + 1) / 2) * 2 + WIN_U * NT + MISC_DW;   // per wave; + lut_n per workgroup
 }
+// LDS dwords of a whole workgroup: the shared table + WPG wave slices (each rounded to 16 bytes)
+TPS_HD int64_t wg_lds_dwords(const ScanArgs& a) { return ((a.lut_n + 3) & ~3) + (int64_t)WPG * ((lds_dwords(a) + 3) & ~3ll); }
 // misc layout (dwords)
 constexpr int M_BEST = 0;        // 2: step-1 arg-max keys (count << 5 | 31 - pattern) of the two sides
 constexpr int M_CMASK = 64;      // 2: conflict masks of step 1 (start, end)
@@ -221,16 +231,16 @@ constexpr int M_MAXSC = 76;      // u64 (8-byte aligned): best f64 score bits
 constexpr int M_BESTB = 78;      // i32: largest b among the candidates with the best score
 constexpr int M_NTIE = 79;       // candidates within float noise of the best score
 // exact Binseg tournament scratch (dwords, relative to its base)
-constexpr int X_Q = 0;           // 64: scan partials
+constexpr int X_Q = 0;           // 64: scan partials (NT/16 groups + total)
 constexpr int X_BS = 64;         // NT: chunk sums
-constexpr int X_CD = 320;        // NT x u64: candidate |D|
-constexpr int X_CDEN = 832;      // NT x u64: candidate b(n-b)
-constexpr int X_CB = 1344;       // NT x i32: candidate b
-constexpr int X_R = 1600;        // 16 x (u64, u64, i32)
+constexpr int X_CD = X_BS + NT;          // NT x u64: candidate |D|
+constexpr int X_CDEN = X_CD + 2 * NT;    // NT x u64: candidate b(n-b)
+constexpr int X_CB = X_CDEN + 2 * NT;    // NT x i32: candidate b
+constexpr int X_R = X_CB + NT;           // 16 x (u64, u64, i32): second-level reduction
 
 // ------------------------------------------------------------------ workgroup exclusive scan (in place)
-// arr[0..n) in LDS -> exclusive prefix sums; returns the grand total.  Called by every thread of
-// the workgroup outside TPS_PHASE.  scratch: 8 dwords.
+// arr[0..n) in LDS -> exclusive prefix sums; returns the grand total.  Called by every lane of
+// the wave outside TPS_PHASE.
 #ifdef TPS_EMU
 TPS_DEV uint32_t wg_exclusive_scan(uint32_t* arr, int n, uint32_t* scratch) {
     (void)scratch;
@@ -240,9 +250,10 @@ TPS_DEV uint32_t wg_exclusive_scan(uint32_t* arr, int n, uint32_t* scratch) {
 }
 #else
 TPS_DEV uint32_t wg_exclusive_scan(uint32_t* arr, int n, uint32_t* scratch) {
-    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    (void)scratch;
+    const int lane = (int)(threadIdx.x & 63u);
     const int per = (n + NT - 1) / NT;
-    const int lo = tid * per, hi = (lo + per < n) ? lo + per : n;
+    const int lo = lane * per, hi = (lo + per < n) ? lo + per : n;
     uint32_t s = 0;
     for (int i = lo; i < hi; ++i) s += arr[i];
     uint32_t inc = s;
@@ -251,18 +262,11 @@ TPS_DEV uint32_t wg_exclusive_scan(uint32_t* arr, int n, uint32_t* scratch) {
         uint32_t t = __shfl_up(inc, d);
         if (lane >= d) inc += t;
     }
-    if (lane == 63) scratch[wave] = inc;
-    __syncthreads();
-    uint32_t woff = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < NT / 64; ++w) {
-        uint32_t t = scratch[w];
-        if (w < wave) woff += t;
-        total += t;
-    }
-    uint32_t run = woff + inc - s;
+    const uint32_t total = __shfl(inc, 63);
+    uint32_t run = inc - s;
+    TPS_SYNC();
     for (int i = lo; i < hi; ++i) { uint32_t t = arr[i]; arr[i] = run; run += t; }
-    __syncthreads();
+    TPS_SYNC();
     return total;
 }
 #endif
@@ -418,13 +422,13 @@ TPS_DEV void greedy_count(const uint32_t* lut, const uint32_t* seq2, const uint3
 }
 
 // ------------------------------------------------------------------ step 1: TRC counts of both tails
-// Threads 0-127 take the first-bases head, 128-255 the reversed-last-bases head.  A thread handles
+// Lanes 0-31 take the first-bases head, 32-63 the reversed-last-bases head.  A lane handles
 // groups of 8 consecutive start positions: two LDS reads give the 16 packed bases that hold all
 // eight k-mers (k <= 7), the eight table lookups are independent.  Matches go to one of 16
 // private histograms (lane % 16) so that LDS atomics rarely collide.
 TPS_DEV void trc_count_thread(const ScanArgs& a, const Lds& l, const Stage& st_s, const Stage& st_e, int tid) {
     const PatInfo& pat = a.pat;
-    const int side = tid >> 7, t = tid & 127;
+    const int side = tid >> 5, t = tid & 31;
     const int delta = side ? st_e.delta : st_s.delta;
     const uint32_t* seq2 = l.seq2 + side * a.head_dw;
     const uint32_t* val = l.val + side * a.head_dw;
@@ -433,7 +437,7 @@ TPS_DEV void trc_count_thread(const ScanArgs& a, const Lds& l, const Stage& st_s
     const int npos = st_s.n - pat.k + 1;
     uint32_t* hist = l.blk + (side * HIST_COPIES + (tid & (HIST_COPIES - 1))) * 32;
     uint32_t cm = 0;
-    for (int p0 = t * 8; p0 < npos; p0 += 128 * 8) {
+    for (int p0 = t * 8; p0 < npos; p0 += 32 * 8) {
         const int q0 = delta + p0, idx = q0 >> 4;
         const uint32_t sh = (uint32_t)(q0 & 15) * 2u;
         const uint32_t d0 = seq2[idx], d1 = seq2[idx + 1], d2 = seq2[idx + 2];
@@ -465,7 +469,7 @@ TPS_DEV void trc_count_thread(const ScanArgs& a, const Lds& l, const Stage& st_s
 // it leftmost-non-overlapping (sequential, rare); publish the count and bid for the side's
 // arg-max with key = count << 5 | (31 - p), so the FIRST pattern with the largest count wins.
 TPS_DEV void trc_sum_thread(const ScanArgs& a, const Lds& l, const Stage& st_s, const Stage& st_e, int64_t r, int tid) {
-    const int side = tid >> 7, p = tid & 127;
+    const int side = tid >> 5, p = tid & 31;
     if (p < a.pat.P) {
         uint32_t sm = 0;
         TPS_UNROLL
@@ -558,20 +562,42 @@ TPS_DEV uint32_t window_exact(const ScanArgs& a, const Lds& l, int delta, int wl
     return sum;
 }
 
-TPS_DEV void windows_thread(const ScanArgs& a, const Lds& l, int delta, int w0, int nw_tile, int64_t out_base, int tid) {
+// One group of WIN_U * NT consecutive windows of the tile, starting at tile-local window `base`:
+// lane `tid` computes windows base + u*NT + tid, stores S_w to HBM and leaves it in row[u*NT + tid]
+// (0 beyond the tile) for the prefix scan that follows.
+TPS_DEV void windows_group(const ScanArgs& a, const Lds& l, int delta, int w0, int nw_tile, int64_t out_base, int base, int tid) {
     const PatInfo& pat = a.pat;
     const int q = a.q;
-    for (int wl = tid; wl < nw_tile; wl += NT) {
-        uint32_t m = l.Gp[wl + q];
-        for (int i = 0; i < q; ++i) m |= l.G[wl + i];
-        int je = wl + q;
-        uint32_t cnt = ((uint32_t)l.C1[je] + l.Tot[je >> a.blk_log2]) - ((uint32_t)l.C0[wl] + l.Tot[wl >> a.blk_log2]);
-        uint32_t present = m & pat.all_mask;
-        uint32_t sw = cnt + (uint32_t)(pat.P - popc(present));
-        uint8_t* raw_row = a.raw ? a.raw + (out_base + w0 + wl) * (int64_t)pat.P : nullptr;
-        if ((m & FLAG_CONFLICT) || raw_row) sw = window_exact(a, l, delta, wl, present, raw_row);
-        l.S[w0 + wl] = (uint16_t)sw;
-        if (a.sums) a.sums[out_base + w0 + wl] = (int32_t)sw;
+    for (int u = 0; u < WIN_U; ++u) {
+        const int wl = base + u * NT + tid;
+        uint32_t sw = 0;
+        if (wl < nw_tile) {
+            uint32_t m = l.Gp[wl + q];
+            for (int i = 0; i < q; ++i) m |= l.G[wl + i];
+            int je = wl + q;
+            uint32_t cnt = ((uint32_t)l.C1[je] + l.Tot[je >> a.blk_log2]) - ((uint32_t)l.C0[wl] + l.Tot[wl >> a.blk_log2]);
+            uint32_t present = m & pat.all_mask;
+            sw = cnt + (uint32_t)(pat.P - popc(present));
+            uint8_t* raw_row = a.raw ? a.raw + (out_base + w0 + wl) * (int64_t)pat.P : nullptr;
+            if ((m & FLAG_CONFLICT) || raw_row) sw = window_exact(a, l, delta, wl, present, raw_row);
+            a.sums[out_base + w0 + wl] = (int32_t)sw;
+        }
+        l.row[u * NT + tid] = sw;
+    }
+}
+
+// After the in-place exclusive scan of row[]: lane `tid` records the left sums of the change-point
+// candidates among its windows (global window index divisible by jump).
+TPS_DEV void candidates_group(const ScanArgs& a, const Lds& l, int w0, int nw_tile, int base, uint32_t carry, int tid) {
+    const uint32_t jump = (uint32_t)a.prm.jump;
+    TPS_UNROLL
+    for (int u = 0; u < WIN_U; ++u) {
+        const int wl = base + u * NT + tid;
+        if (wl < nw_tile) {
+            const uint32_t w = (uint32_t)(w0 + wl);
+            const uint32_t c = (uint32_t)(((uint64_t)w * a.jump_magic) >> 32);
+            if (c * jump == w && (int)c < a.lc_cap) l.Lc[c] = carry + l.row[u * NT + tid];
+        }
     }
 }
 
@@ -711,39 +737,36 @@ TPS_DEV void blocks_span_slow(const ScanArgs& a, const Lds& l, int delta, int sp
 }
 
 template <int S>
-TPS_DEV void windows_thread_s(const ScanArgs& a, const Lds& l, int delta, int w0, int nw_tile, int64_t out_base, int tid) {
+TPS_DEV void windows_group_s(const ScanArgs& a, const Lds& l, int delta, int w0, int nw_tile, int64_t out_base, int base, int tid) {
     typedef Geo<S> g_;
     constexpr int B = g_::B, LOG2B = g_::LOG2B, LOG2C = g_::LOG2C;
-    constexpr int U = 4;                           // windows in flight per lane
     const PatInfo& pat = a.pat;
     const int q = a.q;
-    for (int base = tid; base < nw_tile; base += U * NT) {
-        uint32_t sw[U], mm[U];
-        TPS_UNROLL
-        for (int u = 0; u < U; ++u) {
-            const int wl = base + u * NT;
-            sw[u] = 0; mm[u] = 0;
-            if (wl < nw_tile) {
-                const int e = wl + q;
-                const u32x2 rw = l.rec[(wl & (B - 1)) * a.rec_rs + (wl >> LOG2B)];
-                const u32x2 re = l.rec[(e & (B - 1)) * a.rec_rs + (e >> LOG2B)];
-                uint32_t m = (rw.x & 0xFFFFu) | (re.x >> 16);
-                for (int c = (wl >> LOG2C) + 1; c < (e >> LOG2C); ++c) m |= l.full[c];
-                uint32_t cnt = ((re.y >> 16) + l.Tot[e >> LOG2B]) - ((rw.y & 0xFFFFu) + l.Tot[wl >> LOG2B]);
-                mm[u] = m;
-                sw[u] = cnt + (uint32_t)(pat.P - popc(m & pat.all_mask));
-            }
+    uint32_t sw[WIN_U], mm[WIN_U];
+    TPS_UNROLL
+    for (int u = 0; u < WIN_U; ++u) {
+        const int wl = base + u * NT + tid;
+        sw[u] = 0; mm[u] = 0;
+        if (wl < nw_tile) {
+            const int e = wl + q;
+            const u32x2 rw = l.rec[(wl & (B - 1)) * a.rec_rs + (wl >> LOG2B)];
+            const u32x2 re = l.rec[(e & (B - 1)) * a.rec_rs + (e >> LOG2B)];
+            uint32_t m = (rw.x & 0xFFFFu) | (re.x >> 16);
+            for (int c = (wl >> LOG2C) + 1; c < (e >> LOG2C); ++c) m |= l.full[c];
+            uint32_t cnt = ((re.y >> 16) + l.Tot[e >> LOG2B]) - ((rw.y & 0xFFFFu) + l.Tot[wl >> LOG2B]);
+            mm[u] = m;
+            sw[u] = cnt + (uint32_t)(pat.P - popc(m & pat.all_mask));
         }
-        TPS_UNROLL
-        for (int u = 0; u < U; ++u) {
-            const int wl = base + u * NT;
-            if (wl < nw_tile) {
-                uint8_t* raw_row = a.raw ? a.raw + (out_base + w0 + wl) * (int64_t)pat.P : nullptr;
-                if ((mm[u] & FLAG16) || raw_row) sw[u] = window_exact(a, l, delta, wl, mm[u] & pat.all_mask, raw_row);
-                l.S[w0 + wl] = (uint16_t)sw[u];
-                if (a.sums) a.sums[out_base + w0 + wl] = (int32_t)sw[u];
-            }
+    }
+    TPS_UNROLL
+    for (int u = 0; u < WIN_U; ++u) {
+        const int wl = base + u * NT + tid;
+        if (wl < nw_tile) {
+            uint8_t* raw_row = a.raw ? a.raw + (out_base + w0 + wl) * (int64_t)pat.P : nullptr;
+            if ((mm[u] & FLAG16) || raw_row) sw[u] = window_exact(a, l, delta, wl, mm[u] & pat.all_mask, raw_row);
+            a.sums[out_base + w0 + wl] = (int32_t)sw[u];
         }
+        l.row[u * NT + tid] = sw[u];
     }
 }
 
@@ -818,8 +841,9 @@ TPS_DEV Cand binseg_exact_wg(const ST* S, int n, int jump, int min_size, uint32_
         xs[X_BS + tid] = sm;
     }
     TPS_SYNC();
+    constexpr int NG = NT / 16;                   // groups of 16 lanes
     TPS_PHASE {
-        if (tid < 16) {
+        if (tid < NG) {
             uint32_t sm = 0;
             for (int i = 0; i < 16; ++i) sm += xs[X_BS + tid * 16 + i];
             xs[X_Q + tid] = sm;
@@ -829,7 +853,7 @@ TPS_DEV Cand binseg_exact_wg(const ST* S, int n, int jump, int min_size, uint32_
     TPS_PHASE {
         if (tid == 0) {
             uint32_t run = 0;
-            for (int i = 0; i < 16; ++i) { uint32_t t = xs[X_Q + i]; xs[X_Q + i] = run; run += t; }
+            for (int i = 0; i < NG; ++i) { uint32_t t = xs[X_Q + i]; xs[X_Q + i] = run; run += t; }
             xs[X_Q + 16] = run;
         }
     }
@@ -845,7 +869,7 @@ TPS_DEV Cand binseg_exact_wg(const ST* S, int n, int jump, int min_size, uint32_
     }
     TPS_SYNC();
     TPS_PHASE {
-        if (tid < 16) {
+        if (tid < NG) {
             Cand best{0, 1, -1};
             for (int i = 0; i < 16; ++i) {
                 int t = tid * 16 + i;
@@ -859,7 +883,7 @@ TPS_DEV Cand binseg_exact_wg(const ST* S, int n, int jump, int min_size, uint32_
     }
     TPS_SYNC();
     Cand best{0, 1, -1};
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < NG; ++i) {
         Cand c{((uint64_t*)&xs[X_R])[i], ((uint64_t*)&xs[X_R + 32])[i], ((int32_t*)&xs[X_R + 64])[i]};
         if (cand_better(c, best)) best = c;
     }
@@ -955,16 +979,74 @@ TPS_DEV void binseg_wg(const ST* S, int n, int jump, int min_size, int n_pattern
     }
 }
 
+// Fused Binseg from the candidate left sums Lc[c] = sum_{w < c*jump} S_w (c = 1 .. (n-1)/jump) and
+// the total T: float64 scores, wave arg-max; if more than one candidate lies within float noise of
+// the best score the exact integer tournament re-reads S_w from HBM (rare).
+TPS_DEV void binseg_from_lc(const uint32_t* Lc, const int32_t* S_global, int n, uint64_t tot, int jump, int min_size,
+                            int n_patterns, uint32_t* misc, uint32_t* xs, int& bkp, double& gain) {
+    const int ncand = (n - 1) / jump;              // candidates b = c*jump, 1 <= c <= ncand  (b < n)
+#ifdef TPS_EMU
+    double* keep = (double*)xs;
+#endif
+    double best = -1.0, second = -1.0;
+    int best_b = -1;
+    TPS_PHASE {
+        if (tid == 0) { *(uint64_t*)&misc[M_MAXSC] = 0ull; misc[M_BESTB] = (uint32_t)-1; misc[M_NTIE] = 0u; }
+    }
+    TPS_SYNC();
+    TPS_PHASE {
+        best = -1.0; second = -1.0; best_b = -1;
+        for (int c = 1 + tid; c <= ncand; c += NT) {
+            const int b = c * jump;
+            if (b >= min_size && n - b >= min_size) {
+                int64_t d = (int64_t)n * (int64_t)Lc[c] - (int64_t)tot * (int64_t)b;
+                double sc = score_f64(d, (uint64_t)b * (uint64_t)(n - b));
+                if (sc >= best) { second = best; best = sc; best_b = b; }
+                else if (sc > second) second = sc;
+            }
+        }
+        uint64_t bits = 0;
+        if (best >= 0.0) __builtin_memcpy(&bits, &best, 8);   // non-negative doubles order like integers
+        wg_max_bits(bits, (uint64_t*)&misc[M_MAXSC]);
+#ifdef TPS_EMU
+        keep[3 * tid] = best; keep[3 * tid + 1] = second; keep[3 * tid + 2] = (double)best_b;
+#endif
+    }
+    TPS_SYNC();
+    TPS_PHASE {
+#ifdef TPS_EMU
+        best = keep[3 * tid]; second = keep[3 * tid + 1]; best_b = (int)keep[3 * tid + 2];
+#endif
+        double m;
+        __builtin_memcpy(&m, &misc[M_MAXSC], 8);
+        const double thr = m * (1.0 - 1e-14);
+        uint32_t near = (best >= thr && best >= 0.0 ? 1u : 0u) + (second >= thr && second >= 0.0 ? 1u : 0u);
+        if (near) lds_add(&misc[M_NTIE], near);
+        if (best == m && best_b >= 0) lds_max_i32((int32_t*)&misc[M_BESTB], best_b);
+    }
+    TPS_SYNC();
+    if (misc[M_NTIE] > 1u) {                      // float noise cannot separate them: exact integers decide
+        Cand ex = binseg_exact_wg(S_global, n, jump, min_size, xs);
+        bkp = ex.b;
+        gain = ex.b < 0 ? 0.0 : gain_from((int64_t)ex.d, ex.den, n, n_patterns);
+    } else {
+        bkp = (int32_t)misc[M_BESTB];
+        double m;
+        __builtin_memcpy(&m, &misc[M_MAXSC], 8);
+        gain = bkp < 0 ? 0.0 : m / (double)n / ((double)n_patterns * (double)n_patterns);
+    }
+}
+
 // ------------------------------------------------------------------ the per-read program
-// `lds_base` is the workgroup's LDS (dynamic shared memory); `r` the read index.  SV = 0 runs the
+// `lds_base` is this wave's LDS slice, `lut` the workgroup's lookup table (already loaded), `r` the read index.  SV = 0 runs the
 // generic block/window path, SV > 0 the path specialised for slide == SV; SO = the pattern table
 // holds self-overlapping k-mers (only meaningful for SV > 0; the generic path tests it at run time).
-// In the device build every thread of the workgroup executes this function; TPS_PHASE bodies
-// run once per thread and TPS_SYNC() is __syncthreads().  In the emulation TPS_PHASE loops
-// over the 256 thread ids, so phases run in program order.
+// In the device build every lane of the wave executes this function; TPS_PHASE bodies run once
+// per lane and TPS_SYNC() is a wave-level fence.  In the emulation TPS_PHASE loops over the 64
+// lane ids, so phases run in program order.
 template <int SV, bool SO>
-TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base) {
-    const Lds l = carve(lds_base, a);
+TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_t* lut) {
+    const Lds l = carve(lds_base, lut, a);
     const PatInfo& pat = a.pat;
     const tps_params& prm = a.prm;
     const int64_t off = a.offsets[r];
@@ -977,13 +1059,11 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base) {
     const Stage st_e = stage_plan(seq, L, true, 0, 0, n1);      // last n1 bases, reversed
 
     TPS_STAMP(0);
-    TPS_PHASE { if (tid < MISC_DW) l.misc[tid] = 0; }
+    TPS_PHASE { for (int i = tid; i < MISC_DW; i += NT) l.misc[i] = 0; }
     TPS_SYNC();
     TPS_STAMP(1);
     TPS_PHASE {
-        // table load, histogram reset and the staging of both step-1 heads are independent: one
-        // phase, so their global-memory latencies overlap
-        for (int i = tid; i < a.lut_n; i += NT) l.lut[i] = a.lut[i];
+        // histogram reset and the staging of both step-1 heads are independent: one phase
         if (step1) {
             for (int i = tid; i < HIST_DW; i += NT) l.blk[i] = 0;
             // the heads are staged side by side: [0, head_dw) and [head_dw, 2 head_dw)
@@ -1031,11 +1111,12 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base) {
     TPS_STAMP(4);
 
     int n_win = 0;
+    uint64_t s_total = 0;                           // sum of S_w so far (uniform across the wave)
     if (pass && (prm.flags & TPS_F_WINDOWS)) {
         const int64_t m = L < prm.maxlen ? L : prm.maxlen;
         const int64_t n_s = m - prm.trimfirst;
         if (n_s >= prm.window) n_win = (int)((n_s - prm.window) / prm.slide) + 1;
-        if (n_win > a.s_cap) n_win = 0;            // host plans s_cap >= max n_win
+        if (n_win / prm.jump + 1 > a.lc_cap) n_win = 0;   // host plans lc_cap from the longest read
         const int blk_per_tile = a.spans_per_tile << a.blk_log2;
         const int tw = blk_per_tile - a.q - 1;     // windows per tile
         const int64_t out_base = a.win_off ? a.win_off[r] : 0;
@@ -1070,11 +1151,17 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base) {
             if (w0 == 0) TPS_STAMP(6);
             wg_exclusive_scan(l.Tot, spans, &l.misc[M_SCAN]);
             if (w0 == 0) TPS_STAMP(7);
-            TPS_PHASE {
-                if constexpr (SV == 0) windows_thread(a, l, st.delta, w0, nw_tile, out_base, tid);
-                else windows_thread_s<SV>(a, l, st.delta, w0, nw_tile, out_base, tid);
+            for (int base = 0; base < nw_tile; base += WIN_U * NT) {
+                TPS_PHASE {
+                    if constexpr (SV == 0) windows_group(a, l, st.delta, w0, nw_tile, out_base, base, tid);
+                    else windows_group_s<SV>(a, l, st.delta, w0, nw_tile, out_base, base, tid);
+                }
+                TPS_SYNC();
+                const uint32_t gsum = wg_exclusive_scan(l.row, WIN_U * NT, &l.misc[M_SCAN]);
+                TPS_PHASE { candidates_group(a, l, w0, nw_tile, base, (uint32_t)s_total, tid); }
+                s_total += gsum;
+                TPS_SYNC();
             }
-            TPS_SYNC();
             if (w0 == 0) TPS_STAMP(8);
         }
     }
@@ -1084,7 +1171,11 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base) {
     if (n_win > 0 && (prm.flags & TPS_F_BINSEG) && binseg_admissible(n_win, prm.jump, prm.min_size)) {
         int bkp;
         double gain;
-        binseg_wg(l.S, n_win, prm.jump, prm.min_size, pat.P, l.Tot /* tot_dw >= NT */, l.misc, l.blk, bkp, gain);
+#ifndef TPS_EMU
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // S_w stores of this wave visible to its (rare) exact re-read
+#endif
+        binseg_from_lc(l.Lc, a.sums + (a.win_off ? a.win_off[r] : 0), n_win, s_total, prm.jump, prm.min_size, pat.P,
+                       l.misc, l.blk, bkp, gain);
         res.bkp = bkp;
         res.gain = gain;
     }
@@ -1092,14 +1183,14 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base) {
     TPS_STAMP(10);
 }
 
-// standalone Binseg over window sums in global memory (tps_binseg_l2)
-constexpr int BINSEG_SMEM_DW = XS_DW + MISC_DW + NT;
+// standalone Binseg over window sums in global memory (tps_binseg_l2); smem = this wave's slice
+constexpr int BINSEG_SMEM_DW = ((XS_DW + 2 + MISC_DW + NT + 3) / 4) * 4;
 TPS_DEV void binseg_read(const BinsegArgs& a, int64_t r, uint32_t* smem) {
     const int64_t lo = a.win_off[r];
     const int n = (int)(a.win_off[r + 1] - lo);
     const int32_t* S = a.sums + lo;
     uint32_t* xs = smem;
-    uint32_t* misc = smem + XS_DW;
+    uint32_t* misc = smem + ((XS_DW + 1) / 2) * 2;
     uint32_t* bs = misc + MISC_DW;
     int bkp = -1;
     double gain = 0.0;

@@ -74,10 +74,11 @@ inline std::string build_patterns(const char* pats, int P, int k, std::vector<ui
 inline bool has_specialised_slide(int s) { return s == 5 || s == 6 || s == 7 || s == 8; }
 
 // Geometry of one scan: fills variant, lut_n, lw/q/r, span_dw, blk_log2, spans_per_tile, nblk_cap,
-// rec_rs, seq_dw, head_dw, tot_dw, blk_dw, s_cap.  budget_dw = LDS dwords one workgroup may use;
-// target_dw = preferred LDS size (occupancy), spans_pref > 0 forces the spans per tile.
+// rec_rs, seq_dw, head_dw, tot_dw, blk_dw, lc_cap, jump_magic.  budget_dw = LDS dwords one workgroup (WPG waves +
+// the shared table) may use; target_dw = preferred workgroup LDS size (occupancy); spans_pref > 0
+// forces the spans per tile.
 inline std::string plan_geometry(ScanArgs& a, const tps_params& prm, int k, int P, int64_t max_nwin, int64_t budget_dw,
-                                 int spans_pref, int force_generic = 0, int64_t target_dw = 10 * 1024) {
+                                 int spans_pref, int force_generic = 0, int64_t target_dw = 32 * 256) {
     a.lut_n = 1 << (2 * k);
     a.lw = std::max(0, prm.window - k);            // k-mer start positions in a (W-1)-char window
     a.q = a.lw / prm.slide;
@@ -90,37 +91,40 @@ inline std::string plan_geometry(ScanArgs& a, const tps_params& prm, int k, int 
     const int chunk = bps < 8 ? bps : 8;
     a.variant = (!force_generic && has_specialised_slide(prm.slide) && P <= 15 && a.q >= chunk) ? prm.slide : 0;
     if (max_nwin > 500000) return "too many windows per read (" + std::to_string(max_nwin) + ")";
-    a.s_cap = (int)std::max<int64_t>(max_nwin, 1);
+    const int jump = std::max(prm.jump, 1);
+    a.lc_cap = (int)(max_nwin / jump + 2);
+    a.jump_magic = (uint32_t)(((1ull << 32) + (uint64_t)jump - 1) / (uint64_t)jump);
     a.head_dw = (prm.no_bp + 30) / 16 + 3;
     const int max_spans = 2 * NT;
     const int min_spans = (a.q + 2 + bps - 1) / bps;        // a tile must hold >= 1 window
     const int64_t need_blk = max_nwin + a.q + 1;            // no more spans than the longest read uses
     const int need_spans = (int)std::min<int64_t>((need_blk + bps - 1) / bps, max_spans);
-    int spans = spans_pref > 0 ? std::min(spans_pref, max_spans) : std::max(need_spans, 1);
+    int spans = spans_pref > 0 ? std::min(spans_pref, max_spans) : std::min(std::max(need_spans, 1), (int)NT);
     spans = std::max(min_spans, std::min(spans, std::max(need_spans, 1)));
     if (spans > max_spans) return "window/slide combination needs " + std::to_string(spans) + " spans per tile (max " + std::to_string(max_spans) + ")";
-    bool shrink_to_target = spans_pref <= 0;
-    for (;;) {
-        a.spans_per_tile = spans;
-        a.nblk_cap = spans * bps;
-        a.rec_rs = ((spans + 31) / 32) * 32 + 32 / bps;
-        a.tot_dw = std::max(((spans + 2) / 2) * 2, (int)NT);
-        a.seq_dw = std::max(spans * a.span_dw + 4, 2 * a.head_dw);
+    auto fill = [&](int sp) {
+        a.spans_per_tile = sp;
+        a.nblk_cap = sp * bps;
+        a.rec_rs = ((sp + 31) / 32) * 32 + 32 / bps;
+        a.tot_dw = std::max(((sp + 2) / 2) * 2, (int)NT);
+        a.seq_dw = std::max(sp * a.span_dw + 4, 2 * a.head_dw);
         a.blk_dw = (int32_t)blk_region_dw(a);
-        const int64_t need = lds_dwords(a);
-        if (need <= (shrink_to_target ? std::min(target_dw, budget_dw) : budget_dw)) break;
-        if (spans <= min_spans) {
-            if (shrink_to_target) { shrink_to_target = false; if (need <= budget_dw) break; }
+        return wg_lds_dwords(a);
+    };
+    if (spans_pref > 0) {
+        if (fill(spans) > budget_dw)
+            return "LDS plan does not fit with " + std::to_string(spans) + " spans per tile";
+        return "";
+    }
+    // prefer one span per lane; halve (down to 16 spans) while the workgroup is above the target,
+    // then keep halving only if it does not fit the hardware budget at all
+    const int floor_spans = std::max(min_spans, std::min(spans, 16));
+    while (fill(spans) > std::min(target_dw, budget_dw) && spans / 2 >= floor_spans) spans = std::max(floor_spans, spans / 2);
+    while (fill(spans) > budget_dw) {
+        if (spans <= min_spans)
             return "LDS plan does not fit: window=" + std::to_string(prm.window) + " slide=" + std::to_string(prm.slide) +
                    " k=" + std::to_string(k) + " windows/read=" + std::to_string(max_nwin);
-        }
-        // prefer a tile count that divides the read evenly
-        int tiles = 2;
-        while (true) {
-            int sp = (int)((need_blk + (int64_t)tiles * bps - 1) / ((int64_t)tiles * bps)) + (a.q + 1 + bps - 1) / bps;
-            if (sp < spans) { spans = std::max(min_spans, sp); break; }
-            if (++tiles > 4096) { spans = std::max(min_spans, spans - 1); break; }
-        }
+        spans = std::max(min_spans, spans / 2);
     }
     return "";
 }
