@@ -17,9 +17,13 @@ sc.lib.tps_debug_stamps_get.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_i
 rc = sc.lib.tps_debug_stamps_get(sc._h, 0, st.ctypes.data_as(C.c_void_p), 10000)
 assert rc == 0
 st = st.astype(np.int64)
-names = ["lut+zero", "stage heads", "trc count", "trc sum+decide", "stage tile0", "blocks tile0", "scan tile0", "windows tile0", "rest tiles", "binseg+result"]
-d = np.diff(st[:, :11], axis=1)
 tot = (st[:, 10] - st[:, 0])
 print("mean total clocks per read:", tot.mean(), " kernel span clocks:", st[:, 10].max() - st[:, 0].min())
-for i, n in enumerate(names):
-    print(f"{n:16s} {d[:, i].mean():10.0f}  {100 * d[:, i].mean() / tot.mean():5.1f}%")
+segs = [("misc zero", 0, 1), ("stage heads", 1, 2), ("trc count", 2, 3), ("trc sum+decide", 3, 4), ("stage tile0", 4, 5),
+        ("t0 blocks (ph1)", 5, 6), ("t0 XT scan", 6, 7), ("t0 windows (ph2)", 7, 11), ("t0 row scan", 11, 12), ("t0 store+cand (ph3)", 12, 8),
+        ("rest tiles", 8, 9), ("binseg+result", 9, 10)]
+for n, a_, b_ in segs:
+    dd = (st[:, b_] - st[:, a_])
+    if (st[:, b_] == 0).all() or (st[:, a_] == 0).all():
+        continue
+    print(f"{n:20s} {dd.mean():10.0f}  {100 * dd.mean() / tot.mean():5.1f}%")

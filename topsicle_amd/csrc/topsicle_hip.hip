@@ -18,31 +18,32 @@
 // One wave per read, tps::WPG waves per workgroup.  The lookup table is loaded once per workgroup
 // (the only workgroup barrier in the kernel); after that every wave runs its own read with
 // wave-level synchronisation only.
-#define TPS_SCAN_KERNEL(NAME, SV, SO)                                                                     \
-    extern "C" __global__ void __launch_bounds__(tps::NT * tps::WPG, (SO) ? 2 : 3) NAME(tps::ScanArgs a) { \
+#define TPS_SCAN_KERNEL(NAME, SV, SO, MINW)                                                                   \
+    extern "C" __global__ void __launch_bounds__(tps::NT * tps::WPG, MINW) NAME(tps::ScanArgs a) {         \
         extern __shared__ __attribute__((aligned(16))) uint32_t lds[];                                     \
         uint32_t* lut = lds;                                                                               \
         for (int i = (int)threadIdx.x; i < a.lut_n; i += tps::NT * tps::WPG) lut[i] = a.lut[i];            \
         __syncthreads();                                                                                   \
-        const int wave = (int)(threadIdx.x >> 6);                                                          \
+        /* readfirstlane: the wave index is uniform -> everything per read lives in SGPRs */              \
+        const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));                          \
         const int64_t r = (int64_t)blockIdx.x * tps::WPG + wave;                                           \
         if (r >= a.n_reads) return;                                                                        \
         const int64_t wave_dw = (tps::lds_dwords(a) + 3) & ~3ll;                                           \
         tps::scan_read<SV, SO>(a, r, lds + ((a.lut_n + 3) & ~3) + wave * wave_dw, lut);                    \
     }
-TPS_SCAN_KERNEL(tps_scan_kernel, 0, false)          // generic: any slide, up to 31 patterns
-TPS_SCAN_KERNEL(tps_scan_kernel_s5, 5, false)       // specialised: compile-time slide, <= 15 patterns
-TPS_SCAN_KERNEL(tps_scan_kernel_s6, 6, false)
-TPS_SCAN_KERNEL(tps_scan_kernel_s7, 7, false)
-TPS_SCAN_KERNEL(tps_scan_kernel_s8, 8, false)
-TPS_SCAN_KERNEL(tps_scan_kernel_s5so, 5, true)      // ... with self-overlapping k-mers in the table
-TPS_SCAN_KERNEL(tps_scan_kernel_s6so, 6, true)
-TPS_SCAN_KERNEL(tps_scan_kernel_s7so, 7, true)
-TPS_SCAN_KERNEL(tps_scan_kernel_s8so, 8, true)
+TPS_SCAN_KERNEL(tps_scan_kernel, 0, false, 4)          // generic: any slide, up to 31 patterns
+TPS_SCAN_KERNEL(tps_scan_kernel_s5, 5, false, 3)       // specialised: compile-time slide, <= 15 patterns
+TPS_SCAN_KERNEL(tps_scan_kernel_s6, 6, false, 3)
+TPS_SCAN_KERNEL(tps_scan_kernel_s7, 7, false, 3)
+TPS_SCAN_KERNEL(tps_scan_kernel_s8, 8, false, 3)
+TPS_SCAN_KERNEL(tps_scan_kernel_s5so, 5, true, 2)      // ... with self-overlapping k-mers in the table
+TPS_SCAN_KERNEL(tps_scan_kernel_s6so, 6, true, 3)
+TPS_SCAN_KERNEL(tps_scan_kernel_s7so, 7, true, 2)
+TPS_SCAN_KERNEL(tps_scan_kernel_s8so, 8, true, 4)
 
 extern "C" __global__ void __launch_bounds__(tps::NT * tps::WPG) tps_binseg_kernel(tps::BinsegArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t smem[tps::WPG * tps::BINSEG_SMEM_DW];
-    const int wave = (int)(threadIdx.x >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t r = (int64_t)blockIdx.x * tps::WPG + wave;
     if (r >= a.n_reads) return;
     tps::binseg_read(a, r, smem + wave * tps::BINSEG_SMEM_DW);
@@ -117,7 +118,8 @@ struct tps_ctx {
     bool have_pat = false;
     Slot slots[TPS_MAX_SLOTS + 1];
     std::vector<EventPair> ev_pool;
-    size_t ev_used = 0;
+    size_t ev_used = 0;      // next free event pair (never rewound: re-recording old events was measured slow)
+    size_t ev_base = 0;      // first pair of the current measurement window
     int spans_override = 0;
     int want_stamps = 0;
     int force_generic = 0;
@@ -270,11 +272,11 @@ int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm) {
         c->lds_set_v[kidx] = sl.lds_bytes;
     }
     if (c->ev_used == c->ev_pool.size()) {
-        if (c->ev_pool.size() >= 8192) {
-            c->ev_used = 0;                               // wrap: oldest timings are dropped
+        if (c->ev_pool.size() >= 16384) {
+            c->ev_used = c->ev_base = 0;                  // wrap: the measurement window restarts
         } else {
             // events are created in batches, never one per launch (hipEventCreate costs ~60 us)
-            const size_t grow = c->ev_pool.empty() ? 256 : c->ev_pool.size();
+            const size_t grow = c->ev_pool.empty() ? 512 : c->ev_pool.size();
             for (size_t i = 0; i < grow; ++i) {
                 EventPair ep;
                 HIP_TRY(hipEventCreate(&ep.a));
@@ -559,14 +561,15 @@ int tps_kernel_time_ms(tps_ctx* c, int32_t* n_launches, double* total_ms, double
     if ((rc = bind(c))) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     double tot = 0.0;
-    for (size_t i = 0; i < c->ev_used; ++i) {
+    for (size_t i = c->ev_base; i < c->ev_used; ++i) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, c->ev_pool[i].a, c->ev_pool[i].b));
         tot += ms;
     }
-    if (n_launches) *n_launches = (int32_t)c->ev_used;
+    const size_t cnt = c->ev_used - c->ev_base;
+    if (n_launches) *n_launches = (int32_t)cnt;
     if (total_ms) *total_ms = tot;
-    if (mean_ms) *mean_ms = c->ev_used ? tot / (double)c->ev_used : 0.0;
+    if (mean_ms) *mean_ms = cnt ? tot / (double)cnt : 0.0;
     return TPS_OK;
 }
 
@@ -585,7 +588,7 @@ int tps_kernel_time_reset(tps_ctx* c) {
     int rc;
     if ((rc = bind(c))) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
-    c->ev_used = 0;
+    c->ev_base = c->ev_used;
     return TPS_OK;
 }
 

@@ -33,6 +33,7 @@
 #define TPS_SYNC() ((void)0)
 #define TPS_UNROLL
 #define TPS_SCHED_BARRIER() ((void)0)
+#define TPS_PIN(x) ((void)0)
 #else
 #define TPS_DEV __device__ __forceinline__
 #define TPS_HD __host__ __device__ inline
@@ -43,6 +44,8 @@
 #define TPS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 #define TPS_UNROLL _Pragma("unroll")
 #define TPS_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+// zero-cost "redefinition" of a register: nothing computed from x can be hoisted above this point
+#define TPS_PIN(x) asm volatile("" : "+v"(x))
 #endif
 
 namespace tps {
@@ -79,6 +82,7 @@ TPS_DEV uint32_t perm(uint32_t s0, uint32_t s1, uint32_t sel) {
 }
 TPS_DEV int popc(uint32_t x) { return __builtin_popcount(x); }
 TPS_DEV int ffs0(uint32_t x) { return __builtin_ctz(x); }
+TPS_DEV uint32_t uniform(uint32_t x) { return x; }
 TPS_DEV void lds_add(uint32_t* p, uint32_t v) { *p += v; }
 TPS_DEV void lds_or(uint32_t* p, uint32_t v) { *p |= v; }
 TPS_DEV void lds_max_u64(uint64_t* p, uint64_t v) { if (v > *p) *p = v; }
@@ -92,6 +96,8 @@ TPS_DEV uint32_t udot4(uint32_t a, uint32_t b) { return __builtin_amdgcn_udot4(a
 TPS_DEV uint32_t perm(uint32_t s0, uint32_t s1, uint32_t sel) { return __builtin_amdgcn_perm(s0, s1, sel); }
 TPS_DEV int popc(uint32_t x) { return __builtin_popcount(x); }
 TPS_DEV int ffs0(uint32_t x) { return __builtin_ctz(x); }
+// a value every lane of the wave agrees on (e.g. read from LDS): tell the compiler it is scalar
+TPS_DEV uint32_t uniform(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 TPS_DEV void lds_add(uint32_t* p, uint32_t v) { atomicAdd(p, v); }
 TPS_DEV void lds_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
 TPS_DEV void lds_max_u64(uint64_t* p, uint64_t v) { atomicMax((unsigned long long*)p, (unsigned long long)v); }
@@ -178,25 +184,33 @@ struct Lds {
     uint32_t* Gp;      // per block: OR over its first r positions
     uint16_t* C0;      // per block: matches before the block (span-local running count)
     uint16_t* C1;      // per block: matches before position r of the block
-    // specialised path views of blk
-    u32x2* rec;        // per block {suf | preP << 16, C0 | C1 << 16}, index (blk % B) * rec_rs + blk / B
-    uint16_t* full;    // per chunk of C blocks: OR of all its block masks
+    // specialised (fused) path views of blk: what a lane publishes for the lanes before it
+    uint16_t* XP;      // [B][XLANES] prefix-OR of the lane's chunk up to (and r positions into) block b
+    uint16_t* XC;      // [B][XLANES] span-local match count before position r of block b
+    uint16_t* XF;      // per chunk of C blocks: OR of all its block masks
+    uint32_t* XT;      // [XLANES] matches in the lane's span, then exclusive prefix over lanes
     uint32_t* Tot;     // per span: matches in the span, then exclusive prefix over spans
     uint32_t* Lc;      // Lc[c] = sum of S_w over w < c * jump: left sums of the change-point candidates
     uint32_t* row;     // WIN_U * NT dwords: one group of window sums, scanned in place
     uint32_t* misc;
 };
+constexpr int XLANES = NT + 16;                  // exchange rows hold NT lanes + halo lanes read past the tile end
+TPS_HD int64_t xchg_dw(const ScanArgs& a) {      // fused path: XP, XC (u16 [B][XLANES]), XF (u16 per chunk), XT (u32 per lane)
+    const int bps = 1 << a.blk_log2;
+    return 2ll * ((bps * XLANES + 1) / 2) + (a.nblk_cap + 32 + 1) / 2 + XLANES;
+}
 TPS_HD int64_t blk_region_dw(const ScanArgs& a) {
-    int64_t need;
-    if (a.variant == 0) {
-        need = 2ll * a.nblk_cap + 2ll * ((a.nblk_cap + 1) / 2);
-    } else {
-        int bps = 1 << a.blk_log2;
-        need = 2ll * bps * a.rec_rs + (a.nblk_cap + 1) / 2 + 2;
-    }
+    // generic arrays G, Gp (u32) and C0, C1 (u16) per block; the specialised kernels also use them for
+    // tiles that hold non-ACGT letters
+    int64_t need = 2ll * a.nblk_cap + 2ll * ((a.nblk_cap + 1) / 2);
+    if (a.variant != 0 && need < xchg_dw(a)) need = xchg_dw(a);
     if (need < XS_DW) need = XS_DW;
     if (need < HIST_DW) need = HIST_DW;
     return (need + 3) & ~3ll;
+}
+TPS_HD int64_t row_dw(const ScanArgs& a) {
+    const int64_t fused = a.variant ? ((int64_t)NT << a.blk_log2) + NT : 0;      // + one pad word per lane
+    return fused > WIN_U * NT ? fused : WIN_U * NT;
 }
 TPS_DEV Lds carve(uint32_t* base, uint32_t* lut, const ScanArgs& a) {
     Lds l;
@@ -207,18 +221,23 @@ TPS_DEV Lds carve(uint32_t* base, uint32_t* lut, const ScanArgs& a) {
     l.val = p;  p += a.seq_dw;
     l.Tot = p;  p += a.tot_dw;
     l.Lc = p;   p += ((a.lc_cap + 1) / 2) * 2;   // even dword counts keep misc 8-byte aligned
-    l.row = p;  p += WIN_U * NT;
+    l.row = p;  p += row_dw(a);
     l.misc = p;
     l.G = l.blk;
     l.Gp = l.G + a.nblk_cap;
     l.C0 = (uint16_t*)(l.Gp + a.nblk_cap);
     l.C1 = l.C0 + ((a.nblk_cap + 1) / 2) * 2;
-    l.rec = (u32x2*)l.blk;
-    l.full = (uint16_t*)(l.blk + 2 * (1 << a.blk_log2) * a.rec_rs);
+    {
+        const int bps = 1 << a.blk_log2;
+        l.XP = (uint16_t*)l.blk;
+        l.XC = l.XP + ((bps * XLANES + 1) / 2) * 2;
+        l.XF = l.XC + ((bps * XLANES + 1) / 2) * 2;
+        l.XT = (uint32_t*)(l.XF + ((a.nblk_cap + 32 + 1) / 2) * 2);
+    }
     return l;
 }
 TPS_HD int64_t lds_dwords(const ScanArgs& a) {
-    return (int64_t)a.blk_dw + 2ll * a.seq_dw + a.tot_dw + ((a.lc_cap + 1) / 2) * 2 + WIN_U * NT + MISC_DW;   // per wave; + lut_n per workgroup
+    return (int64_t)a.blk_dw + 2ll * a.seq_dw + a.tot_dw + ((a.lc_cap + 1) / 2) * 2 + row_dw(a) + MISC_DW;   // per wave; + lut_n per workgroup
 }
 // LDS dwords of a whole workgroup: the shared table + WPG wave slices (each rounded to 16 bytes)
 TPS_HD int64_t wg_lds_dwords(const ScanArgs& a) { return ((a.lut_n + 3) & ~3) + (int64_t)WPG * ((lds_dwords(a) + 3) & ~3ll); }
@@ -241,31 +260,33 @@ constexpr int X_R = X_CB + NT;           // 16 x (u64, u64, i32): second-level r
 // ------------------------------------------------------------------ workgroup exclusive scan (in place)
 // arr[0..n) in LDS -> exclusive prefix sums; returns the grand total.  Called by every lane of
 // the wave outside TPS_PHASE.
+// Logical entry i lives at arr[i + (i >> pad_log2)]: one pad word per 2^pad_log2 entries keeps the
+// per-lane runs (lane l owns entries l*per .. l*per+per-1) on different LDS banks.
+TPS_DEV int padded(int i, int pad_log2) { return i + (i >> pad_log2); }
 #ifdef TPS_EMU
-TPS_DEV uint32_t wg_exclusive_scan(uint32_t* arr, int n, uint32_t* scratch) {
+TPS_DEV uint32_t wg_exclusive_scan(uint32_t* arr, int n, uint32_t* scratch, int pad_log2 = 30) {
     (void)scratch;
     uint32_t run = 0;
-    for (int i = 0; i < n; ++i) { uint32_t t = arr[i]; arr[i] = run; run += t; }
+    for (int i = 0; i < n; ++i) { uint32_t t = arr[padded(i, pad_log2)]; arr[padded(i, pad_log2)] = run; run += t; }
     return run;
 }
 #else
-TPS_DEV uint32_t wg_exclusive_scan(uint32_t* arr, int n, uint32_t* scratch) {
+TPS_DEV uint32_t wg_exclusive_scan(uint32_t* arr, int n, uint32_t* scratch, int pad_log2 = 30) {
     (void)scratch;
     const int lane = (int)(threadIdx.x & 63u);
     const int per = (n + NT - 1) / NT;
     const int lo = lane * per, hi = (lo + per < n) ? lo + per : n;
     uint32_t s = 0;
-    for (int i = lo; i < hi; ++i) s += arr[i];
+    for (int i = lo; i < hi; ++i) s += arr[padded(i, pad_log2)];
     uint32_t inc = s;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         uint32_t t = __shfl_up(inc, d);
         if (lane >= d) inc += t;
     }
-    const uint32_t total = __shfl(inc, 63);
+    const uint32_t total = uniform(__shfl(inc, 63));
     uint32_t run = inc - s;
-    TPS_SYNC();
-    for (int i = lo; i < hi; ++i) { uint32_t t = arr[i]; arr[i] = run; run += t; }
+    for (int i = lo; i < hi; ++i) { uint32_t t = arr[padded(i, pad_log2)]; arr[padded(i, pad_log2)] = run; run += t; }
     TPS_SYNC();
     return total;
 }
@@ -617,157 +638,169 @@ struct Geo {
     static constexpr int LOG2C = clog2(C);
 };
 
+// One fused tile: NT spans (one per lane), blocks AND windows in registers.
+//   phase 1  a lane scans its span (B blocks): per block the suffix-OR of its chunk and the running
+//            count stay in registers; the prefix-OR / count at the partial point go to the exchange
+//            arrays because the windows that END in this lane's blocks belong to earlier lanes.
+//   phase 2  window j of lane L (blocks L*B+j .. +q, plus r positions) = own suffix | full chunks in
+//            between | prefix published by lane L + (j+q)/B for block (j+q)%B; S_w -> row[].
+//   phase 3  (after an exclusive scan of row[]) lane-strided: S_w to HBM coalesced, left sums of the
+//            change-point candidates to Lc[].
+// Windows beyond nw_tile (they need blocks of the next tile) are simply not produced.
 template <int S, bool SO>
-TPS_DEV void blocks_span_s(const ScanArgs& a, const Lds& l, int delta, int span) {
+TPS_DEV void tile_fused_s(const ScanArgs& a, const Lds& l, int delta, int w0, int nw_tile, int64_t out_base,
+                          uint64_t& s_total, int64_t r) {
     typedef Geo<S> g_;
-    constexpr int SPAN = g_::SPAN, B = g_::B, C = g_::C;
+    constexpr int SPAN = g_::SPAN, B = g_::B, C = g_::C, LOG2B = g_::LOG2B, LOG2C = g_::LOG2C;
     const PatInfo& pat = a.pat;
-    const int r = a.r;
+    const int rp = a.r, q = a.q;              // rp: positions of the partial block (a.r)
     const uint32_t kmask = pat.kmask;
-    const uint32_t sh2 = (uint32_t)(delta & 15) * 2u;
-    const int d0 = (delta >> 4) + span * SPAN;
-    uint32_t w[SPAN + 1];
-    {
-        uint32_t prev = l.seq2[d0];
-        TPS_UNROLL
-        for (int i = 0; i <= SPAN; ++i) {
-            uint32_t nx = l.seq2[d0 + i + 1];
-            w[i] = alignbit(nx, prev, sh2);
-            prev = nx;
-        }
-    }
-    uint32_t cnt = 0, run_or = 0;
-    uint32_t pg[C], cc[C];                        // per block of the current chunk: gm | pp << 16, c0 | c1 << 16
-    // table lookups run one block ahead of their use (software pipeline, 2 S values in flight)
-    uint32_t hc[S], vc[S], hn[S], vn[S];
-    auto fetch = [&](int blk, uint32_t* hh, uint32_t* vv) {
-        TPS_UNROLL
-        for (int i = 0; i < S; ++i) {
-            const int p = blk * S + i;            // constant after unrolling
-            const int dw = p >> 4, bit = p & 15;
-            uint32_t v = bit ? alignbit(w[dw + 1], w[dw], 2u * bit) : w[dw];
-            uint32_t h = l.lut[v & kmask];
-            hh[i] = h;
-            vv[i] = v;
-        }
-    };
-    fetch(0, hc, vc);
-    TPS_UNROLL
-    for (int blk = 0; blk < B; ++blk) {
-        const int bc = blk % C;
-        if (blk + 1 < B) fetch(blk + 1, hn, vn);
-        if (bc == 0) run_or = 0;
-        uint32_t g = 0;
-        uint32_t c0 = cnt, c1 = cnt, pp = run_or;
-        TPS_UNROLL
-        for (int i = 0; i < S; ++i) {
-            const uint32_t h = hc[i];
-            if (SO) {
-                if ((h & pat.so_mask) && conflict_bits(pat, vc[i], h)) g |= FLAG16;
-            }
-            g |= h;
-            cnt += (uint32_t)popc(h);
-            if (i + 1 == r) { c1 = cnt; pp = run_or | g; }
-        }
-        pg[bc] = (g & 0xFFFFu) | (pp << 16);
-        cc[bc] = (c0 & 0xFFFFu) | (c1 << 16);
-        run_or |= g;
-        if (bc == C - 1) {                        // chunk complete: suffix ORs, records, chunk total
-            uint32_t sfx = 0;
+    uint32_t sufc0[B];                            // per block: suffix-OR of its chunk | count before it << 16
+#ifdef TPS_EMU
+    uint32_t keep[NT][B];                         // registers that live across the phases
+#endif
+    TPS_PHASE {
+        const int span = tid;
+        const uint32_t sh2 = (uint32_t)(delta & 15) * 2u;
+        const int d0 = (delta >> 4) + span * SPAN;
+        uint32_t w[SPAN + 1];
+        {
+            uint32_t prev = l.seq2[d0];
             TPS_UNROLL
-            for (int j = C - 1; j >= 0; --j) {
-                const int b = blk - (C - 1) + j;
-                sfx |= pg[j] & 0xFFFFu;
-                u32x2 rec;
-                rec.x = sfx | (pg[j] & 0xFFFF0000u);
-                rec.y = cc[j];
-                l.rec[b * a.rec_rs + span] = rec;
+            for (int i = 0; i <= SPAN; ++i) {
+                uint32_t nx = l.seq2[d0 + i + 1];
+                w[i] = alignbit(nx, prev, sh2);
+                prev = nx;
             }
-            l.full[span * (B / C) + blk / C] = (uint16_t)sfx;
         }
-        TPS_UNROLL
-        for (int i = 0; i < S; ++i) { hc[i] = hn[i]; vc[i] = vn[i]; }
-        TPS_SCHED_BARRIER();
-    }
-    l.Tot[span] = cnt;
-}
-
-// Same records as blocks_span_s, written by plain loops with per-position validity checks: used
-// for tiles that hold non-ACGT letters (rare), so the fast path carries no validity logic.
-template <int S>
-TPS_DEV void blocks_span_slow(const ScanArgs& a, const Lds& l, int delta, int span) {
-    typedef Geo<S> g_;
-    constexpr int B = g_::B, C = g_::C;
-    const PatInfo& pat = a.pat;
-    const int r = a.r;
-    const int q0 = delta + span * B * S;          // LDS position of the span's first base
-    uint32_t cnt = 0;
-    for (int ch = 0; ch < B / C; ++ch) {
-        uint32_t run_or = 0;
-        for (int bc = 0; bc < C; ++bc) {
-            const int blk = ch * C + bc;
-            uint32_t g = 0, c0 = cnt, c1 = cnt, pp = run_or;
+        uint32_t cnt = 0, run_or = 0;
+        uint32_t gsave[C];
+        // table lookups run one block ahead of their use (software pipeline, 2 S values in flight)
+        uint32_t hc[S], vc[S], hn[S], vn[S];
+        auto fetch = [&](int blk, uint32_t* hh, uint32_t* vv) {
+            TPS_UNROLL
+            for (int i = 0; i <= SPAN; ++i) TPS_PIN(w[i]);   // keep the k-mer extraction of later blocks from being hoisted
+            TPS_UNROLL
             for (int i = 0; i < S; ++i) {
-                const int q = q0 + blk * S + i;
-                const uint32_t v = v_at(l.seq2, q);
-                uint32_t h = l.lut[v & pat.kmask];
-                if (h && invalid_at(l.val, q, pat.k)) h = 0;
-                if ((h & pat.so_mask) && conflict_bits(pat, v, h)) g |= FLAG16;
+                const int p = blk * S + i;        // constant after unrolling
+                const int dw = p >> 4, bit = p & 15;
+                uint32_t v = bit ? alignbit(w[dw + 1], w[dw], 2u * bit) : w[dw];
+                hh[i] = l.lut[v & kmask];
+                vv[i] = v;
+            }
+        };
+        fetch(0, hc, vc);
+        TPS_UNROLL
+        for (int blk = 0; blk < B; ++blk) {
+            const int bc = blk % C;
+            if (blk + 1 < B) fetch(blk + 1, hn, vn);
+            if (bc == 0) run_or = 0;
+            uint32_t g = 0;
+            uint32_t c0 = cnt, c1 = cnt, pp = run_or;
+            TPS_UNROLL
+            for (int i = 0; i < S; ++i) {
+                const uint32_t h = hc[i];
+                if (SO) {
+                    if ((h & pat.so_mask) && conflict_bits(pat, vc[i], h)) g |= FLAG16;
+                }
                 g |= h;
                 cnt += (uint32_t)popc(h);
-                if (i + 1 == r) { c1 = cnt; pp = run_or | g; }
+                if (i + 1 == rp) { c1 = cnt; pp = run_or | g; }
             }
-            u32x2 rec;
-            rec.x = (g & 0xFFFFu) | (pp << 16);
-            rec.y = (c0 & 0xFFFFu) | (c1 << 16);
-            l.rec[blk * a.rec_rs + span] = rec;
+            l.XP[blk * XLANES + span] = (uint16_t)pp;
+            l.XC[blk * XLANES + span] = (uint16_t)c1;
+            sufc0[blk] = c0 << 16;
+            gsave[bc] = g & 0xFFFFu;
             run_or |= g;
+            if (bc == C - 1) {                    // chunk complete: suffix ORs, chunk total
+                uint32_t sfx = 0;
+                TPS_UNROLL
+                for (int j = C - 1; j >= 0; --j) {
+                    sfx |= gsave[j];
+                    sufc0[blk - (C - 1) + j] |= sfx;
+                }
+                l.XF[span * (B / C) + blk / C] = (uint16_t)sfx;
+            }
+            TPS_UNROLL
+            for (int i = 0; i < S; ++i) { hc[i] = hn[i]; vc[i] = vn[i]; }
+            TPS_SCHED_BARRIER();
         }
-        uint32_t sfx = 0;
-        for (int bc = C - 1; bc >= 0; --bc) {     // suffix ORs over the chunk (re-reads this thread's own records)
-            const int blk = ch * C + bc;
-            u32x2 rec = l.rec[blk * a.rec_rs + span];
-            sfx |= rec.x & 0xFFFFu;
-            rec.x = sfx | (rec.x & 0xFFFF0000u);
-            l.rec[blk * a.rec_rs + span] = rec;
-        }
-        l.full[span * (B / C) + ch] = (uint16_t)sfx;
+        l.XT[span] = cnt;
+#ifdef TPS_EMU
+        for (int j = 0; j < B; ++j) keep[tid][j] = sufc0[j];
+#endif
     }
-    l.Tot[span] = cnt;
-}
-
-template <int S>
-TPS_DEV void windows_group_s(const ScanArgs& a, const Lds& l, int delta, int w0, int nw_tile, int64_t out_base, int base, int tid) {
-    typedef Geo<S> g_;
-    constexpr int B = g_::B, LOG2B = g_::LOG2B, LOG2C = g_::LOG2C;
-    const PatInfo& pat = a.pat;
-    const int q = a.q;
-    uint32_t sw[WIN_U], mm[WIN_U];
-    TPS_UNROLL
-    for (int u = 0; u < WIN_U; ++u) {
-        const int wl = base + u * NT + tid;
-        sw[u] = 0; mm[u] = 0;
-        if (wl < nw_tile) {
-            const int e = wl + q;
-            const u32x2 rw = l.rec[(wl & (B - 1)) * a.rec_rs + (wl >> LOG2B)];
-            const u32x2 re = l.rec[(e & (B - 1)) * a.rec_rs + (e >> LOG2B)];
-            uint32_t m = (rw.x & 0xFFFFu) | (re.x >> 16);
-            for (int c = (wl >> LOG2C) + 1; c < (e >> LOG2C); ++c) m |= l.full[c];
-            uint32_t cnt = ((re.y >> 16) + l.Tot[e >> LOG2B]) - ((rw.y & 0xFFFFu) + l.Tot[wl >> LOG2B]);
-            mm[u] = m;
-            sw[u] = cnt + (uint32_t)(pat.P - popc(m & pat.all_mask));
+    TPS_SYNC();
+    if (w0 == 0) TPS_STAMP(6);
+    wg_exclusive_scan(l.XT, NT, &l.misc[M_SCAN]);
+    if (w0 == 0) TPS_STAMP(7);
+    TPS_PHASE {
+#ifdef TPS_EMU
+        for (int j = 0; j < B; ++j) sufc0[j] = keep[tid][j];
+#endif
+        const int rot = q & (B - 1), dl0 = q >> LOG2B;
+        const uint32_t tot_l = l.XT[tid];
+        uint32_t redo = 0;
+        uint32_t present[(B + 1) / 2];
+        TPS_UNROLL
+        for (int t = 0; t < (B + 1) / 2; ++t) present[t] = 0;
+        TPS_UNROLL
+        for (int j = 0; j < B; ++j) {
+            const int wl = tid * B + j;
+            const int jr = j + rot;                   // uniform: source block index and lane distance
+            const int src = tid + dl0 + (jr >> LOG2B);
+            const int idx = jr & (B - 1);
+            uint32_t m = (sufc0[j] & 0xFFFFu) | l.XP[idx * XLANES + src];
+            // whole chunks strictly between the window's first and last chunk: the count is the same
+            // for every lane (B is a multiple of C), only the first chunk index depends on the lane
+            const int nfull = ((j + q) >> LOG2C) - (j >> LOG2C) - 1;
+            const int ch0 = tid * (B / C) + (j >> LOG2C) + 1;
+            for (int t = 0; t < nfull; ++t) m |= l.XF[ch0 + t];
+            uint32_t cnt = ((uint32_t)l.XC[idx * XLANES + src] + l.XT[src]) - ((sufc0[j] >> 16) + tot_l);
+            uint32_t sw = (cnt & 0xFFFFu) + (uint32_t)(pat.P - popc(m & pat.all_mask));
+            if (wl >= nw_tile) sw = 0;
+            else if ((m & FLAG16) || a.raw) redo |= 1u << j;
+            l.row[padded(wl, LOG2B)] = sw;
+            present[j / 2] |= (m & pat.all_mask) << (16 * (j & 1));
+            if ((j & 3) == 3) TPS_SCHED_BARRIER();
         }
-    }
-    TPS_UNROLL
-    for (int u = 0; u < WIN_U; ++u) {
-        const int wl = base + u * NT + tid;
-        if (wl < nw_tile) {
+        // rare: windows with overlapping occurrences of a self-overlapping k-mer, or raw counts wanted
+        while (redo) {
+            const int j = ffs0(redo);
+            redo &= redo - 1;
+            const int wl = tid * B + j;
+            uint32_t pm = 0;
+            TPS_UNROLL
+            for (int t = 0; t < B / 2; ++t)
+                if (t == (j >> 1)) pm = present[t];
+            pm = (pm >> (16 * (j & 1))) & 0xFFFFu;
             uint8_t* raw_row = a.raw ? a.raw + (out_base + w0 + wl) * (int64_t)pat.P : nullptr;
-            if ((mm[u] & FLAG16) || raw_row) sw[u] = window_exact(a, l, delta, wl, mm[u] & pat.all_mask, raw_row);
-            a.sums[out_base + w0 + wl] = (int32_t)sw[u];
+            l.row[padded(wl, LOG2B)] = window_exact(a, l, delta, wl, pm, raw_row);
         }
-        l.row[u * NT + tid] = sw[u];
     }
+    TPS_SYNC();
+    if (w0 == 0) TPS_STAMP(11);
+    const uint32_t gsum = wg_exclusive_scan(l.row, NT * B, &l.misc[M_SCAN], LOG2B);
+    if (w0 == 0) TPS_STAMP(12);
+    TPS_PHASE {
+        const uint32_t jump = (uint32_t)a.prm.jump;
+        const uint32_t carry = (uint32_t)s_total;
+        TPS_UNROLL
+        for (int u = 0; u < B; ++u) {
+            const int wl = u * NT + tid;
+            if (wl < nw_tile) {
+                const uint32_t pre = l.row[padded(wl, LOG2B)];
+                const uint32_t nxt = (wl + 1 < NT * B) ? l.row[padded(wl + 1, LOG2B)] : gsum;
+                a.sums[out_base + w0 + wl] = (int32_t)(nxt - pre);
+                const uint32_t wg = (uint32_t)(w0 + wl);
+                const uint32_t c = (uint32_t)(((uint64_t)wg * a.jump_magic) >> 32);
+                if (c * jump == wg && (int)c < a.lc_cap) l.Lc[c] = carry + pre;
+            }
+            if (u & 1) TPS_SCHED_BARRIER();
+        }
+    }
+    s_total += gsum;
+    TPS_SYNC();
 }
 
 // ------------------------------------------------------------------ step 3: single-split Binseg (l2)
@@ -1025,12 +1058,12 @@ TPS_DEV void binseg_from_lc(const uint32_t* Lc, const int32_t* S_global, int n, 
         if (best == m && best_b >= 0) lds_max_i32((int32_t*)&misc[M_BESTB], best_b);
     }
     TPS_SYNC();
-    if (misc[M_NTIE] > 1u) {                      // float noise cannot separate them: exact integers decide
+    if (uniform(misc[M_NTIE]) > 1u) {             // float noise cannot separate them: exact integers decide
         Cand ex = binseg_exact_wg(S_global, n, jump, min_size, xs);
         bkp = ex.b;
         gain = ex.b < 0 ? 0.0 : gain_from((int64_t)ex.d, ex.den, n, n_patterns);
     } else {
-        bkp = (int32_t)misc[M_BESTB];
+        bkp = (int32_t)uniform(misc[M_BESTB]);
         double m;
         __builtin_memcpy(&m, &misc[M_MAXSC], 8);
         gain = bkp < 0 ? 0.0 : m / (double)n / ((double)n_patterns * (double)n_patterns);
@@ -1094,7 +1127,7 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
         TPS_STAMP(3);
         TPS_PHASE { trc_sum_thread(a, l, st_s, st_e, r, tid); }
         TPS_SYNC();
-        const uint32_t ks = l.misc[M_BEST], ke = l.misc[M_BEST + 1];
+        const uint32_t ks = uniform(l.misc[M_BEST]), ke = uniform(l.misc[M_BEST + 1]);
         res.best_start = (int32_t)(ks >> 5); res.best_start_idx = 31 - (int32_t)(ks & 31u);
         res.best_end = (int32_t)(ke >> 5); res.best_end_idx = 31 - (int32_t)(ke & 31u);
         // forward only if strictly larger (allsteps.py:193); strict cutoff and length tests
@@ -1120,47 +1153,97 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
         const int blk_per_tile = a.spans_per_tile << a.blk_log2;
         const int tw = blk_per_tile - a.q - 1;     // windows per tile
         const int64_t out_base = a.win_off ? a.win_off[r] : 0;
-        for (int w0 = 0; w0 < n_win; w0 += tw) {
-            const int nw_tile = (n_win - w0) < tw ? (n_win - w0) : tw;
-            const int64_t i0 = (int64_t)w0 * prm.slide;
+        // staging plan of the tile that starts at window w0
+        auto tile_stage = [&](int w0_) {
+            const int64_t i0 = (int64_t)w0_ * prm.slide;
             int64_t n_stage = n_s - i0;
             const int64_t cap = (int64_t)blk_per_tile * prm.slide + 32;
             if (n_stage > cap) n_stage = cap;
-            const Stage st = stage_plan(seq, L, tail == 1, prm.trimfirst, i0, (int)n_stage);
+            return stage_plan(seq, L, tail == 1, prm.trimfirst, i0, (int)n_stage);
+        };
+        // Software prefetch (tiles of at most PF*NT chunks): the 16-byte loads of the NEXT tile are issued
+        // right after the current tile has been packed into LDS and complete while it is being
+        // scanned, so a wave pays the HBM latency once per read instead of once per tile.
+        constexpr int PF = 4;
+        const bool prefetch = a.seq_dw <= PF * NT;
+        u32x4 pf[PF];
+#ifdef TPS_EMU
+        u32x4 pf_keep[NT][PF];
+#endif
+        auto pf_load = [&](const Stage& stn, int tid_) {
+            TPS_UNROLL
+            for (int u = 0; u < PF; ++u) {
+                const int c = tid_ + u * NT;
+                pf[u].x = pf[u].y = pf[u].z = pf[u].w = 0;
+                if (c < a.seq_dw && c < stn.nch) pf[u] = load16(stage_addr(stn, c));
+#ifdef TPS_EMU
+                pf_keep[tid_][u] = pf[u];
+#endif
+            }
+        };
+        if (prefetch && n_win > 0) {
+            const Stage st0 = tile_stage(0);
+            TPS_PHASE { pf_load(st0, tid); }
+        }
+        for (int w0 = 0; w0 < n_win; w0 += tw) {
+            const int nw_tile = (n_win - w0) < tw ? (n_win - w0) : tw;
+            const Stage st = tile_stage(w0);
             // spans needed for this tile's blocks 0 .. nw_tile-1+q (+ the partial block)
             const int blk_need = nw_tile + a.q + 1;
             const int spans = (blk_need + (1 << a.blk_log2) - 1) >> a.blk_log2;
-            const int ndw = spans * a.span_dw + 4 < a.seq_dw ? spans * a.span_dw + 4 : a.seq_dw;
+            int ndw = spans * a.span_dw + 4 < a.seq_dw ? spans * a.span_dw + 4 : a.seq_dw;
+            if (SV != 0 && a.spans_per_tile == NT) ndw = a.seq_dw;   // fused tiles read every lane's span
             TPS_PHASE { if (tid == 0) l.misc[M_INVALID] = 0; }
             TPS_SYNC();
-            TPS_PHASE { stage_thread(st, l.seq2, l.val, ndw, &l.misc[M_INVALID], tid); }
-            TPS_SYNC();
-            if (w0 == 0) TPS_STAMP(5);
-            const bool inv = l.misc[M_INVALID] != 0;
-            TPS_PHASE {
-                for (int sp = tid; sp < spans; sp += NT) {
-                    if constexpr (SV == 0) {
-                        blocks_span(a, l, st.delta, sp);
-                    } else {
-                        if (inv) blocks_span_slow<SV>(a, l, st.delta, sp);
-                        else blocks_span_s<SV, SO>(a, l, st.delta, sp);
+            if (prefetch) {
+                TPS_PHASE {
+                    TPS_UNROLL
+                    for (int u = 0; u < PF; ++u) {
+                        const int c = tid + u * NT;
+#ifdef TPS_EMU
+                        pf[u] = pf_keep[tid][u];
+#endif
+                        if (c < a.seq_dw) {
+                            uint32_t packed = 0, bad = 0;
+                            if (c < st.nch) stage_pack(st, c, pf[u], packed, bad);
+                            if (bad) l.misc[M_INVALID] = 1u;
+                            l.seq2[c] = packed;
+                            l.val[c] = bad;
+                        }
                     }
                 }
+                TPS_SYNC();
+                if (w0 + tw < n_win) {
+                    const Stage stn = tile_stage(w0 + tw);
+                    TPS_PHASE { pf_load(stn, tid); }
+                }
+            } else {
+                TPS_PHASE { stage_thread(st, l.seq2, l.val, ndw, &l.misc[M_INVALID], tid); }
+                TPS_SYNC();
             }
-            TPS_SYNC();
-            if (w0 == 0) TPS_STAMP(6);
-            wg_exclusive_scan(l.Tot, spans, &l.misc[M_SCAN]);
-            if (w0 == 0) TPS_STAMP(7);
-            for (int base = 0; base < nw_tile; base += WIN_U * NT) {
+            if (w0 == 0) TPS_STAMP(5);
+            const bool inv = uniform(l.misc[M_INVALID]) != 0;
+            bool fused = false;
+            if constexpr (SV != 0) fused = !inv && a.spans_per_tile == NT;
+            if (fused) {
+                if constexpr (SV != 0) tile_fused_s<SV, SO>(a, l, st.delta, w0, nw_tile, out_base, s_total, r);
+            } else {
+                // generic tile (any slide / pattern count; also tiles with non-ACGT letters)
                 TPS_PHASE {
-                    if constexpr (SV == 0) windows_group(a, l, st.delta, w0, nw_tile, out_base, base, tid);
-                    else windows_group_s<SV>(a, l, st.delta, w0, nw_tile, out_base, base, tid);
+                    for (int sp = tid; sp < spans; sp += NT) blocks_span(a, l, st.delta, sp);
                 }
                 TPS_SYNC();
-                const uint32_t gsum = wg_exclusive_scan(l.row, WIN_U * NT, &l.misc[M_SCAN]);
-                TPS_PHASE { candidates_group(a, l, w0, nw_tile, base, (uint32_t)s_total, tid); }
-                s_total += gsum;
-                TPS_SYNC();
+                if (w0 == 0) TPS_STAMP(6);
+                wg_exclusive_scan(l.Tot, spans, &l.misc[M_SCAN]);
+                if (w0 == 0) TPS_STAMP(7);
+                for (int base = 0; base < nw_tile; base += WIN_U * NT) {
+                    TPS_PHASE { windows_group(a, l, st.delta, w0, nw_tile, out_base, base, tid); }
+                    TPS_SYNC();
+                    const uint32_t gsum = wg_exclusive_scan(l.row, WIN_U * NT, &l.misc[M_SCAN]);
+                    TPS_PHASE { candidates_group(a, l, w0, nw_tile, base, (uint32_t)s_total, tid); }
+                    s_total += gsum;
+                    TPS_SYNC();
+                }
             }
             if (w0 == 0) TPS_STAMP(8);
         }

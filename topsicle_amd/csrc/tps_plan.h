@@ -89,7 +89,10 @@ inline std::string plan_geometry(ScanArgs& a, const tps_params& prm, int k, int 
     a.blk_log2 = 0;
     while ((1 << a.blk_log2) < bps) ++a.blk_log2;
     const int chunk = bps < 8 ? bps : 8;
-    a.variant = (!force_generic && has_specialised_slide(prm.slide) && P <= 15 && a.q >= chunk) ? prm.slide : 0;
+    // fused kernels: compile-time slide, 16-bit masks, the window must span at least one chunk and its
+    // far end must lie within the exchange halo (XLANES - NT lanes)
+    a.variant = (!force_generic && has_specialised_slide(prm.slide) && P <= 15 && a.q >= chunk && (a.q / bps) + 2 < (XLANES - NT) &&
+                 a.q / chunk < 30) ? prm.slide : 0;
     if (max_nwin > 500000) return "too many windows per read (" + std::to_string(max_nwin) + ")";
     const int jump = std::max(prm.jump, 1);
     a.lc_cap = (int)(max_nwin / jump + 2);
@@ -100,7 +103,8 @@ inline std::string plan_geometry(ScanArgs& a, const tps_params& prm, int k, int 
     const int64_t need_blk = max_nwin + a.q + 1;            // no more spans than the longest read uses
     const int need_spans = (int)std::min<int64_t>((need_blk + bps - 1) / bps, max_spans);
     int spans = spans_pref > 0 ? std::min(spans_pref, max_spans) : std::min(std::max(need_spans, 1), (int)NT);
-    spans = std::max(min_spans, std::min(spans, std::max(need_spans, 1)));
+    if (a.variant && spans_pref <= 0) spans = NT;            // fused tiles: one span per lane, always
+    if (!(a.variant && spans_pref <= 0)) spans = std::max(min_spans, std::min(spans, std::max(need_spans, 1)));
     if (spans > max_spans) return "window/slide combination needs " + std::to_string(spans) + " spans per tile (max " + std::to_string(max_spans) + ")";
     auto fill = [&](int sp) {
         a.spans_per_tile = sp;
@@ -118,8 +122,7 @@ inline std::string plan_geometry(ScanArgs& a, const tps_params& prm, int k, int 
     }
     // prefer one span per lane; halve (down to 16 spans) while the workgroup is above the target,
     // then keep halving only if it does not fit the hardware budget at all
-    const int floor_spans = std::max(min_spans, std::min(spans, 16));
-    while (fill(spans) > std::min(target_dw, budget_dw) && spans / 2 >= floor_spans) spans = std::max(floor_spans, spans / 2);
+    (void)target_dw;
     while (fill(spans) > budget_dw) {
         if (spans <= min_spans)
             return "LDS plan does not fit: window=" + std::to_string(prm.window) + " slide=" + std::to_string(prm.slide) +
