@@ -35,7 +35,7 @@ TPS_SCAN_KERNEL(tps_scan_kernel, 0, false, 4)          // generic: any slide, up
 TPS_SCAN_KERNEL(tps_scan_kernel_s5, 5, false, 3)       // specialised: compile-time slide, <= 15 patterns
 TPS_SCAN_KERNEL(tps_scan_kernel_s6, 6, false, 3)
 TPS_SCAN_KERNEL(tps_scan_kernel_s7, 7, false, 3)
-TPS_SCAN_KERNEL(tps_scan_kernel_s8, 8, false, 3)
+TPS_SCAN_KERNEL(tps_scan_kernel_s8, 8, false, 4)
 TPS_SCAN_KERNEL(tps_scan_kernel_s5so, 5, true, 2)      // ... with self-overlapping k-mers in the table
 TPS_SCAN_KERNEL(tps_scan_kernel_s6so, 6, true, 3)
 TPS_SCAN_KERNEL(tps_scan_kernel_s7so, 7, true, 2)

@@ -104,7 +104,17 @@ TPS_DEV void lds_max_u64(uint64_t* p, uint64_t v) { atomicMax((unsigned long lon
 TPS_DEV void lds_max_i32(int32_t* p, int32_t v) { atomicMax(p, v); }
 typedef uint4 u32x4;
 typedef uint2 u32x2;
-TPS_DEV u32x4 load16(const uint8_t* p) { return *reinterpret_cast<const uint4*>(p); }
+// 16-byte load that is KNOWN to hit global memory: the address was rebuilt from an integer (aligned
+// down), which makes the compiler fall back to FLAT loads -- those also count on lgkmcnt and would
+// stall every LDS wait behind the prefetch.  An explicit global address space keeps them on vmcnt.
+TPS_DEV u32x4 load16(const uint8_t* p) {
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(1))) v4u* gptr_t;
+    const v4u t = *(gptr_t)(uintptr_t)p;
+    u32x4 r;
+    r.x = t.x; r.y = t.y; r.z = t.z; r.w = t.w;
+    return r;
+}
 #endif
 
 constexpr int cgcd(int a, int b) { return b == 0 ? a : cgcd(b, a % b); }
@@ -173,7 +183,8 @@ struct BinsegArgs {
 // ------------------------------------------------------------------ LDS carve
 constexpr int MISC_DW = 96;
 constexpr int XS_DW = 64 + NT + 4 * NT + NT + 16 * 5 + 8;   // scratch of the exact Binseg tournament (aliases the block region)
-constexpr int HIST_DW = 2 * HIST_COPIES * 32;   // step-1 private histograms (alias the block region)
+constexpr int HIST_STRIDE = 33;          // odd stride: the copies of one pattern sit on different LDS banks
+constexpr int HIST_DW = 2 * HIST_COPIES * HIST_STRIDE;   // step-1 private histograms (alias the block region)
 struct Lds {
     uint32_t* lut;
     uint32_t* seq2;    // 2-bit packed bases, 16 per dword
@@ -278,13 +289,15 @@ TPS_DEV uint32_t wg_exclusive_scan(uint32_t* arr, int n, uint32_t* scratch, int 
     const int lo = lane * per, hi = (lo + per < n) ? lo + per : n;
     uint32_t s = 0;
     for (int i = lo; i < hi; ++i) s += arr[padded(i, pad_log2)];
+    // inclusive wave scan with DPP row shifts / broadcasts: six VALU adds, no LDS round trips
     uint32_t inc = s;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(inc, d);
-        if (lane >= d) inc += t;
-    }
-    const uint32_t total = uniform(__shfl(inc, 63));
+    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xf, 0xf, false);   // row_shr:1
+    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xf, 0xf, false);   // row_shr:2
+    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xf, 0xf, false);   // row_shr:4
+    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xf, 0xf, false);   // row_shr:8
+    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
     uint32_t run = inc - s;
     for (int i = lo; i < hi; ++i) { uint32_t t = arr[padded(i, pad_log2)]; arr[padded(i, pad_log2)] = run; run += t; }
     TPS_SYNC();
@@ -456,7 +469,7 @@ TPS_DEV void trc_count_thread(const ScanArgs& a, const Lds& l, const Stage& st_s
     const bool inv = l.misc[M_INVALID] != 0;
     const bool so = pat.so_mask != 0;
     const int npos = st_s.n - pat.k + 1;
-    uint32_t* hist = l.blk + (side * HIST_COPIES + (tid & (HIST_COPIES - 1))) * 32;
+    uint32_t* hist = l.blk + (side * HIST_COPIES + (tid & (HIST_COPIES - 1))) * HIST_STRIDE;
     uint32_t cm = 0;
     for (int p0 = t * 8; p0 < npos; p0 += 32 * 8) {
         const int q0 = delta + p0, idx = q0 >> 4;
@@ -494,7 +507,7 @@ TPS_DEV void trc_sum_thread(const ScanArgs& a, const Lds& l, const Stage& st_s, 
     if (p < a.pat.P) {
         uint32_t sm = 0;
         TPS_UNROLL
-        for (int c = 0; c < HIST_COPIES; ++c) sm += l.blk[(side * HIST_COPIES + c) * 32 + p];
+        for (int c = 0; c < HIST_COPIES; ++c) sm += l.blk[(side * HIST_COPIES + c) * HIST_STRIDE + p];
         if ((l.misc[M_CMASK + side] >> p) & 1u) {
             int occ, g;
             greedy_count(l.lut, l.seq2 + side * a.head_dw, l.val + side * a.head_dw, a.pat, side ? st_e.delta : st_s.delta,
@@ -1151,7 +1164,12 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
         if (n_s >= prm.window) n_win = (int)((n_s - prm.window) / prm.slide) + 1;
         if (n_win / prm.jump + 1 > a.lc_cap) n_win = 0;   // host plans lc_cap from the longest read
         const int blk_per_tile = a.spans_per_tile << a.blk_log2;
-        const int tw = blk_per_tile - a.q - 1;     // windows per tile
+        // fused tiles stage exactly NT * SPAN dwords (SPAN 16-byte loads per lane): the last span(s) of the
+        // tile are halo only, so their windows move to the next tile
+        constexpr int FSPAN = SV ? Geo<SV ? SV : 1>::SPAN : 1;
+        constexpr int FDROP = SV ? (FSPAN >= 2 ? 1 : 2) : 0;
+        const bool fused_plan = SV != 0 && a.spans_per_tile == NT;
+        const int tw = blk_per_tile - a.q - 1 - (fused_plan ? (FDROP << a.blk_log2) : 0);     // windows per tile
         const int64_t out_base = a.win_off ? a.win_off[r] : 0;
         // staging plan of the tile that starts at window w0
         auto tile_stage = [&](int w0_) {
@@ -1164,8 +1182,9 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
         // Software prefetch (tiles of at most PF*NT chunks): the 16-byte loads of the NEXT tile are issued
         // right after the current tile has been packed into LDS and complete while it is being
         // scanned, so a wave pays the HBM latency once per read instead of once per tile.
-        constexpr int PF = 4;
-        const bool prefetch = a.seq_dw <= PF * NT;
+        constexpr int PF = FSPAN;
+        const bool prefetch = fused_plan;
+        const int pf_dw = NT * PF;                 // dwords staged per fused tile
         u32x4 pf[PF];
 #ifdef TPS_EMU
         u32x4 pf_keep[NT][PF];
@@ -1175,7 +1194,7 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
             for (int u = 0; u < PF; ++u) {
                 const int c = tid_ + u * NT;
                 pf[u].x = pf[u].y = pf[u].z = pf[u].w = 0;
-                if (c < a.seq_dw && c < stn.nch) pf[u] = load16(stage_addr(stn, c));
+                if (c < stn.nch) pf[u] = load16(stage_addr(stn, c));
 #ifdef TPS_EMU
                 pf_keep[tid_][u] = pf[u];
 #endif
@@ -1192,7 +1211,6 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
             const int blk_need = nw_tile + a.q + 1;
             const int spans = (blk_need + (1 << a.blk_log2) - 1) >> a.blk_log2;
             int ndw = spans * a.span_dw + 4 < a.seq_dw ? spans * a.span_dw + 4 : a.seq_dw;
-            if (SV != 0 && a.spans_per_tile == NT) ndw = a.seq_dw;   // fused tiles read every lane's span
             TPS_PHASE { if (tid == 0) l.misc[M_INVALID] = 0; }
             TPS_SYNC();
             if (prefetch) {
@@ -1203,7 +1221,7 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
 #ifdef TPS_EMU
                         pf[u] = pf_keep[tid][u];
 #endif
-                        if (c < a.seq_dw) {
+                        if (c < pf_dw) {
                             uint32_t packed = 0, bad = 0;
                             if (c < st.nch) stage_pack(st, c, pf[u], packed, bad);
                             if (bad) l.misc[M_INVALID] = 1u;
@@ -1224,7 +1242,7 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
             if (w0 == 0) TPS_STAMP(5);
             const bool inv = uniform(l.misc[M_INVALID]) != 0;
             bool fused = false;
-            if constexpr (SV != 0) fused = !inv && a.spans_per_tile == NT;
+            if constexpr (SV != 0) fused = !inv && fused_plan;
             if (fused) {
                 if constexpr (SV != 0) tile_fused_s<SV, SO>(a, l, st.delta, w0, nw_tile, out_base, s_total, r);
             } else {
