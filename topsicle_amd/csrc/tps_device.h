@@ -460,14 +460,17 @@ TPS_DEV void greedy_count(const uint32_t* lut, const uint32_t* seq2, const uint3
 // groups of 8 consecutive start positions: two LDS reads give the 16 packed bases that hold all
 // eight k-mers (k <= 7), the eight table lookups are independent.  Matches go to one of 16
 // private histograms (lane % 16) so that LDS atomics rarely collide.
+template <bool PLAIN>
 TPS_DEV void trc_count_thread(const ScanArgs& a, const Lds& l, const Stage& st_s, const Stage& st_e, int tid) {
+    // PLAIN: no non-ACGT letter staged, no self-overlapping k-mer, no duplicate in the pattern list --
+    // the common case, one predicated LDS atomic per matching position and nothing else.
     const PatInfo& pat = a.pat;
     const int side = tid >> 5, t = tid & 31;
     const int delta = side ? st_e.delta : st_s.delta;
     const uint32_t* seq2 = l.seq2 + side * a.head_dw;
     const uint32_t* val = l.val + side * a.head_dw;
-    const bool inv = l.misc[M_INVALID] != 0;
-    const bool so = pat.so_mask != 0;
+    const bool inv = !PLAIN && l.misc[M_INVALID] != 0;
+    const bool so = !PLAIN && pat.so_mask != 0;
     const int npos = st_s.n - pat.k + 1;
     uint32_t* hist = l.blk + (side * HIST_COPIES + (tid & (HIST_COPIES - 1))) * HIST_STRIDE;
     uint32_t cm = 0;
@@ -486,18 +489,22 @@ TPS_DEV void trc_count_thread(const ScanArgs& a, const Lds& l, const Stage& st_s
         for (int j = 0; j < 8; ++j) {
             uint32_t hj = h[j];
             if (p0 + j >= npos) hj = 0;
-            if (hj && inv && invalid_at(val, q0 + j, pat.k)) hj = 0;
-            if (hj) {
-                if (so && (hj & pat.so_mask)) cm |= conflict_bits(pat, v[j], hj);
-                do {
-                    int b = ffs0(hj);
-                    hj &= hj - 1;
-                    lds_add(&hist[b], 1u);
-                } while (hj);
+            if (PLAIN) {
+                if (hj) lds_add(&hist[ffs0(hj)], 1u);
+            } else {
+                if (hj && inv && invalid_at(val, q0 + j, pat.k)) hj = 0;
+                if (hj) {
+                    if (so && (hj & pat.so_mask)) cm |= conflict_bits(pat, v[j], hj);
+                    do {
+                        int b = ffs0(hj);
+                        hj &= hj - 1;
+                        lds_add(&hist[b], 1u);
+                    } while (hj);
+                }
             }
         }
     }
-    if (cm) lds_or(&l.misc[M_CMASK + side], cm);
+    if (!PLAIN && cm) lds_or(&l.misc[M_CMASK + side], cm);
 }
 // Thread (side, p): sum the private histograms; if pattern p has overlapping occurrences, recount
 // it leftmost-non-overlapping (sequential, rare); publish the count and bid for the side's
@@ -1135,7 +1142,11 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
 
     TPS_STAMP(2);
     if (step1) {
-        TPS_PHASE { trc_count_thread(a, l, st_s, st_e, tid); }
+        if (uniform(l.misc[M_INVALID]) == 0 && pat.so_mask == 0 && pat.dup_mask == 0) {
+            TPS_PHASE { trc_count_thread<true>(a, l, st_s, st_e, tid); }
+        } else {
+            TPS_PHASE { trc_count_thread<false>(a, l, st_s, st_e, tid); }
+        }
         TPS_SYNC();
         TPS_STAMP(3);
         TPS_PHASE { trc_sum_thread(a, l, st_s, st_e, r, tid); }
