@@ -122,6 +122,9 @@ struct tps_ctx {
     size_t ev_base = 0;      // first pair of the current measurement window
     int spans_override = 0;
     int want_stamps = 0;
+    int no_events = 0;
+    int no_copy = 0;
+    int zero_copy = 1;       // per-read results are written by the kernel straight into mapped pinned host memory
     int force_generic = 0;
     int64_t lds_target_dw = 32 * 256;
     size_t lds_set_v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -216,7 +219,7 @@ int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm) {
         if (sl.h_results) (void)hipHostFree(sl.h_results);
         sl.h_results = nullptr;
         size_t want = (size_t)n + (size_t)n / 8 + 16;
-        HIP_TRY(hipHostMalloc((void**)&sl.h_results, want * sizeof(tps_read_result), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void**)&sl.h_results, want * sizeof(tps_read_result), hipHostMallocMapped));
         sl.h_results_cap = want;
     }
     tps::ScanArgs& a = sl.args;
@@ -224,7 +227,7 @@ int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm) {
     a.offsets = (const int64_t*)sl.offsets.p;
     a.tails_in = ((prm.flags & TPS_F_TAILS_IN) && !(prm.flags & TPS_F_STEP1)) ? (const uint8_t*)sl.tails.p : nullptr;
     a.lut = (const uint32_t*)c->lut.p;
-    a.results = (tps_read_result*)sl.results.p;
+    a.results = c->zero_copy ? sl.h_results : (tps_read_result*)sl.results.p;
     a.c_start = a.c_end = nullptr;
     if (prm.flags & TPS_F_STEP1) {
         if ((rc = sl.c_start.ensure((size_t)std::max<int64_t>(n * P, 1) * 4))) return rc;
@@ -285,14 +288,14 @@ int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm) {
             }
         }
     }
-    EventPair& ep = c->ev_pool[c->ev_used++];
-    HIP_TRY(hipEventRecord(ep.a, c->stream));
+    EventPair& ep = c->ev_pool[c->no_events ? 0 : c->ev_used++];
+    if (!c->no_events) HIP_TRY(hipEventRecord(ep.a, c->stream));
     {
         void* kargs[] = {(void*)&a};
         HIP_TRY(hipLaunchKernel(kfn, dim3((unsigned)((n + tps::WPG - 1) / tps::WPG)), dim3(tps::NT * tps::WPG), kargs, sl.lds_bytes, c->stream));
     }
-    HIP_TRY(hipEventRecord(ep.b, c->stream));
-    HIP_TRY(hipMemcpyAsync(sl.h_results, sl.results.p, (size_t)n * sizeof(tps_read_result), hipMemcpyDeviceToHost, c->stream));
+    if (!c->no_events) HIP_TRY(hipEventRecord(ep.b, c->stream));
+    if (!c->no_copy && !c->zero_copy) HIP_TRY(hipMemcpyAsync(sl.h_results, sl.results.p, (size_t)n * sizeof(tps_read_result), hipMemcpyDeviceToHost, c->stream));
     sl.scanned = true;
     return TPS_OK;
 }
@@ -338,6 +341,9 @@ int tps_ctx_create(int device, tps_ctx** out) {
     }
     if (const char* s = getenv("TPS_SPANS_PER_TILE")) c->spans_override = atoi(s);
     if (const char* s = getenv("TPS_FORCE_GENERIC")) c->force_generic = atoi(s);
+    if (const char* s = getenv("TPS_NO_EVENTS")) c->no_events = atoi(s);
+    if (const char* s = getenv("TPS_NO_COPY")) c->no_copy = atoi(s);
+    if (const char* s = getenv("TPS_ZERO_COPY")) c->zero_copy = atoi(s);
     if (const char* s = getenv("TPS_LDS_TARGET_KB")) c->lds_target_dw = (int64_t)atoi(s) * 256;
     *out = c;
     return TPS_OK;
