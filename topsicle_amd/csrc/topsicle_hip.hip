@@ -35,11 +35,11 @@ TPS_SCAN_KERNEL(tps_scan_kernel, 0, false, 4)          // generic: any slide, up
 TPS_SCAN_KERNEL(tps_scan_kernel_s5, 5, false, 3)       // specialised: compile-time slide, <= 15 patterns
 TPS_SCAN_KERNEL(tps_scan_kernel_s6, 6, false, 3)
 TPS_SCAN_KERNEL(tps_scan_kernel_s7, 7, false, 3)
-TPS_SCAN_KERNEL(tps_scan_kernel_s8, 8, false, 4)
-TPS_SCAN_KERNEL(tps_scan_kernel_s5so, 5, true, 2)      // ... with self-overlapping k-mers in the table
+TPS_SCAN_KERNEL(tps_scan_kernel_s8, 8, false, 3)
+TPS_SCAN_KERNEL(tps_scan_kernel_s5so, 5, true, 3)      // ... with self-overlapping k-mers in the table
 TPS_SCAN_KERNEL(tps_scan_kernel_s6so, 6, true, 3)
-TPS_SCAN_KERNEL(tps_scan_kernel_s7so, 7, true, 2)
-TPS_SCAN_KERNEL(tps_scan_kernel_s8so, 8, true, 4)
+TPS_SCAN_KERNEL(tps_scan_kernel_s7so, 7, true, 3)
+TPS_SCAN_KERNEL(tps_scan_kernel_s8so, 8, true, 3)
 
 extern "C" __global__ void __launch_bounds__(tps::NT * tps::WPG) tps_binseg_kernel(tps::BinsegArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t smem[tps::WPG * tps::BINSEG_SMEM_DW];

@@ -54,7 +54,7 @@ constexpr int NT = 64;                            // lanes that cooperate on one
 constexpr int WPG = 4;                            // independent waves (reads) per workgroup
 constexpr uint32_t FLAG_CONFLICT = 0x80000000u;   // generic path: bit 31 of a block mask
 constexpr uint32_t FLAG16 = 0x8000u;              // specialised path: bit 15 of a 16-bit mask
-constexpr int HIST_COPIES = 16;                   // private step-1 histograms (lane % 16)
+constexpr int HIST_COPIES = 8;                    // private step-1 histograms (lane % 8)
 constexpr int WIN_U = 4;                          // windows per lane and group in the window phase
 
 typedef unsigned __int128 u128;
@@ -208,13 +208,11 @@ struct Lds {
 constexpr int XLANES = NT + 16;                  // exchange rows hold NT lanes + halo lanes read past the tile end
 TPS_HD int64_t xchg_dw(const ScanArgs& a) {      // fused path: XP, XC (u16 [B][XLANES]), XF (u16 per chunk), XT (u32 per lane)
     const int bps = 1 << a.blk_log2;
-    return 2ll * ((bps * XLANES + 1) / 2) + (a.nblk_cap + 32 + 1) / 2 + XLANES;
+    return 2ll * ((bps * XLANES + 1) / 2) + (XLANES + 1) / 2 + XLANES;
 }
 TPS_HD int64_t blk_region_dw(const ScanArgs& a) {
-    // generic arrays G, Gp (u32) and C0, C1 (u16) per block; the specialised kernels also use them for
-    // tiles that hold non-ACGT letters
-    int64_t need = 2ll * a.nblk_cap + 2ll * ((a.nblk_cap + 1) / 2);
-    if (a.variant != 0 && need < xchg_dw(a)) need = xchg_dw(a);
+    // generic kernel: G, Gp (u32) and C0, C1 (u16) per block; fused kernels: the exchange arrays
+    int64_t need = a.variant ? xchg_dw(a) : 2ll * a.nblk_cap + 2ll * ((a.nblk_cap + 1) / 2);
     if (need < XS_DW) need = XS_DW;
     if (need < HIST_DW) need = HIST_DW;
     return (need + 3) & ~3ll;
@@ -243,7 +241,7 @@ TPS_DEV Lds carve(uint32_t* base, uint32_t* lut, const ScanArgs& a) {
         l.XP = (uint16_t*)l.blk;
         l.XC = l.XP + ((bps * XLANES + 1) / 2) * 2;
         l.XF = l.XC + ((bps * XLANES + 1) / 2) * 2;
-        l.XT = (uint32_t*)(l.XF + ((a.nblk_cap + 32 + 1) / 2) * 2);
+        l.XT = (uint32_t*)(l.XF + ((XLANES + 1) / 2) * 2);
     }
     return l;
 }
@@ -650,12 +648,18 @@ TPS_DEV void candidates_group(const ScanArgs& a, const Lds& l, int w0, int nw_ti
 // suffix[first block] | full chunks in between | prefix[partial block].
 template <int S>
 struct Geo {
-    static constexpr int G = cgcd(S, 16);
-    static constexpr int SPAN = S / G;
-    static constexpr int B = 16 / G;
-    static constexpr int LOG2B = clog2(B);
-    static constexpr int C = B < 8 ? B : 8;
-    static constexpr int LOG2C = clog2(C);
+    static constexpr int B = 8;                   // blocks (= windows) per lane
+    static constexpr int LOG2B = 3;
+    static constexpr int C = 8;                   // chunk of the prefix/suffix ORs = the lane's blocks
+    static constexpr int LOG2C = 3;
+    static constexpr int POS = B * S;             // positions per lane
+    // dwords (16 positions each) a lane needs after shifting its first position to bit 0: its
+    // positions plus the look-ahead of the last k-mer and of the overlap test (k + d <= 13 bases)
+    static constexpr int WDW = (POS + 13 + 15) / 16;
+    // a tile is NT lanes; its last lane is halo only, so NT-1 lanes of positions (+ look-ahead and
+    // the sub-dword start offset) are staged: PF 16-byte chunks per lane
+    static constexpr int TILE_DW = ((NT - 1) * POS + 13 + 15 + 15) / 16 + 1;
+    static constexpr int PF = (TILE_DW + NT - 1) / NT;
 };
 
 // One fused tile: NT spans (one per lane), blocks AND windows in registers.
@@ -667,11 +671,11 @@ struct Geo {
 //   phase 3  (after an exclusive scan of row[]) lane-strided: S_w to HBM coalesced, left sums of the
 //            change-point candidates to Lc[].
 // Windows beyond nw_tile (they need blocks of the next tile) are simply not produced.
-template <int S, bool SO>
+template <int S, bool SO, bool INV>
 TPS_DEV void tile_fused_s(const ScanArgs& a, const Lds& l, int delta, int w0, int nw_tile, int64_t out_base,
                           uint64_t& s_total, int64_t r) {
     typedef Geo<S> g_;
-    constexpr int SPAN = g_::SPAN, B = g_::B, C = g_::C, LOG2B = g_::LOG2B, LOG2C = g_::LOG2C;
+    constexpr int WDW = g_::WDW, B = g_::B, C = g_::C, LOG2B = g_::LOG2B, LOG2C = g_::LOG2C, POS = g_::POS;
     const PatInfo& pat = a.pat;
     const int rp = a.r, q = a.q;              // rp: positions of the partial block (a.r)
     const uint32_t kmask = pat.kmask;
@@ -681,13 +685,16 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const Lds& l, int delta, int w0, in
 #endif
     TPS_PHASE {
         const int span = tid;
-        const uint32_t sh2 = (uint32_t)(delta & 15) * 2u;
-        const int d0 = (delta >> 4) + span * SPAN;
-        uint32_t w[SPAN + 1];
+        // the lane's first position sits at an arbitrary bit offset: one per-lane funnel shift aligns
+        // it to bit 0, after which every k-mer extraction uses immediate shifts
+        const int p0 = delta + span * POS;
+        const uint32_t sh2 = (uint32_t)(p0 & 15) * 2u;
+        const int d0 = p0 >> 4;
+        uint32_t w[WDW];
         {
             uint32_t prev = l.seq2[d0];
             TPS_UNROLL
-            for (int i = 0; i <= SPAN; ++i) {
+            for (int i = 0; i < WDW; ++i) {
                 uint32_t nx = l.seq2[d0 + i + 1];
                 w[i] = alignbit(nx, prev, sh2);
                 prev = nx;
@@ -699,13 +706,15 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const Lds& l, int delta, int w0, in
         uint32_t hc[S], vc[S], hn[S], vn[S];
         auto fetch = [&](int blk, uint32_t* hh, uint32_t* vv) {
             TPS_UNROLL
-            for (int i = 0; i <= SPAN; ++i) TPS_PIN(w[i]);   // keep the k-mer extraction of later blocks from being hoisted
-            TPS_UNROLL
             for (int i = 0; i < S; ++i) {
                 const int p = blk * S + i;        // constant after unrolling
                 const int dw = p >> 4, bit = p & 15;
-                uint32_t v = bit ? alignbit(w[dw + 1], w[dw], 2u * bit) : w[dw];
-                hh[i] = l.lut[v & kmask];
+                uint32_t v = bit ? alignbit(dw + 1 < WDW ? w[dw + 1] : 0u, w[dw], 2u * bit) : w[dw];
+                uint32_t h = l.lut[v & kmask];
+                if (INV) {
+                    if (h && invalid_at(l.val, p0 + p, pat.k)) h = 0;   // tiles with non-ACGT letters only
+                }
+                hh[i] = h;
                 vv[i] = v;
             }
         };
@@ -1174,90 +1183,27 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
         const int64_t n_s = m - prm.trimfirst;
         if (n_s >= prm.window) n_win = (int)((n_s - prm.window) / prm.slide) + 1;
         if (n_win / prm.jump + 1 > a.lc_cap) n_win = 0;   // host plans lc_cap from the longest read
-        const int blk_per_tile = a.spans_per_tile << a.blk_log2;
-        // fused tiles stage exactly NT * SPAN dwords (SPAN 16-byte loads per lane): the last span(s) of the
-        // tile are halo only, so their windows move to the next tile
-        constexpr int FSPAN = SV ? Geo<SV ? SV : 1>::SPAN : 1;
-        constexpr int FDROP = SV ? (FSPAN >= 2 ? 1 : 2) : 0;
-        const bool fused_plan = SV != 0 && a.spans_per_tile == NT;
-        const int tw = blk_per_tile - a.q - 1 - (fused_plan ? (FDROP << a.blk_log2) : 0);     // windows per tile
         const int64_t out_base = a.win_off ? a.win_off[r] : 0;
-        // staging plan of the tile that starts at window w0
-        auto tile_stage = [&](int w0_) {
-            const int64_t i0 = (int64_t)w0_ * prm.slide;
-            int64_t n_stage = n_s - i0;
-            const int64_t cap = (int64_t)blk_per_tile * prm.slide + 32;
-            if (n_stage > cap) n_stage = cap;
-            return stage_plan(seq, L, tail == 1, prm.trimfirst, i0, (int)n_stage);
-        };
-        // Software prefetch (tiles of at most PF*NT chunks): the 16-byte loads of the NEXT tile are issued
-        // right after the current tile has been packed into LDS and complete while it is being
-        // scanned, so a wave pays the HBM latency once per read instead of once per tile.
-        constexpr int PF = FSPAN;
-        const bool prefetch = fused_plan;
-        const int pf_dw = NT * PF;                 // dwords staged per fused tile
-        u32x4 pf[PF];
-#ifdef TPS_EMU
-        u32x4 pf_keep[NT][PF];
-#endif
-        auto pf_load = [&](const Stage& stn, int tid_) {
-            TPS_UNROLL
-            for (int u = 0; u < PF; ++u) {
-                const int c = tid_ + u * NT;
-                pf[u].x = pf[u].y = pf[u].z = pf[u].w = 0;
-                if (c < stn.nch) pf[u] = load16(stage_addr(stn, c));
-#ifdef TPS_EMU
-                pf_keep[tid_][u] = pf[u];
-#endif
-            }
-        };
-        if (prefetch && n_win > 0) {
-            const Stage st0 = tile_stage(0);
-            TPS_PHASE { pf_load(st0, tid); }
-        }
-        for (int w0 = 0; w0 < n_win; w0 += tw) {
-            const int nw_tile = (n_win - w0) < tw ? (n_win - w0) : tw;
-            const Stage st = tile_stage(w0);
-            // spans needed for this tile's blocks 0 .. nw_tile-1+q (+ the partial block)
-            const int blk_need = nw_tile + a.q + 1;
-            const int spans = (blk_need + (1 << a.blk_log2) - 1) >> a.blk_log2;
-            int ndw = spans * a.span_dw + 4 < a.seq_dw ? spans * a.span_dw + 4 : a.seq_dw;
-            TPS_PHASE { if (tid == 0) l.misc[M_INVALID] = 0; }
-            TPS_SYNC();
-            if (prefetch) {
-                TPS_PHASE {
-                    TPS_UNROLL
-                    for (int u = 0; u < PF; ++u) {
-                        const int c = tid + u * NT;
-#ifdef TPS_EMU
-                        pf[u] = pf_keep[tid][u];
-#endif
-                        if (c < pf_dw) {
-                            uint32_t packed = 0, bad = 0;
-                            if (c < st.nch) stage_pack(st, c, pf[u], packed, bad);
-                            if (bad) l.misc[M_INVALID] = 1u;
-                            l.seq2[c] = packed;
-                            l.val[c] = bad;
-                        }
-                    }
-                }
+        if constexpr (SV == 0) {
+            // ---------------- generic tiles: spans_per_tile spans of span_dw dwords each
+            const int blk_per_tile = a.spans_per_tile << a.blk_log2;
+            const int tw = blk_per_tile - a.q - 1;     // windows per tile
+            for (int w0 = 0; w0 < n_win; w0 += tw) {
+                const int nw_tile = (n_win - w0) < tw ? (n_win - w0) : tw;
+                const int64_t i0 = (int64_t)w0 * prm.slide;
+                int64_t n_stage = n_s - i0;
+                const int64_t cap = (int64_t)blk_per_tile * prm.slide + 32;
+                if (n_stage > cap) n_stage = cap;
+                const Stage st = stage_plan(seq, L, tail == 1, prm.trimfirst, i0, (int)n_stage);
+                // spans needed for this tile's blocks 0 .. nw_tile-1+q (+ the partial block)
+                const int blk_need = nw_tile + a.q + 1;
+                const int spans = (blk_need + (1 << a.blk_log2) - 1) >> a.blk_log2;
+                const int ndw = spans * a.span_dw + 4 < a.seq_dw ? spans * a.span_dw + 4 : a.seq_dw;
+                TPS_PHASE { if (tid == 0) l.misc[M_INVALID] = 0; }
                 TPS_SYNC();
-                if (w0 + tw < n_win) {
-                    const Stage stn = tile_stage(w0 + tw);
-                    TPS_PHASE { pf_load(stn, tid); }
-                }
-            } else {
                 TPS_PHASE { stage_thread(st, l.seq2, l.val, ndw, &l.misc[M_INVALID], tid); }
                 TPS_SYNC();
-            }
-            if (w0 == 0) TPS_STAMP(5);
-            const bool inv = uniform(l.misc[M_INVALID]) != 0;
-            bool fused = false;
-            if constexpr (SV != 0) fused = !inv && fused_plan;
-            if (fused) {
-                if constexpr (SV != 0) tile_fused_s<SV, SO>(a, l, st.delta, w0, nw_tile, out_base, s_total, r);
-            } else {
-                // generic tile (any slide / pattern count; also tiles with non-ACGT letters)
+                if (w0 == 0) TPS_STAMP(5);
                 TPS_PHASE {
                     for (int sp = tid; sp < spans; sp += NT) blocks_span(a, l, st.delta, sp);
                 }
@@ -1273,8 +1219,73 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
                     s_total += gsum;
                     TPS_SYNC();
                 }
+                if (w0 == 0) TPS_STAMP(8);
             }
-            if (w0 == 0) TPS_STAMP(8);
+        } else {
+            // ---------------- fused tiles: NT lanes x 8 blocks, the last lane is halo only
+            typedef Geo<SV ? SV : 1> g_;
+            constexpr int PF = g_::PF;
+            const int tw = NT * g_::B - a.q - 1 - g_::B;   // windows per tile
+            auto tile_stage = [&](int w0_) {
+                const int64_t i0 = (int64_t)w0_ * prm.slide;
+                int64_t n_stage = n_s - i0;
+                const int64_t cap = (int64_t)(g_::TILE_DW - 1) * 16;
+                if (n_stage > cap) n_stage = cap;
+                return stage_plan(seq, L, tail == 1, prm.trimfirst, i0, (int)n_stage);
+            };
+            // Software prefetch: the 16-byte loads of the NEXT tile are issued right after the current
+            // tile has been packed into LDS and complete while it is being scanned, so a wave pays
+            // the HBM latency once per read instead of once per tile.
+            u32x4 pf[PF];
+#ifdef TPS_EMU
+            u32x4 pf_keep[NT][PF];
+#endif
+            auto pf_load = [&](const Stage& stn, int tid_) {
+                TPS_UNROLL
+                for (int u = 0; u < PF; ++u) {
+                    const int c = tid_ + u * NT;
+                    pf[u].x = pf[u].y = pf[u].z = pf[u].w = 0;
+                    if (c < stn.nch) pf[u] = load16(stage_addr(stn, c));
+#ifdef TPS_EMU
+                    pf_keep[tid_][u] = pf[u];
+#endif
+                }
+            };
+            if (n_win > 0) {
+                const Stage st0 = tile_stage(0);
+                TPS_PHASE { pf_load(st0, tid); }
+            }
+            for (int w0 = 0; w0 < n_win; w0 += tw) {
+                const int nw_tile = (n_win - w0) < tw ? (n_win - w0) : tw;
+                const Stage st = tile_stage(w0);
+                TPS_PHASE { if (tid == 0) l.misc[M_INVALID] = 0; }
+                TPS_SYNC();
+                TPS_PHASE {
+                    TPS_UNROLL
+                    for (int u = 0; u < PF; ++u) {
+                        const int c = tid + u * NT;
+#ifdef TPS_EMU
+                        pf[u] = pf_keep[tid][u];
+#endif
+                        uint32_t packed = 0, bad = 0;
+                        if (c < st.nch) stage_pack(st, c, pf[u], packed, bad);
+                        if (bad) l.misc[M_INVALID] = 1u;
+                        l.seq2[c] = packed;
+                        l.val[c] = bad;
+                    }
+                }
+                TPS_SYNC();
+                if (w0 + tw < n_win) {
+                    const Stage stn = tile_stage(w0 + tw);
+                    TPS_PHASE { pf_load(stn, tid); }
+                }
+                if (w0 == 0) TPS_STAMP(5);
+                if (uniform(l.misc[M_INVALID]) != 0)
+                    tile_fused_s<SV ? SV : 1, SO, true>(a, l, st.delta, w0, nw_tile, out_base, s_total, r);
+                else
+                    tile_fused_s<SV ? SV : 1, SO, false>(a, l, st.delta, w0, nw_tile, out_base, s_total, r);
+                if (w0 == 0) TPS_STAMP(8);
+            }
         }
     }
     res.n_win = n_win;

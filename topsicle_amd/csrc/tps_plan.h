@@ -83,33 +83,49 @@ inline std::string plan_geometry(ScanArgs& a, const tps_params& prm, int k, int 
     a.lw = std::max(0, prm.window - k);            // k-mer start positions in a (W-1)-char window
     a.q = a.lw / prm.slide;
     a.r = a.lw % prm.slide;
-    const int g = gcd_i(prm.slide, 16);
-    a.span_dw = prm.slide / g;
-    const int bps = 16 / g;
-    a.blk_log2 = 0;
-    while ((1 << a.blk_log2) < bps) ++a.blk_log2;
-    const int chunk = bps < 8 ? bps : 8;
-    // fused kernels: compile-time slide, 16-bit masks, the window must span at least one chunk and its
-    // far end must lie within the exchange halo (XLANES - NT lanes)
-    a.variant = (!force_generic && has_specialised_slide(prm.slide) && P <= 15 && a.q >= chunk && (a.q / bps) + 2 < (XLANES - NT) &&
-                 a.q / chunk < 30) ? prm.slide : 0;
     if (max_nwin > 500000) return "too many windows per read (" + std::to_string(max_nwin) + ")";
     const int jump = std::max(prm.jump, 1);
     a.lc_cap = (int)(max_nwin / jump + 2);
     a.jump_magic = (uint32_t)(((1ull << 32) + (uint64_t)jump - 1) / (uint64_t)jump);
     a.head_dw = (prm.no_bp + 30) / 16 + 3;
+    (void)target_dw;
+    // fused kernels: compile-time slide, 16-bit masks (<= 15 patterns), a window spans at least one
+    // 8-block chunk and its far end lies within the exchange halo (XLANES - NT lanes)
+    const bool fused = !force_generic && spans_pref <= 0 && has_specialised_slide(prm.slide) && P <= 15 && a.q >= 8 &&
+                       a.q / 8 + 2 < (XLANES - NT);
+    if (fused) {
+        a.variant = prm.slide;
+        a.blk_log2 = 3;                            // 8 blocks per lane for every slide
+        a.span_dw = 0;                             // lanes start at arbitrary bit offsets (per-lane shift)
+        a.spans_per_tile = NT;
+        a.nblk_cap = NT * 8;
+        a.rec_rs = 0;
+        a.tot_dw = 2;
+        const int pos = 8 * prm.slide;
+        const int tile_dw = ((NT - 1) * pos + 13 + 15 + 15) / 16 + 1;     // = Geo<S>::TILE_DW
+        const int pf = (tile_dw + NT - 1) / NT;                            // = Geo<S>::PF
+        a.seq_dw = std::max(pf * (int)NT + 8, 2 * a.head_dw);
+        a.blk_dw = (int32_t)blk_region_dw(a);
+        if (wg_lds_dwords(a) > budget_dw) return "LDS plan does not fit (fused kernel, " + std::to_string(max_nwin) + " windows per read)";
+        return "";
+    }
+    a.variant = 0;
+    const int g = gcd_i(prm.slide, 16);
+    a.span_dw = prm.slide / g;
+    const int bps = 16 / g;
+    a.blk_log2 = 0;
+    while ((1 << a.blk_log2) < bps) ++a.blk_log2;
     const int max_spans = 2 * NT;
     const int min_spans = (a.q + 2 + bps - 1) / bps;        // a tile must hold >= 1 window
     const int64_t need_blk = max_nwin + a.q + 1;            // no more spans than the longest read uses
     const int need_spans = (int)std::min<int64_t>((need_blk + bps - 1) / bps, max_spans);
     int spans = spans_pref > 0 ? std::min(spans_pref, max_spans) : std::min(std::max(need_spans, 1), (int)NT);
-    if (a.variant && spans_pref <= 0) spans = NT;            // fused tiles: one span per lane, always
-    if (!(a.variant && spans_pref <= 0)) spans = std::max(min_spans, std::min(spans, std::max(need_spans, 1)));
+    spans = std::max(min_spans, std::min(spans, std::max(need_spans, 1)));
     if (spans > max_spans) return "window/slide combination needs " + std::to_string(spans) + " spans per tile (max " + std::to_string(max_spans) + ")";
     auto fill = [&](int sp) {
         a.spans_per_tile = sp;
         a.nblk_cap = sp * bps;
-        a.rec_rs = ((sp + 31) / 32) * 32 + 32 / bps;
+        a.rec_rs = 0;
         a.tot_dw = std::max(((sp + 2) / 2) * 2, (int)NT);
         a.seq_dw = std::max(sp * a.span_dw + 4, 2 * a.head_dw);
         a.blk_dw = (int32_t)blk_region_dw(a);
@@ -120,9 +136,6 @@ inline std::string plan_geometry(ScanArgs& a, const tps_params& prm, int k, int 
             return "LDS plan does not fit with " + std::to_string(spans) + " spans per tile";
         return "";
     }
-    // prefer one span per lane; halve (down to 16 spans) while the workgroup is above the target,
-    // then keep halving only if it does not fit the hardware budget at all
-    (void)target_dw;
     while (fill(spans) > budget_dw) {
         if (spans <= min_spans)
             return "LDS plan does not fit: window=" + std::to_string(prm.window) + " slide=" + std::to_string(prm.slide) +
