@@ -69,6 +69,8 @@ extern "C" int emu_scan(const char* pats, int P, int k, const uint8_t* bases, co
     a.n_reads = n;
     a.prm = *prm;
     std::vector<uint32_t> lutbuf(lut);            // the workgroup-shared table (read-only for the waves)
+    if (a.variant)
+        for (auto& m : lutbuf) m = (m << 16) | (uint32_t)__builtin_popcount(m);   // fused kernels: mask << 16 | count
     std::vector<uint32_t> ldsbuf((size_t)tps::lds_dwords(a) + 16);
     uint32_t* lds_al = (uint32_t*)(((uintptr_t)ldsbuf.data() + 15) & ~(uintptr_t)15);
     struct { uint32_t* p; size_t n; uint32_t* data() { return p; } uint32_t* begin() { return p; } uint32_t* end() { return p + n; } } lds{lds_al, (size_t)tps::lds_dwords(a)};

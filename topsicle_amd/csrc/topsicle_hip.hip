@@ -22,7 +22,10 @@
     extern "C" __global__ void __launch_bounds__(tps::NT * tps::WPG, MINW) NAME(tps::ScanArgs a) {         \
         extern __shared__ __attribute__((aligned(16))) uint32_t lds[];                                     \
         uint32_t* lut = lds;                                                                               \
-        for (int i = (int)threadIdx.x; i < a.lut_n; i += tps::NT * tps::WPG) lut[i] = a.lut[i];            \
+        for (int i = (int)threadIdx.x; i < a.lut_n; i += tps::NT * tps::WPG) {                             \
+            const uint32_t m_ = a.lut[i];                                                                  \
+            lut[i] = (SV) ? ((m_ << 16) | (uint32_t)__builtin_popcount(m_)) : m_;                          \
+        }                                                                                                  \
         __syncthreads();                                                                                   \
         /* readfirstlane: the wave index is uniform -> everything per read lives in SGPRs */              \
         const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));                          \

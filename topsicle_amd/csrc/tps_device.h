@@ -194,7 +194,8 @@ constexpr int XS_DW = 64 + NT + 4 * NT + NT + 16 * 5 + 8;   // scratch of the ex
 constexpr int HIST_STRIDE = 33;          // odd stride: the copies of one pattern sit on different LDS banks
 constexpr int HIST_DW = 2 * HIST_COPIES * HIST_STRIDE;   // step-1 private histograms (alias the block region)
 struct Lds {
-    uint32_t* lut;
+    uint32_t* lut;     // generic kernel: mask over the pattern list; fused kernels: mask << 16 | popcount(mask)
+    int lshift;        // 0 or 16: lut[code] >> lshift is the mask
     uint32_t* seq2;    // 2-bit packed bases, 16 per dword
     uint32_t* val;     // bit j of val[c] set = position 16c+j is NOT one of acgtACGT
     uint32_t* blk;     // block region
@@ -234,6 +235,7 @@ TPS_DEV Lds carve(uint32_t* base, uint32_t* lut, const ScanArgs& a) {
     uint32_t* p = base;
     l.blk = p;  p += a.blk_dw;                 // first: 16-byte aligned for the 8-byte records
     l.lut = lut;                               // one table per workgroup, shared by its waves
+    l.lshift = a.variant ? 16 : 0;
     l.seq2 = p; p += a.seq_dw;
     l.val = p;  p += a.seq_dw;
     l.Tot = p;  p += a.tot_dw;
@@ -431,8 +433,8 @@ TPS_DEV bool invalid_at(const uint32_t* val, int q, int k) {
     return ((v >> (q & 15)) & ((1ull << k) - 1ull)) != 0;
 }
 // mask of list patterns whose k-mer starts at position q
-TPS_DEV uint32_t h_at(const uint32_t* lut, const uint32_t* seq2, const uint32_t* val, const PatInfo& pat, int q, bool any_invalid) {
-    uint32_t h = lut[v_at(seq2, q) & pat.kmask];
+TPS_DEV uint32_t h_at(const uint32_t* lut, int lshift, const uint32_t* seq2, const uint32_t* val, const PatInfo& pat, int q, bool any_invalid) {
+    uint32_t h = lut[v_at(seq2, q) & pat.kmask] >> lshift;
     if (any_invalid && h && invalid_at(val, q, pat.k)) h = 0;
     return h;
 }
@@ -448,12 +450,12 @@ TPS_DEV uint32_t conflict_bits(const PatInfo& pat, uint32_t v, uint32_t h) {
 
 // Leftmost non-overlapping count of list pattern `bit` over `npos` start positions from
 // position q0 -- exactly what len(list(re.finditer(p, text))) gives (allsteps.py:182, 281).
-TPS_DEV void greedy_count(const uint32_t* lut, const uint32_t* seq2, const uint32_t* val, const PatInfo& pat, int q0,
+TPS_DEV void greedy_count(const uint32_t* lut, int lshift, const uint32_t* seq2, const uint32_t* val, const PatInfo& pat, int q0,
                           int npos, int bit, bool any_invalid, int& occ, int& greedy) {
     occ = 0; greedy = 0;
     int cursor = 0;
     for (int p = 0; p < npos; ++p) {
-        uint32_t h = h_at(lut, seq2, val, pat, q0 + p, any_invalid);
+        uint32_t h = h_at(lut, lshift, seq2, val, pat, q0 + p, any_invalid);
         if ((h >> bit) & 1u) {
             ++occ;
             if (p >= cursor) { ++greedy; cursor = p + pat.k; }
@@ -489,7 +491,7 @@ TPS_DEV void trc_count_thread(const ScanArgs& a, const Lds& l, const Stage& st_s
         TPS_UNROLL
         for (int j = 0; j < 8; ++j) {
             v[j] = j ? alignbit(w1, w0, 2u * j) : w0;
-            h[j] = l.lut[v[j] & pat.kmask];
+            h[j] = l.lut[v[j] & pat.kmask] >> l.lshift;
         }
         TPS_UNROLL
         for (int j = 0; j < 8; ++j) {
@@ -523,7 +525,7 @@ TPS_DEV void trc_sum_thread(const ScanArgs& a, const Lds& l, const Stage& st_s, 
         for (int c = 0; c < HIST_COPIES; ++c) sm += l.blk[(side * HIST_COPIES + c) * HIST_STRIDE + p];
         if ((l.misc[M_CMASK + side] >> p) & 1u) {
             int occ, g;
-            greedy_count(l.lut, l.seq2 + side * a.head_dw, l.val + side * a.head_dw, a.pat, side ? st_e.delta : st_s.delta,
+            greedy_count(l.lut, l.lshift, l.seq2 + side * a.head_dw, l.val + side * a.head_dw, a.pat, side ? st_e.delta : st_s.delta,
                          st_s.n - a.pat.k + 1, p, l.misc[M_INVALID] != 0, occ, g);
             sm = (uint32_t)g;
         }
@@ -590,20 +592,83 @@ TPS_DEV void blocks_span(const ScanArgs& a, const Lds& l, int delta, int span) {
 }
 
 // ------------------------------------------------------------------ step 2, exact window recount
-// Exact count of every pattern in tile-local window wl (slow path: overlapping occurrences of a
-// self-overlapping k-mer inside the window, or raw output requested).
-TPS_DEV uint32_t window_exact(const ScanArgs& a, const Lds& l, int delta, int wl, uint32_t present, uint8_t* raw_row) {
+// Sequential scan of one window's `npos` start positions from LDS position q0 with a rolling 32-base
+// register window (one LDS read per 16 positions): calls f(p, mask) for every position.
+template <typename F>
+TPS_DEV void scan_positions(const Lds& l, const PatInfo& pat, int q0, int npos, bool inv, F f) {
+    const int idx = q0 >> 4;
+    const uint32_t sh = (uint32_t)(q0 & 15) * 2u;
+    uint32_t d1 = l.seq2[idx + 1];
+    uint32_t cur = alignbit(d1, l.seq2[idx], sh), nxt = 0;
+    for (int p = 0; p < npos; ++p) {
+        const int j = p & 15;
+        if (j == 0) {
+            if (p) cur = nxt;
+            const uint32_t d2 = l.seq2[idx + (p >> 4) + 2];
+            nxt = alignbit(d2, d1, sh);
+            d1 = d2;
+        }
+        const uint32_t v = j ? alignbit(nxt, cur, 2u * (uint32_t)j) : cur;
+        uint32_t h = l.lut[v & pat.kmask] >> l.lshift;
+        if (inv && h && invalid_at(l.val, q0 + p, pat.k)) h = 0;
+        f(p, h);
+    }
+}
+
+// Exact S_w of tile-local window wl (and, if raw_row is set, the per-pattern counts c'_p).
+// Only self-overlapping k-mers can make the leftmost-non-overlapping count (what re.finditer yields,
+// allsteps.py:281) differ from the plain occurrence count, so:
+//   sums only : S_w = fast S_w - sum over present self-overlapping patterns of (occurrences - greedy)
+//   raw counts: one pass accumulates all occurrence counts in packed bytes, then the present
+//               self-overlapping patterns are recounted greedily; zeros are floored to 1.
+TPS_DEV uint32_t window_exact(const ScanArgs& a, const Lds& l, int delta, int wl, uint32_t present, uint32_t fast_sw,
+                              uint8_t* raw_row) {
     const PatInfo& pat = a.pat;
     const bool inv = l.misc[M_INVALID] != 0;
+    const int q0 = delta + wl * a.prm.slide;
+    uint32_t redo = present & pat.so_mask;
+    if (!raw_row) {
+        uint32_t sum = fast_sw;
+        while (redo) {
+            const int bit = ffs0(redo);
+            redo &= redo - 1;
+            int occ = 0, greedy = 0, cursor = 0;
+            scan_positions(l, pat, q0, a.lw, inv, [&](int p, uint32_t h) {
+                if ((h >> bit) & 1u) {
+                    ++occ;
+                    if (p >= cursor) { ++greedy; cursor = p + pat.k; }
+                }
+            });
+            sum -= (uint32_t)(occ - greedy);
+        }
+        return sum;
+    }
+    uint64_t clo = 0, chi = 0, c3 = 0, c4 = 0;          // packed byte counters: patterns 0-7, 8-15, 16-23, 24-31
+    scan_positions(l, pat, q0, a.lw, inv, [&](int, uint32_t h) {
+        while (h) {
+            const int b = ffs0(h);
+            h &= h - 1;
+            const uint64_t inc = 1ull << (8 * (b & 7));
+            const int g = b >> 3;
+            clo += g == 0 ? inc : 0ull;
+            chi += g == 1 ? inc : 0ull;
+            c3 += g == 2 ? inc : 0ull;
+            c4 += g == 3 ? inc : 0ull;
+        }
+    });
     uint32_t sum = 0;
     for (int b = 0; b < pat.P; ++b) {
-        int c = 0;
-        if ((present >> b) & 1u) {
-            int occ;
-            greedy_count(l.lut, l.seq2, l.val, pat, delta + wl * a.prm.slide, a.lw, b, inv, occ, c);
+        const uint64_t word = (b >> 3) == 0 ? clo : (b >> 3) == 1 ? chi : (b >> 3) == 2 ? c3 : c4;
+        int c = (int)((word >> (8 * (b & 7))) & 255u);
+        if ((redo >> b) & 1u) {
+            int greedy = 0, cursor = 0;
+            scan_positions(l, pat, q0, a.lw, inv, [&](int p, uint32_t h) {
+                if (((h >> b) & 1u) && p >= cursor) { ++greedy; cursor = p + pat.k; }
+            });
+            c = greedy;
         }
         if (c == 0) c = 1;                         // `matches or 1` (allsteps.py:281, 288)
-        if (raw_row) raw_row[b] = (uint8_t)c;
+        raw_row[b] = (uint8_t)c;
         sum += (uint32_t)c;
     }
     return sum;
@@ -626,7 +691,7 @@ TPS_DEV void windows_group(const ScanArgs& a, const Lds& l, int delta, int w0, i
             uint32_t present = m & pat.all_mask;
             sw = cnt + (uint32_t)(pat.P - popc(present));
             uint8_t* raw_row = a.raw ? a.raw + (out_base + w0 + wl) * (int64_t)pat.P : nullptr;
-            if ((m & FLAG_CONFLICT) || raw_row) sw = window_exact(a, l, delta, wl, present, raw_row);
+            if ((m & FLAG_CONFLICT) || raw_row) sw = window_exact(a, l, delta, wl, present, sw, raw_row);
             a.sums[out_base + w0 + wl] = (int32_t)sw;
         }
         l.row[u * NT + tid] = sw;
@@ -679,25 +744,27 @@ struct Geo {
 //   phase 3  (after an exclusive scan of row[]) lane-strided: S_w to HBM coalesced, left sums of the
 //            change-point candidates to Lc[].
 // Windows beyond nw_tile (they need blocks of the next tile) are simply not produced.
-template <int S, bool SO, bool INV>
+template <int S, bool SO, bool INV, bool RZ>
 TPS_DEV void tile_fused_s(const ScanArgs& a, const Lds& l, int delta, int w0, int nw_tile, int64_t out_base,
                           uint64_t& s_total, int64_t r) {
+    // RZ: the window has no partial block (W - k divisible by the slide), so nothing is captured mid-block
     typedef Geo<S> g_;
     constexpr int WDW = g_::WDW, B = g_::B, C = g_::C, LOG2B = g_::LOG2B, LOG2C = g_::LOG2C, POS = g_::POS;
     const PatInfo& pat = a.pat;
     const int rp = a.r, q = a.q;              // rp: positions of the partial block (a.r)
-    const uint32_t kmask = pat.kmask;
+    const uint32_t amask = pat.kmask << 2;    // k-mer code as a byte offset into the 4-byte table
     uint32_t sufc0[B];                            // per block: suffix-OR of its chunk | count before it << 16
 #ifdef TPS_EMU
     uint32_t keep[NT][B];                         // registers that live across the phases
 #endif
     TPS_PHASE {
         const int span = tid;
-        // the lane's first position sits at an arbitrary bit offset: one per-lane funnel shift aligns
-        // it to bit 0, after which every k-mer extraction uses immediate shifts
-        const int p0 = delta + span * POS;
-        const uint32_t sh2 = (uint32_t)(p0 & 15) * 2u;
-        const int d0 = p0 >> 4;
+        // The lane's bases start at an arbitrary bit offset; one per-lane funnel shift aligns the base
+        // BEFORE its first one to bit 0.  Then `alignbit(w[dw+1], w[dw], 2*(p%16)) & (kmask << 2)` is
+        // the k-mer code of position p times 4 -- the table's byte offset -- with immediate shifts only.
+        const int p0 = delta + span * POS;        // >= 16: fused tiles are staged one dword into seq2
+        const uint32_t sh2 = (uint32_t)((p0 - 1) & 15) * 2u;
+        const int d0 = (p0 - 1) >> 4;
         uint32_t w[WDW];
         {
             uint32_t prev = l.seq2[d0];
@@ -708,8 +775,8 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const Lds& l, int delta, int w0, in
                 prev = nx;
             }
         }
-        uint32_t cnt = 0, run_or = 0;
-        uint32_t gsave[C];
+        uint32_t cnt = 0, run_or = 0;             // table entries are mask << 16 | popcount: OR keeps the masks
+        uint32_t gsave[C];                        // in the high half, ADD the match count in the low half
         // table lookups run one block ahead of their use (software pipeline, 2 S values in flight)
         uint32_t hc[S], vc[S], hn[S], vn[S];
         auto fetch = [&](int blk, uint32_t* hh, uint32_t* vv) {
@@ -717,13 +784,13 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const Lds& l, int delta, int w0, in
             for (int i = 0; i < S; ++i) {
                 const int p = blk * S + i;        // constant after unrolling
                 const int dw = p >> 4, bit = p & 15;
-                uint32_t v = bit ? alignbit(dw + 1 < WDW ? w[dw + 1] : 0u, w[dw], 2u * bit) : w[dw];
-                uint32_t h = l.lut[v & kmask];
+                uint32_t v4 = bit ? alignbit(dw + 1 < WDW ? w[dw + 1] : 0u, w[dw], 2u * bit) : w[dw];
+                uint32_t h = *(const uint32_t*)((const char*)l.lut + (v4 & amask));
                 if (INV) {
                     if (h && invalid_at(l.val, p0 + p, pat.k)) h = 0;   // tiles with non-ACGT letters only
                 }
                 hh[i] = h;
-                vv[i] = v;
+                vv[i] = v4 >> 2;
             }
         };
         fetch(0, hc, vc);
@@ -733,21 +800,25 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const Lds& l, int delta, int w0, in
             if (blk + 1 < B) fetch(blk + 1, hn, vn);
             if (bc == 0) run_or = 0;
             uint32_t g = 0;
-            uint32_t c0 = cnt, c1 = cnt, pp = run_or;
+            const uint32_t c0 = cnt;
+            uint32_t c1 = cnt, pp = run_or;
             TPS_UNROLL
             for (int i = 0; i < S; ++i) {
                 const uint32_t h = hc[i];
                 if (SO) {
-                    if ((h & pat.so_mask) && conflict_bits(pat, vc[i], h)) g |= FLAG16;
+                    if ((h >> 16) & pat.so_mask)
+                        if (conflict_bits(pat, vc[i], h >> 16)) g |= FLAG16 << 16;
                 }
                 g |= h;
-                cnt += (uint32_t)popc(h);
-                if (i + 1 == rp) { c1 = cnt; pp = run_or | g; }
+                cnt += h;
+                if (!RZ) {
+                    if (i + 1 == rp) { c1 = cnt; pp = run_or | g; }
+                }
             }
-            l.XP[blk * XLANES + span] = (uint16_t)pp;
+            l.XP[blk * XLANES + span] = (uint16_t)(pp >> 16);
             l.XC[blk * XLANES + span] = (uint16_t)c1;
             sufc0[blk] = c0 << 16;
-            gsave[bc] = g & 0xFFFFu;
+            gsave[bc] = g >> 16;
             run_or |= g;
             if (bc == C - 1) {                    // chunk complete: suffix ORs, chunk total
                 uint32_t sfx = 0;
@@ -762,7 +833,7 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const Lds& l, int delta, int w0, in
             for (int i = 0; i < S; ++i) { hc[i] = hn[i]; vc[i] = vn[i]; }
             TPS_SCHED_BARRIER();
         }
-        l.XT[span] = cnt;
+        l.XT[span] = cnt & 0xFFFFu;
 #ifdef TPS_EMU
         for (int j = 0; j < B; ++j) keep[tid][j] = sufc0[j];
 #endif
@@ -812,7 +883,7 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const Lds& l, int delta, int w0, in
                 if (t == (j >> 1)) pm = present[t];
             pm = (pm >> (16 * (j & 1))) & 0xFFFFu;
             uint8_t* raw_row = a.raw ? a.raw + (out_base + w0 + wl) * (int64_t)pat.P : nullptr;
-            l.row[padded(wl, LOG2B)] = window_exact(a, l, delta, wl, pm, raw_row);
+            l.row[padded(wl, LOG2B)] = window_exact(a, l, delta, wl, pm, l.row[padded(wl, LOG2B)], raw_row);
         }
     }
     TPS_SYNC();
@@ -1278,9 +1349,10 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
                         uint32_t packed = 0, bad = 0;
                         if (c < st.nch) stage_pack(st, c, pf[u], packed, bad);
                         if (bad) l.misc[M_INVALID] = 1u;
-                        l.seq2[c] = packed;
-                        l.val[c] = bad;
+                        l.seq2[c + 1] = packed;        // one dword in: lanes also read the base before their first
+                        l.val[c + 1] = bad;
                     }
+                    if (tid == 0) { l.seq2[0] = 0; l.val[0] = 0; }
                 }
                 TPS_SYNC();
                 if (w0 + tw < n_win) {
@@ -1288,10 +1360,13 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
                     TPS_PHASE { pf_load(stn, tid); }
                 }
                 if (w0 == 0) TPS_STAMP(5);
+                const int fdelta = st.delta + 16;      // LDS position of the tile's first base
                 if (uniform(l.misc[M_INVALID]) != 0)
-                    tile_fused_s<SV ? SV : 1, SO, true>(a, l, st.delta, w0, nw_tile, out_base, s_total, r);
+                    tile_fused_s<SV ? SV : 1, SO, true, false>(a, l, fdelta, w0, nw_tile, out_base, s_total, r);
+                else if (a.r == 0)
+                    tile_fused_s<SV ? SV : 1, SO, false, true>(a, l, fdelta, w0, nw_tile, out_base, s_total, r);
                 else
-                    tile_fused_s<SV ? SV : 1, SO, false>(a, l, st.delta, w0, nw_tile, out_base, s_total, r);
+                    tile_fused_s<SV ? SV : 1, SO, false, false>(a, l, fdelta, w0, nw_tile, out_base, s_total, r);
                 if (w0 == 0) TPS_STAMP(8);
             }
         }
