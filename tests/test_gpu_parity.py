@@ -199,3 +199,62 @@ def test_full_size_properties(sc):
     assert np.median(err) <= 60, np.median(err)
     # S_w range: P <= S_w <= P * floor(99 / k)
     assert sums.min() >= len(pats) and sums.max() <= len(pats) * (99 // k)
+
+
+def test_cli_demo_on_gpu(tmp_path, gold_dir):
+    """`topsicle` CLI end to end on the MI355X: the reference's demo CSV, log lines and filtered fastq."""
+    import json
+    import shutil
+    from topsicle_amd import main as cli, seqio
+    d = tmp_path / "in"
+    d.mkdir()
+    fq = d / "Col-0-6909_GWHBDNP00000001.1_nano_right.fastq.gz"
+    shutil.copyfile(os.path.join(gold_dir, "demo_col0.fastq.gz"), fq)
+    out = tmp_path / "out"
+    cli.main(["--inputDir", str(d), "--outputDir", str(out), "--pattern", "CCCTAAA", "--slide", "6", "--rawcountpattern"])
+    got = open(out / "telolengths_all.csv").read().splitlines()
+    want = open(os.path.join(gold_dir, "demo_telolengths_all.csv")).read().splitlines()
+    assert got == want
+    log = open(out / "topsicle_run.log").read()
+    g = json.load(open(os.path.join(gold_dir, "demo_run_log.json")))
+    for key in ("patterns_line", "median_line", "asymptotic_line", "filtered_line"):
+        assert g[key] in log, key
+    recs = list(seqio.read_records(str(out / "Col-0-6909_GWHBDNP00000001.1_nano_right.fastq_trc_over_0.7.fastq")))
+    assert [r.id for r in recs] == [w.split(",")[3] for w in want[1:]]
+    meta = json.load(open(os.path.join(gold_dir, "demo_windows.json")))
+    arrs = np.load(os.path.join(gold_dir, "demo_windows.npz"))
+    raw = list(csv.reader(open(out / "rawcount_5_3.csv")))[1:]
+    assert np.array_equal(np.array([int(r[4]) for r in raw]).reshape(-1, 14), arrs["counts_2"])
+
+
+def test_invalid_bases_and_self_overlap_at_scale(sc):
+    """Thousands of reads with N / lower case sprinkled in and a self-overlapping table (CCCTAA, k=5):
+    spot-check against the oracle, and the raw-count path must agree with the sums path everywhere."""
+    motif, k = "CCCTAA", 5
+    pats = orc.kmer_table(motif, k)
+    sc.set_patterns(pats)
+    bases, offsets, truth = synth.make_reads(2000, 6000, motif, seed=99, tract_min=500, tract_max=3000)
+    rng = np.random.default_rng(1)
+    b = bases.copy()
+    pos = rng.integers(0, b.size, b.size // 200)
+    b[pos] = np.frombuffer(b"NnacgtRY", dtype=np.uint8)[rng.integers(0, 8, pos.size)]
+    sc.upload(4, b, offsets)
+    prm = hiplib.make_params(min_len=1000, min_count=-1, flags=hiplib.F_STEP1 | hiplib.F_WINDOWS | hiplib.F_BINSEG | hiplib.F_STORE_SUMS)
+    sc.scan(4, prm)
+    sc.sync()
+    res = sc.results(4).copy()
+    sums, win_off = sc.window_sums(4)
+    prm.flags |= hiplib.F_STORE_RAW
+    sc.scan(4, prm)
+    sc.sync()
+    raw, _ = sc.window_raw(4)
+    sums2, _ = sc.window_sums(4)
+    assert np.array_equal(sums, sums2) and np.array_equal(raw.astype(np.int64).sum(axis=1), sums)
+    seqs = synth.split_reads(b, offsets)
+    for i in range(0, 2000, 97):
+        tail = ["forward", "reverse"][res["tail"][i]]
+        cs, ce = orc.trc_counts(seqs[i], pats)
+        assert (res["best_start"][i], res["best_end"][i]) == (max(cs), max(ce))
+        _, counts = orc.window_count_matrix(seqs[i], tail, pats, 100, 6, 100, 20000)
+        assert np.array_equal(raw[win_off[i]:win_off[i + 1]], counts)
+        assert res["bkp"][i] == orc.binseg_l2_exact(counts.sum(axis=1))

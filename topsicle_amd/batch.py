@@ -28,8 +28,11 @@ def record_batches(records, max_bases: int = BATCH_BASES, max_reads: int = BATCH
 
 
 def scan_records(engine, recs, prm: hiplib.Params, slot: int = 0, want_sums=False, want_raw=False):
-    """Fused scan of one batch of records.  Returns (results, sums, raw, win_off)."""
-    bases, offsets = hiplib.pack_reads([r.seq for r in recs])
+    """Fused scan of one batch (a list of records or a seqio.RecordBatch).  Returns (results, sums, raw, win_off)."""
+    if hasattr(recs, "bases"):
+        bases, offsets = recs.bases, recs.offsets
+    else:
+        bases, offsets = hiplib.pack_reads([r.seq for r in recs])
     engine.upload(slot, bases, offsets)
     flags = prm.flags | (hiplib.F_STORE_SUMS if want_sums else 0) | (hiplib.F_STORE_RAW if want_raw else 0)
     p = hiplib.Params.from_buffer_copy(prm)
@@ -57,11 +60,23 @@ class EnginePool:
         for e in self.engines:
             e.set_patterns(patterns)
 
+    def scan_file(self, filepath, prm, want_sums=False, want_raw=False, max_bases=None):
+        """Like scan_stream over the records of a FASTA/FASTQ(.gz) file, decoded natively into batch
+        buffers (seqio.read_batches); yields (RecordBatch, results, sums, raw, win_off)."""
+        from . import seqio
+        n = len(self.engines)
+        if max_bases is None:
+            max_bases = BATCH_BASES if n == 1 else BATCH_BASES // 4
+        return self._scan_batches(seqio.read_batches(filepath, max_bases=max_bases), prm, want_sums, want_raw)
+
     def scan_stream(self, records, prm, want_sums=False, want_raw=False, max_bases=None):
         n = len(self.engines)
         if max_bases is None:
             max_bases = BATCH_BASES if n == 1 else BATCH_BASES // 4
-        batches = record_batches(records, max_bases=max_bases)
+        return self._scan_batches(record_batches(records, max_bases=max_bases), prm, want_sums, want_raw)
+
+    def _scan_batches(self, batches, prm, want_sums, want_raw):
+        n = len(self.engines)
         if n == 1:
             for recs in batches:
                 res, sums, raw, win_off = scan_records(self.engines[0], recs, prm, 0, want_sums, want_raw)

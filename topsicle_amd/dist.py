@@ -19,6 +19,8 @@ class Group:
         if self.world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
+            if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
+                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # the container hostname may not resolve
             import torch.distributed as dist
             dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
             self._dist = dist

@@ -80,13 +80,12 @@ def process_file(args, seq_loc, telo_phrase, pattern, sliding_val, engines):
     csv_path = f"{args.outputDir}/telolengths_all.csv"
     pool = batch.EnginePool(engines, pattern)
     try:
-        for recs, res, sums, raw, win_off in pool.scan_stream(seqio.read_records(seq_loc), prm, want_sums, want_raw):
+        for rb, res, sums, raw, win_off in pool.scan_file(seq_loc, prm, want_sums, want_raw):
             with open(csv_path, mode="a", newline="") as fh:
                 writer = csv.writer(fh)
-                for i, rec in enumerate(recs):
+                for i in np.nonzero(res["pass"])[0]:
                     r = res[i]
-                    if not r["pass"]:
-                        continue
+                    rec = rb.record(int(i))
                     if out_handle is not None:
                         seqio.write_record(out_handle, rec, fmt)
                     if args.read_check and rec.id != args.read_check:

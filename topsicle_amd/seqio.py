@@ -120,3 +120,123 @@ def write_record(handle, rec: Record, fmt: str):
             handle.write(rec.seq[i:i + 60] + "\n")
     else:
         raise ValueError(fmt)
+
+
+# ---------------------------------------------------------------------------- native batch reader
+class RecordBatch:
+    """A batch of reads in the layout tps_batch_upload takes (concatenated bases + offsets); record
+    objects are only materialised on request (for the few reads that are written back out)."""
+
+    def __init__(self, bases, offsets, heads: bytes, head_off, quals=None, fmt="fastq"):
+        self.bases, self.offsets, self.heads, self.head_off, self.quals, self.fmt = bases, offsets, heads, head_off, quals, fmt
+        self.n = len(offsets) - 1
+        self._ids = None
+
+    def __len__(self):
+        return self.n
+
+    @property
+    def ids(self):
+        if self._ids is None:
+            h, o = self.heads, self.head_off
+            self._ids = [_first_token(h[o[i]:o[i + 1]].decode("utf-8", "replace")) for i in range(self.n)]
+        return self._ids
+
+    def record(self, i: int) -> Record:
+        d = self.heads[self.head_off[i]:self.head_off[i + 1]].decode("utf-8", "replace")
+        lo, hi = int(self.offsets[i]), int(self.offsets[i + 1])
+        seq = self.bases[lo:hi].tobytes().decode("ascii", "replace")
+        qual = self.quals[lo:hi].tobytes().decode("ascii", "replace") if self.quals is not None else None
+        return Record(_first_token(d), d, seq, qual)
+
+    @classmethod
+    def from_records(cls, recs, fmt="fastq"):
+        import numpy as np
+        heads = [r.description.encode() for r in recs]
+        seqs = [r.seq.encode("ascii", "replace") for r in recs]
+        offsets = np.zeros(len(recs) + 1, np.int64)
+        head_off = np.zeros(len(recs) + 1, np.int64)
+        if recs:
+            np.cumsum([len(x) for x in seqs], out=offsets[1:])
+            np.cumsum([len(x) for x in heads], out=head_off[1:])
+        bases = np.frombuffer(b"".join(seqs), dtype=np.uint8) if recs else np.zeros(0, np.uint8)
+        quals = None
+        if recs and all(r.qual is not None for r in recs):
+            quals = np.frombuffer(b"".join((r.qual + "!" * len(r.seq))[:len(r.seq)].encode() for r in recs), dtype=np.uint8)
+        b = cls(bases, offsets, b"".join(heads), head_off, quals, fmt)
+        b._ids = [r.id for r in recs]
+        return b
+
+
+_io_lib = None
+
+
+def _load_io():
+    """libtopsicle_io.so (csrc/tps_io.cpp): C++ FASTA/FASTQ(.gz) decoder; None if not built."""
+    global _io_lib
+    if _io_lib is None:
+        import ctypes as C
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libtopsicle_io.so")
+        if not os.path.exists(path):
+            _io_lib = False
+            return None
+        lib = C.CDLL(path)
+        lib.tps_io_last_error.restype = C.c_char_p
+        lib.tps_reader_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        lib.tps_reader_format.argtypes = [C.c_void_p]
+        lib.tps_reader_close.argtypes = [C.c_void_p]
+        lib.tps_reader_next.restype = C.c_int64
+        lib.tps_reader_next.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                        C.c_void_p, C.c_void_p]
+        _io_lib = lib
+    return _io_lib or None
+
+
+def read_batches(filepath: str, max_bases: int = 256 << 20, max_records: int = 1 << 20, want_quals: bool = True):
+    """Generator of RecordBatch over a FASTA/FASTQ(.gz) file: the native decoder when it is built,
+    otherwise the pure-Python parser above (same records either way; this is host I/O, not compute)."""
+    import numpy as np
+    lib = _load_io()
+    if lib is None:
+        fmt = check_file_type(filepath)
+        cur, nb = [], 0
+        for rec in read_records(filepath):
+            if cur and (nb + len(rec.seq) > max_bases or len(cur) >= max_records):
+                yield RecordBatch.from_records(cur, fmt or "fasta")
+                cur, nb = [], 0
+            cur.append(rec)
+            nb += len(rec.seq)
+        if cur:
+            yield RecordBatch.from_records(cur, fmt or "fasta")
+        return
+    import ctypes as C
+    h = C.c_void_p()
+    if lib.tps_reader_open(filepath.encode(), C.byref(h)) != 0:
+        logging.error("Error parsing file: %s", lib.tps_io_last_error().decode())
+        return
+    try:
+        fmt = {1: "fasta", 2: "fastq"}.get(lib.tps_reader_format(h), "fasta")
+        cap = max_bases
+        while True:
+            bases = np.empty(cap, np.uint8)
+            quals = np.empty(cap, np.uint8) if (want_quals and fmt == "fastq") else None
+            nrec = min(max_records, cap // 64 + 1024)
+            offsets = np.empty(nrec + 1, np.int64)
+            head_off = np.empty(nrec + 1, np.int64)
+            heads = np.empty(max(cap // 8, 1 << 20), np.uint8)
+            n = lib.tps_reader_next(h, bases.ctypes.data, cap, offsets.ctypes.data, nrec, heads.ctypes.data, len(heads),
+                                    head_off.ctypes.data, quals.ctypes.data if quals is not None else None)
+            if n == -2:                     # a single record larger than the buffers: grow and retry
+                cap *= 2
+                continue
+            if n < 0:
+                logging.error("Error parsing file: %s", lib.tps_io_last_error().decode())
+                return
+            if n == 0:
+                return
+            nb = int(offsets[n])
+            yield RecordBatch(bases[:nb], offsets[:n + 1].copy(), heads[:int(head_off[n])].tobytes(), head_off[:n + 1].copy(),
+                              quals[:nb] if quals is not None else None, fmt)
+    finally:
+        lib.tps_reader_close(h)
