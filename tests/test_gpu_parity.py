@@ -258,3 +258,29 @@ def test_invalid_bases_and_self_overlap_at_scale(sc):
         _, counts = orc.window_count_matrix(seqs[i], tail, pats, 100, 6, 100, 20000)
         assert np.array_equal(raw[win_off[i]:win_off[i + 1]], counts)
         assert res["bkp"][i] == orc.binseg_l2_exact(counts.sum(axis=1))
+
+
+@pytest.mark.parametrize("k,with_n", [(5, True), (4, True), (6, False)])
+def test_run_to_run_determinism(sc, k, with_n):
+    """Same batch scanned repeatedly must give bit-identical window sums (guards against scheduling /
+    uninitialised-LDS hazards that only show on the device)."""
+    motif = "CCCTAA"
+    sc.set_patterns(orc.kmer_table(motif, k))
+    bases, offsets, _ = synth.make_reads(1500, 6000, motif, seed=7, tract_min=500, tract_max=3000)
+    b = bases.copy()
+    if with_n:
+        rng = np.random.default_rng(2)
+        pos = rng.integers(0, b.size, b.size // 200)
+        b[pos] = np.frombuffer(b"NnacgtRY", dtype=np.uint8)[rng.integers(0, 8, pos.size)]
+    sc.upload(5, b, offsets)
+    prm = hiplib.make_params(min_len=1000, min_count=-1, flags=hiplib.F_STEP1 | hiplib.F_WINDOWS | hiplib.F_BINSEG | hiplib.F_STORE_SUMS)
+    sc.scan(5, prm)
+    sc.sync()
+    ref, _ = sc.window_sums(5)
+    ref_res = sc.results(5).copy()
+    for _ in range(4):
+        sc.scan(5, prm)
+        sc.sync()
+        s, _ = sc.window_sums(5)
+        assert np.array_equal(s, ref)
+        assert np.array_equal(sc.results(5)["bkp"], ref_res["bkp"])

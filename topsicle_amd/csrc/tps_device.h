@@ -32,6 +32,7 @@
 #define TPS_PHASE for (int tid = 0; tid < tps::NT; ++tid)
 #define TPS_SYNC() ((void)0)
 #define TPS_UNROLL
+#define TPS_NOVEC
 #define TPS_SCHED_BARRIER() ((void)0)
 #define TPS_PIN(x) ((void)0)
 #else
@@ -51,7 +52,13 @@ __device__ __forceinline__ int tps_fresh_lane() {
 // across this point (no s_barrier, no cross-wave skew)
 #define TPS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 #define TPS_UNROLL _Pragma("unroll")
-#define TPS_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+// short runtime-bounded loops: keep them as plain scalar loops (the vectoriser turns a 1-2 iteration loop
+// into prologue / vector body / epilogue control flow that costs more than the loop)
+#define TPS_NOVEC _Pragma("clang loop vectorize(disable) interleave(disable) unroll(disable)")
+// (__builtin_amdgcn_sched_barrier(0) was used here to bound register pressure; with ROCm 7.2 it made the
+// self-overlap + invalid-base instance of the fused tile nondeterministic on gfx950, and it is no longer
+// needed once every phase launders its lane id)
+#define TPS_SCHED_BARRIER() ((void)0)
 // zero-cost "redefinition" of a register: nothing computed from x can be hoisted above this point
 #define TPS_PIN(x) asm volatile("" : "+v"(x))
 #endif
@@ -441,6 +448,7 @@ TPS_DEV uint32_t h_at(const uint32_t* lut, int lshift, const uint32_t* seq2, con
 // patterns p (subset of `h`) that occur again d < k positions later (d a period of p)
 TPS_DEV uint32_t conflict_bits(const PatInfo& pat, uint32_t v, uint32_t h) {
     uint32_t c = 0;
+    TPS_NOVEC
     for (int i = 0; i < pat.n_periods; ++i) {
         uint32_t hp = h & pat.period_pat[i];
         if (hp && (((v ^ (v >> (2 * pat.period[i]))) & pat.kmask) == 0)) c |= hp;
@@ -847,7 +855,14 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const Lds& l, int delta, int w0, in
         for (int j = 0; j < B; ++j) sufc0[j] = keep[tid][j];
 #endif
         const int rot = q & (B - 1), dl0 = q >> LOG2B;
-        const uint32_t tot_l = l.XT[tid];
+        // A window's last (partial) block lies dl0 or dl0+1 lanes ahead; the whole chunks strictly in
+        // between are the next dl0-1 (or dl0) lanes' chunks: two ORs and two span-total prefixes per lane,
+        // selected per window by a wave-uniform condition.
+        uint32_t foa = 0;
+        TPS_NOVEC
+        for (int t = 1; t < dl0; ++t) foa |= l.XF[tid + t];
+        const uint32_t fob = foa | l.XF[tid + dl0];
+        const uint32_t tot_l = l.XT[tid], tot_a = l.XT[tid + dl0], tot_b = l.XT[tid + dl0 + 1];
         uint32_t redo = 0;
         uint32_t present[(B + 1) / 2];
         TPS_UNROLL
@@ -856,15 +871,11 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const Lds& l, int delta, int w0, in
         for (int j = 0; j < B; ++j) {
             const int wl = tid * B + j;
             const int jr = j + rot;                   // uniform: source block index and lane distance
-            const int src = tid + dl0 + (jr >> LOG2B);
+            const bool far = (jr >> LOG2B) != 0;
+            const int src = tid + dl0 + (far ? 1 : 0);
             const int idx = jr & (B - 1);
-            uint32_t m = (sufc0[j] & 0xFFFFu) | l.XP[idx * XLANES + src];
-            // whole chunks strictly between the window's first and last chunk: the count is the same
-            // for every lane (B is a multiple of C), only the first chunk index depends on the lane
-            const int nfull = ((j + q) >> LOG2C) - (j >> LOG2C) - 1;
-            const int ch0 = tid * (B / C) + (j >> LOG2C) + 1;
-            for (int t = 0; t < nfull; ++t) m |= l.XF[ch0 + t];
-            uint32_t cnt = ((uint32_t)l.XC[idx * XLANES + src] + l.XT[src]) - ((sufc0[j] >> 16) + tot_l);
+            const uint32_t m = (sufc0[j] & 0xFFFFu) | l.XP[idx * XLANES + src] | (far ? fob : foa);
+            uint32_t cnt = ((uint32_t)l.XC[idx * XLANES + src] + (far ? tot_b : tot_a)) - ((sufc0[j] >> 16) + tot_l);
             uint32_t sw = (cnt & 0xFFFFu) + (uint32_t)(pat.P - popc(m & pat.all_mask));
             if (wl >= nw_tile) sw = 0;
             else if ((m & FLAG16) || a.raw) redo |= 1u << j;
