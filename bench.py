@@ -38,6 +38,9 @@ CONFIGS = {
     "config2": dict(n_reads=10000, read_len=15000, motif="CCCTAA", k=4, window=100, slide=6,
                     errors=synth.ONT, seed=20250919 + 1,
                     desc="BASELINE configs[1]: 10k synthetic ONT reads x 15 kb, --pattern CCCTAA, window=100 slide=6"),
+    "config4_sample": dict(n_reads=10000, read_len=30000, motif="CCCTAA", k=4, window=100, slide=6,
+                           errors=synth.ONT, seed=20250919 + 3,
+                           desc="BASELINE configs[3] sample: 10k synthetic ONT reads x 30 kb, --pattern CCCTAA (20 kb scanned per read)"),
     "config3_per_gpu": dict(n_reads=25000, read_len=20000, motif="AAACCCT", k=5, window=100, slide=7,
                             errors=synth.HIFI, seed=20250919 + 2,
                             desc="BASELINE configs[2] shard: 25k synthetic HiFi reads x 20 kb per GPU, --pattern AAACCCT"),

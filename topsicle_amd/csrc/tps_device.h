@@ -132,6 +132,19 @@ TPS_DEV u32x4 load16(const uint8_t* p) {
 }
 #endif
 
+// table entry at byte offset `off` (already masked to the table size).  The table starts at the
+// workgroup's LDS offset 0, i.e. it is aligned to any power of two, so base | off == base + off and the
+// mask + base fold into one v_and_or_b32.
+#ifdef TPS_EMU
+TPS_DEV uint32_t lut_at(const uint32_t* lut, uint32_t v4, uint32_t amask) { return *(const uint32_t*)((const char*)lut + (v4 & amask)); }
+#else
+TPS_DEV uint32_t lut_at(const uint32_t* lut, uint32_t v4, uint32_t amask) {
+    typedef const __attribute__((address_space(3))) uint32_t* lptr_t;
+    const uint32_t base = (uint32_t)(uintptr_t)(lptr_t)lut;
+    return *(lptr_t)(uintptr_t)((v4 & amask) | base);
+}
+#endif
+
 constexpr int cgcd(int a, int b) { return b == 0 ? a : cgcd(b, a % b); }
 constexpr int clog2(int x) { return x <= 1 ? 0 : 1 + clog2(x / 2); }
 
@@ -793,7 +806,7 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const Lds& l, int delta, int w0, in
                 const int p = blk * S + i;        // constant after unrolling
                 const int dw = p >> 4, bit = p & 15;
                 uint32_t v4 = bit ? alignbit(dw + 1 < WDW ? w[dw + 1] : 0u, w[dw], 2u * bit) : w[dw];
-                uint32_t h = *(const uint32_t*)((const char*)l.lut + (v4 & amask));
+                uint32_t h = lut_at(l.lut, v4, amask);
                 if (INV) {
                     if (h && invalid_at(l.val, p0 + p, pat.k)) h = 0;   // tiles with non-ACGT letters only
                 }
@@ -902,20 +915,33 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const Lds& l, int delta, int w0, in
     const uint32_t gsum = wg_exclusive_scan(l.row, NT * B, &l.misc[M_SCAN], LOG2B);
     if (w0 == 0) TPS_STAMP(12);
     TPS_PHASE {
-        const uint32_t jump = (uint32_t)a.prm.jump;
+        // lane-strided: window wl = 64 u + lane.  Its padded row index is 72 u + lane + lane/8, so both
+        // LDS reads use one per-lane base plus an immediate; valid windows never reach entry 512
+        // (nw_tile <= 488), so the "next" entry always exists.  The candidate test w % jump == 0 and the
+        // candidate index w / jump advance incrementally (64 = qs * jump + rs) instead of two
+        // quarter-rate multiplies per window.
+        const uint32_t lane = (uint32_t)tid;
+        const uint32_t jump = (uint32_t)a.prm.jump, lc_cap = (uint32_t)a.lc_cap;
         const uint32_t carry = (uint32_t)s_total;
+        const uint32_t qs = 64u / jump, rs = 64u - qs * jump;
+        const uint32_t* rp0 = l.row + (lane + (lane >> 3));
+        const uint32_t* rp1 = l.row + ((lane + 1u) + ((lane + 1u) >> 3));
+        int32_t* out = a.sums + (out_base + w0);
+        const uint32_t wg0 = (uint32_t)w0 + lane;
+        uint32_t c = (uint32_t)(((uint64_t)wg0 * a.jump_magic) >> 32);
+        uint32_t rem = wg0 - c * jump;
         TPS_UNROLL
         for (int u = 0; u < B; ++u) {
-            const int wl = u * NT + tid;
-            if (wl < nw_tile) {
-                const uint32_t pre = l.row[padded(wl, LOG2B)];
-                const uint32_t nxt = (wl + 1 < NT * B) ? l.row[padded(wl + 1, LOG2B)] : gsum;
-                a.sums[out_base + w0 + wl] = (int32_t)(nxt - pre);
-                const uint32_t wg = (uint32_t)(w0 + wl);
-                const uint32_t c = (uint32_t)(((uint64_t)wg * a.jump_magic) >> 32);
-                if (c * jump == wg && (int)c < a.lc_cap) l.Lc[c] = carry + pre;
+            const uint32_t wl = (uint32_t)(u * NT) + lane;
+            if ((int)wl < nw_tile) {
+                const uint32_t pre = rp0[u * (NT + NT / 8)];
+                const uint32_t nxt = rp1[u * (NT + NT / 8)];
+                out[wl] = (int32_t)(nxt - pre);
+                if (rem == 0 && c < lc_cap) l.Lc[c] = carry + pre;
             }
-            if (u & 1) TPS_SCHED_BARRIER();
+            c += qs;
+            rem += rs;
+            if (rem >= jump) { rem -= jump; c += 1; }
         }
     }
     s_total += gsum;
