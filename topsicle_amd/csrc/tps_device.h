@@ -224,20 +224,23 @@ struct Lds {
     uint32_t* Gp;      // per block: OR over its first r positions
     uint16_t* C0;      // per block: matches before the block (span-local running count)
     uint16_t* C1;      // per block: matches before position r of the block
-    // specialised (fused) path views of blk: what a lane publishes for the lanes before it
-    uint16_t* XP;      // [B][XLANES] prefix-OR of the lane's chunk up to (and r positions into) block b
-    uint16_t* XC;      // [B][XLANES] span-local match count before position r of block b
-    uint16_t* XF;      // per chunk of C blocks: OR of all its block masks
+    // specialised (fused) path views of blk: what a lane publishes about its 8 blocks.  Every word is
+    // mask << 16 | count, like the table entries, indexed by the padded block number b + b / 8
+    // (lane L's blocks sit at 9 L .. 9 L + 7: conflict-free for lane-contiguous AND lane-strided access)
+    uint32_t* XPC;     // per block: OR of the lane's earlier blocks and r positions of this one | lane-local count there
+    uint32_t* XF;      // [XLANES] OR of all the lane's block masks (high half)
     uint32_t* XT;      // [XLANES] matches in the lane's span, then exclusive prefix over lanes
+    uint32_t* FOA;     // [NT] per start lane: OR of the whole lanes a window skips | count they add  (near end lane)
+    uint32_t* FOB;     // [NT] the same when the window's end lies one lane further
     uint32_t* Tot;     // per span: matches in the span, then exclusive prefix over spans
     uint32_t* Lc;      // Lc[c] = sum of S_w over w < c * jump: left sums of the change-point candidates
     uint32_t* row;     // WIN_U * NT dwords: one group of window sums, scanned in place
     uint32_t* misc;
 };
 constexpr int XLANES = NT + 16;                  // exchange rows hold NT lanes + halo lanes read past the tile end
-TPS_HD int64_t xchg_dw(const ScanArgs& a) {      // fused path: XP, XC (u16 [B][XLANES]), XF (u16 per chunk), XT (u32 per lane)
-    const int bps = 1 << a.blk_log2;
-    return 2ll * ((bps * XLANES + 1) / 2) + (XLANES + 1) / 2 + XLANES;
+TPS_HD int64_t xchg_dw(const ScanArgs& a) {      // fused path: XPC (9 words per lane), XF, XT, FOA, FOB
+    (void)a;
+    return 9ll * NT + 2ll * XLANES + 2ll * NT;
 }
 TPS_HD int64_t blk_region_dw(const ScanArgs& a) {
     // generic kernel: G, Gp (u32) and C0, C1 (u16) per block; fused kernels: the exchange arrays
@@ -266,13 +269,11 @@ TPS_DEV Lds carve(uint32_t* base, uint32_t* lut, const ScanArgs& a) {
     l.Gp = l.G + a.nblk_cap;
     l.C0 = (uint16_t*)(l.Gp + a.nblk_cap);
     l.C1 = l.C0 + ((a.nblk_cap + 1) / 2) * 2;
-    {
-        const int bps = 1 << a.blk_log2;
-        l.XP = (uint16_t*)l.blk;
-        l.XC = l.XP + ((bps * XLANES + 1) / 2) * 2;
-        l.XF = l.XC + ((bps * XLANES + 1) / 2) * 2;
-        l.XT = (uint32_t*)(l.XF + ((XLANES + 1) / 2) * 2);
-    }
+    l.XPC = l.blk;
+    l.XF = l.XPC + 9 * NT;
+    l.XT = l.XF + XLANES;
+    l.FOA = l.XT + XLANES;
+    l.FOB = l.FOA + NT;
     return l;
 }
 TPS_HD int64_t lds_dwords(const ScanArgs& a) {
@@ -756,28 +757,32 @@ struct Geo {
     static constexpr int PF = (TILE_DW + NT - 1) / NT;
 };
 
-// One fused tile: NT spans (one per lane), blocks AND windows in registers.
-//   phase 1  a lane scans its span (B blocks): per block the suffix-OR of its chunk and the running
-//            count stay in registers; the prefix-OR / count at the partial point go to the exchange
-//            arrays because the windows that END in this lane's blocks belong to earlier lanes.
-//   phase 2  window j of lane L (blocks L*B+j .. +q, plus r positions) = own suffix | full chunks in
-//            between | prefix published by lane L + (j+q)/B for block (j+q)%B; S_w -> row[].
-//   phase 3  (after an exclusive scan of row[]) lane-strided: S_w to HBM coalesced, left sums of the
-//            change-point candidates to Lc[].
-// Windows beyond nw_tile (they need blocks of the next tile) are simply not produced.
+// One fused tile: NT lanes x B blocks.
+//   phase 1  (lane-contiguous) a lane scans its B blocks with the packed bases in registers and
+//            publishes two words per block, both mask << 16 | count like the table entries:
+//              XS [b]  OR of this and the lane's later blocks | lane-local count before the block
+//              XPC[b]  OR of the lane's earlier blocks and r positions of this one | count there
+//            plus the OR / match total of the whole lane (XF, XT).
+//   phase 1b (after the scan of XT) per start lane: OR and match count of the whole lanes a window
+//            skips between its first and last lane, for both possible lane distances (FOA, FOB).
+//   phase 2  (lane-strided) window w = 64 u + lane starts at block w and ends r positions into block
+//            w + q, which lies in a LATER lane because q >= 8:  XS[w] | skipped lanes | XPC[w + q].
+//            Three LDS reads at per-lane bases + immediates, S_w to HBM coalesced and into row[].
+//   phase 3  (after the exclusive scan of row[]) candidate-strided: Lc[c] = left sum of window c * jump.
+// XS aliases row[]: the only reader of XS[w] is the lane that then writes row[w].
+// Windows beyond nw_tile (they need blocks of the next tile) are not produced.
+TPS_DEV uint32_t pack_hi_lo(uint32_t hi_src, uint32_t lo_src) { return perm(hi_src, lo_src, 0x07060100u); }
+
 template <int S, bool SO, bool INV, bool RZ>
 TPS_DEV void tile_fused_s(const ScanArgs& a, const Lds& l, int delta, int w0, int nw_tile, int64_t out_base,
                           uint64_t& s_total, int64_t r) {
     // RZ: the window has no partial block (W - k divisible by the slide), so nothing is captured mid-block
     typedef Geo<S> g_;
-    constexpr int WDW = g_::WDW, B = g_::B, C = g_::C, LOG2B = g_::LOG2B, LOG2C = g_::LOG2C, POS = g_::POS;
+    constexpr int WDW = g_::WDW, B = g_::B, LOG2B = g_::LOG2B, POS = g_::POS;
+    constexpr int RS = NT + NT / B;               // row stride of the padded layout between u and u + 1
     const PatInfo& pat = a.pat;
-    const int rp = a.r, q = a.q;              // rp: positions of the partial block (a.r)
-    const uint32_t amask = pat.kmask << 2;    // k-mer code as a byte offset into the 4-byte table
-    uint32_t sufc0[B];                            // per block: suffix-OR of its chunk | count before it << 16
-#ifdef TPS_EMU
-    uint32_t keep[NT][B];                         // registers that live across the phases
-#endif
+    const int rp = a.r, q = a.q;                  // rp: positions of the partial block (a.r)
+    const uint32_t amask = pat.kmask << 2;        // k-mer code as a byte offset into the 4-byte table
     TPS_PHASE {
         const int span = tid;
         // The lane's bases start at an arbitrary bit offset; one per-lane funnel shift aligns the base
@@ -797,7 +802,9 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const Lds& l, int delta, int w0, in
             }
         }
         uint32_t cnt = 0, run_or = 0;             // table entries are mask << 16 | popcount: OR keeps the masks
-        uint32_t gsave[C];                        // in the high half, ADD the match count in the low half
+        uint32_t gs[B], c0s[B];                   // in the high half, ADD the match count in the low half
+        uint32_t* xs = l.row + span * (B + 1);
+        uint32_t* xpc = l.XPC + span * (B + 1);
         // table lookups run one block ahead of their use (software pipeline, 2 S values in flight)
         uint32_t hc[S], vc[S], hn[S], vn[S];
         auto fetch = [&](int blk, uint32_t* hh, uint32_t* vv) {
@@ -817,11 +824,9 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const Lds& l, int delta, int w0, in
         fetch(0, hc, vc);
         TPS_UNROLL
         for (int blk = 0; blk < B; ++blk) {
-            const int bc = blk % C;
             if (blk + 1 < B) fetch(blk + 1, hn, vn);
-            if (bc == 0) run_or = 0;
             uint32_t g = 0;
-            const uint32_t c0 = cnt;
+            c0s[blk] = cnt;
             uint32_t c1 = cnt, pp = run_or;
             TPS_UNROLL
             for (int i = 0; i < S; ++i) {
@@ -836,112 +841,113 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const Lds& l, int delta, int w0, in
                     if (i + 1 == rp) { c1 = cnt; pp = run_or | g; }
                 }
             }
-            l.XP[blk * XLANES + span] = (uint16_t)(pp >> 16);
-            l.XC[blk * XLANES + span] = (uint16_t)c1;
-            sufc0[blk] = c0 << 16;
-            gsave[bc] = g >> 16;
+            xpc[blk] = pack_hi_lo(pp, c1);
+            gs[blk] = g;
             run_or |= g;
-            if (bc == C - 1) {                    // chunk complete: suffix ORs, chunk total
-                uint32_t sfx = 0;
-                TPS_UNROLL
-                for (int j = C - 1; j >= 0; --j) {
-                    sfx |= gsave[j];
-                    sufc0[blk - (C - 1) + j] |= sfx;
-                }
-                l.XF[span * (B / C) + blk / C] = (uint16_t)sfx;
-            }
             TPS_UNROLL
             for (int i = 0; i < S; ++i) { hc[i] = hn[i]; vc[i] = vn[i]; }
-            TPS_SCHED_BARRIER();
         }
+        uint32_t sfx = 0;
+        TPS_UNROLL
+        for (int j = B - 1; j >= 0; --j) {
+            sfx |= gs[j];
+            xs[j] = pack_hi_lo(sfx, c0s[j]);
+        }
+        l.XF[span] = sfx;
         l.XT[span] = cnt & 0xFFFFu;
-#ifdef TPS_EMU
-        for (int j = 0; j < B; ++j) keep[tid][j] = sufc0[j];
-#endif
     }
     TPS_SYNC();
     if (w0 == 0) TPS_STAMP(6);
     wg_exclusive_scan(l.XT, NT, &l.misc[M_SCAN]);
     if (w0 == 0) TPS_STAMP(7);
+    const int rot = q & (B - 1), dl0 = q >> LOG2B;
     TPS_PHASE {
-#ifdef TPS_EMU
-        for (int j = 0; j < B; ++j) sufc0[j] = keep[tid][j];
-#endif
-        const int rot = q & (B - 1), dl0 = q >> LOG2B;
-        // A window's last (partial) block lies dl0 or dl0+1 lanes ahead; the whole chunks strictly in
-        // between are the next dl0-1 (or dl0) lanes' chunks: two ORs and two span-total prefixes per lane,
-        // selected per window by a wave-uniform condition.
+        // A window's last (partial) block lies dl0 or dl0+1 lanes ahead of its first; the whole lanes
+        // strictly in between are the next dl0-1 (or dl0) lanes.
         uint32_t foa = 0;
         TPS_NOVEC
         for (int t = 1; t < dl0; ++t) foa |= l.XF[tid + t];
         const uint32_t fob = foa | l.XF[tid + dl0];
         const uint32_t tot_l = l.XT[tid], tot_a = l.XT[tid + dl0], tot_b = l.XT[tid + dl0 + 1];
-        uint32_t redo = 0;
-        uint32_t present[(B + 1) / 2];
+        l.FOA[tid] = pack_hi_lo(foa, tot_a - tot_l);
+        l.FOB[tid] = pack_hi_lo(fob, tot_b - tot_l);
+    }
+    TPS_SYNC();
+    TPS_PHASE {
+        const uint32_t lane = (uint32_t)tid;
+        const bool farl = (((lane & (B - 1)) + (uint32_t)rot) >> LOG2B) != 0;
+        uint32_t* ps = l.row + (lane + (lane >> LOG2B));                         // XS in, S_w out
+        const uint32_t* pe = l.XPC + ((lane + (uint32_t)q) + ((lane + (uint32_t)q) >> LOG2B));
+        const uint32_t* pf = (farl ? l.FOB : l.FOA) + (lane >> LOG2B);
+        int32_t* out = a.sums + (out_base + w0);
+        const uint32_t am = pat.all_mask << 16;
+        const int nfull = nw_tile >> 6;                                          // uniform
+        const uint32_t npart = (uint32_t)(nw_tile & 63);
+        uint32_t flags = 0;                          // bit u: window 64 u + lane needs the exact recount
+        uint32_t present[B / 2];                     // SO only: the windows' presence masks, two per word
         TPS_UNROLL
-        for (int t = 0; t < (B + 1) / 2; ++t) present[t] = 0;
+        for (int t = 0; t < B / 2; ++t) present[t] = 0;
         TPS_UNROLL
-        for (int j = 0; j < B; ++j) {
-            const int wl = tid * B + j;
-            const int jr = j + rot;                   // uniform: source block index and lane distance
-            const bool far = (jr >> LOG2B) != 0;
-            const int src = tid + dl0 + (far ? 1 : 0);
-            const int idx = jr & (B - 1);
-            const uint32_t m = (sufc0[j] & 0xFFFFu) | l.XP[idx * XLANES + src] | (far ? fob : foa);
-            uint32_t cnt = ((uint32_t)l.XC[idx * XLANES + src] + (far ? tot_b : tot_a)) - ((sufc0[j] >> 16) + tot_l);
-            uint32_t sw = (cnt & 0xFFFFu) + (uint32_t)(pat.P - popc(m & pat.all_mask));
-            if (wl >= nw_tile) sw = 0;
-            else if ((m & FLAG16) || a.raw) redo |= 1u << j;
-            l.row[padded(wl, LOG2B)] = sw;
-            present[j / 2] |= (m & pat.all_mask) << (16 * (j & 1));
-            if ((j & 3) == 3) TPS_SCHED_BARRIER();
+        for (int u = 0; u < B; ++u) {
+            uint32_t sw = 0;
+            if (u <= nfull) {
+                const bool valid = (u < nfull) || (lane < npart);
+                if (valid) {
+                    const uint32_t x = ps[u * RS], e = pe[u * RS], f = pf[u * (NT / B)];
+                    const uint32_t m = x | e | f;
+                    sw = ((e - x + f) & 0xFFFFu) + (uint32_t)popc(~m & am);
+                    if (SO) {
+                        flags |= (m >> 31) << u;
+                        present[u / 2] |= (u & 1) ? (m & 0xFFFF0000u) : (m >> 16);
+                    }
+                    out[(uint32_t)(u * NT) + lane] = (int32_t)sw;
+                }
+            }
+            ps[u * RS] = sw;
         }
         // rare: windows with overlapping occurrences of a self-overlapping k-mer, or raw counts wanted
-        while (redo) {
-            const int j = ffs0(redo);
-            redo &= redo - 1;
-            const int wl = tid * B + j;
+        if (a.raw) {
+            const int nv = nfull + ((lane < npart) ? 1 : 0);
+            flags = nv >= B ? (1u << B) - 1u : (1u << nv) - 1u;
+        }
+        while (flags) {
+            const int u = ffs0(flags);
+            flags &= flags - 1;
+            const int wl = u * NT + (int)lane;
             uint32_t pm = 0;
-            TPS_UNROLL
-            for (int t = 0; t < B / 2; ++t)
-                if (t == (j >> 1)) pm = present[t];
-            pm = (pm >> (16 * (j & 1))) & 0xFFFFu;
+            if (SO) {
+                TPS_UNROLL
+                for (int t = 0; t < B / 2; ++t)
+                    if (t == (u >> 1)) pm = present[t];
+                pm = (pm >> (16 * (u & 1))) & pat.all_mask;
+            }
             uint8_t* raw_row = a.raw ? a.raw + (out_base + w0 + wl) * (int64_t)pat.P : nullptr;
-            l.row[padded(wl, LOG2B)] = window_exact(a, l, delta, wl, pm, l.row[padded(wl, LOG2B)], raw_row);
+            const uint32_t sw = window_exact(a, l, delta, wl, pm, l.row[padded(wl, LOG2B)], raw_row);
+            l.row[padded(wl, LOG2B)] = sw;
+            out[wl] = (int32_t)sw;
         }
     }
     TPS_SYNC();
     if (w0 == 0) TPS_STAMP(11);
     const uint32_t gsum = wg_exclusive_scan(l.row, NT * B, &l.misc[M_SCAN], LOG2B);
     if (w0 == 0) TPS_STAMP(12);
-    TPS_PHASE {
-        // lane-strided: window wl = 64 u + lane.  Its padded row index is 72 u + lane + lane/8, so both
-        // LDS reads use one per-lane base plus an immediate; valid windows never reach entry 512
-        // (nw_tile <= 488), so the "next" entry always exists.  The candidate test w % jump == 0 and the
-        // candidate index w / jump advance incrementally (64 = qs * jump + rs) instead of two
-        // quarter-rate multiplies per window.
-        const uint32_t lane = (uint32_t)tid;
-        const uint32_t jump = (uint32_t)a.prm.jump, lc_cap = (uint32_t)a.lc_cap;
-        const uint32_t carry = (uint32_t)s_total;
-        const uint32_t qs = 64u / jump, rs = 64u - qs * jump;
-        const uint32_t* rp0 = l.row + (lane + (lane >> 3));
-        const uint32_t* rp1 = l.row + ((lane + 1u) + ((lane + 1u) >> 3));
-        int32_t* out = a.sums + (out_base + w0);
-        const uint32_t wg0 = (uint32_t)w0 + lane;
-        uint32_t c = (uint32_t)(((uint64_t)wg0 * a.jump_magic) >> 32);
-        uint32_t rem = wg0 - c * jump;
-        TPS_UNROLL
-        for (int u = 0; u < B; ++u) {
-            const uint32_t wl = (uint32_t)(u * NT) + lane;
-            if ((int)wl < nw_tile) {
-                const uint32_t pre = rp0[u * (NT + NT / 8)];
-                const uint32_t nxt = rp1[u * (NT + NT / 8)];
-                out[wl] = (int32_t)(nxt - pre);
-                if (rem == 0 && c < lc_cap) l.Lc[c] = carry + pre;
+    {
+        // change-point candidates of this tile: c with w0 <= c * jump < w0 + nw_tile, 64 per pass
+        const uint32_t jump = (uint32_t)a.prm.jump;
+        const uint32_t c_lo = (uint32_t)(((uint64_t)((uint32_t)w0 + jump - 1u) * a.jump_magic) >> 32);
+        uint32_t c_hi = (uint32_t)(((uint64_t)((uint32_t)(w0 + nw_tile) + jump - 1u) * a.jump_magic) >> 32);
+        if (c_hi > (uint32_t)a.lc_cap) c_hi = (uint32_t)a.lc_cap;
+        const int passes = c_hi > c_lo ? (int)((c_hi - c_lo + NT - 1) / NT) : 0;
+        TPS_PHASE {
+            const uint32_t carry = (uint32_t)s_total;
+            uint32_t c = c_lo + (uint32_t)tid;
+            uint32_t w = c * jump - (uint32_t)w0;         // tile-local window index of candidate c
+            TPS_NOVEC
+            for (int t = 0; t < passes; ++t) {
+                if (c < c_hi) l.Lc[c] = carry + l.row[w + (w >> LOG2B)];
+                c += NT;
+                w += NT * jump;
             }
-            c += qs;
-            rem += rs;
-            if (rem >= jump) { rem -= jump; c += 1; }
         }
     }
     s_total += gsum;
