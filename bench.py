@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--workload", default="config2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-store-sums", action="store_true", help="do not write S_w to HBM (boundary-only run)")
+    ap.add_argument("--n-reads", type=int, default=0, help="diagnostic: override the batch size (NOT the metric's workload)")
+    ap.add_argument("--flags", type=int, default=0, help="diagnostic: override the scan flags (partial pipelines are NOT the metric)")
     ap.add_argument("--resident-copies", type=int, default=0, help="copies of the batch kept in HBM (0 = enough for >1 GB)")
     args = ap.parse_args()
 
@@ -119,7 +121,10 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
-    cfg = CONFIGS[args.workload]
+    cfg = dict(CONFIGS[args.workload])
+    if args.n_reads:
+        cfg["n_reads"] = args.n_reads
+        cfg["desc"] += f" [diagnostic batch of {args.n_reads} reads]"
     motif, k = cfg["motif"], cfg["k"]
     pats = kmer_table(motif, k)
     P = len(pats)
@@ -133,6 +138,8 @@ def main():
                              flags=hiplib.F_STEP1 | hiplib.F_WINDOWS | hiplib.F_BINSEG |
                              (0 if args.no_store_sums else hiplib.F_STORE_SUMS))
 
+    if args.flags:
+        prm.flags = args.flags
     sc = hiplib.HipScanner(local_rank)
     sc.set_patterns(pats)
     copies = args.resident_copies or max(2, min(hiplib.MAX_SLOTS, -(-(1 << 30) // max(batch_bases, 1))))

@@ -159,6 +159,35 @@ def test_emulation_random_vs_oracle(seed):
         assert out["results"][i]["bkp"] == (-1 if want is None else want)
 
 
+@pytest.mark.parametrize("case", [(6, 100, "CCCTAA", 4), (7, 100, "AAACCCT", 5), (5, 200, "CCCTAA", 4), (8, 260, "CCCTAA", 4)])
+def test_emulation_multi_tile_fused(case):
+    """Reads long enough for several fused tiles: the carried candidate sums (16-bit tile-relative for the
+    default window, 32-bit for wide windows) and the tile seams."""
+    s, W, motif, k = case
+    rng = np.random.default_rng(7 * s + W)
+    pats = orc.kmer_table(motif, k)
+    seqs, tails = [], []
+    for i in range(3):
+        L = int(rng.integers(5000, 9000))
+        tract = int(rng.integers(500, 4000))
+        body = list((motif * (tract // len(motif) + 2))[:tract] + "".join("ACGT"[x] for x in rng.integers(0, 4, L - tract)))
+        for p in rng.integers(0, L, L // 12):
+            body[p] = "ACGT"[int(rng.integers(4))]
+        if i == 2:
+            body[int(rng.integers(L))] = "N"
+        seqs.append("".join(body))
+        tails.append(0)
+    prm = hiplib.make_params(window=W, slide=s, trimfirst=100, maxlen=20000,
+                             flags=hiplib.F_WINDOWS | hiplib.F_BINSEG | hiplib.F_TAILS_IN | hiplib.F_STORE_SUMS)
+    out = emu.scan(pats, seqs, prm, tails=tails)
+    for i, seq in enumerate(seqs):
+        _, counts = orc.window_count_matrix(seq, "forward", pats, W, s, 100, 20000)
+        lo, hi = out["win_off"][i], out["win_off"][i + 1]
+        assert hi - lo == counts.shape[0] and hi - lo > 500
+        assert np.array_equal(out["sums"][lo:hi], counts.sum(axis=1))
+        assert out["results"][i]["bkp"] == orc.binseg_l2_exact(counts.sum(axis=1))
+
+
 def test_emulation_binseg_standalone():
     rng = np.random.default_rng(5)
     sums, off = [], [0]

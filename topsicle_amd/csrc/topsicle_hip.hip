@@ -102,6 +102,7 @@ struct Slot {
     bool planned = false;
     tps_params plan_prm{};
     int plan_k = 0, plan_p = 0;
+    uint32_t plan_dup = 0;            // the plan depends on whether the pattern list holds duplicate k-mers
     tps::ScanArgs args{};
     size_t lds_bytes = 0;
     bool scanned = false;
@@ -145,10 +146,12 @@ using tps::window_count;
 
 int plan_lds(tps_ctx* c, Slot& sl, const tps_params& prm, int64_t max_nwin) {
     const size_t lds_max = c->prop.sharedMemPerBlock > 0 ? std::min<size_t>(c->prop.sharedMemPerBlock, 160 * 1024) : 64 * 1024;
+    sl.args.pat = c->pat;                          // the plan looks at dup_mask
     std::string err = tps::plan_geometry(sl.args, prm, c->pat.k, c->pat.P, max_nwin, (int64_t)lds_max / 4, c->spans_override,
                                          c->force_generic, c->lds_target_dw);
     if (!err.empty()) return fail(TPS_E_CAPACITY, "%s", err.c_str());
     sl.lds_bytes = (size_t)tps::wg_lds_dwords(sl.args) * 4;
+    if (const char* e = getenv("TPS_LDS_PAD_BYTES")) sl.lds_bytes += (size_t)atoi(e);   // diagnostic: occupancy experiments
     return TPS_OK;
 }
 
@@ -196,7 +199,8 @@ int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm) {
         return fail(TPS_E_STATE, "TPS_F_TAILS_IN without tps_batch_set_tails");
     const int64_t n = sl.n;
     const int P = c->pat.P;
-    if (!sl.planned || !same_params(prm, sl.plan_prm) || sl.plan_k != c->pat.k || sl.plan_p != P) {
+    if (!sl.planned || !same_params(prm, sl.plan_prm) || sl.plan_k != c->pat.k || sl.plan_p != P ||
+        (sl.plan_dup != 0) != (c->pat.dup_mask != 0)) {
         sl.h_win_off.resize((size_t)n + 1);
         int64_t acc = 0, mx = 0;
         for (int64_t i = 0; i < n; ++i) {
@@ -214,6 +218,7 @@ int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm) {
         sl.plan_prm = prm;
         sl.plan_k = c->pat.k;
         sl.plan_p = P;
+        sl.plan_dup = c->pat.dup_mask;
         sl.planned = true;
     }
     const int64_t total_win = sl.h_win_off[(size_t)n];

@@ -197,6 +197,12 @@ struct ScanArgs {
     int32_t lc_cap;              // capacity of the candidate-prefix array Lc (u32 entries) = max n_win / jump + 1
     uint32_t jump_magic;         // ceil(2^32 / jump): w / jump == mulhi(w, jump_magic) for w < 2^20
     int32_t q, r, lw;            // window = q full blocks + r positions; lw = W - k start positions
+    // fused path, 16-bit candidate sums: Lc16[c] = left sum of candidate c counted from its tile's first
+    // window, Tc[t] = sum of S_w before tile t; tile of window w = mulhi(w, tw_magic)
+    int32_t lc16;                // 1 = Lc16 + Tc instead of the u32 Lc
+    int32_t tile_cap;            // entries of Tc (tiles of the longest read)
+    int32_t tw;                  // windows per fused tile
+    uint32_t tw_magic;           // ceil(2^32 / tw)
 };
 
 struct BinsegArgs {
@@ -209,7 +215,7 @@ struct BinsegArgs {
 };
 
 // ------------------------------------------------------------------ LDS carve
-constexpr int MISC_DW = 96;
+constexpr int MISC_DW = 20;
 constexpr int XS_DW = 64 + NT + 4 * NT + NT + 16 * 5 + 8;   // scratch of the exact Binseg tournament (aliases the block region)
 constexpr int HIST_STRIDE = 33;          // odd stride: the copies of one pattern sit on different LDS banks
 constexpr int HIST_DW = 2 * HIST_COPIES * HIST_STRIDE;   // step-1 private histograms (alias the block region)
@@ -217,7 +223,7 @@ struct Lds {
     uint32_t* lut;     // generic kernel: mask over the pattern list; fused kernels: mask << 16 | popcount(mask)
     int lshift;        // 0 or 16: lut[code] >> lshift is the mask
     uint32_t* seq2;    // 2-bit packed bases, 16 per dword
-    uint32_t* val;     // bit j of val[c] set = position 16c+j is NOT one of acgtACGT
+    uint16_t* val;     // bit j of val[c] set = position 16c+j is NOT one of acgtACGT
     uint32_t* blk;     // block region
     // generic path views of blk
     uint32_t* G;       // per block: OR of masks over its `slide` positions (+FLAG_CONFLICT)
@@ -228,19 +234,21 @@ struct Lds {
     // mask << 16 | count, like the table entries, indexed by the padded block number b + b / 8
     // (lane L's blocks sit at 9 L .. 9 L + 7: conflict-free for lane-contiguous AND lane-strided access)
     uint32_t* XPC;     // per block: OR of the lane's earlier blocks and r positions of this one | lane-local count there
-    uint32_t* XF;      // [XLANES] OR of all the lane's block masks (high half)
-    uint32_t* XT;      // [XLANES] matches in the lane's span, then exclusive prefix over lanes
-    uint32_t* FOA;     // [NT] per start lane: OR of the whole lanes a window skips | count they add  (near end lane)
-    uint32_t* FOB;     // [NT] the same when the window's end lies one lane further
+    uint32_t* XF;      // [xlanes] OR of all the lane's block masks (high half)
+    uint32_t* XT;      // [xlanes] matches in the lane's span, then exclusive prefix over lanes
+    // after phase 1b XF / XT hold, per START lane: OR of the whole lanes a window skips | matches they add,
+    // for the near (XF) and the far (XT) end lane
     uint32_t* Tot;     // per span: matches in the span, then exclusive prefix over spans
     uint32_t* Lc;      // Lc[c] = sum of S_w over w < c * jump: left sums of the change-point candidates
+    uint16_t* Lc16;    // (lc16) the same, counted from the first window of the candidate's tile
+    uint32_t* Tc;      // (lc16) sum of S_w before each tile
     uint32_t* row;     // WIN_U * NT dwords: one group of window sums, scanned in place
     uint32_t* misc;
 };
-constexpr int XLANES = NT + 16;                  // exchange rows hold NT lanes + halo lanes read past the tile end
-TPS_HD int64_t xchg_dw(const ScanArgs& a) {      // fused path: XPC (9 words per lane), XF, XT, FOA, FOB
-    (void)a;
-    return 9ll * NT + 2ll * XLANES + 2ll * NT;
+constexpr int XLANES = NT + 16;                  // most lanes an exchange row can hold: NT + halo lanes read past the tile end
+TPS_HD int xlanes(const ScanArgs& a) { return (NT + (a.q >> 3) + 2 + 1) & ~1; }   // ... and what this window geometry needs
+TPS_HD int64_t xchg_dw(const ScanArgs& a) {      // fused path: XPC (9 words per lane), XF, XT
+    return 9ll * NT + 2ll * xlanes(a);
 }
 TPS_HD int64_t blk_region_dw(const ScanArgs& a) {
     // generic kernel: G, Gp (u32) and C0, C1 (u16) per block; fused kernels: the exchange arrays
@@ -248,6 +256,11 @@ TPS_HD int64_t blk_region_dw(const ScanArgs& a) {
     if (need < XS_DW) need = XS_DW;
     if (need < HIST_DW) need = HIST_DW;
     return (need + 3) & ~3ll;
+}
+TPS_HD int64_t val_dw(const ScanArgs& a) { return ((a.seq_dw + 4 + 3) / 4) * 2; }   // u16 per 16 positions (+ look-ahead), even
+TPS_HD int64_t lc_dw(const ScanArgs& a) {          // even dword counts keep misc 8-byte aligned
+    if (a.lc16) return ((a.lc_cap + 3) / 4) * 2 + ((a.tile_cap + 1) / 2) * 2;
+    return ((a.lc_cap + 1) / 2) * 2;
 }
 TPS_HD int64_t row_dw(const ScanArgs& a) {
     const int64_t fused = a.variant ? ((int64_t)NT << a.blk_log2) + NT : 0;      // + one pad word per lane
@@ -260,9 +273,12 @@ TPS_DEV Lds carve(uint32_t* base, uint32_t* lut, const ScanArgs& a) {
     l.lut = lut;                               // one table per workgroup, shared by its waves
     l.lshift = a.variant ? 16 : 0;
     l.seq2 = p; p += a.seq_dw;
-    l.val = p;  p += a.seq_dw;
+    l.val = (uint16_t*)p;  p += val_dw(a);
     l.Tot = p;  p += a.tot_dw;
-    l.Lc = p;   p += ((a.lc_cap + 1) / 2) * 2;   // even dword counts keep misc 8-byte aligned
+    l.Lc = p;
+    l.Lc16 = (uint16_t*)p;
+    l.Tc = p + ((a.lc_cap + 3) / 4) * 2;
+    p += lc_dw(a);
     l.row = p;  p += row_dw(a);
     l.misc = p;
     l.G = l.blk;
@@ -271,24 +287,22 @@ TPS_DEV Lds carve(uint32_t* base, uint32_t* lut, const ScanArgs& a) {
     l.C1 = l.C0 + ((a.nblk_cap + 1) / 2) * 2;
     l.XPC = l.blk;
     l.XF = l.XPC + 9 * NT;
-    l.XT = l.XF + XLANES;
-    l.FOA = l.XT + XLANES;
-    l.FOB = l.FOA + NT;
+    l.XT = l.XF + xlanes(a);
     return l;
 }
 TPS_HD int64_t lds_dwords(const ScanArgs& a) {
-    return (int64_t)a.blk_dw + 2ll * a.seq_dw + a.tot_dw + ((a.lc_cap + 1) / 2) * 2 + row_dw(a) + MISC_DW;   // per wave; + lut_n per workgroup
+    return (int64_t)a.blk_dw + a.seq_dw + val_dw(a) + a.tot_dw + lc_dw(a) + row_dw(a) + MISC_DW;   // per wave; + lut_n per workgroup
 }
 // LDS dwords of a whole workgroup: the shared table + WPG wave slices (each rounded to 16 bytes)
 TPS_HD int64_t wg_lds_dwords(const ScanArgs& a) { return ((a.lut_n + 3) & ~3) + (int64_t)WPG * ((lds_dwords(a) + 3) & ~3ll); }
 // misc layout (dwords)
 constexpr int M_BEST = 0;        // 2: step-1 arg-max keys (count << 5 | 31 - pattern) of the two sides
-constexpr int M_CMASK = 64;      // 2: conflict masks of step 1 (start, end)
-constexpr int M_INVALID = 66;    // any non-ACGT base in the staged range
-constexpr int M_SCAN = 68;       // 8: workgroup scan scratch (wave totals, grand total)
-constexpr int M_MAXSC = 76;      // u64 (8-byte aligned): best f64 score bits
-constexpr int M_BESTB = 78;      // i32: largest b among the candidates with the best score
-constexpr int M_NTIE = 79;       // candidates within float noise of the best score
+constexpr int M_CMASK = 2;       // 2: conflict masks of step 1 (start, end)
+constexpr int M_INVALID = 4;     // any non-ACGT base in the staged range
+constexpr int M_SCAN = 10;       // 8: workgroup scan scratch (wave totals, grand total)
+constexpr int M_MAXSC = 6;       // u64 (8-byte aligned): best f64 score bits
+constexpr int M_BESTB = 8;       // i32: largest b among the candidates with the best score
+constexpr int M_NTIE = 9;        // candidates within float noise of the best score
 // exact Binseg tournament scratch (dwords, relative to its base)
 constexpr int X_Q = 0;           // 64: scan partials (NT/16 groups + total)
 constexpr int X_BS = 64;         // NT: chunk sums
@@ -419,7 +433,7 @@ TPS_DEV void stage_chunk(const Stage& st, int c, uint32_t& packed, uint32_t& bad
 
 // one thread stages chunks tid, tid+NT, ... of `ndw` dwords at seq2/val; four 16-byte loads are in
 // flight per lane before the first one is consumed (HBM latency is paid once per four chunks)
-TPS_DEV void stage_thread(const Stage& st, uint32_t* seq2, uint32_t* val, int ndw, uint32_t* invalid_flag, int tid) {
+TPS_DEV void stage_thread(const Stage& st, uint32_t* seq2, uint16_t* val, int ndw, uint32_t* invalid_flag, int tid) {
     for (int base = tid; base < ndw; base += 4 * NT) {
         u32x4 v[4];
         TPS_UNROLL
@@ -436,7 +450,7 @@ TPS_DEV void stage_thread(const Stage& st, uint32_t* seq2, uint32_t* val, int nd
                 if (c < st.nch) stage_pack(st, c, v[u], packed, bad);
                 if (bad) *invalid_flag = 1u;       // benign race: every writer stores 1
                 seq2[c] = packed;
-                val[c] = bad;
+                val[c] = (uint16_t)bad;
             }
         }
     }
@@ -448,13 +462,13 @@ TPS_DEV uint32_t v_at(const uint32_t* seq2, int q) {
     return alignbit(seq2[idx + 1], seq2[idx], (uint32_t)(q & 15) * 2u);
 }
 // 1 if any of the k positions q..q+k-1 is not ACGT
-TPS_DEV bool invalid_at(const uint32_t* val, int q, int k) {
+TPS_DEV bool invalid_at(const uint16_t* val, int q, int k) {
     int idx = q >> 4;
     uint64_t v = (uint64_t)val[idx] | ((uint64_t)val[idx + 1] << 16) | ((uint64_t)val[idx + 2] << 32);
     return ((v >> (q & 15)) & ((1ull << k) - 1ull)) != 0;
 }
 // mask of list patterns whose k-mer starts at position q
-TPS_DEV uint32_t h_at(const uint32_t* lut, int lshift, const uint32_t* seq2, const uint32_t* val, const PatInfo& pat, int q, bool any_invalid) {
+TPS_DEV uint32_t h_at(const uint32_t* lut, int lshift, const uint32_t* seq2, const uint16_t* val, const PatInfo& pat, int q, bool any_invalid) {
     uint32_t h = lut[v_at(seq2, q) & pat.kmask] >> lshift;
     if (any_invalid && h && invalid_at(val, q, pat.k)) h = 0;
     return h;
@@ -472,7 +486,7 @@ TPS_DEV uint32_t conflict_bits(const PatInfo& pat, uint32_t v, uint32_t h) {
 
 // Leftmost non-overlapping count of list pattern `bit` over `npos` start positions from
 // position q0 -- exactly what len(list(re.finditer(p, text))) gives (allsteps.py:182, 281).
-TPS_DEV void greedy_count(const uint32_t* lut, int lshift, const uint32_t* seq2, const uint32_t* val, const PatInfo& pat, int q0,
+TPS_DEV void greedy_count(const uint32_t* lut, int lshift, const uint32_t* seq2, const uint16_t* val, const PatInfo& pat, int q0,
                           int npos, int bit, bool any_invalid, int& occ, int& greedy) {
     occ = 0; greedy = 0;
     int cursor = 0;
@@ -498,7 +512,7 @@ TPS_DEV void trc_count_thread(const ScanArgs& a, const Lds& l, const Stage& st_s
     const int side = tid >> 5, t = tid & 31;
     const int delta = side ? st_e.delta : st_s.delta;
     const uint32_t* seq2 = l.seq2 + side * a.head_dw;
-    const uint32_t* val = l.val + side * a.head_dw;
+    const uint16_t* val = l.val + side * a.head_dw;
     const bool inv = !PLAIN && l.misc[M_INVALID] != 0;
     const bool so = !PLAIN && pat.so_mask != 0;
     const int npos = st_s.n - pat.k + 1;
@@ -536,6 +550,69 @@ TPS_DEV void trc_count_thread(const ScanArgs& a, const Lds& l, const Stage& st_s
     }
     if (!PLAIN && cm) lds_or(&l.misc[M_CMASK + side], cm);
 }
+// Step 1, packed path (fused kernels, PLAIN case: every position matches at most one pattern and
+// occurrences of one pattern never overlap).  Lane (side, t) scans the 16-position chunks t, t+32, ...
+// of its side and counts in sixteen 4-bit fields of one 64-bit register: a table entry is
+// mask << 16 | popcount with the mask in bits 16..30, so clz(entry | 0x8000) - 1 = 14 - pattern for a
+// match and 15 for none (the top field: its overflow leaves the register); no predication, no LDS
+// atomics.  A lane sees `iters` chunks = at most iters * ceil(16 / k) <= 15 non-overlapping occurrences.
+// The lane then widens its fields to bytes (side totals <= npos / k <= 255) and parks them in LDS:
+// 16 bytes per lane = [even fields 0-6 | odd 1-7 | even 8-14 | odd 9-15].
+TPS_DEV bool trc_packed_ok(const ScanArgs& a, int npos) {
+    const int nchunks = (npos + 15) >> 4, iters = (nchunks + 31) >> 5;
+    return a.pat.P <= 15 && npos <= 255 * a.pat.k && iters * ((16 + a.pat.k - 1) / a.pat.k) <= 15;
+}
+TPS_DEV void trc_count_packed(const ScanArgs& a, const Lds& l, const Stage& st_s, const Stage& st_e, int tid) {
+    const PatInfo& pat = a.pat;
+    const int side = tid >> 5, t = tid & 31;
+    const int delta = side ? st_e.delta : st_s.delta;
+    const uint32_t* seq2 = l.seq2 + side * a.head_dw;
+    const uint32_t amask = pat.kmask << 2;
+    const int npos = st_s.n - pat.k + 1;
+    const int nchunks = (npos + 15) >> 4;
+    uint64_t acc = 0;
+    for (int c0 = 0; c0 < nchunks; c0 += 32) {      // uniform trip count
+        const int c = c0 + t;
+        // the base BEFORE the chunk's first one goes to bit 0: alignbit(.., 2 j) & (kmask << 2) is then
+        // the table's byte offset of position j (the two bits below it are masked away)
+        const int qm = delta + 16 * c - 1;
+        const int idx = qm >> 4;                     // -1 for the very first chunk of an aligned head: harmless
+        const uint32_t sh = (uint32_t)(qm & 15) * 2u;
+        const uint32_t d0 = seq2[idx], d1 = seq2[idx + 1], d2 = seq2[idx + 2];
+        const uint32_t w0 = alignbit(d1, d0, sh), w1 = alignbit(d2, d1, sh);
+        uint32_t h[16];
+        TPS_UNROLL
+        for (int j = 0; j < 16; ++j) h[j] = lut_at(l.lut, j ? alignbit(w1, w0, 2u * j) : w0, amask);
+        if (16 * (c0 + 32) > npos) {                 // uniform: the pass that holds the end of the head
+            TPS_UNROLL
+            for (int j = 0; j < 16; ++j)
+                if (16 * c + j >= npos) h[j] = 0;
+        }
+        TPS_UNROLL
+        for (int j = 0; j < 16; ++j) acc += 1ull << ((4u * (uint32_t)__builtin_clz(h[j] | 0x8000u) - 4u) & 63u);
+    }
+    const uint32_t lo = (uint32_t)acc, hi = (uint32_t)(acc >> 32);
+    uint32_t* dst = l.blk + 4 * tid;
+    dst[0] = lo & 0x0F0F0F0Fu;
+    dst[1] = (lo >> 4) & 0x0F0F0F0Fu;
+    dst[2] = hi & 0x0F0F0F0Fu;
+    dst[3] = (hi >> 4) & 0x0F0F0F0Fu;
+}
+// Thread (side, p): add the 32 lanes' byte of pattern p, publish the count and bid for the arg-max.
+TPS_DEV void trc_sum_packed(const ScanArgs& a, const Lds& l, int64_t r, int tid) {
+    const int side = tid >> 5, p = tid & 31;
+    if (p < a.pat.P) {
+        const int f = 14 - p;
+        const uint8_t* src = (const uint8_t*)(l.blk + 4 * 32 * side) + 4 * ((f & 1) + 2 * (f >> 3)) + ((f & 7) >> 1);
+        uint32_t sm = 0;
+        TPS_UNROLL
+        for (int t = 0; t < 32; ++t) sm += src[16 * t];
+        int32_t* dst = side ? a.c_end : a.c_start;
+        if (dst) dst[r * a.pat.P + p] = (int32_t)sm;
+        lds_max_i32((int32_t*)&l.misc[M_BEST + side], (int32_t)((sm << 5) | (uint32_t)(31 - p)));
+    }
+}
+
 // Thread (side, p): sum the private histograms; if pattern p has overlapping occurrences, recount
 // it leftmost-non-overlapping (sequential, rare); publish the count and bid for the side's
 // arg-max with key = count << 5 | (31 - p), so the FIRST pattern with the largest count wins.
@@ -774,7 +851,7 @@ struct Geo {
 TPS_DEV uint32_t pack_hi_lo(uint32_t hi_src, uint32_t lo_src) { return perm(hi_src, lo_src, 0x07060100u); }
 
 template <int S, bool SO, bool INV, bool RZ>
-TPS_DEV void tile_fused_s(const ScanArgs& a, const Lds& l, int delta, int w0, int nw_tile, int64_t out_base,
+TPS_DEV void tile_fused_s(const ScanArgs& a, const Lds& l, int delta, int w0, int tile, int nw_tile, int64_t out_base,
                           uint64_t& s_total, int64_t r) {
     // RZ: the window has no partial block (W - k divisible by the slide), so nothing is captured mid-block
     typedef Geo<S> g_;
@@ -861,6 +938,10 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const Lds& l, int delta, int w0, in
     wg_exclusive_scan(l.XT, NT, &l.misc[M_SCAN]);
     if (w0 == 0) TPS_STAMP(7);
     const int rot = q & (B - 1), dl0 = q >> LOG2B;
+    uint32_t fo_a = 0, fo_b = 0;
+#ifdef TPS_EMU
+    uint32_t fo_keep[NT][2];
+#endif
     TPS_PHASE {
         // A window's last (partial) block lies dl0 or dl0+1 lanes ahead of its first; the whole lanes
         // strictly in between are the next dl0-1 (or dl0) lanes.
@@ -869,8 +950,19 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const Lds& l, int delta, int w0, in
         for (int t = 1; t < dl0; ++t) foa |= l.XF[tid + t];
         const uint32_t fob = foa | l.XF[tid + dl0];
         const uint32_t tot_l = l.XT[tid], tot_a = l.XT[tid + dl0], tot_b = l.XT[tid + dl0 + 1];
-        l.FOA[tid] = pack_hi_lo(foa, tot_a - tot_l);
-        l.FOB[tid] = pack_hi_lo(fob, tot_b - tot_l);
+        fo_a = pack_hi_lo(foa, tot_a - tot_l);
+        fo_b = pack_hi_lo(fob, tot_b - tot_l);
+#ifdef TPS_EMU
+        fo_keep[tid][0] = fo_a; fo_keep[tid][1] = fo_b;
+#endif
+    }
+    TPS_SYNC();                                   // every lane has read its inputs: XF / XT are reused in place
+    TPS_PHASE {
+#ifdef TPS_EMU
+        fo_a = fo_keep[tid][0]; fo_b = fo_keep[tid][1];
+#endif
+        l.XF[tid] = fo_a;
+        l.XT[tid] = fo_b;
     }
     TPS_SYNC();
     TPS_PHASE {
@@ -878,7 +970,7 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const Lds& l, int delta, int w0, in
         const bool farl = (((lane & (B - 1)) + (uint32_t)rot) >> LOG2B) != 0;
         uint32_t* ps = l.row + (lane + (lane >> LOG2B));                         // XS in, S_w out
         const uint32_t* pe = l.XPC + ((lane + (uint32_t)q) + ((lane + (uint32_t)q) >> LOG2B));
-        const uint32_t* pf = (farl ? l.FOB : l.FOA) + (lane >> LOG2B);
+        const uint32_t* pf = (farl ? l.XT : l.XF) + (lane >> LOG2B);
         int32_t* out = a.sums + (out_base + w0);
         const uint32_t am = pat.all_mask << 16;
         const int nfull = nw_tile >> 6;                                          // uniform
@@ -940,11 +1032,16 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const Lds& l, int delta, int w0, in
         const int passes = c_hi > c_lo ? (int)((c_hi - c_lo + NT - 1) / NT) : 0;
         TPS_PHASE {
             const uint32_t carry = (uint32_t)s_total;
+            if (a.lc16 && tid == 0) l.Tc[tile] = carry;
             uint32_t c = c_lo + (uint32_t)tid;
             uint32_t w = c * jump - (uint32_t)w0;         // tile-local window index of candidate c
             TPS_NOVEC
             for (int t = 0; t < passes; ++t) {
-                if (c < c_hi) l.Lc[c] = carry + l.row[w + (w >> LOG2B)];
+                if (c < c_hi) {
+                    const uint32_t pre = l.row[w + (w >> LOG2B)];
+                    if (a.lc16) l.Lc16[c] = (uint16_t)pre;
+                    else l.Lc[c] = carry + pre;
+                }
                 c += NT;
                 w += NT * jump;
             }
@@ -1166,7 +1263,7 @@ TPS_DEV void binseg_wg(const ST* S, int n, int jump, int min_size, int n_pattern
 // Fused Binseg from the candidate left sums Lc[c] = sum_{w < c*jump} S_w (c = 1 .. (n-1)/jump) and
 // the total T: float64 scores, wave arg-max; if more than one candidate lies within float noise of
 // the best score the exact integer tournament re-reads S_w from HBM (rare).
-TPS_DEV void binseg_from_lc(const uint32_t* Lc, const int32_t* S_global, int n, uint64_t tot, int jump, int min_size,
+TPS_DEV void binseg_from_lc(const ScanArgs& a, const Lds& l, const int32_t* S_global, int n, uint64_t tot, int jump, int min_size,
                             int n_patterns, uint32_t* misc, uint32_t* xs, int& bkp, double& gain) {
     const int ncand = (n - 1) / jump;              // candidates b = c*jump, 1 <= c <= ncand  (b < n)
 #ifdef TPS_EMU
@@ -1183,7 +1280,10 @@ TPS_DEV void binseg_from_lc(const uint32_t* Lc, const int32_t* S_global, int n, 
         for (int c = 1 + tid; c <= ncand; c += NT) {
             const int b = c * jump;
             if (b >= min_size && n - b >= min_size) {
-                int64_t d = (int64_t)n * (int64_t)Lc[c] - (int64_t)tot * (int64_t)b;
+                uint32_t lc;
+                if (a.lc16) lc = l.Tc[(uint32_t)(((uint64_t)(uint32_t)b * a.tw_magic) >> 32)] + l.Lc16[c];
+                else lc = l.Lc[c];
+                int64_t d = (int64_t)n * (int64_t)lc - (int64_t)tot * (int64_t)b;
                 double sc = score_f64(d, (uint64_t)b * (uint64_t)(n - b));
                 if (sc >= best) { second = best; best = sc; best_b = b; }
                 else if (sc > second) second = sc;
@@ -1247,9 +1347,7 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
     TPS_SYNC();
     TPS_STAMP(1);
     TPS_PHASE {
-        // histogram reset and the staging of both step-1 heads are independent: one phase
         if (step1) {
-            for (int i = tid; i < HIST_DW; i += NT) l.blk[i] = 0;
             // the heads are staged side by side: [0, head_dw) and [head_dw, 2 head_dw)
             for (int c = tid; c < 2 * a.head_dw; c += NT) {
                 const int side = c >= a.head_dw;
@@ -1259,7 +1357,7 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
                 else stage_chunk(st_s, cc, packed, bad);
                 if (bad) l.misc[M_INVALID] = 1u;
                 l.seq2[c] = packed;
-                l.val[c] = bad;
+                l.val[c] = (uint16_t)bad;
             }
         }
     }
@@ -1273,14 +1371,26 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
 
     TPS_STAMP(2);
     if (step1) {
-        if (uniform(l.misc[M_INVALID]) == 0 && pat.so_mask == 0 && pat.dup_mask == 0) {
-            TPS_PHASE { trc_count_thread<true>(a, l, st_s, st_e, tid); }
+        const bool plain = uniform(l.misc[M_INVALID]) == 0 && pat.so_mask == 0 && pat.dup_mask == 0;
+        bool packed1 = false;
+        if constexpr (SV != 0) packed1 = plain && trc_packed_ok(a, st_s.n - pat.k + 1);
+        if (packed1) {
+            TPS_PHASE { trc_count_packed(a, l, st_s, st_e, tid); }
+            TPS_SYNC();
+            TPS_STAMP(3);
+            TPS_PHASE { trc_sum_packed(a, l, r, tid); }
         } else {
-            TPS_PHASE { trc_count_thread<false>(a, l, st_s, st_e, tid); }
+            TPS_PHASE { for (int i = tid; i < HIST_DW; i += NT) l.blk[i] = 0; }
+            TPS_SYNC();
+            if (plain) {
+                TPS_PHASE { trc_count_thread<true>(a, l, st_s, st_e, tid); }
+            } else {
+                TPS_PHASE { trc_count_thread<false>(a, l, st_s, st_e, tid); }
+            }
+            TPS_SYNC();
+            TPS_STAMP(3);
+            TPS_PHASE { trc_sum_thread(a, l, st_s, st_e, r, tid); }
         }
-        TPS_SYNC();
-        TPS_STAMP(3);
-        TPS_PHASE { trc_sum_thread(a, l, st_s, st_e, r, tid); }
         TPS_SYNC();
         const uint32_t ks = uniform(l.misc[M_BEST]), ke = uniform(l.misc[M_BEST + 1]);
         res.best_start = (int32_t)(ks >> 5); res.best_start_idx = 31 - (int32_t)(ks & 31u);
@@ -1377,7 +1487,7 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
                 const Stage st0 = tile_stage(0);
                 TPS_PHASE { pf_load(st0, tid); }
             }
-            for (int w0 = 0; w0 < n_win; w0 += tw) {
+            for (int w0 = 0, tile = 0; w0 < n_win; w0 += tw, ++tile) {
                 const int nw_tile = (n_win - w0) < tw ? (n_win - w0) : tw;
                 const Stage st = tile_stage(w0);
                 TPS_PHASE { if (tid == 0) l.misc[M_INVALID] = 0; }
@@ -1393,7 +1503,7 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
                         if (c < st.nch) stage_pack(st, c, pf[u], packed, bad);
                         if (bad) l.misc[M_INVALID] = 1u;
                         l.seq2[c + 1] = packed;        // one dword in: lanes also read the base before their first
-                        l.val[c + 1] = bad;
+                        l.val[c + 1] = (uint16_t)bad;
                     }
                     if (tid == 0) { l.seq2[0] = 0; l.val[0] = 0; }
                 }
@@ -1405,11 +1515,11 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
                 if (w0 == 0) TPS_STAMP(5);
                 const int fdelta = st.delta + 16;      // LDS position of the tile's first base
                 if (uniform(l.misc[M_INVALID]) != 0)
-                    tile_fused_s<SV ? SV : 1, SO, true, false>(a, l, fdelta, w0, nw_tile, out_base, s_total, r);
+                    tile_fused_s<SV ? SV : 1, SO, true, false>(a, l, fdelta, w0, tile, nw_tile, out_base, s_total, r);
                 else if (a.r == 0)
-                    tile_fused_s<SV ? SV : 1, SO, false, true>(a, l, fdelta, w0, nw_tile, out_base, s_total, r);
+                    tile_fused_s<SV ? SV : 1, SO, false, true>(a, l, fdelta, w0, tile, nw_tile, out_base, s_total, r);
                 else
-                    tile_fused_s<SV ? SV : 1, SO, false, false>(a, l, fdelta, w0, nw_tile, out_base, s_total, r);
+                    tile_fused_s<SV ? SV : 1, SO, false, false>(a, l, fdelta, w0, tile, nw_tile, out_base, s_total, r);
                 if (w0 == 0) TPS_STAMP(8);
             }
         }
@@ -1423,7 +1533,7 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
 #ifndef TPS_EMU
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // S_w stores of this wave visible to its (rare) exact re-read
 #endif
-        binseg_from_lc(l.Lc, a.sums + (a.win_off ? a.win_off[r] : 0), n_win, s_total, prm.jump, prm.min_size, pat.P,
+        binseg_from_lc(a, l, a.sums + (a.win_off ? a.win_off[r] : 0), n_win, s_total, prm.jump, prm.min_size, pat.P,
                        l.misc, l.blk, bkp, gain);
         res.bkp = bkp;
         res.gain = gain;

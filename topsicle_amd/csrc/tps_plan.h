@@ -93,6 +93,7 @@ inline std::string plan_geometry(ScanArgs& a, const tps_params& prm, int k, int 
     // 8-block chunk and its far end lies within the exchange halo (XLANES - NT lanes)
     const bool fused = !force_generic && spans_pref <= 0 && has_specialised_slide(prm.slide) && P <= 15 && a.q >= 8 &&
                        a.q / 8 + 2 < (XLANES - NT);
+    a.lc16 = 0; a.tile_cap = 0; a.tw = 0; a.tw_magic = 0;
     if (fused) {
         a.variant = prm.slide;
         a.blk_log2 = 3;                            // 8 blocks per lane for every slide
@@ -104,7 +105,13 @@ inline std::string plan_geometry(ScanArgs& a, const tps_params& prm, int k, int 
         const int pos = 8 * prm.slide;
         const int tile_dw = ((NT - 1) * pos + 13 + 15 + 15) / 16 + 1;     // = Geo<S>::TILE_DW
         const int pf = (tile_dw + NT - 1) / NT;                            // = Geo<S>::PF
-        a.seq_dw = std::max(pf * (int)NT + 8, 2 * a.head_dw);
+        a.seq_dw = std::max(pf * (int)NT + 4, 2 * a.head_dw);
+        // candidate left sums as u16 relative to their tile when a tile's window sums cannot reach 2^16
+        // (every position matches at most one list pattern: S_w <= lw + P)
+        a.tw = (int)NT * 8 - a.q - 1 - 8;
+        a.tw_magic = (uint32_t)(((1ull << 32) + (uint64_t)a.tw - 1) / (uint64_t)a.tw);
+        a.tile_cap = (int)((max_nwin + a.tw - 1) / a.tw) + 1;
+        a.lc16 = (a.pat.dup_mask == 0 && (int64_t)a.tw * (a.lw + P) < 65536) ? 1 : 0;
         a.blk_dw = (int32_t)blk_region_dw(a);
         if (wg_lds_dwords(a) > budget_dw) return "LDS plan does not fit (fused kernel, " + std::to_string(max_nwin) + " windows per read)";
         return "";
