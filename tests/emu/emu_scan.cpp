@@ -68,9 +68,15 @@ extern "C" int emu_scan(const char* pats, int P, int k, const uint8_t* bases, co
     a.raw = (prm->flags & TPS_F_STORE_RAW) ? raw : nullptr;
     a.n_reads = n;
     a.prm = *prm;
-    std::vector<uint32_t> lutbuf(lut);            // the workgroup-shared table (read-only for the waves)
-    if (a.variant)
-        for (auto& m : lutbuf) m = (m << 16) | (uint32_t)__builtin_popcount(m);   // fused kernels: mask << 16 | count
+    // the workgroup-shared tables (read-only for the waves): [pair table][single table]
+    std::vector<uint32_t> lutbuf((size_t)a.pair_n + lut.size());
+    uint32_t* lut1 = lutbuf.data() + a.pair_n;
+    for (size_t i = 0; i < lut.size(); ++i)
+        lut1[i] = a.variant ? ((lut[i] << 16) | (uint32_t)__builtin_popcount(lut[i])) : lut[i];   // fused kernels: mask << 16 | count
+    for (int c = 0; c < a.pair_n; ++c) {
+        const uint32_t e1 = lut1[c & a.pat.kmask], e2 = lut1[(c >> 2) & a.pat.kmask];
+        lutbuf[(size_t)c] = ((e1 | e2) & 0xFFFF0000u) | ((e1 + e2) & 0xFFFFu);
+    }
     std::vector<uint32_t> ldsbuf((size_t)tps::lds_dwords(a) + 16);
     uint32_t* lds_al = (uint32_t*)(((uintptr_t)ldsbuf.data() + 15) & ~(uintptr_t)15);
     struct { uint32_t* p; size_t n; uint32_t* data() { return p; } uint32_t* begin() { return p; } uint32_t* end() { return p + n; } } lds{lds_al, (size_t)tps::lds_dwords(a)};
@@ -79,11 +85,11 @@ extern "C" int emu_scan(const char* pats, int P, int k, const uint8_t* bases, co
         for (auto& w : lds) w = 0xDEADBEEFu;          // LDS content is undefined at workgroup start
         const bool so = a.pat.so_mask != 0;
         switch (a.variant) {
-            case 5: so ? tps::scan_read<5, true>(a, r, lds.data(), lutbuf.data()) : tps::scan_read<5, false>(a, r, lds.data(), lutbuf.data()); break;
-            case 6: so ? tps::scan_read<6, true>(a, r, lds.data(), lutbuf.data()) : tps::scan_read<6, false>(a, r, lds.data(), lutbuf.data()); break;
-            case 7: so ? tps::scan_read<7, true>(a, r, lds.data(), lutbuf.data()) : tps::scan_read<7, false>(a, r, lds.data(), lutbuf.data()); break;
-            case 8: so ? tps::scan_read<8, true>(a, r, lds.data(), lutbuf.data()) : tps::scan_read<8, false>(a, r, lds.data(), lutbuf.data()); break;
-            default: tps::scan_read<0, false>(a, r, lds.data(), lutbuf.data()); break;
+            case 5: so ? tps::scan_read<5, true>(a, r, lds.data(), lut1) : a.pair_n ? tps::scan_read<5, false, true>(a, r, lds.data(), lut1) : tps::scan_read<5, false>(a, r, lds.data(), lut1); break;
+            case 6: so ? tps::scan_read<6, true>(a, r, lds.data(), lut1) : a.pair_n ? tps::scan_read<6, false, true>(a, r, lds.data(), lut1) : tps::scan_read<6, false>(a, r, lds.data(), lut1); break;
+            case 7: so ? tps::scan_read<7, true>(a, r, lds.data(), lut1) : a.pair_n ? tps::scan_read<7, false, true>(a, r, lds.data(), lut1) : tps::scan_read<7, false>(a, r, lds.data(), lut1); break;
+            case 8: so ? tps::scan_read<8, true>(a, r, lds.data(), lut1) : a.pair_n ? tps::scan_read<8, false, true>(a, r, lds.data(), lut1) : tps::scan_read<8, false>(a, r, lds.data(), lut1); break;
+            default: tps::scan_read<0, false>(a, r, lds.data(), lut1); break;
         }
     }
     return TPS_OK;

@@ -18,13 +18,18 @@
 // One wave per read, tps::WPG waves per workgroup.  The lookup table is loaded once per workgroup
 // (the only workgroup barrier in the kernel); after that every wave runs its own read with
 // wave-level synchronisation only.
-#define TPS_SCAN_KERNEL(NAME, SV, SO, MINW)                                                                   \
+#define TPS_SCAN_KERNEL(NAME, SV, SO, PAIR, MINW)                                                             \
     extern "C" __global__ void __launch_bounds__(tps::NT * tps::WPG, MINW) NAME(tps::ScanArgs a) {         \
         extern __shared__ __attribute__((aligned(16))) uint32_t lds[];                                     \
-        uint32_t* lut = lds;                                                                               \
+        /* workgroup-shared tables: [pair table (PAIR kernels)][single table], both aligned to their size */ \
+        uint32_t* lut = lds + ((PAIR) ? a.pair_n : 0);                                                     \
         for (int i = (int)threadIdx.x; i < a.lut_n; i += tps::NT * tps::WPG) {                             \
             const uint32_t m_ = a.lut[i];                                                                  \
             lut[i] = (SV) ? ((m_ << 16) | (uint32_t)__builtin_popcount(m_)) : m_;                          \
+        }                                                                                                  \
+        if (PAIR) {   /* host-built pair table, stored right behind the plain table */                      \
+            for (int c = 4 * (int)threadIdx.x; c < a.pair_n; c += 4 * tps::NT * tps::WPG)                  \
+                *(uint4*)(lds + c) = *(const uint4*)(a.lut + a.lut_n + c);                                 \
         }                                                                                                  \
         __syncthreads();                                                                                   \
         /* readfirstlane: the wave index is uniform -> everything per read lives in SGPRs */              \
@@ -32,17 +37,21 @@
         const int64_t r = (int64_t)blockIdx.x * tps::WPG + wave;                                           \
         if (r >= a.n_reads) return;                                                                        \
         const int64_t wave_dw = (tps::lds_dwords(a) + 3) & ~3ll;                                           \
-        tps::scan_read<SV, SO>(a, r, lds + ((a.lut_n + 3) & ~3) + wave * wave_dw, lut);                    \
+        tps::scan_read<SV, SO, PAIR>(a, r, lut + ((a.lut_n + 3) & ~3) + wave * wave_dw, lut);              \
     }
-TPS_SCAN_KERNEL(tps_scan_kernel, 0, false, 4)          // generic: any slide, up to 31 patterns
-TPS_SCAN_KERNEL(tps_scan_kernel_s5, 5, false, 3)       // specialised: compile-time slide, <= 15 patterns
-TPS_SCAN_KERNEL(tps_scan_kernel_s6, 6, false, 3)
-TPS_SCAN_KERNEL(tps_scan_kernel_s7, 7, false, 3)
-TPS_SCAN_KERNEL(tps_scan_kernel_s8, 8, false, 3)
-TPS_SCAN_KERNEL(tps_scan_kernel_s5so, 5, true, 3)      // ... with self-overlapping k-mers in the table
-TPS_SCAN_KERNEL(tps_scan_kernel_s6so, 6, true, 3)
-TPS_SCAN_KERNEL(tps_scan_kernel_s7so, 7, true, 3)
-TPS_SCAN_KERNEL(tps_scan_kernel_s8so, 8, true, 3)
+TPS_SCAN_KERNEL(tps_scan_kernel, 0, false, false, 4)          // generic: any slide, up to 31 patterns
+TPS_SCAN_KERNEL(tps_scan_kernel_s5, 5, false, false, 3)       // specialised: compile-time slide, <= 15 patterns
+TPS_SCAN_KERNEL(tps_scan_kernel_s6, 6, false, false, 3)
+TPS_SCAN_KERNEL(tps_scan_kernel_s7, 7, false, false, 3)
+TPS_SCAN_KERNEL(tps_scan_kernel_s8, 8, false, false, 3)
+TPS_SCAN_KERNEL(tps_scan_kernel_s5p, 5, false, true, 3)       // ... k <= 4: two positions per table lookup
+TPS_SCAN_KERNEL(tps_scan_kernel_s6p, 6, false, true, 3)
+TPS_SCAN_KERNEL(tps_scan_kernel_s7p, 7, false, true, 3)
+TPS_SCAN_KERNEL(tps_scan_kernel_s8p, 8, false, true, 3)
+TPS_SCAN_KERNEL(tps_scan_kernel_s5so, 5, true, false, 3)      // ... with self-overlapping k-mers in the table
+TPS_SCAN_KERNEL(tps_scan_kernel_s6so, 6, true, false, 3)
+TPS_SCAN_KERNEL(tps_scan_kernel_s7so, 7, true, false, 3)
+TPS_SCAN_KERNEL(tps_scan_kernel_s8so, 8, true, false, 3)
 
 extern "C" __global__ void __launch_bounds__(tps::NT * tps::WPG) tps_binseg_kernel(tps::BinsegArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t smem[tps::WPG * tps::BINSEG_SMEM_DW];
@@ -102,7 +111,7 @@ struct Slot {
     bool planned = false;
     tps_params plan_prm{};
     int plan_k = 0, plan_p = 0;
-    uint32_t plan_dup = 0;            // the plan depends on whether the pattern list holds duplicate k-mers
+    uint32_t plan_dup = 0, plan_so = 0;   // the plan depends on whether the pattern list holds duplicate / self-overlapping k-mers
     tps::ScanArgs args{};
     size_t lds_bytes = 0;
     bool scanned = false;
@@ -131,7 +140,7 @@ struct tps_ctx {
     int zero_copy = 1;       // per-read results are written by the kernel straight into mapped pinned host memory
     int force_generic = 0;
     int64_t lds_target_dw = 32 * 256;
-    size_t lds_set_v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    size_t lds_set_v[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 namespace {
@@ -200,7 +209,7 @@ int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm) {
     const int64_t n = sl.n;
     const int P = c->pat.P;
     if (!sl.planned || !same_params(prm, sl.plan_prm) || sl.plan_k != c->pat.k || sl.plan_p != P ||
-        (sl.plan_dup != 0) != (c->pat.dup_mask != 0)) {
+        (sl.plan_dup != 0) != (c->pat.dup_mask != 0) || (sl.plan_so != 0) != (c->pat.so_mask != 0)) {
         sl.h_win_off.resize((size_t)n + 1);
         int64_t acc = 0, mx = 0;
         for (int64_t i = 0; i < n; ++i) {
@@ -219,6 +228,7 @@ int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm) {
         sl.plan_k = c->pat.k;
         sl.plan_p = P;
         sl.plan_dup = c->pat.dup_mask;
+        sl.plan_so = c->pat.so_mask;
         sl.planned = true;
     }
     const int64_t total_win = sl.h_win_off[(size_t)n];
@@ -271,11 +281,12 @@ int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm) {
     const void* kfn;
     int kidx;
     const bool so = a.pat.so_mask != 0;
+    const bool pair = a.pair_n != 0;
     switch (a.variant) {
-        case 5: kfn = so ? (const void*)tps_scan_kernel_s5so : (const void*)tps_scan_kernel_s5; kidx = so ? 5 : 1; break;
-        case 6: kfn = so ? (const void*)tps_scan_kernel_s6so : (const void*)tps_scan_kernel_s6; kidx = so ? 6 : 2; break;
-        case 7: kfn = so ? (const void*)tps_scan_kernel_s7so : (const void*)tps_scan_kernel_s7; kidx = so ? 7 : 3; break;
-        case 8: kfn = so ? (const void*)tps_scan_kernel_s8so : (const void*)tps_scan_kernel_s8; kidx = so ? 8 : 4; break;
+        case 5: kfn = so ? (const void*)tps_scan_kernel_s5so : pair ? (const void*)tps_scan_kernel_s5p : (const void*)tps_scan_kernel_s5; kidx = so ? 5 : pair ? 9 : 1; break;
+        case 6: kfn = so ? (const void*)tps_scan_kernel_s6so : pair ? (const void*)tps_scan_kernel_s6p : (const void*)tps_scan_kernel_s6; kidx = so ? 6 : pair ? 10 : 2; break;
+        case 7: kfn = so ? (const void*)tps_scan_kernel_s7so : pair ? (const void*)tps_scan_kernel_s7p : (const void*)tps_scan_kernel_s7; kidx = so ? 7 : pair ? 11 : 3; break;
+        case 8: kfn = so ? (const void*)tps_scan_kernel_s8so : pair ? (const void*)tps_scan_kernel_s8p : (const void*)tps_scan_kernel_s8; kidx = so ? 8 : pair ? 12 : 4; break;
         default: kfn = (const void*)tps_scan_kernel; kidx = 0; break;
     }
     if (sl.lds_bytes > c->lds_set_v[kidx]) {
@@ -388,6 +399,17 @@ int tps_set_patterns(tps_ctx* c, const char* pats, int32_t P, int32_t k) {
     tps::PatInfo pi{};
     std::string err = tps::build_patterns(pats, P, k, lut, pi);
     if (!err.empty()) return fail(TPS_E_PATTERN, "%s", err.c_str());
+    if (k <= 4) {
+        // pair table for the pair kernels (k <= 4, see plan_geometry): entry of the (k+1)-mer code c =
+        // packed entries (mask << 16 | popcount) of the k-mers at p and p+1, masks ORed, counts added
+        const size_t n1 = lut.size(), n2 = n1 * 4;
+        const uint32_t km = (uint32_t)n1 - 1u;
+        lut.resize(n1 + n2);
+        for (size_t cc = 0; cc < n2; ++cc) {
+            const uint32_t m1 = lut[cc & km], m2 = lut[(cc >> 2) & km];
+            lut[n1 + cc] = ((m1 | m2) << 16) | (uint32_t)(__builtin_popcount(m1) + __builtin_popcount(m2));
+        }
+    }
     if ((rc = c->lut.ensure(lut.size() * 4))) return rc;
     HIP_TRY(hipMemcpyAsync(c->lut.p, lut.data(), lut.size() * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));

@@ -200,6 +200,7 @@ struct ScanArgs {
     // fused path, 16-bit candidate sums: Lc16[c] = left sum of candidate c counted from its tile's first
     // window, Tc[t] = sum of S_w before tile t; tile of window w = mulhi(w, tw_magic)
     int32_t lc16;                // 1 = Lc16 + Tc instead of the u32 Lc
+    int32_t pair_n;              // 0, or 4^(k+1): entries of the pair table (two adjacent positions per lookup)
     int32_t tile_cap;            // entries of Tc (tiles of the longest read)
     int32_t tw;                  // windows per fused tile
     uint32_t tw_magic;           // ceil(2^32 / tw)
@@ -221,6 +222,7 @@ constexpr int HIST_STRIDE = 33;          // odd stride: the copies of one patter
 constexpr int HIST_DW = 2 * HIST_COPIES * HIST_STRIDE;   // step-1 private histograms (alias the block region)
 struct Lds {
     uint32_t* lut;     // generic kernel: mask over the pattern list; fused kernels: mask << 16 | popcount(mask)
+    uint32_t* lut2;    // pair kernels: entry of the (k+1)-mer at p = entries of the k-mers at p and p+1 combined (OR | sum)
     int lshift;        // 0 or 16: lut[code] >> lshift is the mask
     uint32_t* seq2;    // 2-bit packed bases, 16 per dword
     uint16_t* val;     // bit j of val[c] set = position 16c+j is NOT one of acgtACGT
@@ -268,6 +270,7 @@ TPS_HD int64_t row_dw(const ScanArgs& a) {
 }
 TPS_DEV Lds carve(uint32_t* base, uint32_t* lut, const ScanArgs& a) {
     Lds l;
+    l.lut2 = lut - a.pair_n;                   // the pair table precedes the single table (both size-aligned)
     uint32_t* p = base;
     l.blk = p;  p += a.blk_dw;                 // first: 16-byte aligned for the 8-byte records
     l.lut = lut;                               // one table per workgroup, shared by its waves
@@ -294,7 +297,7 @@ TPS_HD int64_t lds_dwords(const ScanArgs& a) {
     return (int64_t)a.blk_dw + a.seq_dw + val_dw(a) + a.tot_dw + lc_dw(a) + row_dw(a) + MISC_DW;   // per wave; + lut_n per workgroup
 }
 // LDS dwords of a whole workgroup: the shared table + WPG wave slices (each rounded to 16 bytes)
-TPS_HD int64_t wg_lds_dwords(const ScanArgs& a) { return ((a.lut_n + 3) & ~3) + (int64_t)WPG * ((lds_dwords(a) + 3) & ~3ll); }
+TPS_HD int64_t wg_lds_dwords(const ScanArgs& a) { return a.pair_n + ((a.lut_n + 3) & ~3) + (int64_t)WPG * ((lds_dwords(a) + 3) & ~3ll); }
 // misc layout (dwords)
 constexpr int M_BEST = 0;        // 2: step-1 arg-max keys (count << 5 | 31 - pattern) of the two sides
 constexpr int M_CMASK = 2;       // 2: conflict masks of step 1 (start, end)
@@ -850,7 +853,7 @@ struct Geo {
 // Windows beyond nw_tile (they need blocks of the next tile) are not produced.
 TPS_DEV uint32_t pack_hi_lo(uint32_t hi_src, uint32_t lo_src) { return perm(hi_src, lo_src, 0x07060100u); }
 
-template <int S, bool SO, bool INV, bool RZ>
+template <int S, bool SO, bool INV, bool RZ, bool PAIR>
 TPS_DEV void tile_fused_s(const ScanArgs& a, const Lds& l, int delta, int w0, int tile, int nw_tile, int64_t out_base,
                           uint64_t& s_total, int64_t r) {
     // RZ: the window has no partial block (W - k divisible by the slide), so nothing is captured mid-block
@@ -882,47 +885,95 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const Lds& l, int delta, int w0, in
         uint32_t gs[B], c0s[B];                   // in the high half, ADD the match count in the low half
         uint32_t* xs = l.row + span * (B + 1);
         uint32_t* xpc = l.XPC + span * (B + 1);
-        // table lookups run one block ahead of their use (software pipeline, 2 S values in flight)
-        uint32_t hc[S], vc[S], hn[S], vn[S];
-        auto fetch = [&](int blk, uint32_t* hh, uint32_t* vv) {
-            TPS_UNROLL
-            for (int i = 0; i < S; ++i) {
-                const int p = blk * S + i;        // constant after unrolling
+        if constexpr (PAIR) {
+            // Pair table: one lookup covers positions p and p+1 (entry = OR of their masks | sum of their
+            // counts), so a block costs S/2 lookups (+ one single for an odd slide).  Only tables
+            // without self-overlapping k-mers on tiles without invalid letters take this path.
+            static_assert(!SO && !INV, "pair lookups need per-position independence");
+            constexpr int NP = S / 2, NH = NP + (S & 1);
+            const uint32_t amask2 = (pat.kmask << 4) | 0xCu;     // (k+1)-mer code as a byte offset
+            const int rpe = rp & ~1;                              // capture point rounded down to a pair boundary
+            uint32_t hc[NH], hn[NH];
+            auto v4_at = [&](int p) -> uint32_t {
                 const int dw = p >> 4, bit = p & 15;
-                uint32_t v4 = bit ? alignbit(dw + 1 < WDW ? w[dw + 1] : 0u, w[dw], 2u * bit) : w[dw];
-                uint32_t h = lut_at(l.lut, v4, amask);
-                if (INV) {
-                    if (h && invalid_at(l.val, p0 + p, pat.k)) h = 0;   // tiles with non-ACGT letters only
-                }
-                hh[i] = h;
-                vv[i] = v4 >> 2;
-            }
-        };
-        fetch(0, hc, vc);
-        TPS_UNROLL
-        for (int blk = 0; blk < B; ++blk) {
-            if (blk + 1 < B) fetch(blk + 1, hn, vn);
-            uint32_t g = 0;
-            c0s[blk] = cnt;
-            uint32_t c1 = cnt, pp = run_or;
+                return bit ? alignbit(dw + 1 < WDW ? w[dw + 1] : 0u, w[dw], 2u * bit) : w[dw];
+            };
+            auto fetch = [&](int blk, uint32_t* hh) {
+                TPS_UNROLL
+                for (int j = 0; j < NP; ++j) hh[j] = lut_at(l.lut2, v4_at(blk * S + 2 * j), amask2);
+                if (S & 1) hh[NP] = lut_at(l.lut, v4_at(blk * S + S - 1), amask);
+            };
+            fetch(0, hc);
             TPS_UNROLL
-            for (int i = 0; i < S; ++i) {
-                const uint32_t h = hc[i];
-                if (SO) {
-                    if ((h >> 16) & pat.so_mask)
-                        if (conflict_bits(pat, vc[i], h >> 16)) g |= FLAG16 << 16;
+            for (int blk = 0; blk < B; ++blk) {
+                if (blk + 1 < B) fetch(blk + 1, hn);
+                uint32_t g = 0;
+                c0s[blk] = cnt;
+                if (RZ) xpc[blk] = pack_hi_lo(run_or, cnt);
+                TPS_UNROLL
+                for (int j = 0; j < NH; ++j) {
+                    if (!RZ) {
+                        if (2 * j == rpe) {          // uniform: the window's partial block ends inside / before this pair
+                            uint32_t c1 = cnt, pp = run_or | g;
+                            if (rp & 1) {
+                                const uint32_t h1 = lut_at(l.lut, v4_at(blk * S + 2 * j), amask);
+                                c1 += h1;
+                                pp |= h1;
+                            }
+                            xpc[blk] = pack_hi_lo(pp, c1);
+                        }
+                    }
+                    g |= hc[j];
+                    cnt += hc[j];
                 }
-                g |= h;
-                cnt += h;
-                if (!RZ) {
-                    if (i + 1 == rp) { c1 = cnt; pp = run_or | g; }
-                }
+                gs[blk] = g;
+                run_or |= g;
+                TPS_UNROLL
+                for (int j = 0; j < NH; ++j) hc[j] = hn[j];
             }
-            xpc[blk] = pack_hi_lo(pp, c1);
-            gs[blk] = g;
-            run_or |= g;
+        } else {
+            // table lookups run one block ahead of their use (software pipeline, 2 S values in flight)
+            uint32_t hc[S], vc[S], hn[S], vn[S];
+            auto fetch = [&](int blk, uint32_t* hh, uint32_t* vv) {
+                TPS_UNROLL
+                for (int i = 0; i < S; ++i) {
+                    const int p = blk * S + i;        // constant after unrolling
+                    const int dw = p >> 4, bit = p & 15;
+                    uint32_t v4 = bit ? alignbit(dw + 1 < WDW ? w[dw + 1] : 0u, w[dw], 2u * bit) : w[dw];
+                    uint32_t h = lut_at(l.lut, v4, amask);
+                    if (INV) {
+                        if (h && invalid_at(l.val, p0 + p, pat.k)) h = 0;   // tiles with non-ACGT letters only
+                    }
+                    hh[i] = h;
+                    vv[i] = v4 >> 2;
+                }
+            };
+            fetch(0, hc, vc);
             TPS_UNROLL
-            for (int i = 0; i < S; ++i) { hc[i] = hn[i]; vc[i] = vn[i]; }
+            for (int blk = 0; blk < B; ++blk) {
+                if (blk + 1 < B) fetch(blk + 1, hn, vn);
+                uint32_t g = 0;
+                c0s[blk] = cnt;
+                uint32_t c1 = cnt, pp = run_or;
+                TPS_UNROLL
+                for (int i = 0; i < S; ++i) {
+                    const uint32_t h = hc[i];
+                    if (SO) {
+                        if ((h >> 16) & pat.so_mask)
+                            if (conflict_bits(pat, vc[i], h >> 16)) g |= FLAG16 << 16;
+                    }
+                    g |= h;
+                    cnt += h;
+                    if (!RZ) {
+                        if (i + 1 == rp) { c1 = cnt; pp = run_or | g; }
+                    }
+                }
+                xpc[blk] = pack_hi_lo(pp, c1);
+                gs[blk] = g;
+                run_or |= g;
+                TPS_UNROLL
+                for (int i = 0; i < S; ++i) { hc[i] = hn[i]; vc[i] = vn[i]; }
+            }
         }
         uint32_t sfx = 0;
         TPS_UNROLL
@@ -1328,7 +1379,7 @@ TPS_DEV void binseg_from_lc(const ScanArgs& a, const Lds& l, const int32_t* S_gl
 // In the device build every lane of the wave executes this function; TPS_PHASE bodies run once
 // per lane and TPS_SYNC() is a wave-level fence.  In the emulation TPS_PHASE loops over the 64
 // lane ids, so phases run in program order.
-template <int SV, bool SO>
+template <int SV, bool SO, bool PAIR = false>
 TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_t* lut) {
     const Lds l = carve(lds_base, lut, a);
     const PatInfo& pat = a.pat;
@@ -1515,11 +1566,11 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
                 if (w0 == 0) TPS_STAMP(5);
                 const int fdelta = st.delta + 16;      // LDS position of the tile's first base
                 if (uniform(l.misc[M_INVALID]) != 0)
-                    tile_fused_s<SV ? SV : 1, SO, true, false>(a, l, fdelta, w0, tile, nw_tile, out_base, s_total, r);
+                    tile_fused_s<SV ? SV : 1, SO, true, false, false>(a, l, fdelta, w0, tile, nw_tile, out_base, s_total, r);
                 else if (a.r == 0)
-                    tile_fused_s<SV ? SV : 1, SO, false, true>(a, l, fdelta, w0, tile, nw_tile, out_base, s_total, r);
+                    tile_fused_s<SV ? SV : 1, SO, false, true, PAIR>(a, l, fdelta, w0, tile, nw_tile, out_base, s_total, r);
                 else
-                    tile_fused_s<SV ? SV : 1, SO, false, false>(a, l, fdelta, w0, tile, nw_tile, out_base, s_total, r);
+                    tile_fused_s<SV ? SV : 1, SO, false, false, PAIR>(a, l, fdelta, w0, tile, nw_tile, out_base, s_total, r);
                 if (w0 == 0) TPS_STAMP(8);
             }
         }

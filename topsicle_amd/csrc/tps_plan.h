@@ -93,7 +93,7 @@ inline std::string plan_geometry(ScanArgs& a, const tps_params& prm, int k, int 
     // 8-block chunk and its far end lies within the exchange halo (XLANES - NT lanes)
     const bool fused = !force_generic && spans_pref <= 0 && has_specialised_slide(prm.slide) && P <= 15 && a.q >= 8 &&
                        a.q / 8 + 2 < (XLANES - NT);
-    a.lc16 = 0; a.tile_cap = 0; a.tw = 0; a.tw_magic = 0;
+    a.lc16 = 0; a.tile_cap = 0; a.tw = 0; a.tw_magic = 0; a.pair_n = 0;
     if (fused) {
         a.variant = prm.slide;
         a.blk_log2 = 3;                            // 8 blocks per lane for every slide
@@ -112,6 +112,8 @@ inline std::string plan_geometry(ScanArgs& a, const tps_params& prm, int k, int 
         a.tw_magic = (uint32_t)(((1ull << 32) + (uint64_t)a.tw - 1) / (uint64_t)a.tw);
         a.tile_cap = (int)((max_nwin + a.tw - 1) / a.tw) + 1;
         a.lc16 = (a.pat.dup_mask == 0 && (int64_t)a.tw * (a.lw + P) < 65536) ? 1 : 0;
+        // pair table (two positions per lookup) while it is small: k <= 4 -> at most 4 KB per workgroup
+        a.pair_n = (a.pat.so_mask == 0 && k <= 4) ? (1 << (2 * (k + 1))) : 0;
         a.blk_dw = (int32_t)blk_region_dw(a);
         if (wg_lds_dwords(a) > budget_dw) return "LDS plan does not fit (fused kernel, " + std::to_string(max_nwin) + " windows per read)";
         return "";
