@@ -1320,42 +1320,63 @@ TPS_DEV void binseg_from_lc(const ScanArgs& a, const Lds& l, const int32_t* S_gl
 #ifdef TPS_EMU
     double* keep = (double*)xs;
 #endif
-    double best = -1.0, second = -1.0;
+    // Per lane: the best candidate as a FRACTION (num = D^2, den = b (n - b)); candidates are compared by
+    // cross-multiplication, so the f64 division happens once per lane instead of once per candidate.
+    // `amb` = another candidate of this lane lies within 1e-13 (relative) of the lane's best: if that
+    // best is also the global one, float64 cannot be trusted to separate them -> exact path.
+    double best = -1.0;
     int best_b = -1;
+    bool amb = false;
     TPS_PHASE {
         if (tid == 0) { *(uint64_t*)&misc[M_MAXSC] = 0ull; misc[M_BESTB] = (uint32_t)-1; misc[M_NTIE] = 0u; }
     }
     TPS_SYNC();
+    // admissible candidates: b = c * jump with b >= min_size and n - b >= min_size
+    const int c_min = (min_size + jump - 1) / jump > 1 ? (min_size + jump - 1) / jump : 1;
+    const int c_max = (n - min_size) / jump < ncand ? (n - min_size) / jump : ncand;
+    // D = n L_b - T b as an exact float64 integer when both products stay below 2^53 (always, for the
+    // fused geometry's window sizes); otherwise through int64 like the standalone path
+    const bool exact53 = (double)n * 4294967296.0 < 9007199254740992.0 && (double)tot * (double)n < 9007199254740992.0;
+    const double nf = (double)n, totf = (double)tot;
     TPS_PHASE {
-        best = -1.0; second = -1.0; best_b = -1;
-        for (int c = 1 + tid; c <= ncand; c += NT) {
+        double bn = -1.0, bd = 1.0;
+        best_b = -1;
+        amb = false;
+        TPS_NOVEC
+        for (int c = c_min + tid; c <= c_max; c += NT) {
             const int b = c * jump;
-            if (b >= min_size && n - b >= min_size) {
-                uint32_t lc;
-                if (a.lc16) lc = l.Tc[(uint32_t)(((uint64_t)(uint32_t)b * a.tw_magic) >> 32)] + l.Lc16[c];
-                else lc = l.Lc[c];
-                int64_t d = (int64_t)n * (int64_t)lc - (int64_t)tot * (int64_t)b;
-                double sc = score_f64(d, (uint64_t)b * (uint64_t)(n - b));
-                if (sc >= best) { second = best; best = sc; best_b = b; }
-                else if (sc > second) second = sc;
-            }
+            uint32_t lc;
+            if (a.lc16) lc = l.Tc[(uint32_t)(((uint64_t)(uint32_t)b * a.tw_magic) >> 32)] + l.Lc16[c];
+            else lc = l.Lc[c];
+            const double bf = (double)b;
+            double dd;
+            if (exact53) dd = __builtin_fma(-totf, bf, nf * (double)lc);
+            else dd = (double)((int64_t)n * (int64_t)lc - (int64_t)tot * (int64_t)b);
+            const double num = dd * dd, den = bf * (nf - bf);
+            const double t1 = num * bd, t2 = bn * den;         // num / den  vs  bn / bd
+            const double diff = t1 - t2;
+            const bool near = __builtin_fabs(diff) <= 1e-13 * t2;   // false while bn < 0
+            const bool take = diff >= 0.0;                     // ties -> the later (larger) candidate
+            amb = near || (amb && !take);
+            if (take) { bn = num; bd = den; best_b = b; }
         }
+        best = best_b >= 0 ? bn / bd : -1.0;
         uint64_t bits = 0;
         if (best >= 0.0) __builtin_memcpy(&bits, &best, 8);   // non-negative doubles order like integers
         wg_max_bits(bits, (uint64_t*)&misc[M_MAXSC]);
 #ifdef TPS_EMU
-        keep[3 * tid] = best; keep[3 * tid + 1] = second; keep[3 * tid + 2] = (double)best_b;
+        keep[3 * tid] = best; keep[3 * tid + 1] = amb ? 1.0 : 0.0; keep[3 * tid + 2] = (double)best_b;
 #endif
     }
     TPS_SYNC();
     TPS_PHASE {
 #ifdef TPS_EMU
-        best = keep[3 * tid]; second = keep[3 * tid + 1]; best_b = (int)keep[3 * tid + 2];
+        best = keep[3 * tid]; amb = keep[3 * tid + 1] != 0.0; best_b = (int)keep[3 * tid + 2];
 #endif
         double m;
         __builtin_memcpy(&m, &misc[M_MAXSC], 8);
         const double thr = m * (1.0 - 1e-14);
-        uint32_t near = (best >= thr && best >= 0.0 ? 1u : 0u) + (second >= thr && second >= 0.0 ? 1u : 0u);
+        const uint32_t near = (best >= thr && best >= 0.0) ? (amb ? 2u : 1u) : 0u;
         if (near) lds_add(&misc[M_NTIE], near);
         if (best == m && best_b >= 0) lds_max_i32((int32_t*)&misc[M_BESTB], best_b);
     }
