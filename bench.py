@@ -68,6 +68,28 @@ def algorithmic_bytes(lens, passed, n_win, P, prm):
     return int(step1 + step2 + step3), int(step1), int(step2), int(step3)
 
 
+def profiled_traffic(workload):
+    """HBM bytes per launch of the scan kernel from the newest committed rocprofv3 PMC summary
+    (profiles/*/pmc_per_launch_mean.csv: FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes of
+    this same command; KB units; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
+    Only meaningful for the workload the profile was taken on (config2); None otherwise."""
+    import csv
+    import glob
+    if workload != "config2":
+        return None, None
+    for d in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*")), reverse=True):
+        f = os.path.join(d, "pmc_per_launch_mean.csv")
+        if not os.path.exists(f):
+            continue
+        vals = {}
+        for r in csv.DictReader(open(f)):
+            if r["kernel"].startswith("tps_scan_kernel"):
+                vals[r["counter"]] = float(r["mean_value"])
+        if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+            return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), os.path.relpath(f, ROOT)
+    return None, None
+
+
 def cpu_baseline(seqs, motif, k, prm, budget_s=15.0):
     """The oracle (a port of the reference algorithm) timed on host cores on a bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -180,6 +202,7 @@ def main():
         total_bases = batch_bases * world * args.steps
         value = total_bases / dt
         achieved = alg_total / (k_mean_ms * 1e-3) / 1e9 if k_mean_ms > 0 else 0.0
+        traffic, traffic_src = profiled_traffic(args.workload) if not (args.flags or args.n_reads) else (None, None)
         out = {
             "metric": "bases_scanned_per_sec",
             "value": value,
@@ -213,7 +236,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": alg_total,
                 "algorithmic_bytes_split": {"step1": alg1, "windows": alg2, "binseg": alg3},
                 "kernel_ms_mean": k_mean_ms,
