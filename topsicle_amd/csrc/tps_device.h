@@ -1023,6 +1023,7 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const Lds& l, int delta, int w0, in
         const uint32_t* pe = l.XPC + ((lane + (uint32_t)q) + ((lane + (uint32_t)q) >> LOG2B));
         const uint32_t* pf = (farl ? l.XT : l.XF) + (lane >> LOG2B);
         int32_t* out = a.sums + (out_base + w0);
+        int32_t* outl = out + lane;
         const uint32_t am = pat.all_mask << 16;
         const int nfull = nw_tile >> 6;                                          // uniform
         const uint32_t npart = (uint32_t)(nw_tile & 63);
@@ -1043,7 +1044,7 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const Lds& l, int delta, int w0, in
                         flags |= (m >> 31) << u;
                         present[u / 2] |= (u & 1) ? (m & 0xFFFF0000u) : (m >> 16);
                     }
-                    out[(uint32_t)(u * NT) + lane] = (int32_t)sw;
+                    outl[u * NT] = (int32_t)sw;        // per-lane base + immediate offset
                 }
             }
             ps[u * RS] = sw;
