@@ -50,3 +50,40 @@ def test_native_fasta_multiline_crlf_and_edge_cases(tmp_path):
     big.write_text(">long\n" + "ACGT" * 5000 + "\n")
     recs = all_records(str(big), max_bases=1000)        # a single record larger than the batch grows the buffers
     assert len(recs) == 1 and len(recs[0].seq) == 20000
+
+
+@pytest.mark.skipif(seqio._load_io() is None, reason="libtopsicle_io.so not built")
+@pytest.mark.parametrize("threads", ["1", "5"])
+def test_native_plain_fastq_thread_team(tmp_path, monkeypatch, threads):
+    """Plain 4-line FASTQ goes through the mmap + thread-team decoder; anything irregular (wrapped lines,
+    blank lines, length mismatch) must hand the rest of the file to the streaming decoder with no record
+    lost or duplicated."""
+    monkeypatch.setenv("TPS_IO_THREADS", threads)
+    rng = np.random.default_rng(11)
+
+    def rec(i, n, crlf=False):
+        s = "".join("ACGTNacgt"[x] for x in rng.integers(0, 9, n))
+        q = "".join(chr(33 + int(x)) for x in rng.integers(0, 40, n))
+        nl = "\r\n" if crlf else "\n"
+        return f"@read{i} desc {i}{nl}{s}{nl}+{nl}{q}{nl}", (f"read{i}", f"read{i} desc {i}", s, q)
+
+    # (a) regular file, no trailing newline on the last line, several batches and a re-indexed window
+    parts, want = zip(*[rec(i, int(rng.integers(0, 3000)), crlf=(i % 7 == 0)) for i in range(400)])
+    p = tmp_path / "plain.fastq"
+    p.write_text("".join(parts).rstrip("\n"), newline="")
+    for mb in (1 << 20, 20000, 3500):
+        got = all_records(str(p), max_bases=mb)
+        assert [(r.id, r.description, r.seq, r.qual) for r in got] == list(want), mb
+    assert [(r.id, r.seq, r.qual) for r in seqio.read_records(str(p))] == [(w[0], w[2], w[3]) for w in want]
+    # (b) irregular records in the middle: wrapped sequence, blank line, '+name' separator line
+    irregular = "@w1\nACGT\nACGT\n+\nIIII\nIIII\n\n@w2 x\nAAAA\n+w2\nIIII\n"
+    q = tmp_path / "mixed.fastq"
+    q.write_text("".join(parts[:50]) + irregular + "".join(parts[50:60]) + "\n\n", newline="")
+    got = all_records(str(q), max_bases=30000)
+    exp = list(want[:50]) + [("w1", "w1", "ACGTACGT", "IIIIIIII"), ("w2", "w2 x", "AAAA", "IIII")] + list(want[50:60])
+    assert [(r.id, r.description, r.seq, r.qual) for r in got] == exp
+    # (c) a record larger than the batch buffers grows them; leading blank lines are skipped
+    big = tmp_path / "big.fastq"
+    big.write_text("\n\n@big\n" + "ACGT" * 5000 + "\n+\n" + "I" * 20000 + "\n@s\nAC\n+\nII\n")
+    got = all_records(str(big), max_bases=1000)
+    assert [(r.id, len(r.seq)) for r in got] == [("big", 20000), ("s", 2)]

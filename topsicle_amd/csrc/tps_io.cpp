@@ -6,13 +6,28 @@
 // per-read Python object is created for the ~99 % of reads that are never written back out.
 // Record ids follow Biopython: the first whitespace-delimited token of the header line.
 //
-// Plain C ABI (ctypes-loadable), zlib only.  Build: g++ -O2 -shared -fPIC tps_io.cpp -lz
+//
+// Two decoders behind one interface:
+//   * plain (uncompressed) 4-line FASTQ: the file is mmap'ed; newline positions of a window are indexed
+//     by a team of threads (memchr), records are validated ('@', '+', equal sequence / quality length)
+//     and their sequence, quality and header bytes are copied into the batch buffers by the same team.
+//     Anything unexpected (wrapped lines, blank lines, length mismatch) hands the rest of the file to
+//   * the streaming decoder on zlib (gz or plain, FASTA or FASTQ, wrapped lines), single-threaded.
+//
+// Plain C ABI (ctypes-loadable).  Build: g++ -O2 -shared -fPIC tps_io.cpp -lz -lpthread
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -115,46 +130,216 @@ struct Reader {
     }
 };
 
+
+// ---------------------------------------------------------------- mmap + thread-team decoder
+int io_threads() {
+    if (const char* e = getenv("TPS_IO_THREADS")) { int t = atoi(e); if (t > 0) return std::min(t, 64); }
+    unsigned hc = std::thread::hardware_concurrency();
+    return (int)std::max(1u, std::min(hc ? hc : 1u, 32u));
+}
+template <typename F>
+void team(int nthreads, F f) {                 // f(thread index, thread count); runs inline for one thread
+    if (nthreads <= 1) { f(0, 1); return; }
+    std::vector<std::thread> th;
+    th.reserve((size_t)nthreads - 1);
+    for (int t = 1; t < nthreads; ++t) th.emplace_back([=] { f(t, nthreads); });
+    f(0, nthreads);
+    for (auto& x : th) x.join();
+}
+
+struct Fast {
+    int fd = -1;
+    const char* data = nullptr;
+    size_t size = 0;
+    size_t pos = 0;                            // start of the first unconsumed record
+    std::vector<uint64_t> nl;                  // newline offsets of the indexed window, ascending
+    size_t nl_i = 0;                           // first unconsumed entry of nl
+    size_t win_hi = 0;                         // end of the indexed window
+    bool whole = false;                        // the window reaches the end of the file
+    int threads = 1;
+    struct Rec { uint64_t h0, hl, s0, sl, q0; };
+    std::vector<Rec> recs;
+
+    ~Fast() {
+        if (data) munmap((void*)data, size);
+        if (fd >= 0) close(fd);
+    }
+    void index_window() {
+        const size_t lo = pos, span = std::min<size_t>(size - lo, (size_t)512 << 20);
+        win_hi = lo + span;
+        whole = win_hi == size;
+        const int T = span < (8u << 20) ? 1 : threads;
+        std::vector<std::vector<uint64_t>> part((size_t)T);
+        team(T, [&](int t, int nt) {
+            const size_t a = lo + span * (size_t)t / (size_t)nt, b = lo + span * (size_t)(t + 1) / (size_t)nt;
+            auto& v = part[(size_t)t];
+            v.reserve((b - a) / 2048 + 16);
+            const char* p = data + a;
+            const char* e = data + b;
+            while (p < e) {
+                const char* q = (const char*)memchr(p, '\n', (size_t)(e - p));
+                if (!q) break;
+                v.push_back((uint64_t)(q - data));
+                p = q + 1;
+            }
+        });
+        nl.clear();
+        for (auto& v : part) nl.insert(nl.end(), v.begin(), v.end());
+        if (whole && size && data[size - 1] != '\n') nl.push_back(size);      // last line without a newline
+        nl_i = 0;
+    }
+    // >= 0: records decoded; -3: not plain 4-line FASTQ here -> caller switches to the streaming decoder at `pos`
+    int64_t next(uint8_t* bases, int64_t bases_cap, int64_t* offsets, int64_t max_records, char* heads, int64_t heads_cap,
+                 int64_t* head_off, uint8_t* quals) {
+        recs.clear();
+        int64_t nb = 0, nh = 0;
+        offsets[0] = 0;
+        head_off[0] = 0;
+        size_t p = pos;
+        while ((int64_t)recs.size() < max_records) {
+            if (nl_i + 4 > nl.size()) {                  // fewer than four indexed lines left
+                if (!whole) {
+                    if (!recs.empty()) break;            // hand over what we have; the next call re-indexes
+                    if (p >= size) break;
+                    pos = p;
+                    index_window();                      // window starts at the next record
+                    if (nl.size() >= 4) continue;
+                    if (!whole) return -3;               // one record larger than the window: streaming decoder
+                }
+                if (only_blank(p)) break;                // clean end of file
+                if (recs.empty()) return -3;             // a partial / odd tail: let the streaming decoder judge it
+                break;
+            }
+            const uint64_t e0 = nl[nl_i], e1 = nl[nl_i + 1], e2 = nl[nl_i + 2], e3 = nl[nl_i + 3];
+            auto trim = [&](uint64_t a, uint64_t e) { return (e > a && data[e - 1] == '\r') ? e - 1 : e; };
+            const uint64_t h0 = p, h1 = trim(p, e0), s0 = e0 + 1, s1 = trim(s0, e1), q0 = e2 + 1, q1 = trim(q0, e3);
+            const bool ok = h1 > h0 && data[h0] == '@' && e1 + 1 < size && data[e1 + 1] == '+' && (s1 - s0) == (q1 - q0) &&
+                            (s1 == s0 || (data[s0] != ' ' && data[s0] != '\t' && data[s1 - 1] != ' ' && data[s1 - 1] != '\t'));
+            if (!ok) {
+                if (recs.empty()) return -3;
+                break;
+            }
+            const int64_t sl = (int64_t)(s1 - s0), hl = (int64_t)(h1 - h0 - 1);
+            if (nb + sl > bases_cap || nh + hl > heads_cap) {
+                if (recs.empty()) return -2;
+                break;
+            }
+            recs.push_back(Rec{h0 + 1, (uint64_t)hl, s0, (uint64_t)sl, q0});
+            nb += sl;
+            nh += hl;
+            offsets[recs.size()] = nb;
+            head_off[recs.size()] = nh;
+            nl_i += 4;
+            p = std::min<size_t>((size_t)e3 + 1, size);
+        }
+        return (int64_t)finish(bases, offsets, heads, head_off, quals, p);
+    }
+    bool only_blank(size_t from) const {
+        for (size_t i = from; i < size; ++i)
+            if (data[i] != '\n' && data[i] != '\r' && data[i] != ' ') return false;
+        return true;
+    }
+    size_t finish(uint8_t* bases, const int64_t* offsets, char* heads, const int64_t* head_off, uint8_t* quals, size_t new_pos) {
+        const size_t n = recs.size();
+        const int T = (int64_t)offsets[n] < (4 << 20) ? 1 : threads;
+        team(T, [&](int t, int nt) {
+            const size_t a = n * (size_t)t / (size_t)nt, b = n * (size_t)(t + 1) / (size_t)nt;
+            for (size_t i = a; i < b; ++i) {
+                const Rec& r = recs[i];
+                memcpy(bases + offsets[i], data + r.s0, (size_t)r.sl);
+                if (quals) memcpy(quals + offsets[i], data + r.q0, (size_t)r.sl);
+                memcpy(heads + head_off[i], data + r.h0, (size_t)r.hl);
+            }
+        });
+        pos = new_pos;
+        return n;
+    }
+};
+
+struct Handle {
+    Reader* slow = nullptr;
+    Fast* fast = nullptr;
+    std::string path;
+    int format = 0;
+    ~Handle() {
+        if (slow) { if (slow->gz) gzclose(slow->gz); delete slow; }
+        delete fast;
+    }
+};
+
 }  // namespace
 
 extern "C" {
 
 const char* tps_io_last_error(void) { return g_err.c_str(); }
 
-// Opens a FASTA/FASTQ file (plain or .gz -- zlib reads both transparently).  The format comes from
-// the first byte, like check_file_type (allsteps.py:36-50).  Returns 0 or -1.
-int tps_reader_open(const char* path, void** out) {
-    if (!path || !out) { g_err = "null argument"; return -1; }
-    *out = nullptr;
+// Opens a FASTA/FASTQ file (plain or .gz).  The format comes from the first byte, like check_file_type
+// (allsteps.py:36-50).  Plain FASTQ files are mmap'ed for the thread-team decoder.  Returns 0 or -1.
+static Reader* open_stream(const char* path, int64_t seek_to, int format) {
     gzFile gz = gzopen(path, "rb");
-    if (!gz) { g_err = std::string("cannot open ") + path; return -1; }
+    if (!gz) { g_err = std::string("cannot open ") + path; return nullptr; }
     gzbuffer(gz, 1 << 20);
+    if (seek_to > 0 && gzseek(gz, (z_off_t)seek_to, SEEK_SET) < 0) { g_err = "seek failed"; gzclose(gz); return nullptr; }
     Reader* r = new Reader();
     r->gz = gz;
     r->buf.resize(4 << 20);
-    if (!r->fill() && r->len == 0) { r->format = 0; *out = r; return 0; }      // empty file: no records
+    r->format = format;
+    return r;
+}
+
+int tps_reader_open(const char* path, void** out) {
+    if (!path || !out) { g_err = "null argument"; return -1; }
+    *out = nullptr;
+    Handle* h = new Handle();
+    h->path = path;
+    // plain file?  (gzip magic 1f 8b otherwise)
+    bool plain = false;
+    {
+        FILE* f = fopen(path, "rb");
+        if (!f) { g_err = std::string("cannot open ") + path; delete h; return -1; }
+        unsigned char m[2] = {0, 0};
+        size_t got = fread(m, 1, 2, f);
+        fclose(f);
+        plain = !(got == 2 && m[0] == 0x1f && m[1] == 0x8b);
+    }
+    Reader* r = open_stream(path, 0, 0);
+    if (!r) { delete h; return -1; }
+    h->slow = r;
+    if (!r->fill() && r->len == 0) { h->format = 0; *out = h; return 0; }       // empty file: no records
     size_t i = 0;
     while (i < r->len && (r->buf[i] == '\n' || r->buf[i] == '\r' || r->buf[i] == ' ')) ++i;
     char c = i < r->len ? r->buf[i] : 0;
-    r->format = c == '>' ? 1 : c == '@' ? 2 : 0;
-    if (!r->format) {
+    r->format = h->format = c == '>' ? 1 : c == '@' ? 2 : 0;
+    if (!h->format) {
         g_err = "format cannot be identified (first character is neither '>' nor '@')";
-        gzclose(gz);
-        delete r;
+        delete h;
         return -1;
     }
-    *out = r;
+    if (plain && h->format == 2 && !getenv("TPS_IO_NO_MMAP")) {
+        Fast* f = new Fast();
+        f->fd = open(path, O_RDONLY);
+        struct stat st;
+        if (f->fd >= 0 && fstat(f->fd, &st) == 0 && st.st_size > 0) {
+            void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, f->fd, 0);
+            if (m != MAP_FAILED) {
+                madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+                f->data = (const char*)m;
+                f->size = (size_t)st.st_size;
+                f->pos = i;                        // leading blank lines skipped like the streaming decoder does
+                f->threads = io_threads();
+                h->fast = f;
+                f = nullptr;
+            }
+        }
+        delete f;
+    }
+    *out = h;
     return 0;
 }
 
-int tps_reader_format(void* h) { return h ? ((Reader*)h)->format : 0; }
+int tps_reader_format(void* h) { return h ? ((Handle*)h)->format : 0; }
 
-void tps_reader_close(void* h) {
-    if (!h) return;
-    Reader* r = (Reader*)h;
-    if (r->gz) gzclose(r->gz);
-    delete r;
-}
+void tps_reader_close(void* h) { delete (Handle*)h; }
 
 // Decodes up to max_records records into the caller's buffers, stopping before a record that would
 // overflow bases_cap / heads_cap.  offsets / head_off get n+1 entries (offsets[0] = 0).  quals may be
@@ -162,14 +347,26 @@ void tps_reader_close(void* h) {
 // whose quality length differs from the sequence length are padded with '!' / truncated).
 // Returns the number of records (0 at end of input), -1 on a parse error, -2 if a single record
 // does not fit into empty buffers.
-int64_t tps_reader_next(void* h, uint8_t* bases, int64_t bases_cap, int64_t* offsets, int64_t max_records, char* heads,
+int64_t tps_reader_next(void* hv, uint8_t* bases, int64_t bases_cap, int64_t* offsets, int64_t max_records, char* heads,
                         int64_t heads_cap, int64_t* head_off, uint8_t* quals) {
-    Reader* r = (Reader*)h;
-    if (!r || !bases || !offsets || !heads || !head_off) { g_err = "null argument"; return -1; }
-    int64_t n = 0, nb = 0, nh = 0;
+    Handle* h = (Handle*)hv;
+    if (!h || !bases || !offsets || !heads || !head_off) { g_err = "null argument"; return -1; }
     offsets[0] = 0;
     head_off[0] = 0;
-    if (!r->format) return 0;
+    if (!h->format) return 0;
+    if (h->fast) {
+        const int64_t n = h->fast->next(bases, bases_cap, offsets, max_records, heads, heads_cap, head_off, quals);
+        if (n != -3) return n;
+        // not plain 4-line FASTQ from here on: the streaming decoder takes over at the same byte
+        const int64_t at = (int64_t)h->fast->pos;
+        delete h->fast;
+        h->fast = nullptr;
+        if (h->slow) { if (h->slow->gz) gzclose(h->slow->gz); delete h->slow; }
+        h->slow = open_stream(h->path.c_str(), at, h->format);
+        if (!h->slow) return -1;
+    }
+    Reader* r = h->slow;
+    int64_t n = 0, nb = 0, nh = 0;
     g_err.clear();
     while (n < max_records) {
         if (!r->have_pending) {
