@@ -351,6 +351,20 @@ TPS_DEV uint32_t wg_exclusive_scan(uint32_t* arr, int n, uint32_t* scratch, int 
 }
 #endif
 
+// wave-wide maximum of an unsigned value (device only: DPP row shifts / broadcasts, no LDS round trip)
+#ifndef TPS_EMU
+TPS_DEV uint32_t wave_max_u32(uint32_t v) {
+    auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));   // row_shr:1
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));   // row_shr:2
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));   // row_shr:4
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));   // row_shr:8
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));   // row_bcast:15 -> rows 1, 3
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));   // row_bcast:31 -> rows 2, 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+#endif
+
 // ------------------------------------------------------------------ staging: HBM ASCII -> LDS 2-bit
 // Stages s-indices [i0, i0+n) of a tail string into LDS.  Forward tail: s[i] = seq[t + i];
 // reverse tail: s[i] = seq[L-1-t-i] (allsteps.py:267-271, 176-177).  LDS position of s-index
@@ -1031,15 +1045,24 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const Lds& l, int delta, int w0, in
         uint32_t present[B / 2];                     // SO only: the windows' presence masks, two per word
         TPS_UNROLL
         for (int t = 0; t < B / 2; ++t) present[t] = 0;
+        // all LDS reads of the lane's windows are issued before the first one is used: one LDS round trip
+        // per tile instead of one per window (rows past the tile's windows read in-bounds garbage)
+        uint32_t xv[B], ev[B], fv[B];
+        TPS_UNROLL
+        for (int u = 0; u < B; ++u) {
+            xv[u] = ev[u] = fv[u] = 0;
+            if (u <= nfull) { xv[u] = ps[u * RS]; ev[u] = pe[u * RS]; fv[u] = pf[u * (NT / B)]; }
+        }
         TPS_UNROLL
         for (int u = 0; u < B; ++u) {
             uint32_t sw = 0;
             if (u <= nfull) {
                 const bool valid = (u < nfull) || (lane < npart);
+                const uint32_t x = xv[u], e = ev[u], f = fv[u];
+                const uint32_t m = x | e | f;
+                const uint32_t s_ = ((e - x + f) & 0xFFFFu) + (uint32_t)popc(~m & am);
                 if (valid) {
-                    const uint32_t x = ps[u * RS], e = pe[u * RS], f = pf[u * (NT / B)];
-                    const uint32_t m = x | e | f;
-                    sw = ((e - x + f) & 0xFFFFu) + (uint32_t)popc(~m & am);
+                    sw = s_;
                     if (SO) {
                         flags |= (m >> 31) << u;
                         present[u / 2] |= (u & 1) ? (m & 0xFFFF0000u) : (m >> 16);
@@ -1328,10 +1351,7 @@ TPS_DEV void binseg_from_lc(const ScanArgs& a, const Lds& l, const int32_t* S_gl
     double best = -1.0;
     int best_b = -1;
     bool amb = false;
-    TPS_PHASE {
-        if (tid == 0) { *(uint64_t*)&misc[M_MAXSC] = 0ull; misc[M_BESTB] = (uint32_t)-1; misc[M_NTIE] = 0u; }
-    }
-    TPS_SYNC();
+    uint64_t bits = 0;
     // admissible candidates: b = c * jump with b >= min_size and n - b >= min_size
     const int c_min = (min_size + jump - 1) / jump > 1 ? (min_size + jump - 1) / jump : 1;
     const int c_max = (n - min_size) / jump < ncand ? (n - min_size) / jump : ncand;
@@ -1362,34 +1382,44 @@ TPS_DEV void binseg_from_lc(const ScanArgs& a, const Lds& l, const int32_t* S_gl
             if (take) { bn = num; bd = den; best_b = b; }
         }
         best = best_b >= 0 ? bn / bd : -1.0;
-        uint64_t bits = 0;
+        bits = 0;
         if (best >= 0.0) __builtin_memcpy(&bits, &best, 8);   // non-negative doubles order like integers
-        wg_max_bits(bits, (uint64_t*)&misc[M_MAXSC]);
 #ifdef TPS_EMU
         keep[3 * tid] = best; keep[3 * tid + 1] = amb ? 1.0 : 0.0; keep[3 * tid + 2] = (double)best_b;
 #endif
     }
-    TPS_SYNC();
-    TPS_PHASE {
+    // wave-wide: the best score, how many candidates float64 cannot separate from it, the largest b holding it
+    double m;
+    uint32_t ntie = 0;
+    int32_t bestb = -1;
 #ifdef TPS_EMU
-        best = keep[3 * tid]; amb = keep[3 * tid + 1] != 0.0; best_b = (int)keep[3 * tid + 2];
-#endif
-        double m;
-        __builtin_memcpy(&m, &misc[M_MAXSC], 8);
-        const double thr = m * (1.0 - 1e-14);
-        const uint32_t near = (best >= thr && best >= 0.0) ? (amb ? 2u : 1u) : 0u;
-        if (near) lds_add(&misc[M_NTIE], near);
-        if (best == m && best_b >= 0) lds_max_i32((int32_t*)&misc[M_BESTB], best_b);
+    m = 0.0;
+    for (int t = 0; t < NT; ++t) if (keep[3 * t] > m) m = keep[3 * t];
+    for (int t = 0; t < NT; ++t) {
+        const double bt = keep[3 * t];
+        if (bt >= m * (1.0 - 1e-14) && bt >= 0.0) ntie += keep[3 * t + 1] != 0.0 ? 2u : 1u;
+        if (bt == m && (int)keep[3 * t + 2] >= 0 && (int)keep[3 * t + 2] > bestb) bestb = (int)keep[3 * t + 2];
     }
-    TPS_SYNC();
-    if (uniform(misc[M_NTIE]) > 1u) {             // float noise cannot separate them: exact integers decide
+#else
+    {
+        const uint32_t hi = (uint32_t)(bits >> 32);
+        const uint32_t mh = wave_max_u32(hi);
+        const uint32_t ml = wave_max_u32(hi == mh ? (uint32_t)bits : 0u);
+        const uint64_t mbits = ((uint64_t)mh << 32) | ml;
+        __builtin_memcpy(&m, &mbits, 8);
+        const bool n1 = best >= m * (1.0 - 1e-14) && best >= 0.0;
+        ntie = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(n1)) +
+               (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(n1 && amb));
+        bestb = (int32_t)wave_max_u32((best == m && best_b >= 0) ? (uint32_t)best_b + 1u : 0u) - 1;
+    }
+#endif
+    (void)misc;
+    if (ntie > 1u) {                               // float noise cannot separate them: exact integers decide
         Cand ex = binseg_exact_wg(S_global, n, jump, min_size, xs);
         bkp = ex.b;
         gain = ex.b < 0 ? 0.0 : gain_from((int64_t)ex.d, ex.den, n, n_patterns);
     } else {
-        bkp = (int32_t)uniform(misc[M_BESTB]);
-        double m;
-        __builtin_memcpy(&m, &misc[M_MAXSC], 8);
+        bkp = bestb;
         gain = bkp < 0 ? 0.0 : m / (double)n / ((double)n_patterns * (double)n_patterns);
     }
 }
