@@ -35,6 +35,7 @@
 #define TPS_NOVEC
 #define TPS_SCHED_BARRIER() ((void)0)
 #define TPS_PIN(x) ((void)0)
+#define TPS_PIN_S(x) ((void)0)
 #else
 #define TPS_DEV __device__ __forceinline__
 #define TPS_HD __host__ __device__ inline
@@ -61,6 +62,9 @@ __device__ __forceinline__ int tps_fresh_lane() {
 #define TPS_SCHED_BARRIER() ((void)0)
 // zero-cost "redefinition" of a register: nothing computed from x can be hoisted above this point
 #define TPS_PIN(x) asm volatile("" : "+v"(x))
+// the same for a wave-uniform value: it stays in an SGPR (or a VGPR lane) instead of being re-loaded from the
+// kernel-argument segment inside a loop (an s_load + s_waitcnt that also drains the LDS queue)
+#define TPS_PIN_S(x) asm volatile("" : "+s"(x))
 #endif
 
 namespace tps {
@@ -835,6 +839,20 @@ TPS_DEV void candidates_group(const ScanArgs& a, const Lds& l, int w0, int nw_ti
 // block the record holds the OR over the rest of its chunk (suffix) and the OR over the chunk's
 // earlier blocks plus this block's first r positions (prefix), so a window's presence mask is
 // suffix[first block] | full chunks in between | prefix[partial block].
+// per-read copies of the plan constants the fused tile needs (pinned: see TPS_PIN_S)
+struct TileConst {
+    int32_t q, r;
+    uint32_t jump, jump_magic, lc_cap, lc16;
+};
+TPS_DEV TileConst tile_const(const ScanArgs& a) {
+    TileConst t;
+    t.q = (int32_t)uniform((uint32_t)a.q); t.r = (int32_t)uniform((uint32_t)a.r);
+    t.jump = uniform((uint32_t)a.prm.jump); t.jump_magic = uniform(a.jump_magic);
+    t.lc_cap = uniform((uint32_t)a.lc_cap); t.lc16 = uniform((uint32_t)a.lc16);
+    TPS_PIN_S(t.q); TPS_PIN_S(t.r); TPS_PIN_S(t.jump); TPS_PIN_S(t.jump_magic); TPS_PIN_S(t.lc_cap); TPS_PIN_S(t.lc16);
+    return t;
+}
+
 template <int S>
 struct Geo {
     static constexpr int B = 8;                   // blocks (= windows) per lane
@@ -868,14 +886,14 @@ struct Geo {
 TPS_DEV uint32_t pack_hi_lo(uint32_t hi_src, uint32_t lo_src) { return perm(hi_src, lo_src, 0x07060100u); }
 
 template <int S, bool SO, bool INV, bool RZ, bool PAIR>
-TPS_DEV void tile_fused_s(const ScanArgs& a, const Lds& l, int delta, int w0, int tile, int nw_tile, int64_t out_base,
-                          uint64_t& s_total, int64_t r) {
+TPS_DEV void tile_fused_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int delta, int w0, int tile, int nw_tile,
+                          int64_t out_base, uint64_t& s_total, int64_t r) {
     // RZ: the window has no partial block (W - k divisible by the slide), so nothing is captured mid-block
     typedef Geo<S> g_;
     constexpr int WDW = g_::WDW, B = g_::B, LOG2B = g_::LOG2B, POS = g_::POS;
     constexpr int RS = NT + NT / B;               // row stride of the padded layout between u and u + 1
     const PatInfo& pat = a.pat;
-    const int rp = a.r, q = a.q;                  // rp: positions of the partial block (a.r)
+    const int rp = tc.r, q = tc.q;                // rp: positions of the partial block (a.r)
     const uint32_t amask = pat.kmask << 2;        // k-mer code as a byte offset into the 4-byte table
     TPS_PHASE {
         const int span = tid;
@@ -1100,21 +1118,21 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const Lds& l, int delta, int w0, in
     if (w0 == 0) TPS_STAMP(12);
     {
         // change-point candidates of this tile: c with w0 <= c * jump < w0 + nw_tile, 64 per pass
-        const uint32_t jump = (uint32_t)a.prm.jump;
-        const uint32_t c_lo = (uint32_t)(((uint64_t)((uint32_t)w0 + jump - 1u) * a.jump_magic) >> 32);
-        uint32_t c_hi = (uint32_t)(((uint64_t)((uint32_t)(w0 + nw_tile) + jump - 1u) * a.jump_magic) >> 32);
-        if (c_hi > (uint32_t)a.lc_cap) c_hi = (uint32_t)a.lc_cap;
+        const uint32_t jump = tc.jump;
+        const uint32_t c_lo = (uint32_t)(((uint64_t)((uint32_t)w0 + jump - 1u) * tc.jump_magic) >> 32);
+        uint32_t c_hi = (uint32_t)(((uint64_t)((uint32_t)(w0 + nw_tile) + jump - 1u) * tc.jump_magic) >> 32);
+        if (c_hi > tc.lc_cap) c_hi = tc.lc_cap;
         const int passes = c_hi > c_lo ? (int)((c_hi - c_lo + NT - 1) / NT) : 0;
         TPS_PHASE {
             const uint32_t carry = (uint32_t)s_total;
-            if (a.lc16 && tid == 0) l.Tc[tile] = carry;
+            if (tc.lc16 && tid == 0) l.Tc[tile] = carry;
             uint32_t c = c_lo + (uint32_t)tid;
             uint32_t w = c * jump - (uint32_t)w0;         // tile-local window index of candidate c
             TPS_NOVEC
             for (int t = 0; t < passes; ++t) {
                 if (c < c_hi) {
                     const uint32_t pre = l.row[w + (w >> LOG2B)];
-                    if (a.lc16) l.Lc16[c] = (uint16_t)pre;
+                    if (tc.lc16) l.Lc16[c] = (uint16_t)pre;
                     else l.Lc[c] = carry + pre;
                 }
                 c += NT;
@@ -1560,7 +1578,8 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
             // ---------------- fused tiles: NT lanes x 8 blocks, the last lane is halo only
             typedef Geo<SV ? SV : 1> g_;
             constexpr int PF = g_::PF;
-            const int tw = NT * g_::B - a.q - 1 - g_::B;   // windows per tile
+            const TileConst tc = tile_const(a);
+            const int tw = NT * g_::B - tc.q - 1 - g_::B;   // windows per tile
             auto tile_stage = [&](int w0_) {
                 const int64_t i0 = (int64_t)w0_ * prm.slide;
                 int64_t n_stage = n_s - i0;
@@ -1618,11 +1637,11 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
                 if (w0 == 0) TPS_STAMP(5);
                 const int fdelta = st.delta + 16;      // LDS position of the tile's first base
                 if (uniform(l.misc[M_INVALID]) != 0)
-                    tile_fused_s<SV ? SV : 1, SO, true, false, false>(a, l, fdelta, w0, tile, nw_tile, out_base, s_total, r);
-                else if (a.r == 0)
-                    tile_fused_s<SV ? SV : 1, SO, false, true, PAIR>(a, l, fdelta, w0, tile, nw_tile, out_base, s_total, r);
+                    tile_fused_s<SV ? SV : 1, SO, true, false, false>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r);
+                else if (tc.r == 0)
+                    tile_fused_s<SV ? SV : 1, SO, false, true, PAIR>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r);
                 else
-                    tile_fused_s<SV ? SV : 1, SO, false, false, PAIR>(a, l, fdelta, w0, tile, nw_tile, out_base, s_total, r);
+                    tile_fused_s<SV ? SV : 1, SO, false, false, PAIR>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r);
                 if (w0 == 0) TPS_STAMP(8);
             }
         }
