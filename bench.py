@@ -162,6 +162,9 @@ def main():
 
     if args.flags:
         prm.flags = args.flags
+    # kernel durations come from HIP events stamped by the dispatch itself; every 4th launch is timed (timing a
+    # launch costs ~3.5 us of host/queue work, which would otherwise sit inside every timed step)
+    os.environ.setdefault("TPS_EVENT_STRIDE", "4")
     sc = hiplib.HipScanner(local_rank)
     sc.set_patterns(pats)
     copies = args.resident_copies or max(2, min(hiplib.MAX_SLOTS, -(-(1 << 30) // max(batch_bases, 1))))
