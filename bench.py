@@ -53,6 +53,17 @@ def kmer_table(motif, k):
     return allsteps.patterns_to_search(motif, k)
 
 
+def kernel_name(pats, k, window, slide):
+    """Which member of the kernel family the library launches for this table / geometry
+    (mirrors plan_geometry in csrc/tps_plan.h and the host's kernel selection)."""
+    q = (window - k) // slide
+    fused = slide in (5, 6, 7, 8) and len(pats) <= 15 and q >= 8 and q // 8 + 2 < 16
+    if not fused:
+        return "tps_scan_kernel"
+    so = any(p[d:] == p[:k - d] for p in pats for d in range(1, k))     # a k-mer that can overlap itself
+    return f"tps_scan_kernel_s{slide}" + ("so" if so else "p" if k <= 4 else "")
+
+
 def min_count_for_cutoff(cutoff, no_bp, motif_len):
     from topsicle_amd import allsteps
     return allsteps.min_count_for_cutoff(cutoff, no_bp / motif_len, no_bp)
@@ -234,7 +245,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "tps_scan_kernel",
+                "kernel": kernel_name(pats, k, cfg["window"], cfg["slide"]),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
