@@ -188,6 +188,31 @@ def test_emulation_multi_tile_fused(case):
         assert out["results"][i]["bkp"] == orc.binseg_l2_exact(counts.sum(axis=1))
 
 
+@pytest.mark.parametrize("traps", [3, 400])
+def test_emulation_self_overlap_recount_paths(traps):
+    """Tables with self-overlapping k-mers (CCCTAA at k=5: CTAAC / GATTG have period 4), sums only: a few
+    flagged windows per tile take the whole-wave recount, many take the per-lane recount."""
+    rng = np.random.default_rng(traps)
+    pats = orc.kmer_table("CCCTAA", 5)
+    seqs = []
+    for i in range(2):
+        L = 7000
+        body = list(("CCCTAA" * 700)[:3000] + "".join("ACGT"[x] for x in rng.integers(0, 4, L - 3000)))
+        for p in rng.integers(0, L - 20, traps):
+            body[p:p + 13] = list("CTAACTAACTAAC" if rng.random() < 0.5 else "GATTGATTGATTG")
+        if i:
+            body[int(rng.integers(L))] = "N"
+        seqs.append("".join(body[:L]))
+    prm = hiplib.make_params(window=100, slide=6, trimfirst=100, maxlen=20000,
+                             flags=hiplib.F_WINDOWS | hiplib.F_BINSEG | hiplib.F_TAILS_IN | hiplib.F_STORE_SUMS)
+    out = emu.scan(pats, seqs, prm, tails=[0, 1])
+    for i, seq in enumerate(seqs):
+        _, counts = orc.window_count_matrix(seq, ["forward", "reverse"][i], pats, 100, 6, 100, 20000)
+        lo, hi = out["win_off"][i], out["win_off"][i + 1]
+        assert np.array_equal(out["sums"][lo:hi], counts.sum(axis=1))
+        assert out["results"][i]["bkp"] == orc.binseg_l2_exact(counts.sum(axis=1))
+
+
 def test_emulation_binseg_standalone():
     rng = np.random.default_rng(5)
     sums, off = [], [0]

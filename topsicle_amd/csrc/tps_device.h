@@ -75,6 +75,7 @@ constexpr uint32_t FLAG_CONFLICT = 0x80000000u;   // generic path: bit 31 of a b
 constexpr uint32_t FLAG16 = 0x8000u;              // specialised path: bit 15 of a 16-bit mask
 constexpr int HIST_COPIES = 8;                    // private step-1 histograms (lane % 8)
 constexpr int WIN_U = 4;                          // windows per lane and group in the window phase
+constexpr int COOP_MAX = 24;                      // fused tiles: up to this many windows are recounted by the whole wave, one at a time
 
 typedef unsigned __int128 u128;
 
@@ -104,6 +105,7 @@ TPS_DEV int ffs0(uint32_t x) { return __builtin_ctz(x); }
 TPS_DEV uint32_t uniform(uint32_t x) { return x; }
 TPS_DEV void lds_add(uint32_t* p, uint32_t v) { *p += v; }
 TPS_DEV void lds_or(uint32_t* p, uint32_t v) { *p |= v; }
+TPS_DEV uint32_t lds_add_ret(uint32_t* p, uint32_t v) { uint32_t o = *p; *p += v; return o; }
 TPS_DEV void lds_max_u64(uint64_t* p, uint64_t v) { if (v > *p) *p = v; }
 TPS_DEV void lds_max_i32(int32_t* p, int32_t v) { if (v > *p) *p = v; }
 struct u32x4 { uint32_t x, y, z, w; };
@@ -119,6 +121,7 @@ TPS_DEV int ffs0(uint32_t x) { return __builtin_ctz(x); }
 TPS_DEV uint32_t uniform(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 TPS_DEV void lds_add(uint32_t* p, uint32_t v) { atomicAdd(p, v); }
 TPS_DEV void lds_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
+TPS_DEV uint32_t lds_add_ret(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 TPS_DEV void lds_max_u64(uint64_t* p, uint64_t v) { atomicMax((unsigned long long*)p, (unsigned long long)v); }
 TPS_DEV void lds_max_i32(int32_t* p, int32_t v) { atomicMax(p, v); }
 typedef uint4 u32x4;
@@ -1048,6 +1051,13 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const TileConst& tc, const Lds& l, 
         l.XT[tid] = fo_b;
     }
     TPS_SYNC();
+#ifdef TPS_EMU
+    uint32_t redo_keep[NT][1 + Geo<S>::B / 2];
+#else
+    uint32_t redo_flags = 0, redo_present[Geo<S>::B / 2];
+    TPS_UNROLL
+    for (int t = 0; t < Geo<S>::B / 2; ++t) redo_present[t] = 0;
+#endif
     TPS_PHASE {
         const uint32_t lane = (uint32_t)tid;
         const bool farl = (((lane & (B - 1)) + (uint32_t)rot) >> LOG2B) != 0;
@@ -1090,26 +1100,115 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const TileConst& tc, const Lds& l, 
             }
             ps[u * RS] = sw;
         }
-        // rare: windows with overlapping occurrences of a self-overlapping k-mer, or raw counts wanted
-        if (a.raw) {
-            const int nv = nfull + ((lane < npart) ? 1 : 0);
-            flags = nv >= B ? (1u << B) - 1u : (1u << nv) - 1u;
+        // windows that need the exact recount (overlapping occurrences of a self-overlapping k-mer, or raw
+        // counts wanted) are queued: entry = tile-local window | its presence mask << 16.  The queue lives in
+        // the XPC area, which no window needs any more.
+        if (SO || a.raw) {
+            if (a.raw) {
+                const int nv = nfull + ((lane < npart) ? 1 : 0);
+                flags = nv >= B ? (1u << B) - 1u : (1u << nv) - 1u;
+            }
+#ifdef TPS_EMU
+            redo_keep[tid][0] = flags;
+            for (int t = 0; t < B / 2; ++t) redo_keep[tid][1 + t] = present[t];
+#else
+            redo_flags = flags;
+            TPS_UNROLL
+            for (int t = 0; t < B / 2; ++t) redo_present[t] = present[t];
+#endif
         }
-        while (flags) {
-            const int u = ffs0(flags);
-            flags &= flags - 1;
-            const int wl = u * NT + (int)lane;
-            uint32_t pm = 0;
-            if (SO) {
+    }
+    if (SO || a.raw) {
+        TPS_SYNC();
+        uint32_t* queue = l.XPC;                       // up to NT * B entries
+        uint32_t* occ = l.XPC + NT * B;                // [P <= 15][4] occurrence bits of one window, + the correction
+        TPS_PHASE {
+            uint32_t flags;
+            uint32_t present[B / 2];
+#ifdef TPS_EMU
+            flags = redo_keep[tid][0];
+            for (int t = 0; t < B / 2; ++t) present[t] = redo_keep[tid][1 + t];
+#else
+            flags = redo_flags;
+            TPS_UNROLL
+            for (int t = 0; t < B / 2; ++t) present[t] = redo_present[t];
+#endif
+            while (flags) {
+                const int u = ffs0(flags);
+                flags &= flags - 1;
+                uint32_t pm = 0;
                 TPS_UNROLL
                 for (int t = 0; t < B / 2; ++t)
                     if (t == (u >> 1)) pm = present[t];
                 pm = (pm >> (16 * (u & 1))) & pat.all_mask;
+                const uint32_t e = lds_add_ret(&l.misc[M_NTIE], 1u);
+                queue[e] = (uint32_t)(u * NT + tid) | (pm << 16);
             }
-            uint8_t* raw_row = a.raw ? a.raw + (out_base + w0 + wl) * (int64_t)pat.P : nullptr;
-            const uint32_t sw = window_exact(a, l, delta, wl, pm, l.row[padded(wl, LOG2B)], raw_row);
-            l.row[padded(wl, LOG2B)] = sw;
-            out[wl] = (int32_t)sw;
+            occ[tid] = 0;
+        }
+        TPS_SYNC();
+        const int n_redo = (int)uniform(l.misc[M_NTIE]);
+        int32_t* out = a.sums + (out_base + w0);
+        if (n_redo > 0 && !a.raw && n_redo <= COOP_MAX && a.lw <= 128) {
+            // few windows: the whole wave recounts one window at a time -- lanes look up the window's positions
+            // and publish per-pattern occurrence bits, one lane per pattern walks its bits greedily
+            const bool inv = INV;
+            for (int e = 0; e < n_redo; ++e) {
+                const uint32_t ent = uniform(queue[e]);
+                const int wl = (int)(ent & 0xFFFFu);
+                const uint32_t redo = (ent >> 16) & pat.so_mask;
+                const int q0 = delta + wl * S;
+                TPS_PHASE {
+                    for (int p = tid; p < a.lw; p += NT) {
+                        uint32_t h = h_at(l.lut, l.lshift, l.seq2, l.val, pat, q0 + p, inv) & redo;
+                        while (h) {
+                            const int b = ffs0(h);
+                            h &= h - 1;
+                            lds_or(&occ[4 * b + (p >> 5)], 1u << (p & 31));
+                        }
+                    }
+                }
+                TPS_SYNC();
+                TPS_PHASE {
+                    if (tid < pat.P && ((redo >> tid) & 1u)) {
+                        int n_occ = 0, greedy = 0, cursor = 0;
+                        TPS_UNROLL
+                        for (int wd = 0; wd < 4; ++wd) {
+                            uint32_t m = occ[4 * tid + wd];
+                            n_occ += popc(m);
+                            while (m) {
+                                const int p = 32 * wd + ffs0(m);
+                                m &= m - 1;
+                                if (p >= cursor) { ++greedy; cursor = p + pat.k; }
+                            }
+                            occ[4 * tid + wd] = 0;
+                        }
+                        if (n_occ != greedy) lds_add(&occ[60], (uint32_t)(n_occ - greedy));
+                    }
+                }
+                TPS_SYNC();
+                TPS_PHASE {
+                    if (tid == 0) {
+                        const uint32_t sw = l.row[padded(wl, LOG2B)] - occ[60];
+                        l.row[padded(wl, LOG2B)] = sw;
+                        out[wl] = (int32_t)sw;
+                        occ[60] = 0;
+                    }
+                }
+                TPS_SYNC();
+            }
+        } else if (n_redo > 0) {
+            // many windows (or raw counts): every lane recounts its share of the queue sequentially
+            TPS_PHASE {
+                for (int e = tid; e < n_redo; e += NT) {
+                    const uint32_t ent = queue[e];
+                    const int wl = (int)(ent & 0xFFFFu);
+                    uint8_t* raw_row = a.raw ? a.raw + (out_base + w0 + wl) * (int64_t)pat.P : nullptr;
+                    const uint32_t sw = window_exact(a, l, delta, wl, ent >> 16, l.row[padded(wl, LOG2B)], raw_row);
+                    l.row[padded(wl, LOG2B)] = sw;
+                    out[wl] = (int32_t)sw;
+                }
+            }
         }
     }
     TPS_SYNC();
@@ -1612,7 +1711,7 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
             for (int w0 = 0, tile = 0; w0 < n_win; w0 += tw, ++tile) {
                 const int nw_tile = (n_win - w0) < tw ? (n_win - w0) : tw;
                 const Stage st = tile_stage(w0);
-                TPS_PHASE { if (tid == 0) l.misc[M_INVALID] = 0; }
+                TPS_PHASE { if (tid == 0) { l.misc[M_INVALID] = 0; l.misc[M_NTIE] = 0; } }
                 TPS_SYNC();
                 TPS_PHASE {
                     TPS_UNROLL
