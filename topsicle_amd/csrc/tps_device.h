@@ -968,35 +968,62 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const TileConst& tc, const Lds& l, 
             }
         } else {
             // table lookups run one block ahead of their use (software pipeline, 2 S values in flight)
-            uint32_t hc[S], vc[S], hn[S], vn[S];
-            auto fetch = [&](int blk, uint32_t* hh, uint32_t* vv) {
+            uint32_t hc[S], hn[S];
+            auto fetch = [&](int blk, uint32_t* hh, int cnt_) {
                 TPS_UNROLL
                 for (int i = 0; i < S; ++i) {
-                    const int p = blk * S + i;        // constant after unrolling
-                    const int dw = p >> 4, bit = p & 15;
-                    uint32_t v4 = bit ? alignbit(dw + 1 < WDW ? w[dw + 1] : 0u, w[dw], 2u * bit) : w[dw];
-                    uint32_t h = lut_at(l.lut, v4, amask);
-                    if (INV) {
-                        if (h && invalid_at(l.val, p0 + p, pat.k)) h = 0;   // tiles with non-ACGT letters only
+                    if (i < cnt_) {
+                        const int p = blk * S + i;        // constant after unrolling
+                        const int dw = p >> 4, bit = p & 15;
+                        uint32_t v4 = bit ? alignbit(dw + 1 < WDW ? w[dw + 1] : 0u, w[dw], 2u * bit) : w[dw];
+                        uint32_t h = lut_at(l.lut, v4, amask);
+                        if (INV) {
+                            if (h && invalid_at(l.val, p0 + p, pat.k)) h = 0;   // tiles with non-ACGT letters only
+                        }
+                        hh[i] = h;
+                    } else {
+                        hh[i] = 0;
                     }
-                    hh[i] = h;
-                    vv[i] = v4 >> 2;
                 }
             };
-            fetch(0, hc, vc);
+            // Self-overlapping k-mers: pattern b has OVERLAPPING occurrences iff it matches at p and again at
+            // p + d, d one of its periods (d < k).  With the entries of the next block at hand that is one AND per
+            // position and period: ppd[d] = the patterns with period d (in the entries' mask half).  The planner
+            // only picks these kernels when every period is <= the slide, so p + d lies in this or the next block.
+            constexpr int MAXD = S < 6 ? S : 6;
+            uint32_t ppd[MAXD + 1];
+            if (SO) {
+                TPS_UNROLL
+                for (int d = 0; d <= MAXD; ++d) ppd[d] = 0;
+                TPS_NOVEC
+                for (int i = 0; i < pat.n_periods; ++i) {
+                    TPS_UNROLL
+                    for (int d = 1; d <= MAXD; ++d)
+                        if (pat.period[i] == d) ppd[d] |= pat.period_pat[i] << 16;
+                }
+            }
+            fetch(0, hc, S);
             TPS_UNROLL
             for (int blk = 0; blk < B; ++blk) {
-                if (blk + 1 < B) fetch(blk + 1, hn, vn);
+                if (blk + 1 < B) fetch(blk + 1, hn, S);
+                else if (SO) fetch(B, hn, MAXD);          // look-ahead past the lane's last block (w[] holds 13 extra bases)
                 uint32_t g = 0;
                 c0s[blk] = cnt;
                 uint32_t c1 = cnt, pp = run_or;
+                if (SO) {
+                    uint32_t cf = 0;
+                    TPS_UNROLL
+                    for (int d = 1; d <= MAXD; ++d) {
+                        if (ppd[d]) {                     // uniform
+                            TPS_UNROLL
+                            for (int i = 0; i < S; ++i) cf |= hc[i] & (i + d < S ? hc[i + d] : hn[i + d - S]) & ppd[d];
+                        }
+                    }
+                    if (cf) g = FLAG16 << 16;
+                }
                 TPS_UNROLL
                 for (int i = 0; i < S; ++i) {
                     const uint32_t h = hc[i];
-                    if (SO) {
-                        if ((h >> 16) & pat.so_mask)
-                            if (conflict_bits(pat, vc[i], h >> 16)) g |= FLAG16 << 16;
-                    }
                     g |= h;
                     cnt += h;
                     if (!RZ) {
@@ -1007,7 +1034,7 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const TileConst& tc, const Lds& l, 
                 gs[blk] = g;
                 run_or |= g;
                 TPS_UNROLL
-                for (int i = 0; i < S; ++i) { hc[i] = hn[i]; vc[i] = vn[i]; }
+                for (int i = 0; i < S; ++i) hc[i] = hn[i];
             }
         }
         uint32_t sfx = 0;

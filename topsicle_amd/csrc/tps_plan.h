@@ -91,8 +91,10 @@ inline std::string plan_geometry(ScanArgs& a, const tps_params& prm, int k, int 
     (void)target_dw;
     // fused kernels: compile-time slide, 16-bit masks (<= 15 patterns), a window spans at least one
     // 8-block chunk and its far end lies within the exchange halo (XLANES - NT lanes)
+    int max_period = 0;                            // self-overlap periods of the table (0 = none)
+    for (int i = 0; i < a.pat.n_periods; ++i) max_period = std::max(max_period, a.pat.period[i]);
     const bool fused = !force_generic && spans_pref <= 0 && has_specialised_slide(prm.slide) && P <= 15 && a.q >= 8 &&
-                       a.q / 8 + 2 < (XLANES - NT);
+                       a.q / 8 + 2 < (XLANES - NT) && max_period <= std::min(prm.slide, 6);
     a.lc16 = 0; a.tile_cap = 0; a.tw = 0; a.tw_magic = 0; a.pair_n = 0;
     if (fused) {
         a.variant = prm.slide;
