@@ -202,7 +202,16 @@ def test_emulation_self_overlap_recount_paths(traps):
             body[p:p + 13] = list("CTAACTAACTAAC" if rng.random() < 0.5 else "GATTGATTGATTG")
         if i:
             body[int(rng.integers(L))] = "N"
+        else:
+            body[200:213] = list("CTAACTAACTAAC")            # overlapping occurrences inside the step-1 head
+            body[L - 300:L - 287] = list("GTTAGTTAGTTAG")    # ... and inside the reversed end head (GATTG reversed)
         seqs.append("".join(body[:L]))
+    # step 1: packed counters + conflict mask + greedy recount of the conflicting patterns (read 0, no N),
+    # histogram path (read 1, holds an N)
+    out1 = emu.scan(pats, seqs, hiplib.make_params(no_bp=1000, flags=hiplib.F_STEP1))
+    for i, seq in enumerate(seqs):
+        cs, ce = orc.trc_counts(seq, pats)
+        assert out1["c_start"][i].tolist() == cs and out1["c_end"][i].tolist() == ce
     prm = hiplib.make_params(window=100, slide=6, trimfirst=100, maxlen=20000,
                              flags=hiplib.F_WINDOWS | hiplib.F_BINSEG | hiplib.F_TAILS_IN | hiplib.F_STORE_SUMS)
     out = emu.scan(pats, seqs, prm, tails=[0, 1])

@@ -582,10 +582,26 @@ TPS_DEV void trc_count_thread(const ScanArgs& a, const Lds& l, const Stage& st_s
 // atomics.  A lane sees `iters` chunks = at most iters * ceil(16 / k) <= 15 non-overlapping occurrences.
 // The lane then widens its fields to bytes (side totals <= npos / k <= 255) and parks them in LDS:
 // 16 bytes per lane = [even fields 0-6 | odd 1-7 | even 8-14 | odd 9-15].
+// Tables with self-overlapping k-mers (no invalid letter, no duplicate) take the same path: occurrences are
+// counted as they are, and a pattern that matches at p and again d < k bases later (d one of its periods;
+// one AND per position and period on the table entries, six look-ahead entries per chunk) is reported in
+// the side's conflict mask -- only those patterns are then recounted leftmost-non-overlapping.  An
+// occurrence can repeat every min-period bases, which bounds the 4-bit and 8-bit fields.
+TPS_DEV int min_period(const PatInfo& pat) {
+    int m = pat.k;
+    TPS_NOVEC
+    for (int i = 0; i < pat.n_periods; ++i) m = pat.period[i] < m ? pat.period[i] : m;
+    return m;
+}
 TPS_DEV bool trc_packed_ok(const ScanArgs& a, int npos) {
     const int nchunks = (npos + 15) >> 4, iters = (nchunks + 31) >> 5;
-    return a.pat.P <= 15 && npos <= 255 * a.pat.k && iters * ((16 + a.pat.k - 1) / a.pat.k) <= 15;
+    const int mp = min_period(a.pat);
+    int maxd = 0;
+    TPS_NOVEC
+    for (int i = 0; i < a.pat.n_periods; ++i) maxd = a.pat.period[i] > maxd ? a.pat.period[i] : maxd;
+    return a.pat.P <= 15 && maxd <= 6 && npos <= 255 * mp && iters * ((16 + mp - 1) / mp) <= 15;
 }
+template <bool SO_>
 TPS_DEV void trc_count_packed(const ScanArgs& a, const Lds& l, const Stage& st_s, const Stage& st_e, int tid) {
     const PatInfo& pat = a.pat;
     const int side = tid >> 5, t = tid & 31;
@@ -594,7 +610,20 @@ TPS_DEV void trc_count_packed(const ScanArgs& a, const Lds& l, const Stage& st_s
     const uint32_t amask = pat.kmask << 2;
     const int npos = st_s.n - pat.k + 1;
     const int nchunks = (npos + 15) >> 4;
+    constexpr int LA = SO_ ? 6 : 0;                 // look-ahead entries for the overlap test
+    uint32_t ppd[7];
+    if (SO_) {
+        TPS_UNROLL
+        for (int d = 0; d < 7; ++d) ppd[d] = 0;
+        TPS_NOVEC
+        for (int i = 0; i < pat.n_periods; ++i) {
+            TPS_UNROLL
+            for (int d = 1; d < 7; ++d)
+                if (pat.period[i] == d) ppd[d] |= pat.period_pat[i] << 16;
+        }
+    }
     uint64_t acc = 0;
+    uint32_t cf = 0;
     for (int c0 = 0; c0 < nchunks; c0 += 32) {      // uniform trip count
         const int c = c0 + t;
         // the base BEFORE the chunk's first one goes to bit 0: alignbit(.., 2 j) & (kmask << 2) is then
@@ -604,17 +633,30 @@ TPS_DEV void trc_count_packed(const ScanArgs& a, const Lds& l, const Stage& st_s
         const uint32_t sh = (uint32_t)(qm & 15) * 2u;
         const uint32_t d0 = seq2[idx], d1 = seq2[idx + 1], d2 = seq2[idx + 2];
         const uint32_t w0 = alignbit(d1, d0, sh), w1 = alignbit(d2, d1, sh);
-        uint32_t h[16];
+        uint32_t w2 = 0;
+        if (SO_) w2 = alignbit(seq2[idx + 3], d2, sh);
+        uint32_t h[16 + LA];
         TPS_UNROLL
-        for (int j = 0; j < 16; ++j) h[j] = lut_at(l.lut, j ? alignbit(w1, w0, 2u * j) : w0, amask);
-        if (16 * (c0 + 32) > npos) {                 // uniform: the pass that holds the end of the head
+        for (int j = 0; j < 16 + LA; ++j)
+            h[j] = lut_at(l.lut, j == 0 ? w0 : j < 16 ? alignbit(w1, w0, 2u * j) : j == 16 ? w1 : alignbit(w2, w1, 2u * (j - 16)), amask);
+        if (16 * (c0 + 32) + LA > npos) {            // uniform: the pass that holds the end of the head
             TPS_UNROLL
-            for (int j = 0; j < 16; ++j)
+            for (int j = 0; j < 16 + LA; ++j)
                 if (16 * c + j >= npos) h[j] = 0;
+        }
+        if (SO_) {
+            TPS_UNROLL
+            for (int d = 1; d < 7; ++d) {
+                if (ppd[d]) {                        // uniform
+                    TPS_UNROLL
+                    for (int j = 0; j < 16; ++j) cf |= h[j] & h[j + d] & ppd[d];
+                }
+            }
         }
         TPS_UNROLL
         for (int j = 0; j < 16; ++j) acc += 1ull << ((4u * (uint32_t)__builtin_clz(h[j] | 0x8000u) - 4u) & 63u);
     }
+    if (SO_ && cf) lds_or(&l.misc[M_CMASK + side], cf >> 16);
     const uint32_t lo = (uint32_t)acc, hi = (uint32_t)(acc >> 32);
     uint32_t* dst = l.blk + 4 * tid;
     dst[0] = lo & 0x0F0F0F0Fu;
@@ -622,8 +664,9 @@ TPS_DEV void trc_count_packed(const ScanArgs& a, const Lds& l, const Stage& st_s
     dst[2] = hi & 0x0F0F0F0Fu;
     dst[3] = (hi >> 4) & 0x0F0F0F0Fu;
 }
-// Thread (side, p): add the 32 lanes' byte of pattern p, publish the count and bid for the arg-max.
-TPS_DEV void trc_sum_packed(const ScanArgs& a, const Lds& l, int64_t r, int tid) {
+// Thread (side, p): add the 32 lanes' byte of pattern p (a pattern with overlapping occurrences is recounted
+// leftmost-non-overlapping: sequential, rare), publish the count and bid for the arg-max.
+TPS_DEV void trc_sum_packed(const ScanArgs& a, const Lds& l, const Stage& st_s, const Stage& st_e, int64_t r, int tid) {
     const int side = tid >> 5, p = tid & 31;
     if (p < a.pat.P) {
         const int f = 14 - p;
@@ -631,6 +674,12 @@ TPS_DEV void trc_sum_packed(const ScanArgs& a, const Lds& l, int64_t r, int tid)
         uint32_t sm = 0;
         TPS_UNROLL
         for (int t = 0; t < 32; ++t) sm += src[16 * t];
+        if ((l.misc[M_CMASK + side] >> p) & 1u) {
+            int occ, g;
+            greedy_count(l.lut, l.lshift, l.seq2 + side * a.head_dw, l.val + side * a.head_dw, a.pat, side ? st_e.delta : st_s.delta,
+                         st_s.n - a.pat.k + 1, p, false, occ, g);
+            sm = (uint32_t)g;
+        }
         int32_t* dst = side ? a.c_end : a.c_start;
         if (dst) dst[r * a.pat.P + p] = (int32_t)sm;
         lds_max_i32((int32_t*)&l.misc[M_BEST + side], (int32_t)((sm << 5) | (uint32_t)(31 - p)));
@@ -1618,14 +1667,19 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
 
     TPS_STAMP(2);
     if (step1) {
-        const bool plain = uniform(l.misc[M_INVALID]) == 0 && pat.so_mask == 0 && pat.dup_mask == 0;
+        const bool clean = uniform(l.misc[M_INVALID]) == 0 && pat.dup_mask == 0;
+        const bool plain = clean && pat.so_mask == 0;
         bool packed1 = false;
-        if constexpr (SV != 0) packed1 = plain && trc_packed_ok(a, st_s.n - pat.k + 1);
+        if constexpr (SV != 0) packed1 = clean && trc_packed_ok(a, st_s.n - pat.k + 1);
         if (packed1) {
-            TPS_PHASE { trc_count_packed(a, l, st_s, st_e, tid); }
+            if (SO) {
+                TPS_PHASE { trc_count_packed<true>(a, l, st_s, st_e, tid); }
+            } else {
+                TPS_PHASE { trc_count_packed<false>(a, l, st_s, st_e, tid); }
+            }
             TPS_SYNC();
             TPS_STAMP(3);
-            TPS_PHASE { trc_sum_packed(a, l, r, tid); }
+            TPS_PHASE { trc_sum_packed(a, l, st_s, st_e, r, tid); }
         } else {
             TPS_PHASE { for (int i = tid; i < HIST_DW; i += NT) l.blk[i] = 0; }
             TPS_SYNC();
