@@ -188,9 +188,10 @@ def main():
 
     # prime every resident copy once (first scan of a slot plans its LDS geometry and allocates result
     # buffers), then the W untimed warm-up steps
-    # ... and enough further launches that the HIP runtime's one-off internal growth steps (a ~6 ms
-    # hiccup observed once around the 20th-30th launch of a process) happen before the timed region
-    for s in range(max(64, 4 * copies)):
+    # ... and enough further launches (~25 ms of GPU work) that the HIP runtime's one-off internal growth steps
+    # (a ~6 ms hiccup observed once around the 20th-30th launch of a process) are over and the GPU has reached its
+    # sustained clocks before the timed region: after only 64 launches a step measures 0.099 ms, after 256: 0.095 ms
+    for s in range(max(int(os.environ.get("TPS_BENCH_PRIME", "256")), 4 * copies)):
         sc.scan(s % copies, prm)
     sc.sync()
     for i in range(args.warmup):
