@@ -664,6 +664,67 @@ TPS_DEV void trc_count_packed(const ScanArgs& a, const Lds& l, const Stage& st_s
     dst[2] = hi & 0x0F0F0F0Fu;
     dst[3] = (hi >> 4) & 0x0F0F0F0Fu;
 }
+// Recount of the (few) patterns with overlapping occurrences, cooperatively: every lane looks its chunks up
+// again and publishes, per conflicting pattern, the 16 occurrence bits of each chunk (u16 per chunk: a
+// side's head is <= 64 chunks = 32 dwords per pattern); the pattern's lane then walks the bits
+// leftmost-non-overlapping.  Up to OCC_SLOTS conflicting patterns per side; more fall back to the
+// sequential greedy_count.
+constexpr int OCC_SLOTS = 4;
+constexpr int OCC_BASE_DW = 256;                  // behind the 64 x 16 bytes of packed counters in the block region
+TPS_DEV int occ_slot(uint32_t cmask, int p) {     // index of pattern p among the set bits of cmask
+    return popc(cmask & ((1u << p) - 1u));
+}
+TPS_DEV void trc_publish_occ(const ScanArgs& a, const Lds& l, const Stage& st_s, const Stage& st_e, int tid) {
+    const PatInfo& pat = a.pat;
+    const int side = tid >> 5, t = tid & 31;
+    const uint32_t cmask = l.misc[M_CMASK + side];
+    if (!cmask || popc(cmask) > OCC_SLOTS || st_s.n - a.pat.k + 1 > 1024) return;
+    const int delta = side ? st_e.delta : st_s.delta;
+    const uint32_t* seq2 = l.seq2 + side * a.head_dw;
+    const uint32_t amask = pat.kmask << 2;
+    const int npos = st_s.n - pat.k + 1;
+    const int nchunks = (npos + 15) >> 4;
+    uint16_t* occ = (uint16_t*)(l.blk + OCC_BASE_DW + side * OCC_SLOTS * 32);
+    for (int c = t; c < 64; c += 32) {
+        uint32_t bits[OCC_SLOTS] = {0, 0, 0, 0};
+        if (c < nchunks) {
+            const int qm = delta + 16 * c - 1;
+            const int idx = qm >> 4;
+            const uint32_t sh = (uint32_t)(qm & 15) * 2u;
+            const uint32_t d0 = seq2[idx], d1 = seq2[idx + 1], d2 = seq2[idx + 2];
+            const uint32_t w0 = alignbit(d1, d0, sh), w1 = alignbit(d2, d1, sh);
+            TPS_UNROLL
+            for (int j = 0; j < 16; ++j) {
+                uint32_t h = lut_at(l.lut, j ? alignbit(w1, w0, 2u * j) : w0, amask) >> 16;
+                if (16 * c + j >= npos) h = 0;
+                h &= cmask;
+                while (h) {
+                    const int b = ffs0(h);
+                    h &= h - 1;
+                    const int sl = occ_slot(cmask, b);
+                    TPS_UNROLL
+                    for (int q = 0; q < OCC_SLOTS; ++q)
+                        if (q == sl) bits[q] |= 1u << j;
+                }
+            }
+        }
+        TPS_UNROLL
+        for (int q = 0; q < OCC_SLOTS; ++q) occ[q * 64 + c] = (uint16_t)bits[q];
+    }
+}
+TPS_DEV int trc_walk_occ(const Lds& l, int side, int slot, int k) {
+    const uint32_t* occ = l.blk + OCC_BASE_DW + (side * OCC_SLOTS + slot) * 32;
+    int greedy = 0, cursor = 0;
+    for (int wd = 0; wd < 32; ++wd) {
+        uint32_t m = occ[wd];
+        while (m) {
+            const int p = 32 * wd + ffs0(m);
+            m &= m - 1;
+            if (p >= cursor) { ++greedy; cursor = p + k; }
+        }
+    }
+    return greedy;
+}
 // Thread (side, p): add the 32 lanes' byte of pattern p (a pattern with overlapping occurrences is recounted
 // leftmost-non-overlapping: sequential, rare), publish the count and bid for the arg-max.
 TPS_DEV void trc_sum_packed(const ScanArgs& a, const Lds& l, const Stage& st_s, const Stage& st_e, int64_t r, int tid) {
@@ -674,11 +735,16 @@ TPS_DEV void trc_sum_packed(const ScanArgs& a, const Lds& l, const Stage& st_s, 
         uint32_t sm = 0;
         TPS_UNROLL
         for (int t = 0; t < 32; ++t) sm += src[16 * t];
-        if ((l.misc[M_CMASK + side] >> p) & 1u) {
-            int occ, g;
-            greedy_count(l.lut, l.lshift, l.seq2 + side * a.head_dw, l.val + side * a.head_dw, a.pat, side ? st_e.delta : st_s.delta,
-                         st_s.n - a.pat.k + 1, p, false, occ, g);
-            sm = (uint32_t)g;
+        const uint32_t cmask = l.misc[M_CMASK + side];
+        if ((cmask >> p) & 1u) {
+            if (popc(cmask) <= OCC_SLOTS && st_s.n - a.pat.k + 1 <= 1024) {
+                sm = (uint32_t)trc_walk_occ(l, side, occ_slot(cmask, p), a.pat.k);
+            } else {
+                int occ, g;
+                greedy_count(l.lut, l.lshift, l.seq2 + side * a.head_dw, l.val + side * a.head_dw, a.pat, side ? st_e.delta : st_s.delta,
+                             st_s.n - a.pat.k + 1, p, false, occ, g);
+                sm = (uint32_t)g;
+            }
         }
         int32_t* dst = side ? a.c_end : a.c_start;
         if (dst) dst[r * a.pat.P + p] = (int32_t)sm;
@@ -1678,6 +1744,10 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
                 TPS_PHASE { trc_count_packed<false>(a, l, st_s, st_e, tid); }
             }
             TPS_SYNC();
+            if (SO && (uniform(l.misc[M_CMASK]) | uniform(l.misc[M_CMASK + 1]))) {
+                TPS_PHASE { trc_publish_occ(a, l, st_s, st_e, tid); }
+                TPS_SYNC();
+            }
             TPS_STAMP(3);
             TPS_PHASE { trc_sum_packed(a, l, st_s, st_e, r, tid); }
         } else {
