@@ -259,7 +259,7 @@ def main():
                 "kernel_launches_timed": n_launch,
             },
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:        # the CPU baseline leg runs at N = 1 only
             seqs = synth.split_reads(bases[: offsets[min(n_reads, 4096)]], offsets[: min(n_reads, 4096) + 1])
             out["cpu_baseline"] = cpu_baseline(seqs, motif, k, prm)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
