@@ -427,6 +427,7 @@ int tps_set_patterns(tps_ctx* c, const char* pats, int32_t P, int32_t k) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->pat = pi;
     c->have_pat = true;
+    for (auto& sl : c->slots) sl.planned = false;     // kernel choice and LDS plan depend on the table (periods, duplicates, k)
     return TPS_OK;
 }
 
