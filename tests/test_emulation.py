@@ -222,6 +222,35 @@ def test_emulation_self_overlap_recount_paths(traps):
         assert out["results"][i]["bkp"] == orc.binseg_l2_exact(counts.sum(axis=1))
 
 
+@pytest.mark.parametrize("slide", [5, 6, 8])
+def test_emulation_long_period_table(slide):
+    """CCCTAA at k=7: CCCTAAC / TAACCCT ... have period 6.  Slide 5 cannot see p + 6 from the next block, so
+    the planner must fall back to the generic kernel there; slides 6 and 8 keep the fused kernel."""
+    rng = np.random.default_rng(slide)
+    pats = orc.kmer_table("CCCTAA", 7)
+    L = emu.lib()
+    seqs = []
+    for i in range(2):
+        body = list(("CCCTAA" * 500)[:2400] + "".join("ACGT"[x] for x in rng.integers(0, 4, 2600)))
+        for p in rng.integers(0, 2300, 12):
+            del body[p]                                   # deletions inside the repeat create overlapping 7-mers
+        seqs.append("".join(body))
+    prm = hiplib.make_params(window=100, slide=slide, trimfirst=100, maxlen=20000,
+                             flags=hiplib.F_WINDOWS | hiplib.F_BINSEG | hiplib.F_TAILS_IN | hiplib.F_STORE_SUMS)
+    before = {v: L.emu_variant_calls(v) for v in (0, 5, 6, 8)}
+    out = emu.scan(pats, seqs, prm, tails=[0, 0])
+    used = [v for v in (0, 5, 6, 8) if L.emu_variant_calls(v) > before[v]]
+    assert used == ([0] if slide == 5 else [slide])
+    for i, seq in enumerate(seqs):
+        _, counts = orc.window_count_matrix(seq, "forward", pats, 100, slide, 100, 20000)
+        lo, hi = out["win_off"][i], out["win_off"][i + 1]
+        assert np.array_equal(out["sums"][lo:hi], counts.sum(axis=1))
+    out1 = emu.scan(pats, seqs, hiplib.make_params(no_bp=1000, flags=hiplib.F_STEP1))
+    for i, seq in enumerate(seqs):
+        cs, ce = orc.trc_counts(seq, pats)
+        assert out1["c_start"][i].tolist() == cs and out1["c_end"][i].tolist() == ce
+
+
 def test_emulation_binseg_standalone():
     rng = np.random.default_rng(5)
     sums, off = [], [0]
