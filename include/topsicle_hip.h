@@ -42,7 +42,8 @@ extern "C" {
 #define TPS_E_STATE      -6   /* call order (e.g. scan before upload)                    */
 
 /* limits of this build */
-#define TPS_MAX_K         7   /* k-mer length handled by the LDS lookup table (4^k entries) */
+#define TPS_MAX_K         15  /* k-mer length: 4^k-entry LDS table up to TPS_DIRECT_K, a perfect-hash table above */
+#define TPS_DIRECT_K      7
 #define TPS_MAX_PATTERNS 31   /* patterns in one table (bit 31 of the mask is a flag)       */
 
 /* flags for tps_params.flags */

@@ -277,3 +277,31 @@ def test_zz_specialised_paths_were_exercised():
     L = emu.lib()
     calls = {v: L.emu_variant_calls(v) for v in (0, 5, 6, 7, 8)}
     assert all(c > 0 for c in calls.values()), calls
+
+
+@pytest.mark.parametrize("motif,k,slide", [("CCCTAACCTA", 8, 10), ("TTAGGGTTAGGCA", 11, 6), ("AAAACCCCTT", 9, 7)])
+def test_emulation_long_kmers_hashed_table(motif, k, slide):
+    """k > 7: the 4^k table does not fit LDS, the generic kernel uses a perfect hash of the pattern codes.
+    (AAAACCCCTT at k=9 doubles to k-mers with long self-overlap periods.)"""
+    rng = np.random.default_rng(k)
+    pats = orc.kmer_table(motif, k)
+    seqs = []
+    for i in range(3):
+        L = int(rng.integers(1500, 3500))
+        tract = int(rng.integers(300, 1400))
+        body = list((motif * (tract // len(motif) + 2))[:tract] + "".join("ACGT"[x] for x in rng.integers(0, 4, L - tract)))
+        for p in rng.integers(0, L, L // 30):
+            body[p] = "ACGTNacgt"[int(rng.integers(9))]
+        seqs.append("".join(body))
+    prm = hiplib.make_params(window=100, slide=slide, trimfirst=100, maxlen=20000,
+                             flags=hiplib.F_WINDOWS | hiplib.F_BINSEG | hiplib.F_TAILS_IN | hiplib.F_STORE_SUMS | hiplib.F_STORE_RAW)
+    out = emu.scan(pats, seqs, prm, tails=[0, 1, 0])
+    out1 = emu.scan(pats, seqs, hiplib.make_params(no_bp=1000, flags=hiplib.F_STEP1))
+    for i, seq in enumerate(seqs):
+        cs, ce = orc.trc_counts(seq, pats)
+        assert out1["c_start"][i].tolist() == cs and out1["c_end"][i].tolist() == ce
+        _, counts = orc.window_count_matrix(seq, ["forward", "reverse"][i & 1], pats, 100, slide, 100, 20000)
+        lo, hi = out["win_off"][i], out["win_off"][i + 1]
+        assert hi - lo == counts.shape[0]
+        assert np.array_equal(out["raw"][lo:hi], counts.reshape(-1, len(pats)))
+        assert np.array_equal(out["sums"][lo:hi], counts.sum(axis=1))

@@ -284,3 +284,40 @@ def test_run_to_run_determinism(sc, k, with_n):
         s, _ = sc.window_sums(5)
         assert np.array_equal(s, ref)
         assert np.array_equal(sc.results(5)["bkp"], ref_res["bkp"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("motif,k,slide", [("CCCTAACCTA", 8, 10), ("TTAGGGTTAGGCA", 11, 6), ("AAAACCCCTT", 9, 7)])
+def test_long_kmers_hashed_table(sc, motif, k, slide):
+    """k > 7 goes through the perfect-hash table of the generic kernel: counts bit-exact against the oracle."""
+    rng = np.random.default_rng(k)
+    pats = orc.kmer_table(motif, k)
+    sc.set_patterns(pats)
+    seqs = []
+    for i in range(40):
+        L = int(rng.integers(1200, 6000))
+        tract = int(rng.integers(300, 1100))
+        body = list((motif * (tract // len(motif) + 2))[:tract] + "".join("ACGT"[x] for x in rng.integers(0, 4, L - tract)))
+        for p in rng.integers(0, L, L // 30):
+            body[p] = "ACGTNacgt"[int(rng.integers(9))]
+        s = "".join(body)
+        seqs.append(s if i & 1 else s[::-1])
+    bases, offsets = hiplib.pack_reads(seqs)
+    sc.upload(5, bases, offsets)
+    prm = hiplib.make_params(min_len=0, min_count=-1, window=100, slide=slide,
+                             flags=hiplib.F_STEP1 | hiplib.F_WINDOWS | hiplib.F_BINSEG | hiplib.F_STORE_SUMS | hiplib.F_STORE_RAW)
+    sc.scan(5, prm)
+    sc.sync()
+    res = sc.results(5).copy()
+    raw, win_off = sc.window_raw(5)
+    sums, _ = sc.window_sums(5)
+    cs_all, ce_all = sc.batch_trc_counts(5)
+    for i, seq in enumerate(seqs):
+        cs, ce = orc.trc_counts(seq, pats)
+        assert cs_all[i].tolist() == cs and ce_all[i].tolist() == ce
+        tail = ["forward", "reverse"][res["tail"][i]]
+        _, counts = orc.window_count_matrix(seq, tail, pats, 100, slide, 100, 20000)
+        assert np.array_equal(raw[win_off[i]:win_off[i + 1]], counts.reshape(-1, len(pats)))
+        assert np.array_equal(sums[win_off[i]:win_off[i + 1]], counts.sum(axis=1))
+        want = orc.binseg_l2_exact(counts.sum(axis=1)) if counts.shape[0] >= 7 else None
+        assert res["bkp"][i] == (-1 if want is None else want)

@@ -172,6 +172,9 @@ struct PatInfo {
     int32_t n_periods;
     int32_t period[8];       // union of those periods d (1 <= d < k)
     uint32_t period_pat[8];  // list patterns having period d
+    // k > TPS_DIRECT_K: the table is a collision-free hash of the P k-mer codes, (key, mask) pairs;
+    // slot = (code * hash_mul) >> hash_shift.  hash_shift = 0 means the direct 4^k table.
+    uint32_t hash_mul, hash_shift;
 };
 
 struct ScanArgs {
@@ -491,14 +494,26 @@ TPS_DEV bool invalid_at(const uint16_t* val, int q, int k) {
     uint64_t v = (uint64_t)val[idx] | ((uint64_t)val[idx + 1] << 16) | ((uint64_t)val[idx + 2] << 32);
     return ((v >> (q & 15)) & ((1ull << k) - 1ull)) != 0;
 }
+// mask of list patterns whose k-mer is the low 2k bits of v (direct table or perfect hash)
+TPS_DEV uint32_t lut_mask(const uint32_t* lut, int lshift, const PatInfo& pat, uint32_t v) {
+    const uint32_t code = v & pat.kmask;
+    if (pat.hash_shift) {
+        const uint32_t slot = (code * pat.hash_mul) >> pat.hash_shift;
+        return lut[2 * slot] == code ? lut[2 * slot + 1] : 0u;
+    }
+    return lut[code] >> lshift;
+}
 // mask of list patterns whose k-mer starts at position q
 TPS_DEV uint32_t h_at(const uint32_t* lut, int lshift, const uint32_t* seq2, const uint16_t* val, const PatInfo& pat, int q, bool any_invalid) {
-    uint32_t h = lut[v_at(seq2, q) & pat.kmask] >> lshift;
+    uint32_t h = lut_mask(lut, lshift, pat, v_at(seq2, q));
     if (any_invalid && h && invalid_at(val, q, pat.k)) h = 0;
     return h;
 }
 // patterns p (subset of `h`) that occur again d < k positions later (d a period of p)
 TPS_DEV uint32_t conflict_bits(const PatInfo& pat, uint32_t v, uint32_t h) {
+    // long k-mers (hashed table): k + d bases do not fit the 16-base word, so every occurrence of a
+    // self-overlapping pattern is reported (conservative: the exact recount then decides)
+    if (pat.hash_shift) return h & pat.so_mask;
     uint32_t c = 0;
     TPS_NOVEC
     for (int i = 0; i < pat.n_periods; ++i) {
@@ -551,7 +566,7 @@ TPS_DEV void trc_count_thread(const ScanArgs& a, const Lds& l, const Stage& st_s
         TPS_UNROLL
         for (int j = 0; j < 8; ++j) {
             v[j] = j ? alignbit(w1, w0, 2u * j) : w0;
-            h[j] = l.lut[v[j] & pat.kmask] >> l.lshift;
+            h[j] = lut_mask(l.lut, l.lshift, pat, v[j]);
         }
         TPS_UNROLL
         for (int j = 0; j < 8; ++j) {
@@ -795,7 +810,7 @@ TPS_DEV void blocks_span(const ScanArgs& a, const Lds& l, int delta, int span) {
         TPS_UNROLL
         for (int i = 0; i < 16; ++i) {
             v[i] = i ? alignbit(nxt, cur, 2u * i) : cur;
-            h[i] = l.lut[v[i] & pat.kmask];
+            h[i] = lut_mask(l.lut, 0, pat, v[i]);
         }
         if (inv) {
             int q = ((d0 + dw) << 4) + (delta & 15);
@@ -847,7 +862,7 @@ TPS_DEV void scan_positions(const Lds& l, const PatInfo& pat, int q0, int npos, 
             d1 = d2;
         }
         const uint32_t v = j ? alignbit(nxt, cur, 2u * (uint32_t)j) : cur;
-        uint32_t h = l.lut[v & pat.kmask] >> l.lshift;
+        uint32_t h = lut_mask(l.lut, l.lshift, pat, v);
         if (inv && h && invalid_at(l.val, q0 + p, pat.k)) h = 0;
         f(p, h);
     }

@@ -26,13 +26,15 @@ inline int gcd_i(int a, int b) { while (b) { int t = a % b; a = b; b = t; } retu
 inline std::string build_patterns(const char* pats, int P, int k, std::vector<uint32_t>& lut, PatInfo& pi) {
     if (k < 1 || k > TPS_MAX_K) return "k=" + std::to_string(k) + " not supported (1.." + std::to_string(TPS_MAX_K) + ")";
     if (P < 1 || P > TPS_MAX_PATTERNS) return std::to_string(P) + " patterns not supported (1.." + std::to_string(TPS_MAX_PATTERNS) + ")";
-    lut.assign((size_t)1 << (2 * k), 0u);
+    const bool hashed = k > TPS_DIRECT_K;
+    if (!hashed) lut.assign((size_t)1 << (2 * k), 0u);
     pi = PatInfo{};
     pi.P = P;
     pi.k = k;
     pi.kmask = (1u << (2 * k)) - 1u;
     pi.all_mask = (1u << P) - 1u;
-    uint32_t per_pat[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t per_pat[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    std::vector<uint32_t> code_mask((size_t)P, 0u);
     std::vector<uint32_t> codes((size_t)P);
     for (int p = 0; p < P; ++p) {
         uint32_t code = 0;
@@ -51,7 +53,7 @@ inline std::string build_patterns(const char* pats, int P, int k, std::vector<ui
             }
             code |= v << (2 * i);
         }
-        lut[code] |= 1u << p;
+        if (!hashed) lut[code] |= 1u << p;
         codes[(size_t)p] = code;
         for (int d = 1; d < k; ++d) {             // proper periods -> the k-mer can overlap itself
             bool periodic = true;
@@ -59,10 +61,41 @@ inline std::string build_patterns(const char* pats, int P, int k, std::vector<ui
             if (periodic) { per_pat[d] |= 1u << p; pi.so_mask |= 1u << p; }
         }
     }
+    for (int p = 0; p < P; ++p)                   // mask of all list patterns sharing pattern p's k-mer
+        for (int o = 0; o < P; ++o)
+            if (codes[(size_t)o] == codes[(size_t)p]) code_mask[(size_t)p] |= 1u << o;
     for (int p = 0; p < P; ++p)
-        if (lut[codes[(size_t)p]] & (lut[codes[(size_t)p]] - 1)) pi.dup_mask |= 1u << p;
+        if (code_mask[(size_t)p] & (code_mask[(size_t)p] - 1)) pi.dup_mask |= 1u << p;
+    if (hashed) {
+        // perfect hash of the distinct codes into 256 (key, mask) slots: try odd multipliers until none collide
+        const int log2h = 8;
+        const uint32_t H = 1u << log2h;
+        uint32_t mul = 0;
+        for (uint32_t cand = 0x9E3779B1u, tries = 0; tries < 200000 && !mul; ++tries, cand += 0xC657CB56u) {
+            const uint32_t m = cand | 1u;
+            std::vector<int> owner(H, -1);
+            bool ok = true;
+            for (int p = 0; p < P && ok; ++p) {
+                const uint32_t slot = (codes[(size_t)p] * m) >> (32 - log2h);
+                if (owner[slot] >= 0 && codes[(size_t)owner[slot]] != codes[(size_t)p]) ok = false;
+                else owner[slot] = p;
+            }
+            if (ok) mul = m;
+        }
+        if (!mul) return "no collision-free hash for this pattern table";
+        lut.assign((size_t)2 * H, 0u);
+        for (uint32_t i = 0; i < H; ++i) lut[2 * i] = 0xFFFFFFFFu;           // no k-mer code has all bits set (k <= 15)
+        for (int p = 0; p < P; ++p) {
+            const uint32_t slot = (codes[(size_t)p] * mul) >> (32 - log2h);
+            lut[2 * slot] = codes[(size_t)p];
+            lut[2 * slot + 1] = code_mask[(size_t)p];
+        }
+        pi.hash_mul = mul;
+        pi.hash_shift = 32 - log2h;
+    }
     for (int d = 1; d < k; ++d)
         if (per_pat[d]) {
+            if (pi.n_periods == 8) return "pattern table has more than 8 distinct self-overlap periods";
             pi.period[pi.n_periods] = d;
             pi.period_pat[pi.n_periods] = per_pat[d];
             ++pi.n_periods;
@@ -79,7 +112,7 @@ inline bool has_specialised_slide(int s) { return s == 5 || s == 6 || s == 7 || 
 // forces the spans per tile.
 inline std::string plan_geometry(ScanArgs& a, const tps_params& prm, int k, int P, int64_t max_nwin, int64_t budget_dw,
                                  int spans_pref, int force_generic = 0, int64_t target_dw = 32 * 256) {
-    a.lut_n = 1 << (2 * k);
+    a.lut_n = a.pat.hash_shift ? 2 * 256 : 1 << (2 * k);     // hashed table: 256 (key, mask) pairs
     a.lw = std::max(0, prm.window - k);            // k-mer start positions in a (W-1)-char window
     a.q = a.lw / prm.slide;
     a.r = a.lw % prm.slide;
@@ -93,7 +126,7 @@ inline std::string plan_geometry(ScanArgs& a, const tps_params& prm, int k, int 
     // 8-block chunk and its far end lies within the exchange halo (XLANES - NT lanes)
     int max_period = 0;                            // self-overlap periods of the table (0 = none)
     for (int i = 0; i < a.pat.n_periods; ++i) max_period = std::max(max_period, a.pat.period[i]);
-    const bool fused = !force_generic && spans_pref <= 0 && has_specialised_slide(prm.slide) && P <= 15 && a.q >= 8 &&
+    const bool fused = !force_generic && spans_pref <= 0 && k <= TPS_DIRECT_K && has_specialised_slide(prm.slide) && P <= 15 && a.q >= 8 &&
                        a.q / 8 + 2 < (XLANES - NT) && max_period <= std::min(prm.slide, 6);
     a.lc16 = 0; a.tile_cap = 0; a.tw = 0; a.tw_magic = 0; a.pair_n = 0;
     if (fused) {

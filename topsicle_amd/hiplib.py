@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 # flags (TPS_F_*)
 F_STEP1, F_WINDOWS, F_BINSEG, F_STORE_SUMS, F_STORE_RAW, F_TAILS_IN = 1, 2, 4, 8, 16, 32
-MAX_K, MAX_PATTERNS, MAX_SLOTS = 7, 31, 16
+MAX_K, MAX_PATTERNS, MAX_SLOTS = 15, 31, 16
 
 EXPORTS = [
     "tps_abi_version", "tps_device_count", "tps_ctx_create", "tps_ctx_destroy", "tps_last_error",
