@@ -1173,12 +1173,10 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const TileConst& tc, const Lds& l, 
             sfx |= gs[j];
             xs[j] = pack_hi_lo(sfx, c0s[j]);
         }
-        l.XF[span] = sfx;
-        l.XT[span] = cnt & 0xFFFFu;
+        l.XF[span] = pack_hi_lo(sfx, cnt);        // the lane's OR | the lane's matches
     }
     TPS_SYNC();
     if (w0 == 0) TPS_STAMP(6);
-    wg_exclusive_scan(l.XT, NT, &l.misc[M_SCAN]);
     if (w0 == 0) TPS_STAMP(7);
     const int rot = q & (B - 1), dl0 = q >> LOG2B;
     uint32_t fo_a = 0, fo_b = 0;
@@ -1186,15 +1184,20 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const TileConst& tc, const Lds& l, 
     uint32_t fo_keep[NT][2];
 #endif
     TPS_PHASE {
-        // A window's last (partial) block lies dl0 or dl0+1 lanes ahead of its first; the whole lanes
-        // strictly in between are the next dl0-1 (or dl0) lanes.
-        uint32_t foa = 0;
+        // A window's last (partial) block lies dl0 or dl0+1 lanes ahead of its first.  What it skips: the OR of
+        // the whole lanes strictly in between (the next dl0-1, or dl0, lanes) and the matches of every lane from
+        // its own up to the one before the last (dl0, or dl0+1, lanes) -- sums of a few neighbours' words, so no
+        // prefix scan over the lanes is needed.
+        uint32_t orw = 0, sumw = l.XF[tid];
         TPS_NOVEC
-        for (int t = 1; t < dl0; ++t) foa |= l.XF[tid + t];
-        const uint32_t fob = foa | l.XF[tid + dl0];
-        const uint32_t tot_l = l.XT[tid], tot_a = l.XT[tid + dl0], tot_b = l.XT[tid + dl0 + 1];
-        fo_a = pack_hi_lo(foa, tot_a - tot_l);
-        fo_b = pack_hi_lo(fob, tot_b - tot_l);
+        for (int t = 1; t < dl0; ++t) {
+            const uint32_t v = l.XF[tid + t];
+            orw |= v;
+            sumw += v;
+        }
+        const uint32_t vb = l.XF[tid + dl0];
+        fo_a = pack_hi_lo(orw, sumw);
+        fo_b = pack_hi_lo(orw | vb, sumw + vb);
 #ifdef TPS_EMU
         fo_keep[tid][0] = fo_a; fo_keep[tid][1] = fo_b;
 #endif
