@@ -33,8 +33,6 @@
 #define TPS_SYNC() ((void)0)
 #define TPS_UNROLL
 #define TPS_NOVEC
-#define TPS_SCHED_BARRIER() ((void)0)
-#define TPS_PIN(x) ((void)0)
 #define TPS_PIN_S(x) ((void)0)
 #else
 #define TPS_DEV __device__ __forceinline__
@@ -59,10 +57,7 @@ __device__ __forceinline__ int tps_fresh_lane() {
 // (__builtin_amdgcn_sched_barrier(0) was used here to bound register pressure; with ROCm 7.2 it made the
 // self-overlap + invalid-base instance of the fused tile nondeterministic on gfx950, and it is no longer
 // needed once every phase launders its lane id)
-#define TPS_SCHED_BARRIER() ((void)0)
-// zero-cost "redefinition" of a register: nothing computed from x can be hoisted above this point
-#define TPS_PIN(x) asm volatile("" : "+v"(x))
-// the same for a wave-uniform value: it stays in an SGPR (or a VGPR lane) instead of being re-loaded from the
+// zero-cost "redefinition" of a wave-uniform value: it stays in an SGPR (or a VGPR lane) instead of being re-loaded from the
 // kernel-argument segment inside a loop (an s_load + s_waitcnt that also drains the LDS queue)
 #define TPS_PIN_S(x) asm volatile("" : "+s"(x))
 #endif
