@@ -5,19 +5,21 @@
 //   step 2  sliding-window k-mer counts S_w of the chosen tail        (allsteps.py:257-297)
 //   step 3  single-split l2 change-point on S_w                      (allsteps.py:300-333)
 //
-// Data flow inside the workgroup (everything between HBM and the result lives in LDS):
+// Data flow inside the wave (everything between HBM and the result lives in registers and LDS):
 //   HBM ASCII bases --16 B/lane coalesced loads--> 2-bit packed tile in LDS (seq2)
-//   seq2 --k-mer code per position--> LDS lookup table (4^k masks over the pattern list)
-//   per block of `slide` positions: ORs of masks + running match counts
-//   per window: S_w = matches + #patterns absent  (OR over the window's blocks, count differences)
-//   S_w (u16, LDS) --prefix sums--> arg-max of the split gain (f64 scores, exact-integer tie-break).
+//   seq2 --k-mer code per position--> LDS lookup table (4^k entries over the pattern list; a pair table
+//          for k <= 4; a perfect hash of the pattern codes for k > 7)
+//   per block of `slide` positions: OR of the masks + running match count
+//   per window: S_w = matches + #patterns absent  (OR over the window's blocks, count differences) -> HBM
+//   prefix sums of S_w at the change-point candidates --> arg-max of the split gain (f64 fractions compared by
+//   cross-multiplication, exact 128-bit integer tournament when float64 cannot separate the best).
 //
 // Two block/window code paths share everything else:
-//   * specialised (template <S>): slide S known at compile time, <= 15 patterns.  A thread keeps
-//     its span of the packed read in registers, every shift is an immediate, block results are
-//     8-byte records {suffix-OR, prefix-OR, count, count} laid out bank-conflict-free, and a
-//     window's OR needs 3-4 LDS reads (chunked prefix/suffix ORs) instead of q+1.
-//   * generic: any slide / up to 31 patterns; simple per-block masks, q+1 reads per window.
+//   * fused (template <S>): slide S in {5..8} known at compile time, <= 15 patterns, k <= 7.  A lane keeps its
+//     8 blocks of the packed read in registers (immediate shifts), publishes two words per block
+//     (suffix-OR | count, prefix-OR | count; conflict-free padded layout) and windows are computed
+//     lane-strided from three LDS reads each (tile_fused_s).
+//   * generic: any slide, up to 31 patterns, k up to 15; per-block masks in LDS, q+1 reads per window.
 //
 // The file is written against a tiny portability layer so that the SAME source also builds
 // as a sequential host emulation (tests/emu, -DTPS_EMU) for logic tests without a GPU.
