@@ -176,7 +176,14 @@ def main():
     # kernel durations come from HIP events stamped by the dispatch itself; every 4th launch is timed (timing a
     # launch costs ~3.5 us of host/queue work, which would otherwise sit inside every timed step)
     os.environ.setdefault("TPS_EVENT_STRIDE", "4")
-    sc = hiplib.HipScanner(local_rank)
+    # one GPU per rank; TPS_BENCH_SHARE_GPU=1 (testing the launcher path on a box with fewer GPUs than ranks) wraps around
+    dev = local_rank
+    if os.environ.get("TPS_BENCH_SHARE_GPU"):
+        import ctypes
+        n_dev = ctypes.c_int(0)
+        hiplib.load_library().tps_device_count(ctypes.byref(n_dev))
+        dev = local_rank % max(n_dev.value, 1)
+    sc = hiplib.HipScanner(dev)
     sc.set_patterns(pats)
     copies = args.resident_copies or max(2, min(hiplib.MAX_SLOTS, -(-(1 << 30) // max(batch_bases, 1))))
     for s in range(copies):
