@@ -41,6 +41,9 @@ CONFIGS = {
     "config4_sample": dict(n_reads=10000, read_len=30000, motif="CCCTAA", k=4, window=100, slide=6,
                            errors=synth.ONT, seed=20250919 + 3,
                            desc="BASELINE configs[3] sample: 10k synthetic ONT reads x 30 kb, --pattern CCCTAA (20 kb scanned per read)"),
+    "config4_1pct": dict(n_reads=10000, read_len=30000, motif="CCCTAA", k=4, window=100, slide=6,
+                         errors=synth.ONT, seed=20250919 + 3, telomeric_fraction=0.01,
+                         desc="BASELINE configs[3] sample, 1 % of the reads telomeric (the step-1-dominated regime of real WGS data)"),
     "config3_per_gpu": dict(n_reads=25000, read_len=20000, motif="AAACCCT", k=5, window=100, slide=7,
                             errors=synth.HIFI, seed=20250919 + 2,
                             desc="BASELINE configs[2] shard: 25k synthetic HiFi reads x 20 kb per GPU, --pattern AAACCCT"),
@@ -163,7 +166,7 @@ def main():
     P = len(pats)
     # every rank scans its own, differently seeded batch of the same shape (weak scaling)
     bases, offsets, truth = synth.make_reads(cfg["n_reads"], cfg["read_len"], motif, seed=cfg["seed"] + 1000 * rank,
-                                             errors=cfg["errors"])
+                                             errors=cfg["errors"], telomeric_fraction=cfg.get("telomeric_fraction", 1.0))
     n_reads = cfg["n_reads"]
     batch_bases = int(offsets[-1])
     prm = hiplib.make_params(no_bp=1000, min_len=9000, min_count=min_count_for_cutoff(0.7, 1000, len(motif)),
