@@ -243,12 +243,45 @@ def gen_synth(ref):
     print("synthetic cases:", len(cases))
 
 
+def gen_overview():
+    """Rows behind the reference's exploratory plots (descriptive_plot.py:89-165, 233-313) on the demo file:
+    the k-mer / following-bases crosstab and the motif positions of the first reads."""
+    import re
+    import matplotlib.pyplot as plt
+    import pandas as pd
+    dp = ref_import.load_reference_descriptive_plot()
+    out = {"heatmaps": [], "positions": []}
+    for motif, k in (("CCCTAAA", 5), ("CCCTAAA", 4), ("AAACCCT", 5)):
+        df = dp.patterns_vs_match_heatmap(DEMO_FQ, motif, k, 9000)
+        plt.close("all")
+        tab = pd.crosstab(df["Match"], df["Pattern"])
+        out["heatmaps"].append({"motif": motif, "k": k, "minSeqLength": 9000, "n_rows": int(len(df)),
+                                "patterns": [str(c) for c in tab.columns], "matches": [str(i) for i in tab.index],
+                                "counts": tab.values.astype(int).tolist(),
+                                "first_rows": [[r[0], r[1], list(r[2])] for r in df.head(25).values.tolist()]})
+    # descriptive_plot only draws; restate its two searches on the reference's own record reader for 5 reads
+    trans = str.maketrans("ACGT", "TGCA")
+    for n, (rid, seq) in enumerate(ref_import.read_records(DEMO_FQ)):
+        if len(seq) <= 9000:
+            continue
+        pos = {}
+        for pat in ("CCCTAAA", "CCCTAAA".translate(trans)):
+            s1, s2 = seq[:9000].upper(), seq[::-1][:9000].upper()
+            pos[pat] = [[m.start() for m in re.finditer(re.compile(pat), s1)], [m.start() for m in re.finditer(re.compile(pat), s2)]]
+        out["positions"].append({"id": rid, "motif": "CCCTAAA", "minSeqLength": 9000, "pos": pos})
+        if len(out["positions"]) == 5:
+            break
+    json.dump(out, open(os.path.join(GOLD, "demo_overview.json"), "w"))
+    print("overview goldens:", [(h["motif"], h["k"], h["n_rows"]) for h in out["heatmaps"]])
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     ref = ref_import.load_reference_allsteps()
     gen_patterns(ref)
     gen_demo(ref)
     gen_synth(ref)
+    gen_overview()
     print("fixture bytes:", sum(os.path.getsize(os.path.join(GOLD, f)) for f in os.listdir(GOLD)))
 
 

@@ -95,6 +95,11 @@ def _install_standins():
     sns = types.ModuleType("seaborn")
     sns.color_palette = lambda *a, **k: [(0, 0, 0)] * 30
     sns.set_style = lambda *a, **k: None
+
+    def _heatmap(*a, **k):                     # styling only: hand back the current axes like seaborn does
+        import matplotlib.pyplot as plt
+        return plt.gca()
+    sns.heatmap = _heatmap
     sys.modules["seaborn"] = sns
 
     here = os.path.dirname(os.path.abspath(__file__))
@@ -140,6 +145,13 @@ def load_reference_allsteps():
     # import the submodule directly: Topsicle/__init__.py star-imports descriptive_plot too,
     # which is harmless with the stand-ins in place.
     return importlib.import_module("Topsicle.allsteps")
+
+
+def load_reference_descriptive_plot():
+    """The reference's `Topsicle.descriptive_plot` module (its own code, unchanged; plots go to the Agg backend)."""
+    load_reference_allsteps()
+    import importlib
+    return importlib.import_module("Topsicle.descriptive_plot")
 
 
 def read_records(path):
