@@ -305,3 +305,28 @@ def test_emulation_long_kmers_hashed_table(motif, k, slide):
         assert hi - lo == counts.shape[0]
         assert np.array_equal(out["raw"][lo:hi], counts.reshape(-1, len(pats)))
         assert np.array_equal(out["sums"][lo:hi], counts.sum(axis=1))
+
+
+@pytest.mark.parametrize("jump,min_size,slide", [(1, 2, 6), (3, 2, 6), (8, 4, 7), (1, 1, 11), (13, 2, 6)])
+def test_emulation_other_jump_values(jump, min_size, slide):
+    """The change-point candidates b = c * jump for jumps other than ruptures' default 5 (jump = 1 has no 32-bit
+    reciprocal: found by the GPU sweep scripts/fuzz_gpu.py)."""
+    rng = np.random.default_rng(jump * 31 + slide)
+    pats = orc.kmer_table("CCCTAA", 4)
+    seqs = []
+    for i in range(3):
+        L = int(rng.integers(1500, 7000))
+        tract = int(rng.integers(200, 1400))
+        body = list(("CCCTAA" * 300)[:tract] + "".join("ACGT"[x] for x in rng.integers(0, 4, L - tract)))
+        for p in rng.integers(0, L, L // 20):
+            body[p] = "ACGT"[int(rng.integers(4))]
+        seqs.append("".join(body))
+    prm = hiplib.make_params(window=100, slide=slide, trimfirst=100, maxlen=20000, jump=jump, min_size=min_size,
+                             flags=hiplib.F_WINDOWS | hiplib.F_BINSEG | hiplib.F_TAILS_IN | hiplib.F_STORE_SUMS)
+    out = emu.scan(pats, seqs, prm, tails=[0, 0, 0])
+    for i, seq in enumerate(seqs):
+        _, counts = orc.window_count_matrix(seq, "forward", pats, 100, slide, 100, 20000)
+        lo, hi = out["win_off"][i], out["win_off"][i + 1]
+        assert np.array_equal(out["sums"][lo:hi], counts.sum(axis=1))
+        want = orc.binseg_l2_exact(counts.sum(axis=1), jump, min_size)
+        assert out["results"][i]["bkp"] == (-1 if want is None else want), (jump, min_size, i)

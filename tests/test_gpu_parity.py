@@ -321,3 +321,14 @@ def test_long_kmers_hashed_table(sc, motif, k, slide):
         assert np.array_equal(sums[win_off[i]:win_off[i + 1]], counts.sum(axis=1))
         want = orc.binseg_l2_exact(counts.sum(axis=1)) if counts.shape[0] >= 7 else None
         assert res["bkp"][i] == (-1 if want is None else want)
+
+
+@pytest.mark.gpu
+def test_randomised_parameter_sweep():
+    """scripts/fuzz_gpu.py: random motifs / k / window / slide / trim / maxlen / jump / min_size / no_bp and reads
+    with errors, N, lower case and both strands, checked against the C oracle (it found the jump = 1 bug)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_gpu.py"), "150", "11"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

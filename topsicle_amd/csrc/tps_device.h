@@ -202,7 +202,7 @@ struct ScanArgs {
     int32_t tot_dw;              // dwords of the Tot array (>= spans_per_tile + 1 and >= NT, even)
     int32_t blk_dw;              // dwords of the block region (also step-1 histograms, Binseg scratch)
     int32_t lc_cap;              // capacity of the candidate-prefix array Lc (u32 entries) = max n_win / jump + 1
-    uint32_t jump_magic;         // ceil(2^32 / jump): w / jump == mulhi(w, jump_magic) for w < 2^20
+    uint32_t jump_magic;         // ceil(2^32 / jump): w / jump == mulhi(w, jump_magic) for w < 2^20; 0 for jump == 1 (see div_jump)
     int32_t q, r, lw;            // window = q full blocks + r positions; lw = W - k start positions
     // fused path, 16-bit candidate sums: Lc16[c] = left sum of candidate c counted from its tile's first
     // window, Tc[t] = sum of S_w before tile t; tile of window w = mulhi(w, tw_magic)
@@ -948,6 +948,8 @@ TPS_DEV void windows_group(const ScanArgs& a, const Lds& l, int delta, int w0, i
     }
 }
 
+// w / jump by the host-supplied magic multiplier (jump == 1 has no 32-bit magic: ceil(2^32 / 1) = 2^32)
+TPS_DEV uint32_t div_jump(uint32_t w, uint32_t magic) { return magic ? (uint32_t)(((uint64_t)w * magic) >> 32) : w; }
 // After the in-place exclusive scan of row[]: lane `tid` records the left sums of the change-point
 // candidates among its windows (global window index divisible by jump).
 TPS_DEV void candidates_group(const ScanArgs& a, const Lds& l, int w0, int nw_tile, int base, uint32_t carry, int tid) {
@@ -957,7 +959,7 @@ TPS_DEV void candidates_group(const ScanArgs& a, const Lds& l, int w0, int nw_ti
         const int wl = base + u * NT + tid;
         if (wl < nw_tile) {
             const uint32_t w = (uint32_t)(w0 + wl);
-            const uint32_t c = (uint32_t)(((uint64_t)w * a.jump_magic) >> 32);
+            const uint32_t c = div_jump(w, a.jump_magic);
             if (c * jump == w && (int)c < a.lc_cap) l.Lc[c] = carry + l.row[u * NT + tid];
         }
     }
@@ -1375,8 +1377,8 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const TileConst& tc, const Lds& l, 
     {
         // change-point candidates of this tile: c with w0 <= c * jump < w0 + nw_tile, 64 per pass
         const uint32_t jump = tc.jump;
-        const uint32_t c_lo = (uint32_t)(((uint64_t)((uint32_t)w0 + jump - 1u) * tc.jump_magic) >> 32);
-        uint32_t c_hi = (uint32_t)(((uint64_t)((uint32_t)(w0 + nw_tile) + jump - 1u) * tc.jump_magic) >> 32);
+        const uint32_t c_lo = div_jump((uint32_t)w0 + jump - 1u, tc.jump_magic);
+        uint32_t c_hi = div_jump((uint32_t)(w0 + nw_tile) + jump - 1u, tc.jump_magic);
         if (c_hi > tc.lc_cap) c_hi = tc.lc_cap;
         const int passes = c_hi > c_lo ? (int)((c_hi - c_lo + NT - 1) / NT) : 0;
         TPS_PHASE {

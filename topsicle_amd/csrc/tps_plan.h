@@ -119,7 +119,7 @@ inline std::string plan_geometry(ScanArgs& a, const tps_params& prm, int k, int 
     if (max_nwin > 500000) return "too many windows per read (" + std::to_string(max_nwin) + ")";
     const int jump = std::max(prm.jump, 1);
     a.lc_cap = (int)(max_nwin / jump + 2);
-    a.jump_magic = (uint32_t)(((1ull << 32) + (uint64_t)jump - 1) / (uint64_t)jump);
+    a.jump_magic = jump == 1 ? 0u : (uint32_t)(((1ull << 32) + (uint64_t)jump - 1) / (uint64_t)jump);   // 0: divide by 1
     a.head_dw = (prm.no_bp + 30) / 16 + 3;
     (void)target_dw;
     // fused kernels: compile-time slide, 16-bit masks (<= 15 patterns), a window spans at least one
