@@ -63,6 +63,15 @@ for case in range(n_cases):
     sums, win_off = sc.window_sums(0)
     raw = sc.window_raw(0)[0] if case % 3 == 0 else None
     cs_all, ce_all = sc.batch_trc_counts(0)
+    # the standalone entry points (tps_trc_counts / tps_window_counts / tps_binseg_l2) must agree with the fused scan
+    if case % 5 == 0:
+        cs2, ce2 = sc.trc_counts(bases, offsets, no_bp)
+        s2, wo2, _ = sc.window_counts(bases, offsets, res["tail"].astype(np.uint8), W, s, t, M)
+        b2, _g2 = sc.binseg_l2(sums, win_off, len(pats), jump, min_size)
+        if not (np.array_equal(cs2, cs_all) and np.array_equal(ce2, ce_all) and np.array_equal(wo2, win_off) and np.array_equal(s2, sums)
+                and np.array_equal(b2, res["bkp"])):
+            bad += 1
+            print(f"MISMATCH case {case}: standalone entry points differ from the fused scan (motif {motif} k {k} W {W} s {s} jump {jump} min_size {min_size})")
     for i, q in enumerate(seqs):
         cs, ce = oracle_c.trc_counts(q, pats, no_bp)
         ok = cs_all[i].tolist() == list(cs) and ce_all[i].tolist() == list(ce)
