@@ -332,3 +332,23 @@ def test_randomised_parameter_sweep():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_gpu.py"), "150", "11"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_cli_several_files_concurrently_on_gpu(tmp_path, gold_dir):
+    """Several input files: each is processed on its own host thread with its own context on the same GPU."""
+    import shutil
+    from topsicle_amd import main as cli
+    d = tmp_path / "many"
+    d.mkdir()
+    names = ["a_sample", "b_sample", "c_sample", "d_sample"]
+    for n in names:
+        shutil.copyfile(os.path.join(gold_dir, "demo_col0.fastq.gz"), d / f"{n}.fastq.gz")
+    out = tmp_path / "out"
+    cli.main(["--inputDir", str(d), "--outputDir", str(out), "--pattern", "CCCTAAA", "--slide", "6", "--threads", "4"])
+    want = open(os.path.join(gold_dir, "demo_telolengths_all.csv")).read().splitlines()[1:]
+    rows = list(csv.reader(open(out / "telolengths_all.csv")))[1:]
+    assert len(rows) == len(names) * len(want)
+    for n in names:
+        assert [",".join(r[1:]) for r in rows if r[0] == f"{n}.fastq"] == [w.split(",", 1)[1] for w in want], n
+    assert "processing 4 files, 4 at a time" in open(out / "topsicle_run.log").read()

@@ -151,3 +151,32 @@ def test_cli_fasta_gz_input_and_default_slide(engine, tmp_path, demo_records):
         call = orc.trc_call(cs, ce, pats, 7, 0.5)
         assert f"{call[2]:.3f}" == r[2]
         assert orc.step2(seqs[r[3]], call[1], pats, 100, 7, 100, 20000) == int(r[4])
+
+
+def test_cli_processes_several_files_concurrently(tmp_path, gold_dir):
+    """A directory of input files with an engine factory: files are processed on their own threads and
+    contexts; every file contributes its rows, grouped per file, and its filtered file."""
+    d = tmp_path / "many"
+    d.mkdir()
+    names = ["a_sample", "b_sample", "c_sample"]
+    for n in names:
+        shutil.copyfile(os.path.join(gold_dir, "demo_col0.fastq.gz"), d / f"{n}.fastq.gz")
+    out = tmp_path / "out"
+    made = []
+
+    def factory():
+        made.append(EmuEngine())
+        return [made[-1]]
+
+    args = cli.build_parser().parse_args(["-i", str(d), "-o", str(out), "--pattern", "CCCTAAA", "--slide", "6", "--threads", "3"])
+    cli.tprint.logfile = cli.get_log_path(args)
+    cli.analysis_run(args, engine_factory=factory)
+    assert len(made) >= 2                                      # the first set + at least one worker's own
+    want = open(os.path.join(gold_dir, "demo_telolengths_all.csv")).read().splitlines()[1:]
+    rows = list(csv.reader(open(out / "telolengths_all.csv")))[1:]
+    assert len(rows) == 3 * len(want)
+    for n in names:
+        mine = [",".join(r[1:]) for r in rows if r[0] == f"{n}.fastq"]
+        assert mine == [w.split(",", 1)[1] for w in want], n    # same rows, same order within the file
+        assert os.path.exists(out / f"{n}.fastq_trc_over_0.7.fastq")
+    assert "processing 3 files, 3 at a time" in open(out / "topsicle_run.log").read()

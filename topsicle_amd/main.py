@@ -50,6 +50,9 @@ def _formats(seq_loc: str):
     return "fastq" if fq else "fasta"
 
 
+_CSV_LOCK = __import__("threading").Lock()      # telolengths_all.csv is appended batch by batch from every file in flight
+
+
 def process_file(args, seq_loc, telo_phrase, pattern, sliding_val, engines):
     """One input file: step 1 + filtered file + step 2 rows (main.py:52-154), batched.
     Returns [(file_name, telo_phrase, [[readID, telolen]], trc), ...] in read order."""
@@ -81,7 +84,7 @@ def process_file(args, seq_loc, telo_phrase, pattern, sliding_val, engines):
     pool = batch.EnginePool(engines, pattern)
     try:
         for rb, res, sums, raw, win_off in pool.scan_file(seq_loc, prm, want_sums, want_raw):
-            with open(csv_path, mode="a", newline="") as fh:
+            with _CSV_LOCK, open(csv_path, mode="a", newline="") as fh:
                 writer = csv.writer(fh)
                 for i in np.nonzero(res["pass"])[0]:
                     r = res[i]
@@ -130,7 +133,10 @@ def _write_rawcount(args, telo_phrase, image_num, pattern, slide, block, tail):
     df.to_csv(f"{args.outputDir}/rawcount_{telo_phrase}_{image_num}.csv")
 
 
-def analysis_run(args, engines=None):
+def analysis_run(args, engines=None, engine_factory=None):
+    """`engines`: contexts to use (tests inject theirs).  `engine_factory()` -> a fresh list of contexts: given (or by
+    default on real GPUs), several input files are processed concurrently, one host thread + one set of contexts per
+    file in flight -- the role of upstream's `Pool(num_cores)` over files (main.py:232-235)."""
     print("---- Topsicle run parameters ---")
     for k, v in vars(args).items():
         tprint(f"{k}: {v}")
@@ -168,7 +174,10 @@ def analysis_run(args, engines=None):
     if engines is None:
         n_gpus = max(1, getattr(args, "gpus", 1) or 1)
         first = getattr(args, "device", 0) or 0
-        engines = [hiplib.HipScanner(first + i) for i in range(n_gpus)]
+        if engine_factory is None:
+            def engine_factory():
+                return [hiplib.HipScanner(first + i) for i in range(n_gpus)]
+        engines = engine_factory()
         tprint(f"GPU engines: {[e.device_info() for e in engines]}")
 
     phrase_to_telo = defaultdict(list)
@@ -191,7 +200,7 @@ def analysis_run(args, engines=None):
             filenames.append(args.inputDir)
 
         tprint("begin processing reads")
-        results = [process_file(args, seq_loc, telo_phrase, pattern, sliding_val, engines) for seq_loc in filenames]
+        results = _process_files(args, filenames, telo_phrase, pattern, sliding_val, engines, engine_factory, num_cores)
         tprint("finished processing all reads")
         print("---------------------")
         for file_result in results:
@@ -201,6 +210,34 @@ def analysis_run(args, engines=None):
 
     summarize(args, phrase_to_telo, phrase_to_trc)
     return tprint("All telomere found, have a nice day.")
+
+
+def _process_files(args, filenames, telo_phrase, pattern, sliding_val, engines, engine_factory, num_cores):
+    """All input files of one k: sequentially on the given contexts, or -- several files, a factory for more
+    contexts, no per-read plots (pyplot is not thread-safe) -- up to min(num_cores, 8) files at a time, each on
+    its own thread and contexts (parsing / gunzip is the bottleneck, the GPUs are shared).  Results keep file order."""
+    workers = min(len(filenames), max(1, num_cores), 8)
+    if workers <= 1 or engine_factory is None or args.plot or args.rawcountpattern:
+        return [process_file(args, seq_loc, telo_phrase, pattern, sliding_val, engines) for seq_loc in filenames]
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    local = threading.local()
+    made = []
+
+    def work(seq_loc):
+        if not hasattr(local, "engines"):
+            local.engines = engine_factory()
+            made.append(local.engines)
+        return process_file(args, seq_loc, telo_phrase, pattern, sliding_val, local.engines)
+
+    tprint(f"processing {len(filenames)} files, {workers} at a time")
+    try:
+        with ThreadPoolExecutor(max_workers=workers) as ex:
+            return list(ex.map(work, filenames))
+    finally:
+        for engs in made:
+            for e in engs:
+                e.close()
 
 
 def summarize(args, phrase_to_telo, phrase_to_trc):
