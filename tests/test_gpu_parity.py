@@ -352,3 +352,29 @@ def test_cli_several_files_concurrently_on_gpu(tmp_path, gold_dir):
     for n in names:
         assert [",".join(r[1:]) for r in rows if r[0] == f"{n}.fastq"] == [w.split(",", 1)[1] for w in want], n
     assert "processing 4 files, 4 at a time" in open(out / "topsicle_run.log").read()
+
+
+@pytest.mark.gpu
+def test_error_paths_are_loud(sc):
+    """Misuse of the C ABI returns an error code + message (the Python layer raises); nothing is silently skipped."""
+    with pytest.raises(hiplib.TopsicleHipError):
+        sc.set_patterns(["ACGTACGTACGTACGT"])                 # k = 16 > TPS_MAX_K
+    with pytest.raises(hiplib.TopsicleHipError):
+        sc.set_patterns(["ACGN"])                             # non-ACGT letter in a pattern
+    with pytest.raises(hiplib.TopsicleHipError):
+        sc.set_patterns([f"{'ACGT'[i % 4]}{'ACGT'[(i // 4) % 4]}{'ACGT'[(i // 16) % 4]}A" for i in range(40)])   # > 31 patterns
+    sc.set_patterns(orc.kmer_table("CCCTAA", 4))
+    with pytest.raises(hiplib.TopsicleHipError):
+        sc.scan(9, hiplib.make_params())                      # slot never uploaded
+    bases, offsets = hiplib.pack_reads(["ACGT" * 500])
+    sc.upload(9, bases, offsets)
+    for bad in (dict(window=0), dict(slide=0), dict(jump=0), dict(slide=5000), dict(window=70000)):
+        with pytest.raises(hiplib.TopsicleHipError):
+            sc.scan(9, hiplib.make_params(**bad))
+    with pytest.raises(hiplib.TopsicleHipError):
+        sc.scan(9, hiplib.make_params(flags=hiplib.F_WINDOWS | hiplib.F_TAILS_IN))   # tails promised but never set
+    with pytest.raises(hiplib.TopsicleHipError):
+        hiplib.HipScanner(99)                                 # no such device
+    sc.scan(9, hiplib.make_params(min_len=0, min_count=-1))   # and the context is still usable afterwards
+    sc.sync()
+    assert sc.results(9)["n_win"][0] == hiplib.window_count(2000, 100, 6, 100, 20000)
