@@ -150,8 +150,10 @@ inline std::string plan_geometry(ScanArgs& a, const tps_params& prm, int k, int 
         // pair table (two positions per lookup) while it is small: k <= 4 -> at most 4 KB per workgroup
         a.pair_n = (a.pat.so_mask == 0 && k <= 4) ? (1 << (2 * (k + 1))) : 0;
         a.blk_dw = (int32_t)blk_region_dw(a);
-        if (wg_lds_dwords(a) > budget_dw) return "LDS plan does not fit (fused kernel, " + std::to_string(max_nwin) + " windows per read)";
-        return "";
+        if (wg_lds_dwords(a) <= budget_dw) return "";
+        // does not fit (very long maxlengthtelo: the candidate sums of 4 reads outgrow LDS): the generic kernel,
+        // whose tile size adapts, takes over
+        a.lc16 = 0; a.tile_cap = 0; a.tw = 0; a.tw_magic = 0; a.pair_n = 0;
     }
     a.variant = 0;
     const int g = gcd_i(prm.slide, 16);
