@@ -37,7 +37,7 @@ extern "C" {
 #define TPS_E_NO_DEVICE  -1   /* no HIP device / device index out of range              */
 #define TPS_E_HIP        -2   /* a HIP runtime call failed (message has the HIP error)  */
 #define TPS_E_ARG        -3   /* invalid argument                                        */
-#define TPS_E_PATTERN    -4   /* pattern table not set / unsupported (non-ACGT, k>7, P>31) */
+#define TPS_E_PATTERN    -4   /* pattern table not set / unsupported (non-ACGT, k>15, P>31) */
 #define TPS_E_CAPACITY   -5   /* parameter combination does not fit the kernel's LDS plan */
 #define TPS_E_STATE      -6   /* call order (e.g. scan before upload)                    */
 
