@@ -56,17 +56,6 @@ def kmer_table(motif, k):
     return allsteps.patterns_to_search(motif, k)
 
 
-def kernel_name(pats, k, window, slide):
-    """Which member of the kernel family the library launches for this table / geometry
-    (mirrors plan_geometry in csrc/tps_plan.h and the host's kernel selection)."""
-    q = (window - k) // slide
-    fused = slide in (5, 6, 7, 8) and len(pats) <= 15 and q >= 8 and q // 8 + 2 < 16
-    if not fused:
-        return "tps_scan_kernel"
-    so = any(p[d:] == p[:k - d] for p in pats for d in range(1, k))     # a k-mer that can overlap itself
-    return f"tps_scan_kernel_s{slide}" + ("so" if so else "p" if k <= 4 else "")
-
-
 def min_count_for_cutoff(cutoff, no_bp, motif_len):
     from topsicle_amd import allsteps
     return allsteps.min_count_for_cutoff(cutoff, no_bp / motif_len, no_bp)
@@ -217,6 +206,7 @@ def main():
     n_launch, k_total_ms, k_mean_ms = sc.kernel_time_ms()
 
     res = sc.results((args.steps - 1) % copies)
+    kinfo = sc.kernel_info((args.steps - 1) % copies)
     passed = res["pass"].astype(bool)
     n_win = res["n_win"].astype(np.int64)
     lens = np.diff(offsets)
@@ -256,7 +246,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": kernel_name(pats, k, cfg["window"], cfg["slide"]),
+                "kernel": kinfo.split()[0],
+                "kernel_launch": kinfo,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

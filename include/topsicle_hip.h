@@ -152,6 +152,9 @@ int  tps_kernel_time_ms(tps_ctx* ctx, int32_t* n_launches, double* total_ms, dou
 int  tps_kernel_time_reset(tps_ctx* ctx);
 /* Name of the device and a few properties, as a NUL-terminated string. */
 int  tps_device_info(tps_ctx* ctx, char* buf, int32_t buf_len);
+/* What the last tps_batch_scan of `slot` launched: "<kernel name> lds=<bytes per workgroup> wgs_per_cu=<n>"
+ * (the kernel family is chosen per scan from slide, table and LDS plan; profiles and bench.py name it). */
+int  tps_batch_kernel_info(tps_ctx* ctx, int32_t slot, char* buf, int32_t buf_len);
 
 #ifdef __cplusplus
 }

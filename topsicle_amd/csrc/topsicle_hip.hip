@@ -119,6 +119,7 @@ struct Slot {
     uint32_t plan_dup = 0, plan_so = 0;   // the plan depends on whether the pattern list holds duplicate / self-overlapping k-mers
     tps::ScanArgs args{};
     size_t lds_bytes = 0;
+    const char* kernel_name = "";       // what the last scan of this slot launched
     bool scanned = false;
     uint32_t last_flags = 0;
 };
@@ -296,6 +297,13 @@ int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm) {
         case 8: kfn = so ? (const void*)tps_scan_kernel_s8so : pair ? (const void*)tps_scan_kernel_s8p : (const void*)tps_scan_kernel_s8; kidx = so ? 8 : pair ? 12 : 4; break;
         default: kfn = (const void*)tps_scan_kernel; kidx = 0; break;
     }
+    {
+        static const char* const names[13] = {"tps_scan_kernel", "tps_scan_kernel_s5", "tps_scan_kernel_s6", "tps_scan_kernel_s7",
+                                              "tps_scan_kernel_s8", "tps_scan_kernel_s5so", "tps_scan_kernel_s6so", "tps_scan_kernel_s7so",
+                                              "tps_scan_kernel_s8so", "tps_scan_kernel_s5p", "tps_scan_kernel_s6p", "tps_scan_kernel_s7p",
+                                              "tps_scan_kernel_s8p"};
+        sl.kernel_name = names[kidx];
+    }
     if (sl.lds_bytes > c->lds_set_v[kidx]) {
         HIP_TRY(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sl.lds_bytes));
         c->lds_set_v[kidx] = sl.lds_bytes;
@@ -400,6 +408,16 @@ int tps_device_info(tps_ctx* c, char* buf, int32_t buf_len) {
     if (!c || !buf || buf_len < 1) return fail(TPS_E_ARG, "bad arguments");
     snprintf(buf, (size_t)buf_len, "%s arch=%s CUs=%d LDS/block=%zu clock=%dkHz", c->prop.name, c->prop.gcnArchName,
              c->prop.multiProcessorCount, c->prop.sharedMemPerBlock, c->prop.clockRate);
+    return TPS_OK;
+}
+
+int tps_batch_kernel_info(tps_ctx* c, int32_t slot, char* buf, int32_t buf_len) {
+    if (!c || !buf || buf_len < 1) return fail(TPS_E_ARG, "bad arguments");
+    Slot* sl = get_slot(c, slot);
+    if (!sl) return TPS_E_ARG;
+    if (!sl->scanned) return fail(TPS_E_STATE, "slot %d has not been scanned", slot);
+    const size_t gran = (sl->lds_bytes + 1279) / 1280;
+    snprintf(buf, (size_t)buf_len, "%s lds=%zu wgs_per_cu=%d", sl->kernel_name, sl->lds_bytes, gran ? (int)std::min<size_t>(128 / gran, 8) : 8);
     return TPS_OK;
 }
 

@@ -2,6 +2,7 @@
 // emulation (tests/emu): pattern table -> lookup table + self-overlap info, and the LDS
 // geometry of one scan.  Plain C++, no HIP calls.
 #pragma once
+#include <cstdlib>
 #include <algorithm>
 #include <cstdint>
 #include <string>
@@ -148,8 +149,18 @@ inline std::string plan_geometry(ScanArgs& a, const tps_params& prm, int k, int 
         a.tile_cap = (int)((max_nwin + a.tw - 1) / a.tw) + 1;
         a.lc16 = (a.pat.dup_mask == 0 && (int64_t)a.tw * (a.lw + P) < 65536) ? 1 : 0;
         // pair table (two positions per lookup) while it is small: k <= 4 -> at most 4 KB per workgroup
-        a.pair_n = (a.pat.so_mask == 0 && k <= 4) ? (1 << (2 * (k + 1))) : 0;
+        a.pair_n = (a.pat.so_mask == 0 && k <= 4 && !getenv("TPS_NO_PAIR")) ? (1 << (2 * (k + 1))) : 0;
         a.blk_dw = (int32_t)blk_region_dw(a);
+        if (a.pair_n && !getenv("TPS_FORCE_PAIR")) {
+            // ... unless it costs a workgroup per CU: LDS is handed out in 1280-byte granules, 128 per CU, and one
+            // more resident workgroup (4 waves) is worth more than halving the lookups (measured at config 2:
+            // 0.092 ms with 5 workgroups and single lookups, 0.096 ms with 4 workgroups and the pair table)
+            auto wgs_per_cu = [](int64_t dwords) { return (int)(128 / std::max<int64_t>(1, (dwords * 4 + 1279) / 1280)); };
+            const int with_pair = wgs_per_cu(wg_lds_dwords(a));
+            const int32_t keep = a.pair_n;
+            a.pair_n = 0;
+            if (wgs_per_cu(wg_lds_dwords(a)) <= with_pair) a.pair_n = keep;
+        }
         if (wg_lds_dwords(a) <= budget_dw) return "";
         // does not fit (very long maxlengthtelo: the candidate sums of 4 reads outgrow LDS): the generic kernel,
         // whose tile size adapts, takes over

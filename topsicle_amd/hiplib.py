@@ -23,7 +23,7 @@ EXPORTS = [
     "tps_set_patterns", "tps_batch_upload", "tps_batch_set_tails", "tps_batch_scan", "tps_sync",
     "tps_batch_results", "tps_batch_window_offsets", "tps_batch_window_sums", "tps_batch_window_raw",
     "tps_batch_trc_counts", "tps_trc_counts", "tps_window_counts", "tps_binseg_l2", "tps_window_count",
-    "tps_kernel_time_ms", "tps_kernel_time_reset", "tps_device_info",
+    "tps_kernel_time_ms", "tps_kernel_time_reset", "tps_device_info", "tps_batch_kernel_info",
 ]
 
 
@@ -90,6 +90,7 @@ def load_library(path: str | None = None) -> C.CDLL:
         "tps_kernel_time_ms": (C.c_int, [vp, C.POINTER(i32), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "tps_kernel_time_reset": (C.c_int, [vp]),
         "tps_device_info": (C.c_int, [vp, C.c_char_p, i32]),
+        "tps_batch_kernel_info": (C.c_int, [vp, i32, C.c_char_p, i32]),
     }
     for name, (res, args) in proto.items():
         try:
@@ -172,6 +173,12 @@ class HipScanner:
         return buf.value.decode()
 
     # -- pattern table
+    def kernel_info(self, slot: int) -> str:
+        """'<kernel name> lds=<bytes per workgroup> wgs_per_cu=<n>' of the slot's last scan."""
+        buf = C.create_string_buffer(256)
+        self._check(self.lib.tps_batch_kernel_info(self._h, slot, buf, 256))
+        return buf.value.decode()
+
     def set_patterns(self, patterns: list[str]):
         if not patterns:
             raise TopsicleHipError("empty pattern list")
