@@ -68,6 +68,8 @@ extern "C" int emu_scan(const char* pats, int P, int k, const uint8_t* bases, co
     a.raw = (prm->flags & TPS_F_STORE_RAW) ? raw : nullptr;
     a.n_reads = n;
     a.prm = *prm;
+    std::vector<uint16_t> lc_scratch(a.lc_global ? (size_t)n * (size_t)a.lc_stride + 8 : 8, (uint16_t)0xBEEF);
+    a.lc_scratch = a.lc_global ? lc_scratch.data() : nullptr;
     // the workgroup-shared tables (read-only for the waves): [pair table][single table]
     std::vector<uint32_t> lutbuf((size_t)a.pair_n + lut.size());
     uint32_t* lut1 = lutbuf.data() + a.pair_n;

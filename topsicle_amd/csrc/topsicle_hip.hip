@@ -105,7 +105,7 @@ struct DevBuf {
 };
 
 struct Slot {
-    DevBuf bases, offsets, tails, results, c_start, c_end, win_off, sums, raw, stamps;
+    DevBuf bases, offsets, tails, results, c_start, c_end, win_off, sums, raw, stamps, lc;
     std::vector<int64_t> h_offsets;      // host copy of offsets (n+1)
     std::vector<int64_t> h_win_off;      // window layout of the last plan
     tps_read_result* h_results = nullptr;   // pinned
@@ -274,6 +274,11 @@ int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm) {
         if ((rc = sl.raw.ensure((size_t)std::max<int64_t>(total_win * P, 1)))) return rc;
         a.raw = (uint8_t*)sl.raw.p;
     }
+    a.lc_scratch = nullptr;
+    if (a.lc_global) {
+        if ((rc = sl.lc.ensure((size_t)std::max<int64_t>(n, 1) * (size_t)a.lc_stride * 2))) return rc;
+        a.lc_scratch = (uint16_t*)sl.lc.p;
+    }
     a.stamps = nullptr;
     if (c->want_stamps) {
         if ((rc = sl.stamps.ensure((size_t)std::max<int64_t>(n, 1) * 16 * 8))) return rc;
@@ -394,7 +399,7 @@ int tps_ctx_destroy(tps_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto& sl : c->slots) {
         sl.bases.release(); sl.offsets.release(); sl.tails.release(); sl.results.release();
-        sl.c_start.release(); sl.c_end.release(); sl.win_off.release(); sl.sums.release(); sl.raw.release(); sl.stamps.release();
+        sl.c_start.release(); sl.c_end.release(); sl.win_off.release(); sl.sums.release(); sl.raw.release(); sl.stamps.release(); sl.lc.release();
         if (sl.h_results) (void)hipHostFree(sl.h_results);
     }
     c->lut.release();

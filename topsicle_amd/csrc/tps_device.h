@@ -149,6 +149,22 @@ TPS_DEV uint32_t lut_at(const uint32_t* lut, uint32_t v4, uint32_t amask) {
 }
 #endif
 
+// 16-bit candidate sums kept off-chip: explicit global address space (a generic pointer would become FLAT
+// instructions, which also count on the LDS counter)
+#ifdef TPS_EMU
+TPS_DEV void g16_store(uint64_t base, uint32_t i, uint32_t v) { ((uint16_t*)(uintptr_t)base)[i] = (uint16_t)v; }
+TPS_DEV uint32_t g16_load(uint64_t base, uint32_t i) { return ((const uint16_t*)(uintptr_t)base)[i]; }
+#else
+TPS_DEV void g16_store(uint64_t base, uint32_t i, uint32_t v) {
+    typedef __attribute__((address_space(1))) uint16_t* gp_t;
+    ((gp_t)(uintptr_t)base)[i] = (uint16_t)v;
+}
+TPS_DEV uint32_t g16_load(uint64_t base, uint32_t i) {
+    typedef const __attribute__((address_space(1))) uint16_t* gp_t;
+    return ((gp_t)(uintptr_t)base)[i];
+}
+#endif
+
 constexpr int cgcd(int a, int b) { return b == 0 ? a : cgcd(b, a % b); }
 constexpr int clog2(int x) { return x <= 1 ? 0 : 1 + clog2(x / 2); }
 
@@ -207,6 +223,9 @@ struct ScanArgs {
     // fused path, 16-bit candidate sums: Lc16[c] = left sum of candidate c counted from its tile's first
     // window, Tc[t] = sum of S_w before tile t; tile of window w = mulhi(w, tw_magic)
     int32_t lc16;                // 1 = Lc16 + Tc instead of the u32 Lc
+    int32_t lc_global;           // (lc16) 1 = Lc16 lives off-chip in lc_scratch (lc_stride entries per read): 1 kB of L2 traffic per
+    int32_t lc_stride;           //        read instead of 1 kB of LDS per wave -> one more resident workgroup per CU
+    uint16_t* lc_scratch;
     int32_t pair_n;              // 0, or 4^(k+1): entries of the pair table (two adjacent positions per lookup)
     int32_t tile_cap;            // entries of Tc (tiles of the longest read)
     int32_t tw;                  // windows per fused tile
@@ -268,7 +287,7 @@ TPS_HD int64_t blk_region_dw(const ScanArgs& a) {
 }
 TPS_HD int64_t val_dw(const ScanArgs& a) { return ((a.seq_dw + 4 + 3) / 4) * 2; }   // u16 per 16 positions (+ look-ahead), even
 TPS_HD int64_t lc_dw(const ScanArgs& a) {          // even dword counts keep misc 8-byte aligned
-    if (a.lc16) return ((a.lc_cap + 3) / 4) * 2 + ((a.tile_cap + 1) / 2) * 2;
+    if (a.lc16) return (a.lc_global ? 0 : ((a.lc_cap + 3) / 4) * 2) + ((a.tile_cap + 1) / 2) * 2;
     return ((a.lc_cap + 1) / 2) * 2;
 }
 TPS_HD int64_t row_dw(const ScanArgs& a) {
@@ -287,7 +306,7 @@ TPS_DEV Lds carve(uint32_t* base, uint32_t* lut, const ScanArgs& a) {
     l.Tot = p;  p += a.tot_dw;
     l.Lc = p;
     l.Lc16 = (uint16_t*)p;
-    l.Tc = p + ((a.lc_cap + 3) / 4) * 2;
+    l.Tc = p + ((a.lc16 && a.lc_global) ? 0 : ((a.lc_cap + 3) / 4) * 2);
     p += lc_dw(a);
     l.row = p;  p += row_dw(a);
     l.misc = p;
@@ -975,9 +994,11 @@ TPS_DEV void candidates_group(const ScanArgs& a, const Lds& l, int w0, int nw_ti
 struct TileConst {
     int32_t q, r;
     uint32_t jump, jump_magic, lc_cap, lc16;
+    uint64_t lc_g;               // this read's off-chip Lc16 (0 = Lc16 lives in LDS)
 };
-TPS_DEV TileConst tile_const(const ScanArgs& a) {
+TPS_DEV TileConst tile_const(const ScanArgs& a, int64_t r) {
     TileConst t;
+    t.lc_g = (a.lc16 && a.lc_global) ? (uint64_t)(uintptr_t)(a.lc_scratch + r * (int64_t)a.lc_stride) : 0ull;
     t.q = (int32_t)uniform((uint32_t)a.q); t.r = (int32_t)uniform((uint32_t)a.r);
     t.jump = uniform((uint32_t)a.prm.jump); t.jump_magic = uniform(a.jump_magic);
     t.lc_cap = uniform((uint32_t)a.lc_cap); t.lc16 = uniform((uint32_t)a.lc16);
@@ -1390,8 +1411,12 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const TileConst& tc, const Lds& l, 
             for (int t = 0; t < passes; ++t) {
                 if (c < c_hi) {
                     const uint32_t pre = l.row[w + (w >> LOG2B)];
-                    if (tc.lc16) l.Lc16[c] = (uint16_t)pre;
-                    else l.Lc[c] = carry + pre;
+                    if (tc.lc16) {
+                        if (tc.lc_g) g16_store(tc.lc_g, c, pre);
+                        else l.Lc16[c] = (uint16_t)pre;
+                    } else {
+                        l.Lc[c] = carry + pre;
+                    }
                 }
                 c += NT;
                 w += NT * jump;
@@ -1614,8 +1639,8 @@ TPS_DEV void binseg_wg(const ST* S, int n, int jump, int min_size, int n_pattern
 // Fused Binseg from the candidate left sums Lc[c] = sum_{w < c*jump} S_w (c = 1 .. (n-1)/jump) and
 // the total T: float64 scores, wave arg-max; if more than one candidate lies within float noise of
 // the best score the exact integer tournament re-reads S_w from HBM (rare).
-TPS_DEV void binseg_from_lc(const ScanArgs& a, const Lds& l, const int32_t* S_global, int n, uint64_t tot, int jump, int min_size,
-                            int n_patterns, uint32_t* misc, uint32_t* xs, int& bkp, double& gain) {
+TPS_DEV void binseg_from_lc(const ScanArgs& a, const Lds& l, uint64_t lc_g, const int32_t* S_global, int n, uint64_t tot, int jump,
+                            int min_size, int n_patterns, uint32_t* misc, uint32_t* xs, int& bkp, double& gain) {
     const int ncand = (n - 1) / jump;              // candidates b = c*jump, 1 <= c <= ncand  (b < n)
 #ifdef TPS_EMU
     double* keep = (double*)xs;
@@ -1639,12 +1664,8 @@ TPS_DEV void binseg_from_lc(const ScanArgs& a, const Lds& l, const int32_t* S_gl
         double bn = -1.0, bd = 1.0;
         best_b = -1;
         amb = false;
-        TPS_NOVEC
-        for (int c = c_min + tid; c <= c_max; c += NT) {
+        auto offer = [&](int c, uint32_t lc) {
             const int b = c * jump;
-            uint32_t lc;
-            if (a.lc16) lc = l.Tc[(uint32_t)(((uint64_t)(uint32_t)b * a.tw_magic) >> 32)] + l.Lc16[c];
-            else lc = l.Lc[c];
             const double bf = (double)b;
             double dd;
             if (exact53) dd = __builtin_fma(-totf, bf, nf * (double)lc);
@@ -1656,6 +1677,30 @@ TPS_DEV void binseg_from_lc(const ScanArgs& a, const Lds& l, const int32_t* S_gl
             const bool take = diff >= 0.0;                     // ties -> the later (larger) candidate
             amb = near || (amb && !take);
             if (take) { bn = num; bd = den; best_b = b; }
+        };
+        auto tile_sum = [&](int c) { return l.Tc[(uint32_t)(((uint64_t)(uint32_t)(c * jump) * a.tw_magic) >> 32)]; };
+        constexpr int LCV = 16;
+        if (lc_g && c_max - c_min < LCV * NT) {
+            // off-chip 16-bit sums: all of the lane's values are requested before the first one is used
+            uint32_t lcv[LCV];
+            TPS_UNROLL
+            for (int i = 0; i < LCV; ++i) {
+                const int c = c_min + tid + i * NT;
+                lcv[i] = c <= c_max ? g16_load(lc_g, (uint32_t)c) : 0u;
+            }
+            TPS_UNROLL
+            for (int i = 0; i < LCV; ++i) {
+                const int c = c_min + tid + i * NT;
+                if (c <= c_max) offer(c, tile_sum(c) + lcv[i]);
+            }
+        } else {
+            TPS_NOVEC
+            for (int c = c_min + tid; c <= c_max; c += NT) {
+                uint32_t lc;
+                if (a.lc16) lc = tile_sum(c) + (lc_g ? g16_load(lc_g, (uint32_t)c) : (uint32_t)l.Lc16[c]);
+                else lc = l.Lc[c];
+                offer(c, lc);
+            }
         }
         best = best_b >= 0 ? bn / bd : -1.0;
         bits = 0;
@@ -1845,7 +1890,7 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
             // ---------------- fused tiles: NT lanes x 8 blocks, the last lane is halo only
             typedef Geo<SV ? SV : 1> g_;
             constexpr int PF = g_::PF;
-            const TileConst tc = tile_const(a);
+            const TileConst tc = tile_const(a, r);
             const int tw = NT * g_::B - tc.q - 1 - g_::B;   // windows per tile
             auto tile_stage = [&](int w0_) {
                 const int64_t i0 = (int64_t)w0_ * prm.slide;
@@ -1920,9 +1965,12 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
         int bkp;
         double gain;
 #ifndef TPS_EMU
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // S_w stores of this wave visible to its (rare) exact re-read
+        // same wave, same CU: workgroup scope orders this wave's S_w / off-chip candidate-sum stores before its own
+        // loads (an agent-scope fence writes the L2 back: measured 5x slower)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 #endif
-        binseg_from_lc(a, l, a.sums + (a.win_off ? a.win_off[r] : 0), n_win, s_total, prm.jump, prm.min_size, pat.P,
+        const uint64_t lc_g = (SV != 0 && a.lc16 && a.lc_global) ? (uint64_t)(uintptr_t)(a.lc_scratch + r * (int64_t)a.lc_stride) : 0ull;
+        binseg_from_lc(a, l, lc_g, a.sums + (a.win_off ? a.win_off[r] : 0), n_win, s_total, prm.jump, prm.min_size, pat.P,
                        l.misc, l.blk, bkp, gain);
         res.bkp = bkp;
         res.gain = gain;

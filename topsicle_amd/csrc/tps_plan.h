@@ -129,7 +129,7 @@ inline std::string plan_geometry(ScanArgs& a, const tps_params& prm, int k, int 
     for (int i = 0; i < a.pat.n_periods; ++i) max_period = std::max(max_period, a.pat.period[i]);
     const bool fused = !force_generic && spans_pref <= 0 && k <= TPS_DIRECT_K && has_specialised_slide(prm.slide) && P <= 15 && a.q >= 8 &&
                        a.q / 8 + 2 < (XLANES - NT) && max_period <= std::min(prm.slide, 6);
-    a.lc16 = 0; a.tile_cap = 0; a.tw = 0; a.tw_magic = 0; a.pair_n = 0;
+    a.lc16 = 0; a.tile_cap = 0; a.tw = 0; a.tw_magic = 0; a.pair_n = 0; a.lc_global = 0; a.lc_stride = 0;
     if (fused) {
         a.variant = prm.slide;
         a.blk_log2 = 3;                            // 8 blocks per lane for every slide
@@ -148,23 +148,26 @@ inline std::string plan_geometry(ScanArgs& a, const tps_params& prm, int k, int 
         a.tw_magic = (uint32_t)(((1ull << 32) + (uint64_t)a.tw - 1) / (uint64_t)a.tw);
         a.tile_cap = (int)((max_nwin + a.tw - 1) / a.tw) + 1;
         a.lc16 = (a.pat.dup_mask == 0 && (int64_t)a.tw * (a.lw + P) < 65536) ? 1 : 0;
+        // the 16-bit sums go off-chip (L2-resident scratch, 2 bytes per candidate): LDS per wave drops by ~1 kB
+        a.lc_global = (a.lc16 && !getenv("TPS_LC_IN_LDS")) ? 1 : 0;
+        a.lc_stride = (a.lc_cap + 1) & ~1;
         // pair table (two positions per lookup) while it is small: k <= 4 -> at most 4 KB per workgroup
         a.pair_n = (a.pat.so_mask == 0 && k <= 4 && !getenv("TPS_NO_PAIR")) ? (1 << (2 * (k + 1))) : 0;
         a.blk_dw = (int32_t)blk_region_dw(a);
         if (a.pair_n && !getenv("TPS_FORCE_PAIR")) {
-            // ... unless it costs a workgroup per CU: LDS is handed out in 1280-byte granules, 128 per CU, and one
-            // more resident workgroup (4 waves) is worth more than halving the lookups (measured at config 2:
-            // 0.092 ms with 5 workgroups and single lookups, 0.096 ms with 4 workgroups and the pair table)
-            auto wgs_per_cu = [](int64_t dwords) { return (int)(128 / std::max<int64_t>(1, (dwords * 4 + 1279) / 1280)); };
+            // ... unless it costs a resident workgroup where one is scarce: LDS is handed out in 1280-byte granules,
+            // 128 per CU.  Measured at config 2 (ms per batch): 4 workgroups + pair 0.096 vs 5 + single lookups 0.092;
+            // 5 + pair 0.089 vs 6 + single lookups 0.091 -- so the pair table stays if 5 workgroups still fit.
+            auto wgs_per_cu = [](int64_t dwords) { return (int)std::min<int64_t>(8, 128 / std::max<int64_t>(1, (dwords * 4 + 1279) / 1280)); };
             const int with_pair = wgs_per_cu(wg_lds_dwords(a));
             const int32_t keep = a.pair_n;
             a.pair_n = 0;
-            if (wgs_per_cu(wg_lds_dwords(a)) <= with_pair) a.pair_n = keep;
+            if (with_pair >= 5 || wgs_per_cu(wg_lds_dwords(a)) <= with_pair) a.pair_n = keep;
         }
         if (wg_lds_dwords(a) <= budget_dw) return "";
         // does not fit (very long maxlengthtelo: the candidate sums of 4 reads outgrow LDS): the generic kernel,
         // whose tile size adapts, takes over
-        a.lc16 = 0; a.tile_cap = 0; a.tw = 0; a.tw_magic = 0; a.pair_n = 0;
+        a.lc16 = 0; a.tile_cap = 0; a.tw = 0; a.tw_magic = 0; a.pair_n = 0; a.lc_global = 0; a.lc_stride = 0;
     }
     a.variant = 0;
     const int g = gcd_i(prm.slide, 16);
