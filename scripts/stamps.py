@@ -1,5 +1,7 @@
 """Diagnostic: per-phase clock shares of the scan kernel (thread-0 stamps per read)."""
 import ctypes as C, os, sys
+# needs the diagnostics build: python -c "import __graft_entry__ as g; g.build_hip_diag()"
+os.environ.setdefault("TOPSICLE_HIP_LIB", os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "topsicle_amd", "libtopsicle_hip_diag.so"))
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
 import numpy as np
 from topsicle_amd import hiplib, synth, allsteps

@@ -169,7 +169,7 @@ constexpr int cgcd(int a, int b) { return b == 0 ? a : cgcd(b, a % b); }
 constexpr int clog2(int x) { return x <= 1 ? 0 : 1 + clog2(x / 2); }
 
 // diagnostics: thread 0 stores the shader clock at phase boundaries when ScanArgs::stamps is set
-#ifdef TPS_EMU
+#if defined(TPS_EMU) || !defined(TPS_STAMPS)
 #define TPS_STAMP(i) ((void)0)
 #else
 #define TPS_STAMP(i) do { if (a.stamps && (threadIdx.x & 63u) == 0) a.stamps[r * 16 + (i)] = __builtin_readcyclecounter(); } while (0)

@@ -58,7 +58,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("TOPSICLE_HIP_LIB") or LIB_PATH      # TOPSICLE_HIP_LIB: e.g. the diagnostics build with phase stamps
     if not os.path.exists(p):
         raise TopsicleHipError(f"{p} not found: build the HIP library first (python -c 'import __graft_entry__ as g; g.build()'). "
                                "topsicle_amd has no CPU fallback.")
