@@ -19,7 +19,7 @@
 // One wave per read, tps::WPG waves per workgroup.  The lookup table is loaded once per workgroup
 // (the only workgroup barrier in the kernel); after that every wave runs its own read with
 // wave-level synchronisation only.
-#define TPS_SCAN_KERNEL(NAME, SV, SO, PAIR, MINW)                                                             \
+#define TPS_SCAN_KERNEL(NAME, SV, SO, PAIR, RAW, MINW)                                                             \
     extern "C" __global__ void __launch_bounds__(tps::NT * tps::WPG, MINW) NAME(tps::ScanArgs a) {         \
         extern __shared__ __attribute__((aligned(16))) uint32_t lds[];                                     \
         /* workgroup-shared tables: [pair table (PAIR kernels)][single table], both aligned to their size */ \
@@ -42,21 +42,25 @@
         const int64_t wave_dw = (tps::lds_dwords(a) + 3) & ~3ll;                                           \
         uint32_t* slice = lut + ((a.lut_n + 3) & ~3) + wave * wave_dw;                                     \
         const int64_t r = (int64_t)blockIdx.x * tps::WPG + wave;                                           \
-        if (r < a.n_reads) tps::scan_read<SV, SO, PAIR>(a, r, slice, lut);                                 \
+        if (r < a.n_reads) tps::scan_read<SV, SO, PAIR, RAW>(a, r, slice, lut);                                 \
     }
-TPS_SCAN_KERNEL(tps_scan_kernel, 0, false, false, 4)          // generic: any slide, up to 31 patterns
-TPS_SCAN_KERNEL(tps_scan_kernel_s5, 5, false, false, 3)       // specialised: compile-time slide, <= 15 patterns
-TPS_SCAN_KERNEL(tps_scan_kernel_s6, 6, false, false, 3)
-TPS_SCAN_KERNEL(tps_scan_kernel_s7, 7, false, false, 3)
-TPS_SCAN_KERNEL(tps_scan_kernel_s8, 8, false, false, 3)
-TPS_SCAN_KERNEL(tps_scan_kernel_s5p, 5, false, true, 3)       // ... k <= 4: two positions per table lookup
-TPS_SCAN_KERNEL(tps_scan_kernel_s6p, 6, false, true, 3)
-TPS_SCAN_KERNEL(tps_scan_kernel_s7p, 7, false, true, 3)
-TPS_SCAN_KERNEL(tps_scan_kernel_s8p, 8, false, true, 3)
-TPS_SCAN_KERNEL(tps_scan_kernel_s5so, 5, true, false, 3)      // ... with self-overlapping k-mers in the table
-TPS_SCAN_KERNEL(tps_scan_kernel_s6so, 6, true, false, 3)
-TPS_SCAN_KERNEL(tps_scan_kernel_s7so, 7, true, false, 3)
-TPS_SCAN_KERNEL(tps_scan_kernel_s8so, 8, true, false, 3)
+TPS_SCAN_KERNEL(tps_scan_kernel, 0, false, false, true, 4)          // generic: any slide, up to 31 patterns
+TPS_SCAN_KERNEL(tps_scan_kernel_s5, 5, false, false, false, 3)       // specialised: compile-time slide, <= 15 patterns
+TPS_SCAN_KERNEL(tps_scan_kernel_s6, 6, false, false, false, 3)
+TPS_SCAN_KERNEL(tps_scan_kernel_s7, 7, false, false, false, 3)
+TPS_SCAN_KERNEL(tps_scan_kernel_s8, 8, false, false, false, 3)
+TPS_SCAN_KERNEL(tps_scan_kernel_s5p, 5, false, true, false, 3)       // ... k <= 4: two positions per table lookup
+TPS_SCAN_KERNEL(tps_scan_kernel_s6p, 6, false, true, false, 3)
+TPS_SCAN_KERNEL(tps_scan_kernel_s7p, 7, false, true, false, 3)
+TPS_SCAN_KERNEL(tps_scan_kernel_s8p, 8, false, true, false, 3)
+TPS_SCAN_KERNEL(tps_scan_kernel_s5r, 5, false, false, true, 3)       // ... with the per-pattern raw counts (TPS_F_STORE_RAW)
+TPS_SCAN_KERNEL(tps_scan_kernel_s6r, 6, false, false, true, 3)
+TPS_SCAN_KERNEL(tps_scan_kernel_s7r, 7, false, false, true, 3)
+TPS_SCAN_KERNEL(tps_scan_kernel_s8r, 8, false, false, true, 3)
+TPS_SCAN_KERNEL(tps_scan_kernel_s5so, 5, true, false, true, 3)       // ... with self-overlapping k-mers in the table
+TPS_SCAN_KERNEL(tps_scan_kernel_s6so, 6, true, false, true, 3)
+TPS_SCAN_KERNEL(tps_scan_kernel_s7so, 7, true, false, true, 3)
+TPS_SCAN_KERNEL(tps_scan_kernel_s8so, 8, true, false, true, 3)
 
 extern "C" __global__ void __launch_bounds__(tps::NT * tps::WPG) tps_binseg_kernel(tps::BinsegArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t smem[tps::WPG * tps::BINSEG_SMEM_DW];
@@ -148,7 +152,7 @@ struct tps_ctx {
     int zero_copy = 1;       // per-read results are written by the kernel straight into mapped pinned host memory
     int force_generic = 0;
     int64_t lds_target_dw = 32 * 256;
-    size_t lds_set_v[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    size_t lds_set_v[17] = {0};
 };
 
 namespace {
@@ -295,18 +299,19 @@ int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm) {
     int kidx;
     const bool so = a.pat.so_mask != 0;
     const bool pair = a.pair_n != 0;
+    const bool rawk = !so && a.raw != nullptr;           // the raw-count variants (single lookups; the plan drops the pair table)
     switch (a.variant) {
-        case 5: kfn = so ? (const void*)tps_scan_kernel_s5so : pair ? (const void*)tps_scan_kernel_s5p : (const void*)tps_scan_kernel_s5; kidx = so ? 5 : pair ? 9 : 1; break;
-        case 6: kfn = so ? (const void*)tps_scan_kernel_s6so : pair ? (const void*)tps_scan_kernel_s6p : (const void*)tps_scan_kernel_s6; kidx = so ? 6 : pair ? 10 : 2; break;
-        case 7: kfn = so ? (const void*)tps_scan_kernel_s7so : pair ? (const void*)tps_scan_kernel_s7p : (const void*)tps_scan_kernel_s7; kidx = so ? 7 : pair ? 11 : 3; break;
-        case 8: kfn = so ? (const void*)tps_scan_kernel_s8so : pair ? (const void*)tps_scan_kernel_s8p : (const void*)tps_scan_kernel_s8; kidx = so ? 8 : pair ? 12 : 4; break;
+        case 5: kfn = so ? (const void*)tps_scan_kernel_s5so : rawk ? (const void*)tps_scan_kernel_s5r : pair ? (const void*)tps_scan_kernel_s5p : (const void*)tps_scan_kernel_s5; kidx = so ? 5 : rawk ? 13 : pair ? 9 : 1; break;
+        case 6: kfn = so ? (const void*)tps_scan_kernel_s6so : rawk ? (const void*)tps_scan_kernel_s6r : pair ? (const void*)tps_scan_kernel_s6p : (const void*)tps_scan_kernel_s6; kidx = so ? 6 : rawk ? 14 : pair ? 10 : 2; break;
+        case 7: kfn = so ? (const void*)tps_scan_kernel_s7so : rawk ? (const void*)tps_scan_kernel_s7r : pair ? (const void*)tps_scan_kernel_s7p : (const void*)tps_scan_kernel_s7; kidx = so ? 7 : rawk ? 15 : pair ? 11 : 3; break;
+        case 8: kfn = so ? (const void*)tps_scan_kernel_s8so : rawk ? (const void*)tps_scan_kernel_s8r : pair ? (const void*)tps_scan_kernel_s8p : (const void*)tps_scan_kernel_s8; kidx = so ? 8 : rawk ? 16 : pair ? 12 : 4; break;
         default: kfn = (const void*)tps_scan_kernel; kidx = 0; break;
     }
     {
-        static const char* const names[13] = {"tps_scan_kernel", "tps_scan_kernel_s5", "tps_scan_kernel_s6", "tps_scan_kernel_s7",
+        static const char* const names[17] = {"tps_scan_kernel", "tps_scan_kernel_s5", "tps_scan_kernel_s6", "tps_scan_kernel_s7",
                                               "tps_scan_kernel_s8", "tps_scan_kernel_s5so", "tps_scan_kernel_s6so", "tps_scan_kernel_s7so",
                                               "tps_scan_kernel_s8so", "tps_scan_kernel_s5p", "tps_scan_kernel_s6p", "tps_scan_kernel_s7p",
-                                              "tps_scan_kernel_s8p"};
+                                              "tps_scan_kernel_s8p", "tps_scan_kernel_s5r", "tps_scan_kernel_s6r", "tps_scan_kernel_s7r", "tps_scan_kernel_s8r"};
         sl.kernel_name = names[kidx];
     }
     if (sl.lds_bytes > c->lds_set_v[kidx]) {

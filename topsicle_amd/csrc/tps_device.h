@@ -1038,7 +1038,9 @@ struct Geo {
 // Windows beyond nw_tile (they need blocks of the next tile) are not produced.
 TPS_DEV uint32_t pack_hi_lo(uint32_t hi_src, uint32_t lo_src) { return perm(hi_src, lo_src, 0x07060100u); }
 
-template <int S, bool SO, bool INV, bool RZ, bool PAIR>
+// RAW: this instantiation can also produce the per-pattern counts (TPS_F_STORE_RAW); the kernels without it carry
+// no recount code at all unless the table has self-overlapping k-mers.
+template <int S, bool SO, bool INV, bool RZ, bool PAIR, bool RAW>
 TPS_DEV void tile_fused_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int delta, int w0, int tile, int nw_tile,
                           int64_t out_base, uint64_t& s_total, int64_t r) {
     // RZ: the window has no partial block (W - k divisible by the slide), so nothing is captured mid-block
@@ -1283,8 +1285,8 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const TileConst& tc, const Lds& l, 
         // windows that need the exact recount (overlapping occurrences of a self-overlapping k-mer, or raw
         // counts wanted) are queued: entry = tile-local window | its presence mask << 16.  The queue lives in
         // the XPC area, which no window needs any more.
-        if (SO || a.raw) {
-            if (a.raw) {
+        if (SO || (RAW && a.raw)) {
+            if (RAW && a.raw) {
                 const int nv = nfull + ((lane < npart) ? 1 : 0);
                 flags = nv >= B ? (1u << B) - 1u : (1u << nv) - 1u;
             }
@@ -1298,7 +1300,7 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const TileConst& tc, const Lds& l, 
 #endif
         }
     }
-    if (SO || a.raw) {
+    if (SO || (RAW && a.raw)) {
         TPS_SYNC();
         uint32_t* queue = l.XPC;                       // up to NT * B entries
         uint32_t* occ = l.XPC + NT * B;                // [P <= 15][4] occurrence bits of one window, + the correction
@@ -1329,7 +1331,7 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const TileConst& tc, const Lds& l, 
         TPS_SYNC();
         const int n_redo = (int)uniform(l.misc[M_NTIE]);
         int32_t* out = a.sums + (out_base + w0);
-        if (n_redo > 0 && !a.raw && n_redo <= COOP_MAX && a.lw <= 128) {
+        if (n_redo > 0 && !(RAW && a.raw) && n_redo <= COOP_MAX && a.lw <= 128) {
             // few windows: the whole wave recounts one window at a time -- lanes look up the window's positions
             // and publish per-pattern occurrence bits, one lane per pattern walks its bits greedily
             const bool inv = INV;
@@ -1383,7 +1385,7 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const TileConst& tc, const Lds& l, 
                 for (int e = tid; e < n_redo; e += NT) {
                     const uint32_t ent = queue[e];
                     const int wl = (int)(ent & 0xFFFFu);
-                    uint8_t* raw_row = a.raw ? a.raw + (out_base + w0 + wl) * (int64_t)pat.P : nullptr;
+                    uint8_t* raw_row = (RAW && a.raw) ? a.raw + (out_base + w0 + wl) * (int64_t)pat.P : nullptr;
                     const uint32_t sw = window_exact(a, l, delta, wl, ent >> 16, l.row[padded(wl, LOG2B)], raw_row);
                     l.row[padded(wl, LOG2B)] = sw;
                     out[wl] = (int32_t)sw;
@@ -1752,7 +1754,7 @@ TPS_DEV void binseg_from_lc(const ScanArgs& a, const Lds& l, uint64_t lc_g, cons
 // In the device build every lane of the wave executes this function; TPS_PHASE bodies run once
 // per lane and TPS_SYNC() is a wave-level fence.  In the emulation TPS_PHASE loops over the 64
 // lane ids, so phases run in program order.
-template <int SV, bool SO, bool PAIR = false>
+template <int SV, bool SO, bool PAIR = false, bool RAW = true>
 TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_t* lut) {
     const Lds l = carve(lds_base, lut, a);
     const PatInfo& pat = a.pat;
@@ -1949,11 +1951,11 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
                 if (w0 == 0) TPS_STAMP(5);
                 const int fdelta = st.delta + 16;      // LDS position of the tile's first base
                 if (uniform(l.misc[M_INVALID]) != 0)
-                    tile_fused_s<SV ? SV : 1, SO, true, false, false>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r);
+                    tile_fused_s<SV ? SV : 1, SO, true, false, false, RAW>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r);
                 else if (tc.r == 0)
-                    tile_fused_s<SV ? SV : 1, SO, false, true, PAIR>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r);
+                    tile_fused_s<SV ? SV : 1, SO, false, true, PAIR, RAW>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r);
                 else
-                    tile_fused_s<SV ? SV : 1, SO, false, false, PAIR>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r);
+                    tile_fused_s<SV ? SV : 1, SO, false, false, PAIR, RAW>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r);
                 if (w0 == 0) TPS_STAMP(8);
             }
         }

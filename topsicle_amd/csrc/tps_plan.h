@@ -152,7 +152,7 @@ inline std::string plan_geometry(ScanArgs& a, const tps_params& prm, int k, int 
         a.lc_global = (a.lc16 && !getenv("TPS_LC_IN_LDS")) ? 1 : 0;
         a.lc_stride = (a.lc_cap + 1) & ~1;
         // pair table (two positions per lookup) while it is small: k <= 4 -> at most 4 KB per workgroup
-        a.pair_n = (a.pat.so_mask == 0 && k <= 4 && !getenv("TPS_NO_PAIR")) ? (1 << (2 * (k + 1))) : 0;
+        a.pair_n = (a.pat.so_mask == 0 && k <= 4 && !(prm.flags & TPS_F_STORE_RAW) && !getenv("TPS_NO_PAIR")) ? (1 << (2 * (k + 1))) : 0;   // (the raw-count kernels use single lookups)
         a.blk_dw = (int32_t)blk_region_dw(a);
         if (a.pair_n && !getenv("TPS_FORCE_PAIR")) {
             // ... unless it costs a resident workgroup where one is scarce: LDS is handed out in 1280-byte granules,
