@@ -262,8 +262,8 @@ struct Lds {
     // mask << 16 | count, like the table entries, indexed by the padded block number b + b / 8
     // (lane L's blocks sit at 9 L .. 9 L + 7: conflict-free for lane-contiguous AND lane-strided access)
     uint32_t* XPC;     // per block: OR of the lane's earlier blocks and r positions of this one | lane-local count there
-    uint32_t* XF;      // [xlanes] OR of all the lane's block masks (high half)
-    uint32_t* XT;      // [xlanes] matches in the lane's span, then exclusive prefix over lanes
+    uint32_t* XF;      // [XLANES] OR of all the lane's block masks (high half)
+    uint32_t* XT;      // [XLANES] matches in the lane's span, then exclusive prefix over lanes
     // after phase 1b XF / XT hold, per START lane: OR of the whole lanes a window skips | matches they add,
     // for the near (XF) and the far (XT) end lane
     uint32_t* Tot;     // per span: matches in the span, then exclusive prefix over spans
@@ -274,9 +274,9 @@ struct Lds {
     uint32_t* misc;
 };
 constexpr int XLANES = NT + 16;                  // most lanes an exchange row can hold: NT + halo lanes read past the tile end
-TPS_HD int xlanes(const ScanArgs& a) { return (NT + (a.q >> 3) + 2 + 1) & ~1; }   // ... and what this window geometry needs
 TPS_HD int64_t xchg_dw(const ScanArgs& a) {      // fused path: XPC (9 words per lane), XF, XT
-    return 9ll * NT + 2ll * xlanes(a);
+    (void)a;
+    return 9ll * NT + 2ll * XLANES;
 }
 TPS_HD int64_t blk_region_dw(const ScanArgs& a) {
     // generic kernel: G, Gp (u32) and C0, C1 (u16) per block; fused kernels: the exchange arrays
@@ -316,7 +316,7 @@ TPS_DEV Lds carve(uint32_t* base, uint32_t* lut, const ScanArgs& a) {
     l.C1 = l.C0 + ((a.nblk_cap + 1) / 2) * 2;
     l.XPC = l.blk;
     l.XF = l.XPC + 9 * NT;
-    l.XT = l.XF + xlanes(a);
+    l.XT = l.XF + XLANES;
     return l;
 }
 TPS_HD int64_t lds_dwords(const ScanArgs& a) {
@@ -1021,6 +1021,33 @@ struct Geo {
     static constexpr int TILE_DW = ((NT - 1) * POS + 13 + 15 + 15) / 16 + 1;
     static constexpr int PF = (TILE_DW + NT - 1) / NT;
 };
+
+// LDS slice of a wave in the fused kernels: everything whose size is known at compile time comes first, at
+// compile-time offsets from the slice base (one SGPR for all of it, offsets folded into the DS instructions);
+// only the candidate / tile sums, whose size depends on the longest read, follow.  Sizes = plan_geometry's.
+template <int S>
+TPS_DEV Lds carve_fused(uint32_t* base, uint32_t* lut, const ScanArgs& a) {
+    constexpr int BLK = 9 * NT + 2 * XLANES, ROW = NT * Geo<S>::B + NT, SEQ = Geo<S>::PF * NT + 4, VAL = ((SEQ + 4 + 3) / 4) * 2;
+    Lds l;
+    l.lut2 = lut - a.pair_n;
+    l.lut = lut;
+    l.lshift = 16;
+    l.blk = base;
+    l.XPC = base;
+    l.XF = base + 9 * NT;
+    l.XT = l.XF + XLANES;
+    l.G = l.Gp = base; l.C0 = l.C1 = (uint16_t*)base;      // generic-path views: unused here
+    l.row = base + BLK;
+    l.misc = l.row + ROW;
+    l.Tot = l.misc + MISC_DW;
+    l.seq2 = l.Tot + 2;
+    l.val = (uint16_t*)(l.seq2 + SEQ);
+    uint32_t* p = l.seq2 + SEQ + VAL;
+    l.Lc = p;
+    l.Lc16 = (uint16_t*)p;
+    l.Tc = p + ((a.lc16 && a.lc_global) ? 0 : ((a.lc_cap + 3) / 4) * 2);
+    return l;
+}
 
 // One fused tile: NT lanes x B blocks.
 //   phase 1  (lane-contiguous) a lane scans its B blocks with the packed bases in registers and
@@ -1756,7 +1783,7 @@ TPS_DEV void binseg_from_lc(const ScanArgs& a, const Lds& l, uint64_t lc_g, cons
 // lane ids, so phases run in program order.
 template <int SV, bool SO, bool PAIR = false, bool RAW = true>
 TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_t* lut) {
-    const Lds l = carve(lds_base, lut, a);
+    const Lds l = SV ? carve_fused<SV ? SV : 5>(lds_base, lut, a) : carve(lds_base, lut, a);
     const PatInfo& pat = a.pat;
     const tps_params& prm = a.prm;
     const int64_t off = a.offsets[r];

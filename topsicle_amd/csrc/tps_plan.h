@@ -128,7 +128,8 @@ inline std::string plan_geometry(ScanArgs& a, const tps_params& prm, int k, int 
     int max_period = 0;                            // self-overlap periods of the table (0 = none)
     for (int i = 0; i < a.pat.n_periods; ++i) max_period = std::max(max_period, a.pat.period[i]);
     const bool fused = !force_generic && spans_pref <= 0 && k <= TPS_DIRECT_K && has_specialised_slide(prm.slide) && P <= 15 && a.q >= 8 &&
-                       a.q / 8 + 2 < (XLANES - NT) && max_period <= std::min(prm.slide, 6);
+                       a.q / 8 + 2 < (XLANES - NT) && max_period <= std::min(prm.slide, 6) &&
+                       2 * a.head_dw <= ((((int)NT - 1) * 8 * prm.slide + 43) / 16 + 1 + (int)NT - 1) / (int)NT * (int)NT + 4;   // heads fit the tile buffer
     a.lc16 = 0; a.tile_cap = 0; a.tw = 0; a.tw_magic = 0; a.pair_n = 0; a.lc_global = 0; a.lc_stride = 0;
     if (fused) {
         a.variant = prm.slide;
@@ -141,7 +142,7 @@ inline std::string plan_geometry(ScanArgs& a, const tps_params& prm, int k, int 
         const int pos = 8 * prm.slide;
         const int tile_dw = ((NT - 1) * pos + 13 + 15 + 15) / 16 + 1;     // = Geo<S>::TILE_DW
         const int pf = (tile_dw + NT - 1) / NT;                            // = Geo<S>::PF
-        a.seq_dw = std::max(pf * (int)NT + 4, 2 * a.head_dw);
+        a.seq_dw = pf * (int)NT + 4;               // compile-time size in the kernel (carve_fused); the heads fit (see `fused`)
         // candidate left sums as u16 relative to their tile when a tile's window sums cannot reach 2^16
         // (every position matches at most one list pattern: S_w <= lw + P)
         a.tw = (int)NT * 8 - a.q - 1 - 8;
