@@ -165,6 +165,20 @@ TPS_DEV uint32_t g16_load(uint64_t base, uint32_t i) {
 }
 #endif
 
+#ifdef TPS_EMU
+TPS_DEV void g32_store(uint64_t base, uint32_t i, uint32_t v) { ((uint32_t*)(uintptr_t)base)[i] = v; }
+TPS_DEV uint32_t g32_load(uint64_t base, uint32_t i) { return ((const uint32_t*)(uintptr_t)base)[i]; }
+#else
+TPS_DEV void g32_store(uint64_t base, uint32_t i, uint32_t v) {
+    typedef __attribute__((address_space(1))) uint32_t* gp_t;
+    ((gp_t)(uintptr_t)base)[i] = v;
+}
+TPS_DEV uint32_t g32_load(uint64_t base, uint32_t i) {
+    typedef const __attribute__((address_space(1))) uint32_t* gp_t;
+    return ((gp_t)(uintptr_t)base)[i];
+}
+#endif
+
 constexpr int cgcd(int a, int b) { return b == 0 ? a : cgcd(b, a % b); }
 constexpr int clog2(int x) { return x <= 1 ? 0 : 1 + clog2(x / 2); }
 
@@ -223,7 +237,7 @@ struct ScanArgs {
     // fused path, 16-bit candidate sums: Lc16[c] = left sum of candidate c counted from its tile's first
     // window, Tc[t] = sum of S_w before tile t; tile of window w = mulhi(w, tw_magic)
     int32_t lc16;                // 1 = Lc16 + Tc instead of the u32 Lc
-    int32_t lc_global;           // (lc16) 1 = Lc16 lives off-chip in lc_scratch (lc_stride entries per read): 1 kB of L2 traffic per
+    int32_t lc_global;           // 1 = the candidate sums (Lc16, or the generic kernel's 32-bit Lc) live off-chip in lc_scratch (lc_stride entries per read): 1 kB of L2 traffic per
     int32_t lc_stride;           //        read instead of 1 kB of LDS per wave -> one more resident workgroup per CU
     uint16_t* lc_scratch;
     int32_t pair_n;              // 0, or 4^(k+1): entries of the pair table (two adjacent positions per lookup)
@@ -288,7 +302,7 @@ TPS_HD int64_t blk_region_dw(const ScanArgs& a) {
 TPS_HD int64_t val_dw(const ScanArgs& a) { return ((a.seq_dw + 4 + 3) / 4) * 2; }   // u16 per 16 positions (+ look-ahead), even
 TPS_HD int64_t lc_dw(const ScanArgs& a) {          // even dword counts keep misc 8-byte aligned
     if (a.lc16) return (a.lc_global ? 0 : ((a.lc_cap + 3) / 4) * 2) + ((a.tile_cap + 1) / 2) * 2;
-    return ((a.lc_cap + 1) / 2) * 2;
+    return a.lc_global ? 0 : ((a.lc_cap + 1) / 2) * 2;        // generic kernel: absolute 32-bit sums, also off-chip by default
 }
 TPS_HD int64_t row_dw(const ScanArgs& a) {
     const int64_t fused = a.variant ? ((int64_t)NT << a.blk_log2) + NT : 0;      // + one pad word per lane
@@ -971,7 +985,7 @@ TPS_DEV void windows_group(const ScanArgs& a, const Lds& l, int delta, int w0, i
 TPS_DEV uint32_t div_jump(uint32_t w, uint32_t magic) { return magic ? (uint32_t)(((uint64_t)w * magic) >> 32) : w; }
 // After the in-place exclusive scan of row[]: lane `tid` records the left sums of the change-point
 // candidates among its windows (global window index divisible by jump).
-TPS_DEV void candidates_group(const ScanArgs& a, const Lds& l, int w0, int nw_tile, int base, uint32_t carry, int tid) {
+TPS_DEV void candidates_group(const ScanArgs& a, const Lds& l, uint64_t lc_g, int w0, int nw_tile, int base, uint32_t carry, int tid) {
     const uint32_t jump = (uint32_t)a.prm.jump;
     TPS_UNROLL
     for (int u = 0; u < WIN_U; ++u) {
@@ -979,7 +993,10 @@ TPS_DEV void candidates_group(const ScanArgs& a, const Lds& l, int w0, int nw_ti
         if (wl < nw_tile) {
             const uint32_t w = (uint32_t)(w0 + wl);
             const uint32_t c = div_jump(w, a.jump_magic);
-            if (c * jump == w && (int)c < a.lc_cap) l.Lc[c] = carry + l.row[u * NT + tid];
+            if (c * jump == w && (int)c < a.lc_cap) {
+                if (lc_g) g32_store(lc_g, c, carry + l.row[u * NT + tid]);
+                else l.Lc[c] = carry + l.row[u * NT + tid];
+            }
         }
     }
 }
@@ -1709,7 +1726,7 @@ TPS_DEV void binseg_from_lc(const ScanArgs& a, const Lds& l, uint64_t lc_g, cons
         };
         auto tile_sum = [&](int c) { return l.Tc[(uint32_t)(((uint64_t)(uint32_t)(c * jump) * a.tw_magic) >> 32)]; };
         constexpr int LCV = 16;
-        if (lc_g && c_max - c_min < LCV * NT) {
+        if (a.lc16 && lc_g && c_max - c_min < LCV * NT) {
             // off-chip 16-bit sums: all of the lane's values are requested before the first one is used
             uint32_t lcv[LCV];
             TPS_UNROLL
@@ -1727,7 +1744,7 @@ TPS_DEV void binseg_from_lc(const ScanArgs& a, const Lds& l, uint64_t lc_g, cons
             for (int c = c_min + tid; c <= c_max; c += NT) {
                 uint32_t lc;
                 if (a.lc16) lc = tile_sum(c) + (lc_g ? g16_load(lc_g, (uint32_t)c) : (uint32_t)l.Lc16[c]);
-                else lc = l.Lc[c];
+                else lc = lc_g ? g32_load(lc_g, (uint32_t)c) : l.Lc[c];
                 offer(c, lc);
             }
         }
@@ -1880,6 +1897,7 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
         const int64_t out_base = a.win_off ? a.win_off[r] : 0;
         if constexpr (SV == 0) {
             // ---------------- generic tiles: spans_per_tile spans of span_dw dwords each
+            const uint64_t lc_gen = a.lc_global ? (uint64_t)(uintptr_t)(a.lc_scratch + r * (int64_t)a.lc_stride) : 0ull;
             const int blk_per_tile = a.spans_per_tile << a.blk_log2;
             const int tw = blk_per_tile - a.q - 1;     // windows per tile
             for (int w0 = 0; w0 < n_win; w0 += tw) {
@@ -1909,7 +1927,7 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
                     TPS_PHASE { windows_group(a, l, st.delta, w0, nw_tile, out_base, base, tid); }
                     TPS_SYNC();
                     const uint32_t gsum = wg_exclusive_scan(l.row, WIN_U * NT, &l.misc[M_SCAN]);
-                    TPS_PHASE { candidates_group(a, l, w0, nw_tile, base, (uint32_t)s_total, tid); }
+                    TPS_PHASE { candidates_group(a, l, lc_gen, w0, nw_tile, base, (uint32_t)s_total, tid); }
                     s_total += gsum;
                     TPS_SYNC();
                 }
@@ -1998,7 +2016,7 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
         // loads (an agent-scope fence writes the L2 back: measured 5x slower)
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 #endif
-        const uint64_t lc_g = (SV != 0 && a.lc16 && a.lc_global) ? (uint64_t)(uintptr_t)(a.lc_scratch + r * (int64_t)a.lc_stride) : 0ull;
+        const uint64_t lc_g = a.lc_global ? (uint64_t)(uintptr_t)(a.lc_scratch + r * (int64_t)a.lc_stride) : 0ull;
         binseg_from_lc(a, l, lc_g, a.sums + (a.win_off ? a.win_off[r] : 0), n_win, s_total, prm.jump, prm.min_size, pat.P,
                        l.misc, l.blk, bkp, gain);
         res.bkp = bkp;

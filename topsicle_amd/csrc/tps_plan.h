@@ -171,6 +171,9 @@ inline std::string plan_geometry(ScanArgs& a, const tps_params& prm, int k, int 
         a.lc16 = 0; a.tile_cap = 0; a.tw = 0; a.tw_magic = 0; a.pair_n = 0; a.lc_global = 0; a.lc_stride = 0;
     }
     a.variant = 0;
+    // the generic kernel's 32-bit candidate sums go off-chip too (stride counted in 16-bit units)
+    a.lc_global = getenv("TPS_LC_IN_LDS") ? 0 : 1;
+    a.lc_stride = 2 * ((a.lc_cap + 1) & ~1);
     const int g = gcd_i(prm.slide, 16);
     a.span_dw = prm.slide / g;
     const int bps = 16 / g;
