@@ -80,7 +80,12 @@ def profiled_traffic(workload):
     import glob
     if workload != "config2":
         return None, None
-    for d in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*")), reverse=True):
+    import re
+
+    def version(d):                      # profiles/r<round>_v<version>_<name>
+        m = re.match(r"r(\d+)_v(\d+)", os.path.basename(d))
+        return (int(m.group(1)), int(m.group(2))) if m else (-1, -1)
+    for d in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*")), key=version, reverse=True):
         f = os.path.join(d, "pmc_per_launch_mean.csv")
         if not os.path.exists(f):
             continue
