@@ -44,6 +44,14 @@ CONFIGS = {
     "config4_1pct": dict(n_reads=10000, read_len=30000, motif="CCCTAA", k=4, window=100, slide=6,
                          errors=synth.ONT, seed=20250919 + 3, telomeric_fraction=0.01,
                          desc="BASELINE configs[3] sample, 1 % of the reads telomeric (the step-1-dominated regime of real WGS data)"),
+    # BASELINE configs[4] runs one pass per k (--telophrase 4 5 6) with --rawcountpattern: a sample of one GPU's shard per k
+    # (add --flags 31 for the raw counts; k = 5 and 6 use tables with self-overlapping k-mers)
+    "config5_k4": dict(n_reads=10000, read_len=25000, motif="CCCTAA", k=4, window=100, slide=6, errors=synth.ONT, seed=20250919 + 4,
+                       desc="BASELINE configs[4] sample, k=4 pass: 10k synthetic ONT reads x 25 kb, --pattern CCCTAA"),
+    "config5_k5": dict(n_reads=10000, read_len=25000, motif="CCCTAA", k=5, window=100, slide=6, errors=synth.ONT, seed=20250919 + 4,
+                       desc="BASELINE configs[4] sample, k=5 pass: 10k synthetic ONT reads x 25 kb, --pattern CCCTAA"),
+    "config5_k6": dict(n_reads=10000, read_len=25000, motif="CCCTAA", k=6, window=100, slide=6, errors=synth.ONT, seed=20250919 + 4,
+                       desc="BASELINE configs[4] sample, k=6 pass: 10k synthetic ONT reads x 25 kb, --pattern CCCTAA"),
     "config3_per_gpu": dict(n_reads=25000, read_len=20000, motif="AAACCCT", k=5, window=100, slide=7,
                             errors=synth.HIFI, seed=20250919 + 2,
                             desc="BASELINE configs[2] shard: 25k synthetic HiFi reads x 20 kb per GPU, --pattern AAACCCT"),

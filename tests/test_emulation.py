@@ -330,3 +330,75 @@ def test_emulation_other_jump_values(jump, min_size, slide):
         assert np.array_equal(out["sums"][lo:hi], counts.sum(axis=1))
         want = orc.binseg_l2_exact(counts.sum(axis=1), jump, min_size)
         assert out["results"][i]["bkp"] == (-1 if want is None else want), (jump, min_size, i)
+
+
+def _pp_reads(rng, motif, k, n, L, chain_units):
+    """Telomere-like reads peppered with single-base deletions (pairs of overlapping k-mers), short and long runs
+    of the k-mers' own period (chains of 3+ overlapping occurrences) and random sequence."""
+    pats = orc.kmer_table(motif, k)
+    seqs = []
+    for i in range(n):
+        body = []
+        while len(body) < L:
+            u = rng.random()
+            if u < 0.55:
+                rep = list(motif * int(rng.integers(3, 60)))
+                for _ in range(int(rng.integers(0, 6))):          # deletions / substitutions inside the repeat
+                    p = int(rng.integers(0, len(rep)))
+                    if rng.random() < 0.7:
+                        del rep[p]
+                    else:
+                        rep[p] = "ACGT"[int(rng.integers(4))]
+                body += rep
+            elif u < 0.75 and chain_units:
+                unit = chain_units[int(rng.integers(len(chain_units)))]
+                body += list(unit * int(rng.integers(2, 40)))       # (CCTAA)n-like run: one long chain
+            else:
+                body += ["ACGT"[x] for x in rng.integers(0, 4, int(rng.integers(5, 400)))]
+        seqs.append("".join(body[:L]))
+    return pats, seqs
+
+
+@pytest.mark.parametrize("motif,k,slide,units", [
+    ("CCCTAA", 5, 6, ["CTAA", "GATT"]),          # CTAAC / GATTG: period 4
+    ("CCCTAA", 6, 6, ["CCTAA", "GGATT", "CTAAC"]),   # CCTAAC, CTAACC + complements: period 5
+    ("CCCTAA", 6, 5, ["CCTAA"]),
+    ("CCCTAA", 6, 7, ["CCTAA", "GGATT"]),
+    ("CCCTAA", 6, 8, ["CCTAA"]),
+    ("TTTAGGG", 7, 6, ["TTTAGG", "AAATCC"]),     # period 6 (GGTTTAG ...)
+    ("TTAGGG", 5, 5, ["TTAG", "AATC"]),           # GTTAG: period 4
+    ("CCCTAA", 4, 6, []),                         # no self-overlap: raw counts only
+    ("AAACCCT", 5, 7, []),
+])
+def test_emulation_per_pattern_tiles(motif, k, slide, units):
+    """tile_pp_s: exact per-pattern counts without recounting (canonical picks + start skips), raw and sums-only,
+    both tails, several tiles per read, reads with and without non-ACGT letters."""
+    rng = np.random.default_rng(sum(map(ord, motif)) * 1000 + 10 * k + slide)
+    pats, seqs = _pp_reads(rng, motif, k, 4, 9000, units)
+    seqs[3] = seqs[3][:4000] + "N" + seqs[3][4001:]                  # one tile of read 3 falls back to the recount path
+    so = any(p[:d] == p[-d:] for p in pats for d in range(1, k))
+    L = emu.lib()
+    tails = [0, 1, 0, 1]
+    for raw in (1, 0):
+        if not raw and not so:
+            continue
+        flags = hiplib.F_WINDOWS | hiplib.F_BINSEG | hiplib.F_TAILS_IN | hiplib.F_STORE_SUMS | (hiplib.F_STORE_RAW if raw else 0)
+        prm = hiplib.make_params(window=100, slide=slide, trimfirst=100, maxlen=20000, flags=flags)
+        t0, r0 = L.emu_counter(0), L.emu_counter(1)
+        out = emu.scan(pats, seqs, prm, tails=tails, base_shift=int(rng.integers(16)))
+        tiles, redone = L.emu_counter(0) - t0, L.emu_counter(1) - r0
+        assert tiles >= 8, "per-pattern tiles were not used"
+        nwin_total = 0
+        for i, seq in enumerate(seqs):
+            _, counts = orc.window_count_matrix(seq, ["forward", "reverse"][tails[i]], pats, 100, slide, 100, 20000)
+            lo, hi = out["win_off"][i], out["win_off"][i + 1]
+            nwin_total += hi - lo
+            assert hi - lo == counts.shape[0]
+            assert np.array_equal(out["sums"][lo:hi], counts.sum(axis=1)), (i, raw)
+            if raw:
+                assert np.array_equal(out["raw"][lo:hi], counts), (i, raw)
+            assert out["results"][i]["bkp"] == orc.binseg_l2_exact(counts.sum(axis=1))
+        # recounts only where three or more occurrences chain (the planted runs): far fewer than the windows
+        assert redone < nwin_total // 2, (redone, nwin_total)
+        if not units:
+            assert redone == 0

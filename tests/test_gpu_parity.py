@@ -378,3 +378,37 @@ def test_error_paths_are_loud(sc):
     sc.scan(9, hiplib.make_params(min_len=0, min_count=-1))   # and the context is still usable afterwards
     sc.sync()
     assert sc.results(9)["n_win"][0] == hiplib.window_count(2000, 100, 6, 100, 20000)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("motif,k,slide,units", [
+    ("CCCTAA", 5, 6, ["CTAA", "GATT"]),
+    ("CCCTAA", 6, 6, ["CCTAA", "GGATT", "CTAAC"]),
+    ("CCCTAA", 6, 5, ["CCTAA"]),
+    ("CCCTAA", 6, 8, ["CCTAA"]),
+    ("TTTAGGG", 7, 6, ["TTTAGG", "AAATCC"]),
+    ("TTAGGG", 5, 5, ["TTAG", "AATC"]),
+    ("CCCTAA", 4, 6, []),
+    ("AAACCCT", 5, 7, []),
+])
+def test_per_pattern_tiles_chains_and_raw_rows(sc, motif, k, slide, units):
+    """The per-pattern tiles (exact counts without recounting: canonical picks, start skips, chain-parity repairs,
+    look-back walks; raw rows staged through LDS) on reads full of deletions and runs of the k-mers' own period."""
+    from test_emulation import _pp_reads
+    rng = np.random.default_rng(sum(map(ord, motif)) * 1000 + 10 * k + slide + 7)
+    pats, seqs = _pp_reads(rng, motif, k, 24, 14000, units)
+    seqs[5] = seqs[5][:4000] + "N" + seqs[5][4001:]
+    tails = [int(x) for x in rng.integers(0, 2, len(seqs))]
+    sc.set_patterns(pats)
+    bases, offsets = hiplib.pack_reads(seqs)
+    sums, win_off, raw = sc.window_counts(bases, offsets, tails, 100, slide, 100, 20000, raw=True)
+    sums2, win_off2, _ = sc.window_counts(bases, offsets, tails, 100, slide, 100, 20000, raw=False)
+    bkp, _ = sc.binseg_l2(sums, win_off, len(pats))
+    assert np.array_equal(win_off, win_off2) and np.array_equal(sums, sums2)
+    for i, seq in enumerate(seqs):
+        _, counts = orc.window_count_matrix(seq, ["forward", "reverse"][tails[i]], pats, 100, slide, 100, 20000)
+        lo, hi = win_off[i], win_off[i + 1]
+        assert hi - lo == counts.shape[0]
+        assert np.array_equal(raw[lo:hi], counts.reshape(-1, len(pats))), i
+        assert np.array_equal(sums[lo:hi], counts.sum(axis=1)), i
+        assert bkp[i] == orc.binseg_l2_exact(counts.sum(axis=1))

@@ -36,6 +36,7 @@
 #define TPS_UNROLL
 #define TPS_NOVEC
 #define TPS_PIN_S(x) ((void)0)
+#define TPS_PIN_V(x) ((void)0)
 #else
 #define TPS_DEV __device__ __forceinline__
 #define TPS_HD __host__ __device__ inline
@@ -62,6 +63,9 @@ __device__ __forceinline__ int tps_fresh_lane() {
 // zero-cost "redefinition" of a wave-uniform value: it stays in an SGPR (or a VGPR lane) instead of being re-loaded from the
 // kernel-argument segment inside a loop (an s_load + s_waitcnt that also drains the LDS queue)
 #define TPS_PIN_S(x) asm volatile("" : "+s"(x))
+// the same for a per-lane value: it is computed HERE (the compiler otherwise sinks pure arithmetic past the wave barrier
+// of the next phase and keeps all its inputs alive across it)
+#define TPS_PIN_V(x) asm volatile("" : "+v"(x))
 #endif
 
 namespace tps {
@@ -244,6 +248,8 @@ struct ScanArgs {
     int32_t tile_cap;            // entries of Tc (tiles of the longest read)
     int32_t tw;                  // windows per fused tile
     uint32_t tw_magic;           // ceil(2^32 / tw)
+    int32_t pp_d;                // per-pattern tiles (tile_pp_s): -1 = not eligible, 0 = no self-overlapping k-mer,
+                                 // d > 0 = the one self-overlap period of the table
 };
 
 struct BinsegArgs {
@@ -904,13 +910,14 @@ TPS_DEV void scan_positions(const Lds& l, const PatInfo& pat, int q0, int npos, 
 //   sums only : S_w = fast S_w - sum over present self-overlapping patterns of (occurrences - greedy)
 //   raw counts: one pass accumulates all occurrence counts in packed bytes, then the present
 //               self-overlapping patterns are recounted greedily; zeros are floored to 1.
+//   full      : the raw-count procedure without a row to store (present = every pattern that may overlap).
 TPS_DEV uint32_t window_exact(const ScanArgs& a, const Lds& l, int delta, int wl, uint32_t present, uint32_t fast_sw,
-                              uint8_t* raw_row) {
+                              uint8_t* raw_row, bool full = false) {
     const PatInfo& pat = a.pat;
     const bool inv = l.misc[M_INVALID] != 0;
     const int q0 = delta + wl * a.prm.slide;
     uint32_t redo = present & pat.so_mask;
-    if (!raw_row) {
+    if (!raw_row && !full) {
         uint32_t sum = fast_sw;
         while (redo) {
             const int bit = ffs0(redo);
@@ -951,7 +958,7 @@ TPS_DEV uint32_t window_exact(const ScanArgs& a, const Lds& l, int delta, int wl
             c = greedy;
         }
         if (c == 0) c = 1;                         // `matches or 1` (allsteps.py:281, 288)
-        raw_row[b] = (uint8_t)c;
+        if (raw_row) raw_row[b] = (uint8_t)c;
         sum += (uint32_t)c;
     }
     return sum;
@@ -980,6 +987,14 @@ TPS_DEV void windows_group(const ScanArgs& a, const Lds& l, int delta, int w0, i
         l.row[u * NT + tid] = sw;
     }
 }
+
+// high half of a 32 x 32-bit product (v_mul_hi_u32, full rate) and the sum of the four bytes of a word (v_sad_u8)
+TPS_DEV uint32_t mulhi32(uint32_t x, uint32_t y) { return (uint32_t)(((uint64_t)x * (uint64_t)y) >> 32); }
+#ifdef TPS_EMU
+TPS_DEV uint32_t add_bytes(uint32_t v, uint32_t acc) { return acc + (v & 255u) + ((v >> 8) & 255u) + ((v >> 16) & 255u) + (v >> 24); }
+#else
+TPS_DEV uint32_t add_bytes(uint32_t v, uint32_t acc) { return __builtin_amdgcn_sad_u8(v, 0u, acc); }
+#endif
 
 // w / jump by the host-supplied magic multiplier (jump == 1 has no 32-bit magic: ceil(2^32 / 1) = 2^32)
 TPS_DEV uint32_t div_jump(uint32_t w, uint32_t magic) { return magic ? (uint32_t)(((uint64_t)w * magic) >> 32) : w; }
@@ -1473,6 +1488,466 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const TileConst& tc, const Lds& l, 
     TPS_SYNC();
 }
 
+// After the window phase of a fused tile (row[] = S_w of the tile's windows, padded layout, 0 beyond nw_tile):
+// exclusive scan of row[] and the left sums of the tile's change-point candidates (phase 3 of tile_fused_s).
+TPS_DEV void tile_candidates(const TileConst& tc, const Lds& l, int w0, int tile, int nw_tile, uint64_t& s_total) {
+    constexpr int B = 8, LOG2B = 3;
+    const uint32_t gsum = wg_exclusive_scan(l.row, NT * B, &l.misc[M_SCAN], LOG2B);
+    const uint32_t jump = tc.jump;
+    const uint32_t c_lo = div_jump((uint32_t)w0 + jump - 1u, tc.jump_magic);
+    uint32_t c_hi = div_jump((uint32_t)(w0 + nw_tile) + jump - 1u, tc.jump_magic);
+    if (c_hi > tc.lc_cap) c_hi = tc.lc_cap;
+    const int passes = c_hi > c_lo ? (int)((c_hi - c_lo + NT - 1) / NT) : 0;
+    TPS_PHASE {
+        const uint32_t carry = (uint32_t)s_total;
+        if (tc.lc16 && tid == 0) l.Tc[tile] = carry;
+        uint32_t c = c_lo + (uint32_t)tid;
+        uint32_t w = c * jump - (uint32_t)w0;
+        TPS_NOVEC
+        for (int t = 0; t < passes; ++t) {
+            if (c < c_hi) {
+                const uint32_t pre = l.row[w + (w >> LOG2B)];
+                if (tc.lc16) {
+                    if (tc.lc_g) g16_store(tc.lc_g, c, pre);
+                    else l.Lc16[c] = (uint16_t)pre;
+                } else {
+                    l.Lc[c] = carry + pre;
+                }
+            }
+            c += NT;
+            w += NT * jump;
+        }
+    }
+    s_total += gsum;
+    TPS_SYNC();
+}
+
+// ------------------------------------------------------------------ step 2, per-pattern tiles
+// The exact per-pattern counts c_p of every window (rawCountPattern, allsteps.py:398-411) -- and S_w = sum of
+// max(c_p, 1) from them -- without recounting windows, also for tables whose k-mers can overlap themselves.
+//
+// Counting: a table entry e = 1 << (16 + p) | 1 squares to mulhi(e, e) = 1 << 2p: a one-hot 2-bit field per
+// pattern (no duplicate k-mers in the list).  A block (S <= 8 positions, k >= 4) holds at most 2 non-overlapping
+// occurrences of a pattern, a lane's 8 blocks at most 14: block counts add up in 2-bit fields, lane-local
+// prefixes in nibbles (even / odd patterns in two words), window totals in bytes.
+//
+// Self-overlap (D > 0: the table's k-mers have exactly one period D < k, so 2 D >= k): re.finditer counts
+// leftmost non-overlapping occurrences.  CANONICAL picks are the greedy choice from the head of every chain of
+// overlapping occurrences: pick(p) = occ(p) & ~pick(p - D).  A window that does not start inside a chain sees
+// exactly the canonical picks among its start positions (cutting a chain at the window's END keeps its head).
+// A window whose first occurrence of pattern p is a canonically SKIPPED one (blocked by a pick before the window's
+// first position) picks it instead: one more than canonical if the chain ends there -- the block publishes these
+// "start skips" and the window adds them -- and only if the chain goes on (three or more chained occurrences,
+// e.g. a (CCTAA)n run at k = 6) the window is recounted exactly.
+// A lane learns the picks before its first position from a look-back over the previous lane's last 16 positions
+// (recursion from "nothing picked"; exact unless one pattern chains through the whole look-back: then the
+// windows that touch this lane are recounted).  The first lane of a tile takes the state the previous tile left.
+//
+//   phase 1  (lane-contiguous) picks of the lane's 8 blocks; publishes per block END[b] = lane-local nibble counts
+//            before block b + its first r positions, per lane the nibble totals; keeps V[b] = 14 - counts before
+//            block b + start skips (nibbles) and the recount flags in registers
+//   phase 2  (lane-contiguous) window 8 L + j = own lane from block j on + whole lanes in between + END[8 L + j + q]:
+//            bytes, floored to 1, summed (S_w), transposed into pattern order, stored
+//   phase 3  tile_candidates
+#ifdef TPS_EMU
+inline int& emu_counter(int i) { static int c[4] = {0, 0, 0, 0}; return c[i]; }   // tests: 0 = per-pattern tiles, 1 = windows recounted there
+#endif
+template <int S>
+struct GeoPP {
+    static constexpr int B = 8, POS = B * S, LBK = 16;
+    // base before the look-back + look-back + positions + chain look-ahead (<= 6) + last k-mer (<= 7 bases)
+    static constexpr int WDW = (1 + LBK + POS + 6 + 7 + 15) / 16;
+};
+constexpr uint32_t PP_BIAS = 14;                  // V nibbles = PP_BIAS - prefix + start skips, all in 0..15
+TPS_DEV void pp_expand(uint32_t ne, uint32_t no, uint32_t* b) {   // nibble words (even / odd patterns) -> 4 byte words
+    b[0] = ne & 0x0F0F0F0Fu;                      // patterns 0, 4, 8, 12
+    b[1] = (ne >> 4) & 0x0F0F0F0Fu;               // patterns 2, 6, 10, 14
+    b[2] = no & 0x0F0F0F0Fu;                      // patterns 1, 5, 9, 13
+    b[3] = (no >> 4) & 0x0F0F0F0Fu;               // patterns 3, 7, 11, 15
+}
+
+template <int S, int D>
+TPS_DEV void tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int delta, int w0, int tile, int nw_tile,
+                       int64_t out_base, uint64_t& s_total) {
+    typedef GeoPP<S> g_;
+    constexpr int WDW = g_::WDW, B = g_::B, POS = g_::POS, LBK = g_::LBK;
+    constexpr int DH = D > 0 ? D : 1;
+    constexpr int AHEAD = (D > 0 && 2 * D > S) ? 2 * D - S : 0;   // positions past the lane whose occurrences close a start-skip chain
+    constexpr uint32_t M3 = 0x33333333u;
+    const PatInfo& pat = a.pat;
+    const int rp = tc.r, q = tc.q;
+    const uint32_t amask = pat.kmask << 2;
+    uint32_t* ende = l.XPC;                       // END, even patterns (padded block index)
+    uint32_t* endo = l.row;                       // END, odd patterns; S_w takes the place after phase 2
+    uint32_t* tne = l.XF;                         // per lane: nibble totals
+    uint32_t* tno = l.XT;
+    uint32_t* carry = l.misc + M_SCAN;            // [0, 6): picks of the D positions before the next tile's first; [6]: uncertain
+    const int cblk = a.tw & (B - 1), clane = a.tw >> 3;
+#ifdef TPS_EMU
+    uint32_t keep[NT][2 * B + 3];
+    ++emu_counter(0);
+#endif
+    uint32_t ve[B], vo[B], chm = 0, chw = 0, unc = 0;
+    TPS_PHASE {
+        const int span = tid;
+        const int p0 = delta + span * POS;        // >= 16
+        const uint32_t sh2 = (uint32_t)((p0 - 1) & 15) * 2u;
+        const int d0 = ((p0 - 1) >> 4) - 1;       // >= -1: lane 0 may read one dword before seq2 (its look-back is discarded)
+        uint32_t w[WDW];
+        {
+            uint32_t prev = l.seq2[d0];
+            TPS_UNROLL
+            for (int i = 0; i < WDW; ++i) {
+                uint32_t nx = l.seq2[d0 + i + 1];
+                w[i] = alignbit(nx, prev, sh2);
+                prev = nx;
+            }
+        }
+        // one-hot field of the pattern that starts at position p (relative to the lane's first, -16 <= p)
+        auto look = [&](int p) -> uint32_t {
+            const int idx = p + LBK, dw = idx >> 4, bit = idx & 15;
+            const uint32_t v4 = bit ? alignbit(dw + 1 < WDW ? w[dw + 1] : 0u, w[dw], 2u * bit) : w[dw];
+            const uint32_t h = lut_at(l.lut, v4, amask);
+            return mulhi32(h, h);
+        };
+        uint32_t pk[LBK + POS + AHEAD + 1];       // picks, index p + LBK (registers: only the last D are live)
+        uint32_t tv[POS + 1];                     // skips
+        if (D > 0) {
+            uint32_t ca[LBK];                     // same pattern at p, p - D, p - 2 D, ... down to the look-back's start
+            TPS_UNROLL
+            for (int i = 0; i < LBK; ++i) {
+                const uint32_t h = look(i - LBK);
+                if (i >= DH) {
+                    pk[i] = h ^ (h & pk[i - DH]);
+                    ca[i] = h & ca[i - DH];
+                } else {
+                    pk[i] = h;
+                    ca[i] = h;
+                }
+            }
+            TPS_UNROLL
+            for (int i = LBK - DH; i < LBK; ++i) unc |= ca[i];
+            if (unc && span > 0) {
+                // One pattern chains through the whole look-back: walk the chain further back (rare, a few dependent
+                // lookups).  An odd number of earlier links flips the picks of this chain; a chain that leaves the
+                // staged tile stays unresolved unless the tile is the first (nothing precedes the region).
+                unc = 0;
+                TPS_UNROLL
+                for (int i = LBK - DH; i < LBK; ++i) {
+                    if (ca[i]) {
+                        const int pidx = ffs0(ca[i]) >> 1;
+                        int n = 0, pw = p0 - LBK + (i % DH) - DH;
+                        while (pw >= delta && ((lut_mask(l.lut, l.lshift, pat, v_at(l.seq2, pw)) >> pidx) & 1u)) { ++n; pw -= DH; }
+                        if (pw < delta && w0 != 0) unc |= ca[i];
+                        else if (n & 1) pk[i] ^= ca[i];
+                    }
+                }
+            }
+            if (span == 0) {                      // the state the previous tile left (nothing before the first tile)
+                TPS_UNROLL
+                for (int i = 0; i < DH; ++i) pk[LBK - DH + i] = carry[i];
+                unc = carry[6];
+            }
+        }
+        uint32_t pe = 0, po = 0;                  // lane-local counts so far, nibbles
+        uint32_t ch3[B];
+        TPS_UNROLL
+        for (int blk = 0; blk < B; ++blk) ch3[blk] = 0;
+        TPS_UNROLL
+        for (int blk = 0; blk < B; ++blk) {
+            if (D > 0) {
+                if (blk == cblk && span == clane) {   // this block is the next tile's first
+                    TPS_UNROLL
+                    for (int i = 0; i < DH; ++i) carry[i] = pk[LBK + blk * S - DH + i];
+                    carry[6] = unc;
+                }
+            }
+            uint32_t acc = 0, pb = 0, sfw = 0;
+            TPS_UNROLL
+            for (int i = 0; i < S; ++i) {
+                const int p = blk * S + i;
+                const uint32_t h = look(p);
+                uint32_t t = 0;
+                if (D > 0) {
+                    t = h & pk[LBK + p - DH];
+                    if (i < D) sfw |= t;
+                    const int pm = p - D;         // an occurrence D after a start skip: the chain goes on
+                    if (pm >= 0 && pm % S < D) ch3[pm / S] |= h & tv[pm];
+                }
+                tv[p] = t;
+                const uint32_t pick = h ^ t;
+                pk[LBK + p] = pick;
+                acc += pick;
+                pb = (i + 1 == rp) ? acc : pb;
+            }
+            const uint32_t ee = pe + (pb & M3), eo = po + ((pb >> 2) & M3);
+            ende[span * (B + 1) + blk] = ee;
+            endo[span * (B + 1) + blk] = eo;
+            ve[blk] = PP_BIAS * 0x11111111u - pe + (sfw & M3);
+            vo[blk] = PP_BIAS * 0x11111111u - po + ((sfw >> 2) & M3);
+            pe += acc & M3;
+            po += (acc >> 2) & M3;
+        }
+        if (D > 0) {
+            TPS_UNROLL
+            for (int i = 0; i < AHEAD; ++i) {     // occurrences just past the lane that continue a start-skip chain of its last block
+                const int p = POS + i, pm = p - D;
+                if (pm % S < D) ch3[pm / S] |= look(p) & tv[pm];
+            }
+            TPS_UNROLL
+            for (int blk = 0; blk < B; ++blk) { chm |= ch3[blk] ? (1u << blk) : 0u; chw |= ch3[blk]; }
+        }
+        tne[span] = pe;
+        tno[span] = po;
+        TPS_PIN_V(chm); TPS_PIN_V(chw); TPS_PIN_V(unc);
+        TPS_UNROLL
+        for (int i = 0; i < B; ++i) { TPS_PIN_V(ve[i]); TPS_PIN_V(vo[i]); }
+#ifdef TPS_EMU
+        for (int i = 0; i < B; ++i) { keep[tid][i] = ve[i]; keep[tid][B + i] = vo[i]; }
+        keep[tid][2 * B] = chm; keep[tid][2 * B + 1] = unc; keep[tid][2 * B + 2] = chw;
+        chm = 0; unc = 0; chw = 0;
+#endif
+    }
+    TPS_SYNC();
+    // lanes whose look-back could not fix their state: every window that touches one of them is recounted
+    uint64_t unc_mask = 0;
+    if (D > 0) {
+#ifdef TPS_EMU
+        for (int t = 0; t < NT; ++t) unc_mask |= (uint64_t)(keep[t][2 * B + 1] != 0) << t;
+        emu_counter(2) += __builtin_popcountll(unc_mask);
+#else
+        unc_mask = __builtin_amdgcn_ballot_w64(unc != 0);
+#endif
+    }
+    const int rot = q & (B - 1), dl0 = q >> 3;
+#ifdef TPS_EMU
+    uint32_t sw_keep[NT][B];
+    uint32_t rows_keep[NT][B][3];
+#endif
+    uint32_t swv[B], rows[B][3], todo = 0;
+#ifdef TPS_EMU
+    uint32_t todo_keep[NT];
+    for (int t = 0; t < NT; ++t) todo_keep[t] = 0;
+#endif
+    // raw rows of 4, 8 or 12 bytes are staged through LDS and leave in whole cache lines
+    const bool staged = a.raw != nullptr && (pat.P & 3) == 0 && pat.P <= 12;
+    TPS_PHASE {
+#ifdef TPS_EMU
+        for (int i = 0; i < B; ++i) { ve[i] = keep[tid][i]; vo[i] = keep[tid][B + i]; }
+        chm = keep[tid][2 * B]; chw = keep[tid][2 * B + 2];
+#endif
+        const int lane = tid;
+        // whole lanes a window covers after its own block: near end dl0 lanes (own lane included), far end one more
+        uint32_t fa[4] = {0, 0, 0, 0}, fb[4];
+        TPS_NOVEC
+        for (int t = 0; t < dl0; ++t) {
+            uint32_t x[4];
+            pp_expand(tne[lane + t], tno[lane + t], x);
+            fa[0] += x[0]; fa[1] += x[1]; fa[2] += x[2]; fa[3] += x[3];
+        }
+        {
+            uint32_t x[4];
+            pp_expand(tne[lane + dl0], tno[lane + dl0], x);
+            TPS_UNROLL
+            for (int i = 0; i < 4; ++i) {
+                fa[i] -= PP_BIAS * 0x01010101u;   // the bias of V; the running sums below are whole-word arithmetic
+                fb[i] = fa[i] + x[i];
+            }
+        }
+        bool redo_all = false;
+        if (D > 0) redo_all = ((unc_mask >> lane) & ((2ull << (dl0 + 1)) - 1ull)) != 0;
+        const uint32_t* pee = ende + lane * (B + 1);
+        const uint32_t* peo = endo + lane * (B + 1);
+        uint32_t ee[B], eo[B];
+        TPS_UNROLL
+        for (int j = 0; j < B; ++j) {
+            const int eb = j + q;
+            ee[j] = eo[j] = 0;
+            if (lane * B + j < nw_tile) { ee[j] = pee[eb + (eb >> 3)]; eo[j] = peo[eb + (eb >> 3)]; }
+        }
+        int32_t* out = a.sums + (out_base + w0 + lane * B);
+        if (D > 0) {
+            // windows to repair after the fast pass: bits 0-7 recount (the lane's state before its first position is not
+            // known, or two of its blocks hold chains: chw is ambiguous), bits 8-15 chain parity
+            const bool multi = (chm & (chm - 1u)) != 0;
+            todo = (redo_all || multi) ? (redo_all ? 0xFFu : chm) : (chm << 8);
+#ifdef TPS_EMU
+            todo_keep[tid] = todo;
+#endif
+        }
+        TPS_UNROLL
+        for (int j = 0; j < B; ++j) {
+            const int wl = lane * B + j;
+            uint32_t sw = 0;
+            uint32_t o[4] = {0, 0, 0, 0};
+            if (wl < nw_tile) {
+                const bool far_ = j + rot >= B;    // uniform
+                uint32_t v[4], e[4], c[4];
+                pp_expand(ve[j], vo[j], v);
+                pp_expand(ee[j], eo[j], e);
+                sw = (uint32_t)pat.P - 16u;         // the 16 - P unused fields are floored to 1 like the others
+                TPS_UNROLL
+                for (int i = 0; i < 4; ++i) {
+                    c[i] = (far_ ? fb[i] : fa[i]) + v[i] + e[i];
+                    c[i] += (((c[i] + 0x7F7F7F7Fu) >> 7) & 0x01010101u) ^ 0x01010101u;   // `matches or 1` per byte (counts <= 127)
+                    sw = add_bytes(c[i], sw);
+                }
+                {
+                    // c[0] = patterns 0,4,8,12; c[2] = 1,5,9,13; c[1] = 2,6,10,14; c[3] = 3,7,11,15 -> pattern order
+                    const uint32_t a_lo = perm(c[2], c[0], 0x05010400u), a_hi = perm(c[2], c[0], 0x07030602u);
+                    const uint32_t b_lo = perm(c[3], c[1], 0x05010400u), b_hi = perm(c[3], c[1], 0x07030602u);
+                    o[0] = perm(b_lo, a_lo, 0x05040100u);
+                    o[1] = perm(b_lo, a_lo, 0x07060302u);
+                    o[2] = perm(b_hi, a_hi, 0x05040100u);
+                    o[3] = perm(b_hi, a_hi, 0x07060302u);
+                }
+                if (a.raw && !staged) {
+                    uint8_t* raw_row = a.raw + (out_base + w0 + wl) * (int64_t)pat.P;
+                    const int P = pat.P;
+                    if ((P & 1) == 0) {
+                        uint16_t* r16 = (uint16_t*)raw_row;
+                        TPS_UNROLL
+                        for (int i = 0; i < 8; ++i)
+                            if (2 * i < P) r16[i] = (uint16_t)(o[i >> 1] >> (16 * (i & 1)));
+                    } else {
+                        TPS_UNROLL
+                        for (int i = 0; i < 16; ++i)
+                            if (i < P) raw_row[i] = (uint8_t)(o[i >> 2] >> (8 * (i & 3)));
+                    }
+                }
+                out[j] = (int32_t)sw;
+            }
+            swv[j] = sw;
+            TPS_UNROLL
+            for (int i = 0; i < 3; ++i) rows[j][i] = o[i];
+#ifdef TPS_EMU
+            sw_keep[tid][j] = sw;
+            for (int i = 0; i < 3; ++i) rows_keep[tid][j][i] = o[i];
+#endif
+        }
+    }
+    TPS_SYNC();                                   // every END word has been read: S_w takes the place of the odd half
+    TPS_PHASE {
+        TPS_UNROLL
+        for (int j = 0; j < B; ++j) {
+#ifdef TPS_EMU
+            swv[j] = sw_keep[tid][j];
+#endif
+            l.row[tid * (B + 1) + j] = swv[j];
+        }
+    }
+    if (staged) {
+        // Raw rows leave through LDS: a lane's 8 rows are 8 P contiguous bytes in HBM, LPP lanes per pass mirror a
+        // contiguous stretch of the output in the (now free) END / totals area, and all 64 lanes copy it out in
+        // 16-byte pieces -- full cache lines instead of 64 scattered 12-byte writes per store instruction.
+        constexpr int LPP = 22;                   // 22 lanes x 8 rows x <= 12 bytes = 2112 <= 2944 bytes (XPC + XF + XT)
+        const int pd = pat.P >> 2;                // dwords per row: 1, 2 or 3
+        uint32_t* buf = l.XPC;
+        uint32_t* gout = (uint32_t*)(a.raw + (out_base + w0) * (int64_t)pat.P);
+        for (int l0 = 0; l0 < NT; l0 += LPP) {
+            TPS_PHASE {
+                if (tid >= l0 && tid < l0 + LPP) {
+                    uint32_t* dst = buf + (tid - l0) * B * pd;
+#ifdef TPS_EMU
+                    for (int j = 0; j < B; ++j) for (int i = 0; i < 3; ++i) rows[j][i] = rows_keep[tid][j][i];
+#endif
+                    if (pd == 3) {
+                        TPS_UNROLL
+                        for (int g = 0; g < 6; ++g) {
+                            u32x4 t;
+                            t.x = rows[(4 * g) / 3][(4 * g) % 3]; t.y = rows[(4 * g + 1) / 3][(4 * g + 1) % 3];
+                            t.z = rows[(4 * g + 2) / 3][(4 * g + 2) % 3]; t.w = rows[(4 * g + 3) / 3][(4 * g + 3) % 3];
+                            *(u32x4*)(dst + 4 * g) = t;
+                        }
+                    } else if (pd == 2) {
+                        TPS_UNROLL
+                        for (int j = 0; j < B; ++j) { dst[2 * j] = rows[j][0]; dst[2 * j + 1] = rows[j][1]; }
+                    } else {
+                        TPS_UNROLL
+                        for (int j = 0; j < B; ++j) dst[j] = rows[j][0];
+                    }
+                }
+            }
+            TPS_SYNC();
+            TPS_PHASE {
+                int nvalid = (nw_tile - l0 * B) * pd;          // dwords of this pass that belong to the tile's windows
+                const int ncap = LPP * B * pd;
+                if (nvalid > ncap) nvalid = ncap;
+                uint32_t* g = gout + (int64_t)l0 * B * pd;
+                for (int cdw = 4 * tid; cdw < nvalid; cdw += 4 * NT) {
+                    const u32x4 t = *(const u32x4*)(buf + cdw);
+                    if (cdw + 4 <= nvalid) {
+                        g[cdw] = t.x; g[cdw + 1] = t.y; g[cdw + 2] = t.z; g[cdw + 3] = t.w;
+                    } else {
+                        g[cdw] = t.x;
+                        if (cdw + 1 < nvalid) g[cdw + 1] = t.y;
+                        if (cdw + 2 < nvalid) g[cdw + 2] = t.z;
+                    }
+                }
+            }
+            TPS_SYNC();
+        }
+    } else {
+        TPS_SYNC();
+    }
+    if (D > 0) {
+        // Repairs (rare, lane-divergent): results are in memory by now -- S_w in row[] and HBM, raw rows in HBM.
+#ifndef TPS_EMU
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");      // this wave's own raw-row stores before its byte updates
+#endif
+        TPS_PHASE {
+#ifdef TPS_EMU
+            todo = todo_keep[tid];
+            chw = keep[tid][2 * B + 2];
+#endif
+            const int lane = tid;
+            while (todo) {
+                const int bit = ffs0(todo);
+                todo &= todo - 1u;
+                const int j = bit & 7, wl = lane * B + j;
+                if (wl >= nw_tile) continue;
+                uint8_t* raw_row = a.raw ? a.raw + (out_base + w0 + wl) * (int64_t)pat.P : nullptr;
+                uint32_t sw = l.row[lane * (B + 1) + j];
+                if (bit < 8) {
+#ifdef TPS_EMU
+                    ++emu_counter(1);
+#endif
+                    sw = window_exact(a, l, delta, wl, pat.all_mask, 0u, raw_row, true);
+                } else {
+                    // The window starts on a canonically skipped occurrence x whose chain goes on: it picks x, x + 2D, ...
+                    // = one more than canonical iff the chain has an odd number of elements from x (inside the window).
+                    // The start skip was added; take it back for an even count.
+#ifdef TPS_EMU
+                    ++emu_counter(3);
+#endif
+                    const int a0 = delta + wl * S;
+                    uint32_t fw = chw;
+                    while (fw) {
+                        const int pidx = ffs0(fw) >> 1;
+                        fw &= fw - 1u;
+                        int x = -1;
+                        TPS_NOVEC
+                        for (int i = 0; i < D; ++i)
+                            if ((lut_mask(l.lut, l.lshift, pat, v_at(l.seq2, a0 + i)) >> pidx) & 1u) x = a0 + i;
+                        if (x >= 0) {
+                            int m = 1;
+                            for (int pw = x + D; pw < a0 + a.lw && ((lut_mask(l.lut, l.lshift, pat, v_at(l.seq2, pw)) >> pidx) & 1u); pw += D) ++m;
+                            if ((m & 1) == 0) {
+                                sw -= 1u;
+                                if (raw_row) raw_row[pidx] = (uint8_t)(raw_row[pidx] - 1u);
+                            }
+                        }
+                    }
+                }
+                l.row[lane * (B + 1) + j] = sw;
+                a.sums[out_base + w0 + wl] = (int32_t)sw;
+            }
+        }
+        TPS_SYNC();
+    }
+    tile_candidates(tc, l, w0, tile, nw_tile, s_total);
+}
+
 // ------------------------------------------------------------------ step 3: single-split Binseg (l2)
 // gain(b) = cost(0,n) - cost(0,b) - cost(b,n) = (n L_b - T b)^2 / (n b (n-b))   [y = S / P]
 // so the arg-max over b in {0, jump, 2 jump, ...}, b >= min_size, n-b >= min_size is that of
@@ -1939,6 +2414,8 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
             constexpr int PF = g_::PF;
             const TileConst tc = tile_const(a, r);
             const int tw = NT * g_::B - tc.q - 1 - g_::B;   // windows per tile
+            bool pp = false;
+            if constexpr (RAW) pp = a.pp_d >= 0 && (SO ? a.pp_d > 0 : (a.pp_d == 0 && a.raw != nullptr));
             auto tile_stage = [&](int w0_) {
                 const int64_t i0 = (int64_t)w0_ * prm.slide;
                 int64_t n_stage = n_s - i0;
@@ -1971,7 +2448,10 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
             for (int w0 = 0, tile = 0; w0 < n_win; w0 += tw, ++tile) {
                 const int nw_tile = (n_win - w0) < tw ? (n_win - w0) : tw;
                 const Stage st = tile_stage(w0);
-                TPS_PHASE { if (tid == 0) { l.misc[M_INVALID] = 0; l.misc[M_NTIE] = 0; } }
+                TPS_PHASE {
+                    if (tid == 0) { l.misc[M_INVALID] = 0; l.misc[M_NTIE] = 0; }
+                    if (RAW && pp && w0 == 0 && tid < 8) l.misc[M_SCAN + tid] = 0;      // nothing is picked before the first tile
+                }
                 TPS_SYNC();
                 TPS_PHASE {
                     TPS_UNROLL
@@ -1995,6 +2475,28 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
                 }
                 if (w0 == 0) TPS_STAMP(5);
                 const int fdelta = st.delta + 16;      // LDS position of the tile's first base
+                if constexpr (RAW) {
+                    // per-pattern tiles: raw counts wanted, or a table with one self-overlap period (exact without recounts)
+                    constexpr int SP = SV ? SV : 5;
+                    if (pp && uniform(l.misc[M_INVALID]) == 0) {
+                        if constexpr (SO) {
+                            switch (a.pp_d) {
+                                case 2: tile_pp_s<SP, 2>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
+                                case 3: tile_pp_s<SP, 3>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
+                                case 4: tile_pp_s<SP, 4>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
+                                case 5: tile_pp_s<SP, 5>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
+                                default: tile_pp_s<SP, (SP < 6 ? SP : 6)>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
+                            }
+                        } else {
+                            tile_pp_s<SP, 0>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total);
+                        }
+                        continue;
+                    }
+                    if (pp && SO) {                    // a tile with non-ACGT letters takes the recount path: the next tile starts blind
+                        TPS_PHASE { if (tid == 0) l.misc[M_SCAN + 6] = 1u; }
+                        TPS_SYNC();
+                    }
+                }
                 if (uniform(l.misc[M_INVALID]) != 0)
                     tile_fused_s<SV ? SV : 1, SO, true, false, false, RAW>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r);
                 else if (tc.r == 0)

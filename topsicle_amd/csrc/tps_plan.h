@@ -130,8 +130,15 @@ inline std::string plan_geometry(ScanArgs& a, const tps_params& prm, int k, int 
     const bool fused = !force_generic && spans_pref <= 0 && k <= TPS_DIRECT_K && has_specialised_slide(prm.slide) && P <= 15 && a.q >= 8 &&
                        a.q / 8 + 2 < (XLANES - NT) && max_period <= std::min(prm.slide, 6) &&
                        2 * a.head_dw <= ((((int)NT - 1) * 8 * prm.slide + 43) / 16 + 1 + (int)NT - 1) / (int)NT * (int)NT + 4;   // heads fit the tile buffer
-    a.lc16 = 0; a.tile_cap = 0; a.tw = 0; a.tw_magic = 0; a.pair_n = 0; a.lc_global = 0; a.lc_stride = 0;
+    a.lc16 = 0; a.tile_cap = 0; a.tw = 0; a.tw_magic = 0; a.pair_n = 0; a.lc_global = 0; a.lc_stride = 0; a.pp_d = -1;
     if (fused) {
+        // per-pattern tiles (tile_pp_s): one-hot 2-bit fields per pattern need distinct k-mers; a lane's 8 blocks hold at
+        // most 14 non-overlapping occurrences of a pattern (nibbles), a block at most 2, a window at most 127 (bytes);
+        // self-overlap only with ONE period d (then 2 d >= k: picks alternate along a chain)
+        const bool pp_counts = a.pat.dup_mask == 0 && k >= 4 && (8 * prm.slide + k - 1) / k <= 14 && (prm.slide + k - 1) / k <= 2 &&
+                               a.lw / k + 2 <= 127 && !getenv("TPS_NO_PP");
+        if (pp_counts && a.pat.n_periods == 0) a.pp_d = 0;
+        if (pp_counts && a.pat.n_periods == 1 && a.pat.period[0] >= 2 && 2 * a.pat.period[0] >= k) a.pp_d = a.pat.period[0];
         a.variant = prm.slide;
         a.blk_log2 = 3;                            // 8 blocks per lane for every slide
         a.span_dw = 0;                             // lanes start at arbitrary bit offsets (per-lane shift)
@@ -168,7 +175,7 @@ inline std::string plan_geometry(ScanArgs& a, const tps_params& prm, int k, int 
         if (wg_lds_dwords(a) <= budget_dw) return "";
         // does not fit (very long maxlengthtelo: the candidate sums of 4 reads outgrow LDS): the generic kernel,
         // whose tile size adapts, takes over
-        a.lc16 = 0; a.tile_cap = 0; a.tw = 0; a.tw_magic = 0; a.pair_n = 0; a.lc_global = 0; a.lc_stride = 0;
+        a.lc16 = 0; a.tile_cap = 0; a.tw = 0; a.tw_magic = 0; a.pair_n = 0; a.lc_global = 0; a.lc_stride = 0; a.pp_d = -1;
     }
     a.variant = 0;
     // the generic kernel's 32-bit candidate sums go off-chip too (stride counted in 16-bit units)
