@@ -1583,6 +1583,17 @@ TPS_DEV void tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
     uint32_t* tno = l.XT;
     uint32_t* carry = l.misc + M_SCAN;            // [0, 6): picks of the D positions before the next tile's first; [6]: uncertain
     const int cblk = a.tw & (B - 1), clane = a.tw >> 3;
+    // the state at THIS tile's first position (one lane overwrites `carry` for the next tile during phase 1)
+    uint32_t cold[7];
+    TPS_UNROLL
+    for (int i = 0; i < 7; ++i) cold[i] = (D > 0) ? uniform(carry[i]) : 0u;
+    // was pattern pidx picked at LDS position pos, one of the D positions before the tile (delta - D <= pos < delta)?
+    auto picked_before_tile = [&](int pos, int pidx) -> bool {
+        uint32_t cv = 0;
+        TPS_UNROLL
+        for (int i = 0; i < DH; ++i) cv = (pos - (delta - DH) == i) ? cold[i] : cv;
+        return w0 != 0 && ((cv >> (2 * pidx)) & 1u) != 0;
+    };
 #ifdef TPS_EMU
     uint32_t keep[NT][2 * B + 3];
     ++emu_counter(0);
@@ -1638,15 +1649,18 @@ TPS_DEV void tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
                         const int pidx = ffs0(ca[i]) >> 1;
                         int n = 0, pw = p0 - LBK + (i % DH) - DH;
                         while (pw >= delta && ((lut_mask(l.lut, l.lshift, pat, v_at(l.seq2, pw)) >> pidx) & 1u)) { ++n; pw -= DH; }
-                        if (pw < delta && w0 != 0) unc |= ca[i];
-                        else if (n & 1) pk[i] ^= ca[i];
+                        // the chain's earliest element in the tile is skipped iff the same pattern was picked D before it,
+                        // which for an element within D of the tile's start is what the previous tile left
+                        const bool blocked = pw < delta && picked_before_tile(pw, pidx);
+                        if (pw < delta && w0 != 0 && cold[6]) unc |= ca[i];
+                        else if (((n & 1) != 0) != blocked) pk[i] ^= ca[i];
                     }
                 }
             }
             if (span == 0) {                      // the state the previous tile left (nothing before the first tile)
                 TPS_UNROLL
-                for (int i = 0; i < DH; ++i) pk[LBK - DH + i] = carry[i];
-                unc = carry[6];
+                for (int i = 0; i < DH; ++i) pk[LBK - DH + i] = cold[i];
+                unc = cold[6];
             }
         }
         uint32_t pe = 0, po = 0;                  // lane-local counts so far, nibbles
@@ -1768,9 +1782,8 @@ TPS_DEV void tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
         int32_t* out = a.sums + (out_base + w0 + lane * B);
         if (D > 0) {
             // windows to repair after the fast pass: bits 0-7 recount (the lane's state before its first position is not
-            // known, or two of its blocks hold chains: chw is ambiguous), bits 8-15 chain parity
-            const bool multi = (chm & (chm - 1u)) != 0;
-            todo = (redo_all || multi) ? (redo_all ? 0xFFu : chm) : (chm << 8);
+            // known), bits 8-15 chain parity
+            todo = redo_all ? 0xFFu : (chm << 8);
 #ifdef TPS_EMU
             todo_keep[tid] = todo;
 #endif
@@ -1920,8 +1933,11 @@ TPS_DEV void tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
 #ifdef TPS_EMU
                     ++emu_counter(3);
 #endif
+                    // chw is the union over the lane's flagged blocks, so x's own place in its chain is walked too: n earlier
+                    // links (odd = canonically skipped = a start skip of this window), m elements from x inside the window.
                     const int a0 = delta + wl * S;
                     uint32_t fw = chw;
+                    bool lost = false;
                     while (fw) {
                         const int pidx = ffs0(fw) >> 1;
                         fw &= fw - 1u;
@@ -1930,13 +1946,23 @@ TPS_DEV void tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
                         for (int i = 0; i < D; ++i)
                             if ((lut_mask(l.lut, l.lshift, pat, v_at(l.seq2, a0 + i)) >> pidx) & 1u) x = a0 + i;
                         if (x >= 0) {
+                            int n = 0, pb = x - D;
+                            while (pb >= delta && ((lut_mask(l.lut, l.lshift, pat, v_at(l.seq2, pb)) >> pidx) & 1u)) { ++n; pb -= D; }
+                            const bool blocked = pb < delta && picked_before_tile(pb, pidx);
+                            if (pb < delta && w0 != 0 && cold[6]) lost = true;      // the chain leaves the tile and the state there is unknown
                             int m = 1;
                             for (int pw = x + D; pw < a0 + a.lw && ((lut_mask(l.lut, l.lshift, pat, v_at(l.seq2, pw)) >> pidx) & 1u); pw += D) ++m;
-                            if ((m & 1) == 0) {
+                            if ((((n & 1) != 0) != blocked) && (m & 1) == 0) {
                                 sw -= 1u;
                                 if (raw_row) raw_row[pidx] = (uint8_t)(raw_row[pidx] - 1u);
                             }
                         }
+                    }
+                    if (lost) {
+#ifdef TPS_EMU
+                        ++emu_counter(1);
+#endif
+                        sw = window_exact(a, l, delta, wl, pat.all_mask, 0u, raw_row, true);
                     }
                 }
                 l.row[lane * (B + 1) + j] = sw;
