@@ -1736,15 +1736,17 @@ TPS_DEV void tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
     const int rot = q & (B - 1), dl0 = q >> 3;
 #ifdef TPS_EMU
     uint32_t sw_keep[NT][B];
-    uint32_t rows_keep[NT][B][3];
+    uint32_t rows_keep[NT][B][4];
 #endif
-    uint32_t swv[B], rows[B][3], todo = 0;
+    uint32_t swv[B], rows[B][3], rx[B / 2], todo = 0;     // rx: bytes 12-13 of the rows (14 patterns), two rows per word
 #ifdef TPS_EMU
     uint32_t todo_keep[NT];
     for (int t = 0; t < NT; ++t) todo_keep[t] = 0;
 #endif
     // raw rows of 4, 8 or 12 bytes are staged through LDS and leave in whole cache lines
     const bool staged = a.raw != nullptr && (pat.P & 3) == 0 && pat.P <= 12;
+    // rows of 2, 6, 10 or 14 bytes likewise, padded to 16 bytes in LDS and copied out in 16-bit units
+    const bool staged16 = a.raw != nullptr && (pat.P & 3) == 2 && pat.P <= 14;
     TPS_PHASE {
 #ifdef TPS_EMU
         for (int i = 0; i < B; ++i) { ve[i] = keep[tid][i]; vo[i] = keep[tid][B + i]; }
@@ -1805,7 +1807,7 @@ TPS_DEV void tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
                     c[i] += (((c[i] + 0x7F7F7F7Fu) >> 7) & 0x01010101u) ^ 0x01010101u;   // `matches or 1` per byte (counts <= 127)
                     sw = add_bytes(c[i], sw);
                 }
-                {
+                if (a.raw) {
                     // c[0] = patterns 0,4,8,12; c[2] = 1,5,9,13; c[1] = 2,6,10,14; c[3] = 3,7,11,15 -> pattern order
                     const uint32_t a_lo = perm(c[2], c[0], 0x05010400u), a_hi = perm(c[2], c[0], 0x07030602u);
                     const uint32_t b_lo = perm(c[3], c[1], 0x05010400u), b_hi = perm(c[3], c[1], 0x07030602u);
@@ -1814,7 +1816,7 @@ TPS_DEV void tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
                     o[2] = perm(b_hi, a_hi, 0x05040100u);
                     o[3] = perm(b_hi, a_hi, 0x07060302u);
                 }
-                if (a.raw && !staged) {
+                if (a.raw && !staged && !staged16) {
                     uint8_t* raw_row = a.raw + (out_base + w0 + wl) * (int64_t)pat.P;
                     const int P = pat.P;
                     if ((P & 1) == 0) {
@@ -1833,9 +1835,11 @@ TPS_DEV void tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
             swv[j] = sw;
             TPS_UNROLL
             for (int i = 0; i < 3; ++i) rows[j][i] = o[i];
+            if (j & 1) rx[j >> 1] = pack_hi_lo(o[3] << 16, rx[j >> 1]);
+            else rx[j >> 1] = o[3] & 0xFFFFu;
 #ifdef TPS_EMU
             sw_keep[tid][j] = sw;
-            for (int i = 0; i < 3; ++i) rows_keep[tid][j][i] = o[i];
+            for (int i = 0; i < 4; ++i) rows_keep[tid][j][i] = o[i];
 #endif
         }
     }
@@ -1896,6 +1900,42 @@ TPS_DEV void tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
                         if (cdw + 1 < nvalid) g[cdw + 1] = t.y;
                         if (cdw + 2 < nvalid) g[cdw + 2] = t.z;
                     }
+                }
+            }
+            TPS_SYNC();
+        }
+    } else if (staged16) {
+        constexpr int LPP = 22;                   // 22 lanes x 8 rows x 16 bytes = 2816 <= 2944 bytes
+        const int ph = pat.P >> 1;                // 16-bit units per row: 1, 3, 5 or 7
+        const uint32_t ph_magic = (65536u + (uint32_t)ph - 1u) / (uint32_t)ph;    // u / ph = (u * magic) >> 16 for u < 2^15
+        uint32_t* buf = l.XPC;
+        uint16_t* gout = (uint16_t*)(a.raw + (out_base + w0) * (int64_t)pat.P);
+        for (int l0 = 0; l0 < NT; l0 += LPP) {
+            TPS_PHASE {
+                if (tid >= l0 && tid < l0 + LPP) {
+                    uint32_t* dst = buf + (tid - l0) * B * 4;
+                    TPS_UNROLL
+                    for (int j = 0; j < B; ++j) {
+                        u32x4 t;
+#ifdef TPS_EMU
+                        t.x = rows_keep[tid][j][0]; t.y = rows_keep[tid][j][1]; t.z = rows_keep[tid][j][2]; t.w = rows_keep[tid][j][3] & 0xFFFFu;
+#else
+                        t.x = rows[j][0]; t.y = rows[j][1]; t.z = rows[j][2]; t.w = (rx[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+#endif
+                        *(u32x4*)(dst + 4 * j) = t;
+                    }
+                }
+            }
+            TPS_SYNC();
+            TPS_PHASE {
+                int nvalid = (nw_tile - l0 * B) * ph;          // 16-bit units of this pass that belong to the tile's windows
+                const int ncap = LPP * B * ph;
+                if (nvalid > ncap) nvalid = ncap;
+                uint16_t* g = gout + (int64_t)l0 * B * ph;
+                const uint16_t* b16 = (const uint16_t*)buf;
+                for (int u = tid; u < nvalid; u += NT) {
+                    const uint32_t row = ((uint32_t)u * ph_magic) >> 16;
+                    g[u] = b16[row * 8u + ((uint32_t)u - row * (uint32_t)ph)];
                 }
             }
             TPS_SYNC();
