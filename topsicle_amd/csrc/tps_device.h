@@ -1701,6 +1701,11 @@ TPS_DEV void tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
             vo[blk] = PP_BIAS * 0x11111111u - po + ((sfw >> 2) & M3);
             pe += acc & M3;
             po += (acc >> 2) & M3;
+            if (D > 0 && blk > 0) {               // the chain flags of the previous block are complete (2 D <= 2 S positions on)
+                chm |= ch3[blk - 1] ? (1u << (blk - 1)) : 0u;
+                chw |= ch3[blk - 1];
+                TPS_PIN_V(chm); TPS_PIN_V(chw);
+            }
         }
         if (D > 0) {
             TPS_UNROLL
@@ -1708,8 +1713,8 @@ TPS_DEV void tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
                 const int p = POS + i, pm = p - D;
                 if (pm % S < D) ch3[pm / S] |= look(p) & tv[pm];
             }
-            TPS_UNROLL
-            for (int blk = 0; blk < B; ++blk) { chm |= ch3[blk] ? (1u << blk) : 0u; chw |= ch3[blk]; }
+            chm |= ch3[B - 1] ? (1u << (B - 1)) : 0u;
+            chw |= ch3[B - 1];
         }
         tne[span] = pe;
         tno[span] = po;
