@@ -98,17 +98,37 @@ def batch(bases: np.ndarray, offsets: np.ndarray, patterns, motif_len, no_bp, mi
     return out, int(done), el.value
 
 
+def usable_cores():
+    """CPU parallelism this process can really use: the affinity mask, capped by the cgroup CPU quota (the GPU boxes
+    show 256 CPUs but run under `cpu.max = 1600000 100000`, i.e. 16 CPUs' worth of time)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period) + 0.5)))
+    except (OSError, ValueError):
+        try:                                            # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                n = max(1, min(n, int(q / per + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def timed_baseline(seqs, patterns, motif_len, prm, budget_s=15.0, cutoff=0.7):
     """bench.py's cpu_baseline leg: the C port on all host cores, bounded in time."""
     enc = [s.encode() for s in seqs]
     offsets = np.zeros(len(enc) + 1, np.int64)
     np.cumsum([len(e) for e in enc], out=offsets[1:])
     bases = np.frombuffer(b"".join(enc), np.uint8)
-    cores = len(os.sched_getaffinity(0))
+    cores = usable_cores()
     out, done, el = batch(bases, offsets, patterns, motif_len, prm.no_bp, prm.min_len, cutoff, prm.window, prm.slide,
                           prm.trimfirst, prm.maxlen, both_tails=True, threads=cores, budget_s=budget_s)
     nb = int(offsets[min(done, len(enc))])
     return dict(value=nb / el, unit="bases/s", cores=cores, kind="port", reads_per_s=done / el,
                 sample=f"{done} reads of the same batch through oracle/oracle.c (C restatement of allsteps.py: string windows, "
                        f"per-pattern literal search, numpy-order float64 Binseg; both tails scanned like the reference, single "
-                       f"pass instead of the reference's per-read file re-parse), {cores} threads, {el:.1f} s")
+                       f"pass instead of the reference's per-read file re-parse), {cores} threads = usable CPUs "
+                       f"(affinity {len(os.sched_getaffinity(0))}, cgroup quota applied), {el:.1f} s")
