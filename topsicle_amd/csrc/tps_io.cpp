@@ -135,7 +135,18 @@ struct Reader {
 int io_threads() {
     if (const char* e = getenv("TPS_IO_THREADS")) { int t = atoi(e); if (t > 0) return std::min(t, 64); }
     unsigned hc = std::thread::hardware_concurrency();
-    return (int)std::max(1u, std::min(hc ? hc : 1u, 32u));
+    unsigned n = std::min(hc ? hc : 1u, 32u);
+    // containers: the cgroup CPU quota, not the number of logical CPUs, is what the team can use
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32] = {0};
+        long long period = 0;
+        if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+            const long long quota = atoll(q);
+            if (quota > 0) n = (unsigned)std::min<long long>(n, std::max<long long>(1, (quota + period / 2) / period));
+        }
+        fclose(f);
+    }
+    return (int)std::max(1u, n);
 }
 template <typename F>
 void team(int nthreads, F f) {                 // f(thread index, thread count); runs inline for one thread
