@@ -128,6 +128,22 @@ def test_cli_rawcount_plot_readcheck_and_multik(engine, demo_fastq, tmp_path, de
     assert os.path.exists(out / "plot_5_1.png") and os.path.exists(out / "plot_4_1.png")
 
 
+def test_cli_rawcount_columnar_extension(engine, demo_fastq, tmp_path, demo_windows):
+    """--rawcountformat npz: the same counts as the per-read CSVs, one file per input file and k."""
+    meta, arrs = demo_windows
+    out = tmp_path / "out3"
+    run_cli(engine, ["-i", demo_fastq, "-o", str(out), "--pattern", "CCCTAAA", "--slide", "6", "--rawcountpattern", "--rawcountformat", "npz"])
+    z = np.load(out / f"rawcount_5_{os.path.splitext(os.path.basename(demo_fastq))[0]}.npz")
+    assert not [f for f in os.listdir(out) if f.startswith("rawcount_") and f.endswith(".csv")]
+    ids = [str(x) for x in z["read_id"]]
+    assert len(ids) == len(list(csv.reader(open(out / "telolengths_all.csv")))) - 1
+    assert z["counts"].dtype == np.uint8 and z["counts"].shape[1] == 14 and int(z["slide"]) == 6
+    for j, r in enumerate(meta["reads"]):
+        if f"counts_{j}" in arrs and r["id"] in ids:
+            i = ids.index(r["id"])
+            assert np.array_equal(z["counts"][z["win_off"][i]:z["win_off"][i + 1]], arrs[f"counts_{j}"])
+
+
 def test_cli_fasta_gz_input_and_default_slide(engine, tmp_path, demo_records):
     """FASTA input (wrapped lines, gz), default slide = len(pattern) (main.py:212-215)."""
     fa = tmp_path / "reads.fa.gz"

@@ -80,6 +80,7 @@ def process_file(args, seq_loc, telo_phrase, pattern, sliding_val, engines):
 
     rows = []
     image_num = 1
+    raw_npz = {"read_id": [], "tail": [], "n_win": [], "counts": []} if getattr(args, "rawcountformat", "csv") == "npz" else None
     csv_path = f"{args.outputDir}/telolengths_all.csv"
     pool = batch.EnginePool(engines, pattern)
     try:
@@ -109,12 +110,20 @@ def process_file(args, seq_loc, telo_phrase, pattern, sliding_val, engines):
                         plt.savefig(f"{args.outputDir}/plot_{telo_phrase}_{image_num}.png", format="png", dpi=300)
                         plt.close()
                     if args.rawcountpattern:
-                        _write_rawcount(args, telo_phrase, image_num, pattern, sliding_val,
-                                        raw[win_off[i]:win_off[i + 1]], "forward" if fwd else "reverse")
+                        block = raw[win_off[i]:win_off[i + 1]]
+                        if raw_npz is not None:
+                            raw_npz["read_id"].append(rec.id)
+                            raw_npz["tail"].append("forward" if fwd else "reverse")
+                            raw_npz["n_win"].append(block.shape[0])
+                            raw_npz["counts"].append(np.array(block, dtype=np.uint8))
+                        else:
+                            _write_rawcount(args, telo_phrase, image_num, pattern, sliding_val, block, "forward" if fwd else "reverse")
                     image_num += 1
     finally:
         if out_handle is not None:
             out_handle.close()
+    if raw_npz is not None and raw_npz["read_id"]:
+        _write_rawcount_npz(args, file_name, telo_phrase, pattern, sliding_val, raw_npz)
     if out_handle is not None:
         tprint(f"Temporary fasta file with TRC more than {min_cutoff}:", fasta_temp)
     return rows
@@ -131,6 +140,19 @@ def _write_rawcount(args, telo_phrase, image_num, pattern, slide, block, tail):
         "count": block.reshape(-1).astype(np.int64),
     })
     df.to_csv(f"{args.outputDir}/rawcount_{telo_phrase}_{image_num}.csv")
+
+
+def _write_rawcount_npz(args, file_name, telo_phrase, pattern, slide, acc):
+    """--rawcountformat npz (an extension, not an upstream flag): ONE columnar file per input file and k instead of
+    one 1.2 MB CSV per read -- the same numbers: counts[win_off[i]:win_off[i+1], p] is read i's count of pattern p in
+    the window that starts at position (w - win_off[i]) * slide (the CSV volume is what bounds the
+    raw-count workload end to end)."""
+    n_win = np.array(acc["n_win"], dtype=np.int64)
+    win_off = np.zeros(len(n_win) + 1, dtype=np.int64)
+    np.cumsum(n_win, out=win_off[1:])
+    counts = np.concatenate(acc["counts"], axis=0) if len(acc["counts"]) else np.zeros((0, len(pattern)), np.uint8)
+    np.savez(f"{args.outputDir}/rawcount_{telo_phrase}_{file_name}.npz", read_id=np.array(acc["read_id"]), tail=np.array(acc["tail"]),
+             win_off=win_off, counts=counts, pattern=np.array(pattern), slide=np.int64(slide))
 
 
 def analysis_run(args, engines=None, engine_factory=None):
@@ -286,6 +308,8 @@ def build_parser():
     parser.add_argument("--pattern", metavar="CHAR", type=str, help="Required, Telomere repeat sequence (in 5' to 3' orientation). For e.g., in human use CCCTAA", required=True)
     parser.add_argument("--minSeqLength", metavar="INT", type=int, help="Minimum length of a long read sequence that will be analyzed", default=9000)
     parser.add_argument("--rawcountpattern", action="store_true", help="Output raw count of the k-mer for each window")
+    parser.add_argument("--rawcountformat", choices=["csv", "npz"], default="csv",
+                        help="(extension) csv: one rawcount_{k}_{i}.csv per read like upstream; npz: one columnar rawcount_{k}_{file}.npz per input file and k")
     parser.add_argument("--telophrase", nargs="+", metavar="INT", type=int, help="Length of telomere k-mer to search. By default will use telomere k-mer length minus 2")
     parser.add_argument("--cutoff", nargs="+", metavar="FLOAT", type=float, help="TRC statistics threshold", default=0.7)
     parser.add_argument("--windowSize", metavar="INT", type=int, help="Sliding window size", default=100)
