@@ -118,3 +118,14 @@ extern "C" int emu_plan(int k, int P, const tps_params* prm, int64_t max_nwin, i
     out10[5] = a.lw; out10[6] = a.seq_dw; out10[7] = (int32_t)(tps::wg_lds_dwords(a) * 4); out10[8] = a.variant; out10[9] = a.rec_rs;
     return TPS_OK;
 }
+
+// plan for a real pattern table: out4 = {variant, pp_d, workgroup LDS bytes, pair_n}
+extern "C" int emu_plan_table(const char* pats, int P, int k, const tps_params* prm, int64_t max_nwin, int32_t* out4) {
+    tps::ScanArgs a{};
+    std::vector<uint32_t> lut;
+    std::string err = tps::build_patterns(pats, P, k, lut, a.pat);
+    if (err.empty()) err = tps::plan_geometry(a, *prm, k, P, max_nwin, 160 * 1024 / 4, 0, 0);
+    if (!err.empty()) { g_err = err; return TPS_E_CAPACITY; }
+    out4[0] = a.variant; out4[1] = a.pp_d; out4[2] = (int32_t)(tps::wg_lds_dwords(a) * 4); out4[3] = a.pair_n;
+    return TPS_OK;
+}

@@ -402,3 +402,18 @@ def test_emulation_per_pattern_tiles(motif, k, slide, units):
         assert redone < nwin_total // 2, (redone, nwin_total)
         if not units:
             assert redone == 0
+
+
+def test_planner_picks_per_pattern_tiles():
+    """Which tables take the per-pattern tiles: one self-overlap period (or none), distinct k-mers, k >= 4."""
+    def plan(motif, k, slide, flags=0):
+        return emu.plan_table(orc.kmer_table(motif, k), hiplib.make_params(slide=slide, flags=hiplib.F_WINDOWS | flags), 3301)
+    assert plan("CCCTAA", 4, 6)["pp_d"] == 0 and plan("CCCTAA", 4, 6)["pair_n"] == 1024          # no overlap; pair table for sums only
+    assert plan("CCCTAA", 4, 6, hiplib.F_STORE_RAW)["pair_n"] == 0                               # raw counts: single lookups
+    assert plan("CCCTAA", 5, 6)["pp_d"] == 4 and plan("CCCTAA", 6, 6)["pp_d"] == 5               # CTAAC: period 4; CCTAAC: period 5
+    assert plan("TTTAGGG", 7, 7)["pp_d"] == 6 and plan("AAACCCT", 5, 7)["pp_d"] == 0
+    assert plan("ACACAC", 5, 6)["pp_d"] == -1                                                    # ACACA: periods 2 and 4
+    assert plan("CCCTAA", 3, 6)["pp_d"] == -1                                                    # k < 4: too many occurrences per lane
+    assert plan("CCCTAA", 6, 4)["variant"] == 0                                                  # no fused kernel for this slide
+    for motif, k, s in [("CCCTAA", 4, 6), ("CCCTAA", 5, 6), ("AAACCCT", 5, 7)]:
+        assert plan(motif, k, s)["lds_bytes"] <= 32000                                           # five workgroups per CU
