@@ -87,3 +87,64 @@ def test_native_plain_fastq_thread_team(tmp_path, monkeypatch, threads):
     big.write_text("\n\n@big\n" + "ACGT" * 5000 + "\n+\n" + "I" * 20000 + "\n@s\nAC\n+\nII\n")
     got = all_records(str(big), max_bases=1000)
     assert [(r.id, len(r.seq)) for r in got] == [("big", 20000), ("s", 2)]
+
+
+def _write_bgzf(path, payload: bytes, block=60000, splits=None):
+    """bgzip-compatible file: independent gzip members with the 'BC' extra field (block size - 1), then the empty
+    end-of-file block."""
+    import struct
+    import zlib
+
+    def member(chunk):
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        body = co.compress(chunk) + co.flush()
+        bsize = 12 + 6 + len(body) + 8
+        return (b"\x1f\x8b\x08\x04" + b"\x00" * 4 + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1) +
+                body + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+    cuts = splits or list(range(block, len(payload), block))
+    with open(path, "wb") as h:
+        lo = 0
+        for hi in cuts + [len(payload)]:
+            h.write(member(payload[lo:hi]))
+            lo = hi
+        h.write(member(b""))
+
+
+@pytest.mark.skipif(seqio._load_io() is None, reason="libtopsicle_io.so not built")
+@pytest.mark.parametrize("threads", ["1", "6"])
+def test_native_bgzf_blocks_inflate_in_parallel(tmp_path, monkeypatch, caplog, threads):
+    """bgzip'ed FASTQ: the blocks are inflated by the thread team and decoded like plain FASTQ; records span block
+    boundaries; an irregular record hands over to the streaming decoder; a corrupt block is an error, not a short file."""
+    monkeypatch.setenv("TPS_IO_THREADS", threads)
+    rng = np.random.default_rng(11)
+    recs = []
+    for i in range(900):
+        L = int(rng.integers(0, 9000))
+        seq = "".join("ACGTN"[x] for x in rng.integers(0, 5, L))
+        qual = "".join(chr(33 + int(x)) for x in rng.integers(0, 60, L))
+        recs.append((f"read{i} desc {i}", seq, qual))
+    text = "".join(f"@{h}\n{s}\n+\n{q}\n" for h, s, q in recs)
+    p = tmp_path / "reads.fastq.gz"
+    _write_bgzf(str(p), text.encode(), block=50021)
+    got = all_records(str(p), max_bases=700000)
+    assert [(r.description, r.seq, r.qual) for r in got] == recs
+    monkeypatch.setenv("TPS_IO_BGZF_GROUP", "300000")       # many refills: partial records are carried over
+    got = all_records(str(p), max_bases=2000000)
+    assert [(r.description, r.seq, r.qual) for r in got] == recs
+    monkeypatch.delenv("TPS_IO_BGZF_GROUP")
+    assert [(r.description, r.seq) for r in seqio.read_records(str(p))] == [(h, s) for h, s, _ in recs]     # it is plain gzip too
+    # wrapped sequence lines in the middle: the streaming decoder takes over at that record
+    odd = text + "@wrapped\nAC\nGT\n+\nII\nII\n@last\nA\n+\n#\n"
+    p2 = tmp_path / "odd.fq.gz"
+    _write_bgzf(str(p2), odd.encode(), block=65000)
+    got = all_records(str(p2))
+    assert [(r.id, r.seq, r.qual) for r in got[-2:]] == [("wrapped", "ACGT", "IIII"), ("last", "A", "#")] and len(got) == len(recs) + 2
+    # corrupt payload
+    raw = bytearray(open(p, "rb").read())
+    raw[len(raw) // 2] ^= 0xFF
+    p3 = tmp_path / "bad.fastq.gz"
+    p3.write_bytes(bytes(raw))
+    import logging
+    caplog.set_level(logging.ERROR)
+    assert all_records(str(p3)) == []                   # errors are logged, nothing is returned (the reference's convention)
+    assert any("Error parsing file" in r.getMessage() for r in caplog.records)

@@ -158,8 +158,84 @@ void team(int nthreads, F f) {                 // f(thread index, thread count);
     for (auto& x : th) x.join();
 }
 
+// BGZF (bgzip): a gzip file made of independent <= 64 KiB members whose size is in the header's "BC" extra field
+// -- the one gzip flavour that can be inflated in parallel.  The compressed file is mmap'ed; read_group() inflates
+// the next run of blocks with the thread team and appends the text to `out`.
+struct Bgzf {
+    int fd = -1;
+    const uint8_t* data = nullptr;
+    size_t size = 0, cpos = 0;
+    int threads = 1;
+    bool failed = false;
+    ~Bgzf() {
+        if (data) munmap((void*)data, size);
+        if (fd >= 0) close(fd);
+    }
+    // a BGZF member at p?  -> total block size and header length
+    static bool block_at(const uint8_t* p, size_t avail, size_t& bsize, size_t& hdr) {
+        if (avail < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) return false;
+        const size_t xlen = (size_t)p[10] | ((size_t)p[11] << 8);
+        if (avail < 12 + xlen) return false;
+        for (size_t i = 12; i + 4 <= 12 + xlen;) {
+            const size_t sl = (size_t)p[i + 2] | ((size_t)p[i + 3] << 8);
+            if (p[i] == 'B' && p[i + 1] == 'C' && sl == 2 && i + 6 <= 12 + xlen) {
+                bsize = ((size_t)p[i + 4] | ((size_t)p[i + 5] << 8)) + 1;
+                hdr = 12 + xlen;
+                return bsize >= hdr + 8 && bsize <= avail;
+            }
+            i += 4 + sl;
+        }
+        return false;
+    }
+    bool eof() const { return cpos >= size; }
+    bool read_group(std::vector<char>& out, size_t want) {
+        struct Blk { size_t in, in_len, isize, ooff; uint32_t crc; };
+        std::vector<Blk> blks;
+        size_t total = 0;
+        while (cpos < size && total < want) {
+            size_t bsize = 0, hdr = 0;
+            if (!block_at(data + cpos, size - cpos, bsize, hdr)) { g_err = "not a BGZF block (file truncated or mixed gzip members)"; failed = true; return false; }
+            const uint8_t* tail = data + cpos + bsize - 8;
+            const uint32_t crc = (uint32_t)tail[0] | ((uint32_t)tail[1] << 8) | ((uint32_t)tail[2] << 16) | ((uint32_t)tail[3] << 24);
+            const size_t isize = (size_t)tail[4] | ((size_t)tail[5] << 8) | ((size_t)tail[6] << 16) | ((size_t)tail[7] << 24);
+            blks.push_back(Blk{cpos + hdr, bsize - hdr - 8, isize, total, crc});
+            total += isize;
+            cpos += bsize;
+        }
+        const size_t base = out.size();
+        out.resize(base + total);
+        std::vector<int> bad((size_t)std::max(1, threads), 0);
+        const int T = total < (4u << 20) ? 1 : threads;
+        team(T, [&](int t, int nt) {
+            const size_t a = blks.size() * (size_t)t / (size_t)nt, b = blks.size() * (size_t)(t + 1) / (size_t)nt;
+            z_stream zs;
+            memset(&zs, 0, sizeof zs);
+            if (inflateInit2(&zs, -15) != Z_OK) { bad[(size_t)t] = 1; return; }
+            for (size_t i = a; i < b; ++i) {
+                const Blk& k = blks[i];
+                if (k.isize == 0) continue;                      // the empty end-of-file block
+                inflateReset(&zs);
+                zs.next_in = (Bytef*)(data + k.in);
+                zs.avail_in = (uInt)k.in_len;
+                zs.next_out = (Bytef*)(out.data() + base + k.ooff);
+                zs.avail_out = (uInt)k.isize;
+                const int rc = inflate(&zs, Z_FINISH);
+                if (rc != Z_STREAM_END || zs.total_out != k.isize ||
+                    (uint32_t)crc32(0L, (const Bytef*)(out.data() + base + k.ooff), (uInt)k.isize) != k.crc) { bad[(size_t)t] = 1; break; }
+            }
+            inflateEnd(&zs);
+        });
+        for (int x : bad)
+            if (x) { g_err = "BGZF block failed to inflate (corrupt file)"; failed = true; return false; }
+        return true;
+    }
+};
+
 struct Fast {
     int fd = -1;
+    Bgzf* src = nullptr;                       // BGZF input: `data` is `mem`, refilled group by group
+    std::vector<char> mem;
+    uint64_t base_off = 0;                     // uncompressed offset of data[0] (BGZF)
     const char* data = nullptr;
     size_t size = 0;
     size_t pos = 0;                            // start of the first unconsumed record
@@ -172,13 +248,27 @@ struct Fast {
     std::vector<Rec> recs;
 
     ~Fast() {
-        if (data) munmap((void*)data, size);
+        if (src) delete src;
+        else if (data) munmap((void*)data, size);
         if (fd >= 0) close(fd);
     }
     void index_window() {
-        const size_t lo = pos, span = std::min<size_t>(size - lo, (size_t)512 << 20);
+        if (src) {
+            // keep the unconsumed tail (a partial record), inflate the next group of blocks behind it
+            const size_t keep = size - pos;
+            if (pos) memmove(mem.data(), mem.data() + pos, keep);
+            mem.resize(keep);
+            base_off += pos;
+            pos = 0;
+            size_t group = (size_t)256 << 20;          // text per refill (tests shrink it to exercise the carry-over)
+            if (const char* e = getenv("TPS_IO_BGZF_GROUP")) { const long long g = atoll(e); if (g > 0) group = (size_t)g; }
+            if (!src->eof()) src->read_group(mem, group);
+            data = mem.data();
+            size = mem.size();
+        }
+        const size_t lo = pos, span = src ? size - lo : std::min<size_t>(size - lo, (size_t)512 << 20);
         win_hi = lo + span;
-        whole = win_hi == size;
+        whole = src ? src->eof() : win_hi == size;
         const int T = span < (8u << 20) ? 1 : threads;
         std::vector<std::vector<uint64_t>> part((size_t)T);
         team(T, [&](int t, int nt) {
@@ -211,9 +301,11 @@ struct Fast {
             if (nl_i + 4 > nl.size()) {                  // fewer than four indexed lines left
                 if (!whole) {
                     if (!recs.empty()) break;            // hand over what we have; the next call re-indexes
-                    if (p >= size) break;
+                    if (p >= size && (!src || src->eof())) break;
                     pos = p;
                     index_window();                      // window starts at the next record
+                    p = pos;                             // (BGZF: the buffer was compacted)
+                    if (src && src->failed) return -1;
                     if (nl.size() >= 4) continue;
                     if (!whole) return -3;               // one record larger than the window: streaming decoder
                 }
@@ -316,7 +408,11 @@ int tps_reader_open(const char* path, void** out) {
     Reader* r = open_stream(path, 0, 0);
     if (!r) { delete h; return -1; }
     h->slow = r;
-    if (!r->fill() && r->len == 0) { h->format = 0; *out = h; return 0; }       // empty file: no records
+    g_err.clear();
+    if (!r->fill() && r->len == 0) {
+        if (!g_err.empty()) { delete h; return -1; }                             // unreadable (corrupt gzip), not empty
+        h->format = 0; *out = h; return 0;                                       // empty file: no records
+    }
     size_t i = 0;
     while (i < r->len && (r->buf[i] == '\n' || r->buf[i] == '\r' || r->buf[i] == ' ')) ++i;
     char c = i < r->len ? r->buf[i] : 0;
@@ -325,6 +421,35 @@ int tps_reader_open(const char* path, void** out) {
         g_err = "format cannot be identified (first character is neither '>' nor '@')";
         delete h;
         return -1;
+    }
+    if (!plain && h->format == 2 && !getenv("TPS_IO_NO_MMAP") && !getenv("TPS_IO_NO_BGZF")) {
+        // bgzip'ed FASTQ: blocks inflate in parallel, then the same thread-team record decoder runs over the text
+        Bgzf* z = new Bgzf();
+        z->fd = open(path, O_RDONLY);
+        struct stat st;
+        if (z->fd >= 0 && fstat(z->fd, &st) == 0 && st.st_size >= 28) {
+            void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, z->fd, 0);
+            if (m != MAP_FAILED) {
+                z->data = (const uint8_t*)m;
+                z->size = (size_t)st.st_size;
+                size_t bs = 0, hd = 0;
+                if (Bgzf::block_at(z->data, z->size, bs, hd)) {
+                    madvise(m, z->size, MADV_SEQUENTIAL);
+                    z->threads = io_threads();
+                    Fast* f = new Fast();
+                    f->src = z;
+                    f->threads = z->threads;
+                    f->pos = 0;
+                    f->index_window();                   // first group of blocks; leading blank lines skipped like the streaming decoder does
+                    while (f->pos < f->size && (f->data[f->pos] == '\n' || f->data[f->pos] == '\r' || f->data[f->pos] == ' ')) ++f->pos;
+                    if (f->pos) f->index_window();
+                    h->fast = f;
+                    if (z->failed) { delete h; return -1; }        // (g_err says why; `f` owns `z`)
+                    z = nullptr;
+                }
+            }
+        }
+        delete z;
     }
     if (plain && h->format == 2 && !getenv("TPS_IO_NO_MMAP")) {
         Fast* f = new Fast();
@@ -369,7 +494,7 @@ int64_t tps_reader_next(void* hv, uint8_t* bases, int64_t bases_cap, int64_t* of
         const int64_t n = h->fast->next(bases, bases_cap, offsets, max_records, heads, heads_cap, head_off, quals);
         if (n != -3) return n;
         // not plain 4-line FASTQ from here on: the streaming decoder takes over at the same byte
-        const int64_t at = (int64_t)h->fast->pos;
+        const int64_t at = (int64_t)(h->fast->base_off + h->fast->pos);
         delete h->fast;
         h->fast = nullptr;
         if (h->slow) { if (h->slow->gz) gzclose(h->slow->gz); delete h->slow; }
