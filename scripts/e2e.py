@@ -25,4 +25,14 @@ for rb in seqio.read_batches(path):
     n += len(rb); nb += int(rb.offsets[-1])
 t1 = time.perf_counter()
 print(f"plain FASTQ file -> native parse -> upload -> scan -> results: {n} reads, {nb/(t1-t0)/1e9:.2f} G bases/s ({(t1-t0)*1e3:.0f} ms)")
+# the same through the batched pipeline (host decoding of batch i+1 overlaps the scan of batch i)
+from topsicle_amd import batch
+pool = batch.EnginePool([sc], pats)
+for mb in (64 << 20, 32 << 20):
+    t0 = time.perf_counter()
+    n = nb = 0
+    for rb, res, _s, _r, _w in pool.scan_file(path, prm, max_bases=mb):
+        n += len(rb); nb += int(rb.offsets[-1])
+    t1 = time.perf_counter()
+    print(f"pipelined, {mb >> 20} MB batches: {n} reads, {nb/(t1-t0)/1e9:.2f} G bases/s ({(t1-t0)*1e3:.0f} ms)")
 os.remove(path)

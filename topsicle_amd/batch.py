@@ -76,12 +76,9 @@ class EnginePool:
         return self._scan_batches(record_batches(records, max_bases=max_bases), prm, want_sums, want_raw)
 
     def _scan_batches(self, batches, prm, want_sums, want_raw):
+        # one worker thread per engine, two batches in flight each: the host decodes / packs batch i+1 (native code, the
+        # GIL is released) while the GPU scans batch i and the caller writes the results of batch i-1 -- also with ONE GPU
         n = len(self.engines)
-        if n == 1:
-            for recs in batches:
-                res, sums, raw, win_off = scan_records(self.engines[0], recs, prm, 0, want_sums, want_raw)
-                yield recs, res, sums, raw, win_off
-            return
         from collections import deque
         from concurrent.futures import ThreadPoolExecutor
         workers = [ThreadPoolExecutor(max_workers=1) for _ in range(n)]
