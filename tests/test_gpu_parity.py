@@ -412,3 +412,14 @@ def test_per_pattern_tiles_chains_and_raw_rows(sc, motif, k, slide, units):
         assert np.array_equal(raw[lo:hi], counts.reshape(-1, len(pats))), i
         assert np.array_equal(sums[lo:hi], counts.sum(axis=1)), i
         assert bkp[i] == orc.binseg_l2_exact(counts.sum(axis=1))
+
+
+@pytest.mark.gpu
+def test_per_pattern_tiles_adversarial_sweep():
+    """scripts/fuzz_pp_gpu.py: deletion-ridden repeats and runs of the k-mers' own period over 15 tables / slides, raw rows
+    and sums, both tails, against the C oracle."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_pp_gpu.py"), "90", "3"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
