@@ -89,7 +89,10 @@ extern "C" int emu_scan(const char* pats, int P, int k, const uint8_t* bases, co
         const bool so = a.pat.so_mask != 0;
         switch (a.variant) {
             case 5: so ? tps::scan_read<5, true>(a, r, lds.data(), lut1) : a.pair_n ? tps::scan_read<5, false, true>(a, r, lds.data(), lut1) : tps::scan_read<5, false>(a, r, lds.data(), lut1); break;
-            case 6: so ? tps::scan_read<6, true>(a, r, lds.data(), lut1) : a.pair_n ? tps::scan_read<6, false, true>(a, r, lds.data(), lut1) : tps::scan_read<6, false>(a, r, lds.data(), lut1); break;
+            case 6:
+                if (a.tile_full) a.pair_n ? tps::scan_read<6, false, true, true, true>(a, r, lds.data(), lut1) : tps::scan_read<6, false, false, true, true>(a, r, lds.data(), lut1);
+                else so ? tps::scan_read<6, true>(a, r, lds.data(), lut1) : a.pair_n ? tps::scan_read<6, false, true>(a, r, lds.data(), lut1) : tps::scan_read<6, false>(a, r, lds.data(), lut1);
+                break;
             case 7: so ? tps::scan_read<7, true>(a, r, lds.data(), lut1) : a.pair_n ? tps::scan_read<7, false, true>(a, r, lds.data(), lut1) : tps::scan_read<7, false>(a, r, lds.data(), lut1); break;
             case 8: so ? tps::scan_read<8, true>(a, r, lds.data(), lut1) : a.pair_n ? tps::scan_read<8, false, true>(a, r, lds.data(), lut1) : tps::scan_read<8, false>(a, r, lds.data(), lut1); break;
             default: tps::scan_read<0, false>(a, r, lds.data(), lut1); break;
@@ -119,13 +122,13 @@ extern "C" int emu_plan(int k, int P, const tps_params* prm, int64_t max_nwin, i
     return TPS_OK;
 }
 
-// plan for a real pattern table: out4 = {variant, pp_d, workgroup LDS bytes, pair_n}
+// plan for a real pattern table: out = {variant, pp_d, workgroup LDS bytes, pair_n, tile_full, tw}
 extern "C" int emu_plan_table(const char* pats, int P, int k, const tps_params* prm, int64_t max_nwin, int32_t* out4) {
     tps::ScanArgs a{};
     std::vector<uint32_t> lut;
     std::string err = tps::build_patterns(pats, P, k, lut, a.pat);
     if (err.empty()) err = tps::plan_geometry(a, *prm, k, P, max_nwin, 160 * 1024 / 4, 0, 0);
     if (!err.empty()) { g_err = err; return TPS_E_CAPACITY; }
-    out4[0] = a.variant; out4[1] = a.pp_d; out4[2] = (int32_t)(tps::wg_lds_dwords(a) * 4); out4[3] = a.pair_n;
+    out4[0] = a.variant; out4[1] = a.pp_d; out4[2] = (int32_t)(tps::wg_lds_dwords(a) * 4); out4[3] = a.pair_n; out4[4] = a.tile_full; out4[5] = a.tw;
     return TPS_OK;
 }

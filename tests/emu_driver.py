@@ -86,9 +86,9 @@ def plan(k, P, prm, max_nwin, spans_pref=0, lds_budget=160 * 1024, force_generic
 
 def plan_table(patterns, prm, max_nwin):
     """Plan of a scan with a real pattern table: dict(variant, pp_d, lds_bytes, pair_n)."""
-    out = (C.c_int32 * 4)()
+    out = (C.c_int32 * 6)()
     k = len(patterns[0])
     rc = lib().emu_plan_table("".join(patterns).encode(), len(patterns), k, C.byref(prm), C.c_int64(max_nwin), out)
     if rc != 0:
         raise RuntimeError(lib().emu_last_error().decode())
-    return dict(zip(["variant", "pp_d", "lds_bytes", "pair_n"], list(out)))
+    return dict(zip(["variant", "pp_d", "lds_bytes", "pair_n", "tile_full", "tw"], list(out)))

@@ -417,3 +417,18 @@ def test_planner_picks_per_pattern_tiles():
     assert plan("CCCTAA", 6, 4)["variant"] == 0                                                  # no fused kernel for this slide
     for motif, k, s in [("CCCTAA", 4, 6), ("CCCTAA", 5, 6), ("AAACCCT", 5, 7)]:
         assert plan(motif, k, s)["lds_bytes"] <= 32000                                           # five workgroups per CU
+
+
+def test_planner_full_tiles_when_they_save_a_tile():
+    """Slide 6: tiles that use all 64 lanes (495 instead of 487 windows, a fourth staging chunk per lane) only when the
+    longest read then needs a tile less -- BASELINE config 2 (2467 windows) does, 25-30 kb reads (3301) do not; slides 5
+    and 7 get them for free; raw-count and self-overlap kernels keep the halo lane."""
+    def plan(motif, k, slide, nwin, flags=0):
+        return emu.plan_table(orc.kmer_table(motif, k), hiplib.make_params(slide=slide, flags=hiplib.F_WINDOWS | flags), nwin)
+    p = plan("CCCTAA", 4, 6, 2467)
+    assert (p["tile_full"], p["tw"]) == (1, 495)
+    p = plan("CCCTAA", 4, 6, 3301)
+    assert (p["tile_full"], p["tw"]) == (0, 487)
+    assert plan("CCCTAA", 4, 6, 2467, hiplib.F_STORE_RAW)["tile_full"] == 0 and plan("CCCTAA", 5, 6, 2467)["tile_full"] == 0
+    assert plan("AAACCCT", 5, 7, 2829)["tile_full"] == 1 and plan("TTAGG", 4, 5, 3000)["tile_full"] == 1
+    assert plan("TTTTGGGG", 6, 8, 2000)["tile_full"] == 0

@@ -19,7 +19,7 @@
 // One wave per read, tps::WPG waves per workgroup.  The lookup table is loaded once per workgroup
 // (the only workgroup barrier in the kernel); after that every wave runs its own read with
 // wave-level synchronisation only.
-#define TPS_SCAN_KERNEL(NAME, SV, SO, PAIR, RAW, MINW)                                                             \
+#define TPS_SCAN_KERNEL_F(NAME, SV, SO, PAIR, RAW, MINW, FULL)                                                           \
     extern "C" __global__ void __launch_bounds__(tps::NT * tps::WPG, MINW) NAME(tps::ScanArgs a) {         \
         extern __shared__ __attribute__((aligned(16))) uint32_t lds[];                                     \
         /* workgroup-shared tables: [pair table (PAIR kernels)][single table], both aligned to their size */ \
@@ -42,8 +42,9 @@
         const int64_t wave_dw = (tps::lds_dwords(a) + 3) & ~3ll;                                           \
         uint32_t* slice = lut + ((a.lut_n + 3) & ~3) + wave * wave_dw;                                     \
         const int64_t r = (int64_t)blockIdx.x * tps::WPG + wave;                                           \
-        if (r < a.n_reads) tps::scan_read<SV, SO, PAIR, RAW>(a, r, slice, lut);                                 \
+        if (r < a.n_reads) tps::scan_read<SV, SO, PAIR, RAW, FULL>(a, r, slice, lut);                           \
     }
+#define TPS_SCAN_KERNEL(NAME, SV, SO, PAIR, RAW, MINW) TPS_SCAN_KERNEL_F(NAME, SV, SO, PAIR, RAW, MINW, tps::tile_full_default(SV))
 TPS_SCAN_KERNEL(tps_scan_kernel, 0, false, false, true, 4)          // generic: any slide, up to 31 patterns
 TPS_SCAN_KERNEL(tps_scan_kernel_s5, 5, false, false, false, 3)       // specialised: compile-time slide, <= 15 patterns
 TPS_SCAN_KERNEL(tps_scan_kernel_s6, 6, false, false, false, 3)
@@ -53,6 +54,8 @@ TPS_SCAN_KERNEL(tps_scan_kernel_s5p, 5, false, true, false, 3)       // ... k <=
 TPS_SCAN_KERNEL(tps_scan_kernel_s6p, 6, false, true, false, 3)
 TPS_SCAN_KERNEL(tps_scan_kernel_s7p, 7, false, true, false, 3)
 TPS_SCAN_KERNEL(tps_scan_kernel_s8p, 8, false, true, false, 3)
+TPS_SCAN_KERNEL_F(tps_scan_kernel_s6f, 6, false, false, false, 3, true)   // ... slide 6 with FULL tiles (8 more windows per tile, a fourth staging chunk)
+TPS_SCAN_KERNEL_F(tps_scan_kernel_s6pf, 6, false, true, false, 3, true)
 TPS_SCAN_KERNEL(tps_scan_kernel_s5r, 5, false, false, true, 3)       // ... with the per-pattern raw counts (TPS_F_STORE_RAW)
 TPS_SCAN_KERNEL(tps_scan_kernel_s6r, 6, false, false, true, 3)
 TPS_SCAN_KERNEL(tps_scan_kernel_s7r, 7, false, false, true, 3)
@@ -152,7 +155,7 @@ struct tps_ctx {
     int zero_copy = 1;       // per-read results are written by the kernel straight into mapped pinned host memory
     int force_generic = 0;
     int64_t lds_target_dw = 32 * 256;
-    size_t lds_set_v[17] = {0};
+    size_t lds_set_v[19] = {0};
 };
 
 namespace {
@@ -307,11 +310,16 @@ int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm) {
         case 8: kfn = so ? (const void*)tps_scan_kernel_s8so : rawk ? (const void*)tps_scan_kernel_s8r : pair ? (const void*)tps_scan_kernel_s8p : (const void*)tps_scan_kernel_s8; kidx = so ? 8 : rawk ? 16 : pair ? 12 : 4; break;
         default: kfn = (const void*)tps_scan_kernel; kidx = 0; break;
     }
+    if (a.variant == 6 && a.tile_full) {            // (the planner only asks for FULL tiles at slide 6 for these two)
+        kfn = pair ? (const void*)tps_scan_kernel_s6pf : (const void*)tps_scan_kernel_s6f;
+        kidx = pair ? 18 : 17;
+    }
     {
-        static const char* const names[17] = {"tps_scan_kernel", "tps_scan_kernel_s5", "tps_scan_kernel_s6", "tps_scan_kernel_s7",
+        static const char* const names[19] = {"tps_scan_kernel", "tps_scan_kernel_s5", "tps_scan_kernel_s6", "tps_scan_kernel_s7",
                                               "tps_scan_kernel_s8", "tps_scan_kernel_s5so", "tps_scan_kernel_s6so", "tps_scan_kernel_s7so",
                                               "tps_scan_kernel_s8so", "tps_scan_kernel_s5p", "tps_scan_kernel_s6p", "tps_scan_kernel_s7p",
-                                              "tps_scan_kernel_s8p", "tps_scan_kernel_s5r", "tps_scan_kernel_s6r", "tps_scan_kernel_s7r", "tps_scan_kernel_s8r"};
+                                              "tps_scan_kernel_s8p", "tps_scan_kernel_s5r", "tps_scan_kernel_s6r", "tps_scan_kernel_s7r", "tps_scan_kernel_s8r",
+                                              "tps_scan_kernel_s6f", "tps_scan_kernel_s6pf"};
         sl.kernel_name = names[kidx];
     }
     if (sl.lds_bytes > c->lds_set_v[kidx]) {

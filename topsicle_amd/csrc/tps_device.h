@@ -248,6 +248,7 @@ struct ScanArgs {
     int32_t tile_cap;            // entries of Tc (tiles of the longest read)
     int32_t tw;                  // windows per fused tile
     uint32_t tw_magic;           // ceil(2^32 / tw)
+    int32_t tile_full;           // fused tiles: 1 = all 64 lanes hold windows' blocks (8 more windows per tile), 0 = the last lane is halo
     int32_t pp_d;                // per-pattern tiles (tile_pp_s): -1 = not eligible, 0 = no self-overlapping k-mer,
                                  // d > 0 = the one self-overlap period of the table
 };
@@ -1048,18 +1049,27 @@ struct Geo {
     // dwords (16 positions each) a lane needs after shifting its first position to bit 0: its
     // positions plus the look-ahead of the last k-mer and of the overlap test (k + d <= 13 bases)
     static constexpr int WDW = (POS + 13 + 15) / 16;
-    // a tile is NT lanes; its last lane is halo only, so NT-1 lanes of positions (+ look-ahead and
-    // the sub-dword start offset) are staged: PF 16-byte chunks per lane
-    static constexpr int TILE_DW = ((NT - 1) * POS + 13 + 15 + 15) / 16 + 1;
-    static constexpr int PF = (TILE_DW + NT - 1) / NT;
 };
+// Staging geometry of a tile: NT lanes of positions (+ look-ahead and the sub-dword start offset), staged as PF 16-byte
+// chunks per lane.  HALO tiles leave the last lane unused (its blocks are never a window's); FULL tiles use all 64 lanes
+// and hold 8 more windows.  FULL is free at slides 5 and 7 (same chunks per lane); at slide 6, 64 lanes of bases are 3
+// chunks more than 3 per lane, so FULL costs a fourth chunk per lane to pack: separate kernels (_s6f, _s6pf) that the
+// planner takes when they save a tile (config 2: 2467 windows = 5 x 495 instead of 5 x 487 + 32); slide 8 is always HALO.
+template <int S, bool FULL>
+struct TileGeo {
+    static constexpr int LANES = FULL ? NT : NT - 1;
+    static constexpr int TILE_DW = (LANES * Geo<S>::POS + 13 + 15 + 15) / 16 + 1;
+    static constexpr int PF = (TILE_DW + NT - 1) / NT;
+    static constexpr int SEQ = TILE_DW + 5;       // dwords of seq2: the dword before the tile, the tile, look-ahead reads of the last lane
+};
+constexpr bool tile_full_default(int s) { return s == 5 || s == 7; }
 
 // LDS slice of a wave in the fused kernels: everything whose size is known at compile time comes first, at
 // compile-time offsets from the slice base (one SGPR for all of it, offsets folded into the DS instructions);
 // only the candidate / tile sums, whose size depends on the longest read, follow.  Sizes = plan_geometry's.
-template <int S>
+template <int S, bool FULL>
 TPS_DEV Lds carve_fused(uint32_t* base, uint32_t* lut, const ScanArgs& a) {
-    constexpr int BLK = 9 * NT + 2 * XLANES, ROW = NT * Geo<S>::B + NT, SEQ = Geo<S>::PF * NT + 4, VAL = ((SEQ + 4 + 3) / 4) * 2;
+    constexpr int BLK = 9 * NT + 2 * XLANES, ROW = NT * Geo<S>::B + NT, SEQ = TileGeo<S, FULL>::SEQ, VAL = ((SEQ + 4 + 3) / 4) * 2;
     Lds l;
     l.lut2 = lut - a.pair_n;
     l.lut = lut;
@@ -2344,9 +2354,9 @@ TPS_DEV void binseg_from_lc(const ScanArgs& a, const Lds& l, uint64_t lc_g, cons
 // In the device build every lane of the wave executes this function; TPS_PHASE bodies run once
 // per lane and TPS_SYNC() is a wave-level fence.  In the emulation TPS_PHASE loops over the 64
 // lane ids, so phases run in program order.
-template <int SV, bool SO, bool PAIR = false, bool RAW = true>
+template <int SV, bool SO, bool PAIR = false, bool RAW = true, bool FULL = tile_full_default(SV)>
 TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_t* lut) {
-    const Lds l = SV ? carve_fused<SV ? SV : 5>(lds_base, lut, a) : carve(lds_base, lut, a);
+    const Lds l = SV ? carve_fused<SV ? SV : 5, FULL>(lds_base, lut, a) : carve(lds_base, lut, a);
     const PatInfo& pat = a.pat;
     const tps_params& prm = a.prm;
     const int64_t off = a.offsets[r];
@@ -2482,15 +2492,16 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
         } else {
             // ---------------- fused tiles: NT lanes x 8 blocks, the last lane is halo only
             typedef Geo<SV ? SV : 1> g_;
-            constexpr int PF = g_::PF;
+            typedef TileGeo<SV ? SV : 1, FULL> t_;
+            constexpr int PF = t_::PF;
             const TileConst tc = tile_const(a, r);
-            const int tw = NT * g_::B - tc.q - 1 - g_::B;   // windows per tile
+            const int tw = NT * g_::B - tc.q - 1 - (FULL ? 0 : g_::B);   // windows per tile (= a.tw; the host pairs a.tile_full with the kernel)
             bool pp = false;
             if constexpr (RAW) pp = a.pp_d >= 0 && (SO ? a.pp_d > 0 : (a.pp_d == 0 && a.raw != nullptr));
             auto tile_stage = [&](int w0_) {
                 const int64_t i0 = (int64_t)w0_ * prm.slide;
                 int64_t n_stage = n_s - i0;
-                const int64_t cap = (int64_t)(g_::TILE_DW - 1) * 16;
+                const int64_t cap = (int64_t)(t_::TILE_DW - 1) * 16;
                 if (n_stage > cap) n_stage = cap;
                 return stage_plan(seq, L, tail == 1, prm.trimfirst, i0, (int)n_stage);
             };
@@ -2534,8 +2545,10 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
                         uint32_t packed = 0, bad = 0;
                         if (c < st.nch) stage_pack(st, c, pf[u], packed, bad);
                         if (bad) l.misc[M_INVALID] = 1u;
-                        l.seq2[c + 1] = packed;        // one dword in: lanes also read the base before their first
-                        l.val[c + 1] = (uint16_t)bad;
+                        if (c + 1 < t_::SEQ) {
+                            l.seq2[c + 1] = packed;    // one dword in: lanes also read the base before their first
+                            l.val[c + 1] = (uint16_t)bad;
+                        }
                     }
                     if (tid == 0) { l.seq2[0] = 0; l.val[0] = 0; }
                 }

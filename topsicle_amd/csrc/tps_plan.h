@@ -129,8 +129,8 @@ inline std::string plan_geometry(ScanArgs& a, const tps_params& prm, int k, int 
     for (int i = 0; i < a.pat.n_periods; ++i) max_period = std::max(max_period, a.pat.period[i]);
     const bool fused = !force_generic && spans_pref <= 0 && k <= TPS_DIRECT_K && has_specialised_slide(prm.slide) && P <= 15 && a.q >= 8 &&
                        a.q / 8 + 2 < (XLANES - NT) && max_period <= std::min(prm.slide, 6) &&
-                       2 * a.head_dw <= ((((int)NT - 1) * 8 * prm.slide + 43) / 16 + 1 + (int)NT - 1) / (int)NT * (int)NT + 4;   // heads fit the tile buffer
-    a.lc16 = 0; a.tile_cap = 0; a.tw = 0; a.tw_magic = 0; a.pair_n = 0; a.lc_global = 0; a.lc_stride = 0; a.pp_d = -1;
+                       2 * a.head_dw <= (((int)NT - 1) * 8 * prm.slide + 43) / 16 + 1 + 5;   // heads fit the (smaller, HALO) tile buffer (TileGeo::SEQ)
+    a.lc16 = 0; a.tile_cap = 0; a.tw = 0; a.tw_magic = 0; a.pair_n = 0; a.lc_global = 0; a.lc_stride = 0; a.pp_d = -1; a.tile_full = 0;
     if (fused) {
         // per-pattern tiles (tile_pp_s): one-hot 2-bit fields per pattern need distinct k-mers; a lane's 8 blocks hold at
         // most 14 non-overlapping occurrences of a pattern (nibbles), a block at most 2, a window at most 127 (bytes);
@@ -147,12 +147,22 @@ inline std::string plan_geometry(ScanArgs& a, const tps_params& prm, int k, int 
         a.rec_rs = 0;
         a.tot_dw = 2;
         const int pos = 8 * prm.slide;
-        const int tile_dw = ((NT - 1) * pos + 13 + 15 + 15) / 16 + 1;     // = Geo<S>::TILE_DW
-        const int pf = (tile_dw + NT - 1) / NT;                            // = Geo<S>::PF
-        a.seq_dw = pf * (int)NT + 4;               // compile-time size in the kernel (carve_fused); the heads fit (see `fused`)
+        // FULL tiles (all 64 lanes hold window blocks: 8 more windows per tile) are free at slides 5 and 7; at slide 6 they
+        // cost a fourth staging chunk per lane (kernels _s6f / _s6pf), so they are taken when the longest read then needs
+        // a tile less -- and only by the sums-only kernels of tables without self-overlap
+        {
+            const int64_t tw_halo = (int64_t)NT * 8 - a.q - 1 - 8, tw_full = tw_halo + 8;
+            a.tile_full = 0;
+            if (prm.slide == 5 || prm.slide == 7) a.tile_full = 1;
+            else if (prm.slide == 6 && a.pat.so_mask == 0 && !(prm.flags & TPS_F_STORE_RAW) && tw_halo > 0 && !getenv("TPS_NO_TILE_FULL") &&
+                     ((max_nwin + tw_full - 1) / tw_full < (max_nwin + tw_halo - 1) / tw_halo || getenv("TPS_FORCE_TILE_FULL"))) a.tile_full = 1;
+        }
+        const int lanes = a.tile_full ? (int)NT : (int)NT - 1;             // = TileGeo<S, FULL>::LANES
+        const int tile_dw = (lanes * pos + 13 + 15 + 15) / 16 + 1;         // = TileGeo::TILE_DW
+        a.seq_dw = tile_dw + 5;                    // = TileGeo::SEQ: compile-time size in the kernel (carve_fused); the heads fit (see `fused`)
         // candidate left sums as u16 relative to their tile when a tile's window sums cannot reach 2^16
         // (every position matches at most one list pattern: S_w <= lw + P)
-        a.tw = (int)NT * 8 - a.q - 1 - 8;
+        a.tw = (int)NT * 8 - a.q - 1 - (a.tile_full ? 0 : 8);
         a.tw_magic = (uint32_t)(((1ull << 32) + (uint64_t)a.tw - 1) / (uint64_t)a.tw);
         a.tile_cap = (int)((max_nwin + a.tw - 1) / a.tw) + 1;
         a.lc16 = (a.pat.dup_mask == 0 && (int64_t)a.tw * (a.lw + P) < 65536) ? 1 : 0;
