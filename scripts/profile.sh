@@ -8,7 +8,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH --steps 2000 > $OUT/trace.log 2>&1   # many steps: the 256 clock-ramp priming launches must not weigh on the average
 echo "trace rc=$?"
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -- python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $OUT/pmc_$C.log 2>&1
