@@ -470,14 +470,16 @@ TPS_DEV void stage_pack(const Stage& st, int c, const u32x4& v, uint32_t& packed
     uint32_t lo2 = st.reverse ? (d3 + (d2 << 8)) : (d0 + (d1 << 8));
     uint32_t hi2 = st.reverse ? (d1 + (d0 << 8)) : (d2 + (d3 << 8));
     packed = (lo2 >> 1) | ((hi2 >> 1) << 16);
-    // expected lower-case letter for each 2-bit code: selector 0,2,4,6 -> a,c,t,g
+    // expected lower-case letter for each 2-bit code: selector 0,2,4,6 -> a,c,t,g.  A valid byte differs from it in the
+    // case bit at most; that bit is masked once, after the four words have been OR-ed (one op instead of four)
     const uint32_t s1 = 0x00630061u, s0 = 0x00670074u;
-    uint32_t b0 = (v.x | 0x20202020u) ^ perm(s0, s1, y0);
-    uint32_t b1 = (v.y | 0x20202020u) ^ perm(s0, s1, y1);
-    uint32_t b2 = (v.z | 0x20202020u) ^ perm(s0, s1, y2);
-    uint32_t b3 = (v.w | 0x20202020u) ^ perm(s0, s1, y3);
+    uint32_t b0 = v.x ^ perm(s0, s1, y0);
+    uint32_t b1 = v.y ^ perm(s0, s1, y1);
+    uint32_t b2 = v.z ^ perm(s0, s1, y2);
+    uint32_t b3 = v.w ^ perm(s0, s1, y3);
     bad = 0;
-    if (b0 | b1 | b2 | b3) {
+    if ((b0 | b1 | b2 | b3) & 0xDFDFDFDFu) {
+        b0 &= 0xDFDFDFDFu; b1 &= 0xDFDFDFDFu; b2 &= 0xDFDFDFDFu; b3 &= 0xDFDFDFDFu;
         bad = bad_bits16(b0, b1, b2, b3, st.reverse);
         // keep only positions inside the staged range [delta, delta+n)
         int lo = st.delta - 16 * c, hi = st.delta + st.n - 16 * c;
@@ -2374,16 +2376,24 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
     TPS_STAMP(1);
     TPS_PHASE {
         if (step1) {
-            // the heads are staged side by side: [0, head_dw) and [head_dw, 2 head_dw)
-            for (int c = tid; c < 2 * a.head_dw; c += NT) {
-                const int side = c >= a.head_dw;
-                const int cc = c - side * a.head_dw;
-                uint32_t packed, bad;
-                if (side) stage_chunk(st_e, cc, packed, bad);
-                else stage_chunk(st_s, cc, packed, bad);
-                if (bad) l.misc[M_INVALID] = 1u;
-                l.seq2[c] = packed;
-                l.val[c] = (uint16_t)bad;
+            // the heads are staged side by side: [0, head_dw) and [head_dw, 2 head_dw).  Lane t takes chunk t of BOTH
+            // heads first, the two 16-byte loads in flight together: 1000 bases are at most 64 chunks per head, so the
+            // common case pays the HBM latency once (a flat loop over 2 x 67 dwords paid it three times, the third round
+            // for six lanes); whatever lies beyond (the zeroed slack, longer heads) follows in the same pattern.
+            for (int c0 = tid; c0 < a.head_dw; c0 += NT) {
+                u32x4 vs, ve;
+                vs.x = vs.y = vs.z = vs.w = 0;
+                ve = vs;
+                if (c0 < st_s.nch) vs = load16(stage_addr(st_s, c0));
+                if (c0 < st_e.nch) ve = load16(stage_addr(st_e, c0));
+                uint32_t ps = 0, bs = 0, pe_ = 0, be = 0;
+                if (c0 < st_s.nch) stage_pack(st_s, c0, vs, ps, bs);
+                if (c0 < st_e.nch) stage_pack(st_e, c0, ve, pe_, be);
+                if (bs | be) l.misc[M_INVALID] = 1u;
+                l.seq2[c0] = ps;
+                l.val[c0] = (uint16_t)bs;
+                l.seq2[a.head_dw + c0] = pe_;
+                l.val[a.head_dw + c0] = (uint16_t)be;
             }
         }
     }
