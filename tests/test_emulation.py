@@ -426,9 +426,9 @@ def test_planner_full_tiles_when_they_save_a_tile():
     def plan(motif, k, slide, nwin, flags=0):
         return emu.plan_table(orc.kmer_table(motif, k), hiplib.make_params(slide=slide, flags=hiplib.F_WINDOWS | flags), nwin)
     p = plan("CCCTAA", 4, 6, 2467)
-    assert (p["tile_full"], p["tw"]) == (1, 495)
+    assert (p["tile_full"], p["tw"]) == (1, 494)          # 5 balanced tiles (at most 495 windows each)
     p = plan("CCCTAA", 4, 6, 3301)
-    assert (p["tile_full"], p["tw"]) == (0, 487)
+    assert (p["tile_full"], p["tw"]) == (0, 487)          # 7 tiles either way: halo kernels, a short last tile
     assert plan("CCCTAA", 4, 6, 2467, hiplib.F_STORE_RAW)["tile_full"] == 0 and plan("CCCTAA", 5, 6, 2467)["tile_full"] == 0
     assert plan("AAACCCT", 5, 7, 2829)["tile_full"] == 1 and plan("TTAGG", 4, 5, 3000)["tile_full"] == 1
     assert plan("TTTTGGGG", 6, 8, 2000)["tile_full"] == 0

@@ -2501,17 +2501,24 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
             }
         } else {
             // ---------------- fused tiles: NT lanes x 8 blocks, the last lane is halo only
-            typedef Geo<SV ? SV : 1> g_;
             typedef TileGeo<SV ? SV : 1, FULL> t_;
             constexpr int PF = t_::PF;
             const TileConst tc = tile_const(a, r);
-            const int tw = NT * g_::B - tc.q - 1 - (FULL ? 0 : g_::B);   // windows per tile (= a.tw; the host pairs a.tile_full with the kernel)
+            // windows per tile: at most NT * B - q - 1 (- B with the halo lane); the planner balances the tiles of the longest
+            // read (2467 windows = 5 x 494) -- a tile then stages only what its windows need, which at slide 6 mostly spares
+            // FULL tiles their fourth chunk per lane
+            int tw = (int)uniform((uint32_t)a.tw);
+            TPS_PIN_S(tw);
             bool pp = false;
             if constexpr (RAW) pp = a.pp_d >= 0 && (SO ? a.pp_d > 0 : (a.pp_d == 0 && a.raw != nullptr));
             auto tile_stage = [&](int w0_) {
                 const int64_t i0 = (int64_t)w0_ * prm.slide;
                 int64_t n_stage = n_s - i0;
-                const int64_t cap = (int64_t)(t_::TILE_DW - 1) * 16;
+                int64_t cap = (int64_t)(t_::TILE_DW - 1) * 16;
+                // the last window ends r positions into block tw - 1 + q; + its last k-mer, the pair lookup's extra base and
+                // the look-ahead of the self-overlap tests (<= 13 bases in all)
+                const int64_t need = (int64_t)(tw - 1 + tc.q) * prm.slide + tc.r + 13;
+                if (cap > need) cap = need;
                 if (n_stage > cap) n_stage = cap;
                 return stage_plan(seq, L, tail == 1, prm.trimfirst, i0, (int)n_stage);
             };

@@ -163,6 +163,13 @@ inline std::string plan_geometry(ScanArgs& a, const tps_params& prm, int k, int 
         // candidate left sums as u16 relative to their tile when a tile's window sums cannot reach 2^16
         // (every position matches at most one list pattern: S_w <= lw + P)
         a.tw = (int)NT * 8 - a.q - 1 - (a.tile_full ? 0 : 8);
+        // FULL tiles at slide 6: equal tiles for the longest read (2467 windows = 5 x 494 instead of 4 x 495 + 487) -- a tile
+        // stages only what its windows need, which then mostly fits three chunks per lane.  (Elsewhere a short last tile is
+        // cheaper than equal ones: fewer window iterations.)
+        if (max_nwin > 0 && a.tile_full && prm.slide == 6 && !getenv("TPS_NO_TILE_BALANCE")) {
+            const int64_t tiles = (max_nwin + a.tw - 1) / a.tw;
+            a.tw = (int)std::max<int64_t>(1, std::min<int64_t>(a.tw, (max_nwin + tiles - 1) / tiles));
+        }
         a.tw_magic = (uint32_t)(((1ull << 32) + (uint64_t)a.tw - 1) / (uint64_t)a.tw);
         a.tile_cap = (int)((max_nwin + a.tw - 1) / a.tw) + 1;
         a.lc16 = (a.pat.dup_mask == 0 && (int64_t)a.tw * (a.lw + P) < 65536) ? 1 : 0;
