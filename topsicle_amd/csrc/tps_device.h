@@ -457,8 +457,13 @@ TPS_DEV uint32_t bad_bits16(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, 
 }
 
 // address of chunk c of a staged range
+// = a wave-uniform base + an unsigned 32-bit per-lane offset: one scalar-base load address instead of 64-bit per-lane
+// arithmetic with a select for the direction (5 - 6 VALU instructions per chunk)
+constexpr int STAGE_KMAX = 1 << 16;              // > chunks of any staged range (everything staged fits the 160 KB of LDS)
 TPS_DEV const uint8_t* stage_addr(const Stage& st, int c) {
-    return st.reverse ? st.chunk0 - 16 * (intptr_t)c : st.chunk0 + 16 * (intptr_t)c;
+    const uint8_t* base = st.reverse ? st.chunk0 - 16 * (intptr_t)STAGE_KMAX : st.chunk0;      // uniform
+    const uint32_t off = st.reverse ? 16u * (uint32_t)(STAGE_KMAX - c) : 16u * (uint32_t)c;
+    return base + off;
 }
 // 16 ASCII bytes of chunk c -> (packed 16 bases, 16 invalid bits)
 TPS_DEV void stage_pack(const Stage& st, int c, const u32x4& v, uint32_t& packed, uint32_t& bad) {
