@@ -471,10 +471,12 @@ TPS_DEV void stage_pack(const Stage& st, int c, const u32x4& v, uint32_t& packed
     // bits 1-2 of an ASCII letter: A,C,T,G (either case) -> 0,1,2,3; one dot product packs 4 bases
     uint32_t y0 = v.x & 0x06060606u, y1 = v.y & 0x06060606u, y2 = v.z & 0x06060606u, y3 = v.w & 0x06060606u;
     uint32_t d0 = udot4(y0, w), d1 = udot4(y1, w), d2 = udot4(y2, w), d3 = udot4(y3, w);
-    // d_i = 2 * (8-bit packed codes of 4 bases); halve per 16-bit half so bit 32 is never needed
-    uint32_t lo2 = st.reverse ? (d3 + (d2 << 8)) : (d0 + (d1 << 8));
-    uint32_t hi2 = st.reverse ? (d1 + (d0 << 8)) : (d2 + (d3 << 8));
-    packed = (lo2 >> 1) | ((hi2 >> 1) << 16);
+    // d_i = 2 * (8-bit packed codes of 4 bases); halve per 16-bit half so bit 32 is never needed.  A reversed range
+    // wants the four bytes in the opposite order: one byte permute with a uniform selector instead of a second
+    // assembly and two selects
+    const uint32_t lo2 = d0 + (d1 << 8), hi2 = d2 + (d3 << 8);
+    const uint32_t fwd = (lo2 >> 1) | ((hi2 >> 1) << 16);
+    packed = perm(fwd, fwd, st.reverse ? 0x00010203u : 0x03020100u);
     // expected lower-case letter for each 2-bit code: selector 0,2,4,6 -> a,c,t,g.  A valid byte differs from it in the
     // case bit at most; that bit is masked once, after the four words have been OR-ed (one op instead of four)
     const uint32_t s1 = 0x00630061u, s0 = 0x00670074u;
@@ -1335,10 +1337,7 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const TileConst& tc, const Lds& l, 
         // per tile instead of one per window (rows past the tile's windows read in-bounds garbage)
         uint32_t xv[B], ev[B], fv[B];
         TPS_UNROLL
-        for (int u = 0; u < B; ++u) {
-            xv[u] = ev[u] = fv[u] = 0;
-            if (u <= nfull) { xv[u] = ps[u * RS]; ev[u] = pe[u * RS]; fv[u] = pf[u * (NT / B)]; }
-        }
+        for (int u = 0; u < B; ++u) { xv[u] = ps[u * RS]; ev[u] = pe[u * RS]; fv[u] = pf[u * (NT / B)]; }   // unconditional: no branch, no zeroing
         TPS_UNROLL
         for (int u = 0; u < B; ++u) {
             uint32_t sw = 0;
