@@ -1481,6 +1481,7 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const TileConst& tc, const Lds& l, 
         const int passes = c_hi > c_lo ? (int)((c_hi - c_lo + NT - 1) / NT) : 0;
         TPS_PHASE {
             const uint32_t carry = (uint32_t)s_total;
+            if (tid == 0) { l.misc[M_INVALID] = 0; l.misc[M_NTIE] = 0; }      // for the next tile's staging
             if (tc.lc16 && tid == 0) l.Tc[tile] = carry;
             uint32_t c = c_lo + (uint32_t)tid;
             uint32_t w = c * jump - (uint32_t)w0;         // tile-local window index of candidate c
@@ -1516,6 +1517,7 @@ TPS_DEV void tile_candidates(const TileConst& tc, const Lds& l, int w0, int tile
     const int passes = c_hi > c_lo ? (int)((c_hi - c_lo + NT - 1) / NT) : 0;
     TPS_PHASE {
         const uint32_t carry = (uint32_t)s_total;
+        if (tid == 0) { l.misc[M_INVALID] = 0; l.misc[M_NTIE] = 0; }      // for the next tile's staging
         if (tc.lc16 && tid == 0) l.Tc[tile] = carry;
         uint32_t c = c_lo + (uint32_t)tid;
         uint32_t w = c * jump - (uint32_t)w0;
@@ -2546,16 +2548,16 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
             };
             if (n_win > 0) {
                 const Stage st0 = tile_stage(0);
-                TPS_PHASE { pf_load(st0, tid); }
+                TPS_PHASE {
+                    if (tid == 0) { l.misc[M_INVALID] = 0; l.misc[M_NTIE] = 0; }   // step 1 may have flagged its heads
+                    pf_load(st0, tid);
+                }
             }
             for (int w0 = 0, tile = 0; w0 < n_win; w0 += tw, ++tile) {
                 const int nw_tile = (n_win - w0) < tw ? (n_win - w0) : tw;
                 const Stage st = tile_stage(w0);
-                TPS_PHASE {
-                    if (tid == 0) { l.misc[M_INVALID] = 0; l.misc[M_NTIE] = 0; }
-                    if (RAW && pp && w0 == 0 && tid < 8) l.misc[M_SCAN + tid] = 0;      // nothing is picked before the first tile
-                }
-                TPS_SYNC();
+                // (misc[M_INVALID] / [M_NTIE] are zero here: cleared with the rest of misc at the start of the read and again
+                // by the last phase of every tile -- no extra phase and barrier per tile for that)
                 TPS_PHASE {
                     TPS_UNROLL
                     for (int u = 0; u < PF; ++u) {
