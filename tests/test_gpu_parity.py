@@ -423,3 +423,49 @@ def test_per_pattern_tiles_adversarial_sweep():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_pp_gpu.py"), "90", "3"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [4, 5, 6])
+def test_full_size_raw_count_properties(sc, k):
+    """BASELINE config-5 shape (25 kb ONT reads, --telophrase 4 5 6 --rawcountpattern), 4000 reads per k, no oracle at this
+    size: the raw rows sum to S_w window by window; every count is >= 1 (`matches or 1`) and <= the non-overlapping
+    maximum; the strand-swapped batch gives the rows with pattern p and its complement exchanged; a few reads are checked
+    against the C oracle."""
+    motif = "CCCTAA"
+    pats = orc.kmer_table(motif, k)
+    P = len(pats)
+    sc.set_patterns(pats)
+    n, L = 4000, 25000
+    bases, offsets, _ = synth.make_reads(n, L, motif, seed=20250919 + 4)
+    prm = hiplib.make_params(min_len=9000, min_count=-1,
+                             flags=hiplib.F_STEP1 | hiplib.F_WINDOWS | hiplib.F_BINSEG | hiplib.F_STORE_SUMS | hiplib.F_STORE_RAW)
+    sc.upload(4, bases, offsets)
+    sc.scan(4, prm)
+    sc.sync()
+    res = sc.results(4).copy()
+    sums, win_off = sc.window_sums(4)
+    raw, _ = sc.window_raw(4)
+    raw = raw.reshape(-1, P)
+    assert raw.shape[0] == sums.shape[0] == win_off[-1] == n * 3301
+    assert np.array_equal(raw.sum(axis=1, dtype=np.int64), sums)
+    assert raw.min() >= 1 and raw.max() <= (99 - k) // k + 1
+    # strand symmetry: complement k-mers are the second half of the table (allsteps.py:115-119)
+    comp = np.zeros(256, np.uint8)
+    comp[list(b"ACGT")] = list(b"TGCA")
+    rc = comp[bases.reshape(n, -1)[:, ::-1]].reshape(-1)
+    sc.upload(5, rc, offsets)
+    sc.scan(5, prm)
+    sc.sync()
+    res_rc = sc.results(5)
+    raw_rc, _ = sc.window_raw(5)
+    raw_rc = raw_rc.reshape(-1, P)
+    strict = np.repeat(res["best_start"] != res["best_end"], 3301)
+    half = P // 2
+    swapped = np.concatenate([raw_rc[:, half:], raw_rc[:, :half]], axis=1)
+    assert np.array_equal(raw[strict], swapped[strict])
+    assert np.array_equal(res["tail"][res["best_start"] != res["best_end"]], 1 - res_rc["tail"][res["best_start"] != res["best_end"]])
+    for i in (0, 1, 1999, 3999):
+        seq = bytes(bases[offsets[i]:offsets[i + 1]]).decode()
+        _, counts = orc.window_count_matrix(seq, ["forward", "reverse"][int(res["tail"][i])], pats, 100, 6, 100, 20000)
+        assert np.array_equal(raw[win_off[i]:win_off[i + 1]], counts)
