@@ -60,10 +60,10 @@ TPS_SCAN_KERNEL(tps_scan_kernel_s5r, 5, false, false, true, 3)       // ... with
 TPS_SCAN_KERNEL(tps_scan_kernel_s6r, 6, false, false, true, 3)
 TPS_SCAN_KERNEL(tps_scan_kernel_s7r, 7, false, false, true, 3)
 TPS_SCAN_KERNEL(tps_scan_kernel_s8r, 8, false, false, true, 3)
-TPS_SCAN_KERNEL(tps_scan_kernel_s5so, 5, true, false, true, 4)       // ... with self-overlapping k-mers in the table
-TPS_SCAN_KERNEL(tps_scan_kernel_s6so, 6, true, false, true, 4)
-TPS_SCAN_KERNEL(tps_scan_kernel_s7so, 7, true, false, true, 4)
-TPS_SCAN_KERNEL(tps_scan_kernel_s8so, 8, true, false, true, 4)
+TPS_SCAN_KERNEL(tps_scan_kernel_s5so, 5, true, false, true, 5)       // ... with self-overlapping k-mers in the table
+TPS_SCAN_KERNEL(tps_scan_kernel_s6so, 6, true, false, true, 5)
+TPS_SCAN_KERNEL(tps_scan_kernel_s7so, 7, true, false, true, 5)
+TPS_SCAN_KERNEL(tps_scan_kernel_s8so, 8, true, false, true, 5)
 
 extern "C" __global__ void __launch_bounds__(tps::NT * tps::WPG) tps_binseg_kernel(tps::BinsegArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t smem[tps::WPG * tps::BINSEG_SMEM_DW];
