@@ -1593,7 +1593,8 @@ TPS_DEV void tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
     constexpr int AHEAD = (D > 0 && 2 * D > S) ? 2 * D - S : 0;   // positions past the lane whose occurrences close a start-skip chain
     constexpr uint32_t M3 = 0x33333333u;
     const PatInfo& pat = a.pat;
-    const int rp = tc.r, q = tc.q;
+    int rp = tc.r, q = tc.q;
+    TPS_PIN_S(rp); TPS_PIN_S(q);                  // opaque per tile: what derives from them is recomputed (scalar) per tile, not kept in SGPRs across the read
     const uint32_t amask = pat.kmask << 2;
     uint32_t* ende = l.XPC;                       // END, even patterns (padded block index)
     uint32_t* endo = l.row;                       // END, odd patterns; S_w takes the place after phase 2
