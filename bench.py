@@ -12,7 +12,10 @@ the 256 MiB Infinity Cache (the batch alone is only 150 MB).
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 N > 1: one process per GPU, each scanning its own batch (weak scaling, no data-path collective);
-torch.distributed (gloo) is used only for the barrier and the max-over-ranks time.
+torch.distributed (gloo) is used only for the barrier and the max-over-ranks time.  Run WITHOUT a launcher
+(`python bench.py --gpus 8`, WORLD_SIZE unset) the script spawns its N ranks itself -- fresh child processes, started
+before this process has touched a GPU -- and relays rank 0's JSON line; it fails if fewer than N GPUs are visible
+(TPS_BENCH_SHARE_GPU=1 lets ranks share devices: the launcher test on a 1-GPU box).
 
 Prints ONE JSON line (rank 0).
 """
@@ -27,8 +30,9 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-# the HIP library is loaded BEFORE torch so that its libamdhip64 (ROCm 7.2, /opt/rocm) is the one
-# in the process; torch is only imported for the multi-process barrier and never touches a GPU here.
+# torch is only imported for the multi-process barrier and never touches a GPU here; main() dlopens the HIP library
+# (hiplib.load_library(): no GPU call) BEFORE torch.distributed comes in, so that its libamdhip64 (ROCm 7.2, /opt/rocm)
+# is the HIP runtime of the process.
 from topsicle_amd import hiplib, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ~6290
@@ -70,11 +74,14 @@ def min_count_for_cutoff(cutoff, no_bp, motif_len):
 
 
 def algorithmic_bytes(lens, passed, n_win, P, prm):
-    """fixed formula, independent of implementation choices."""
+    """fixed formula, independent of implementation choices (1 B per scanned base + 4 B per
+    window, + P bytes per window when the raw counts are stored)."""
     lens = np.asarray(lens, dtype=np.int64)
     step1 = (2 * np.minimum(lens, prm.no_bp) + 2 * P * 4).sum()
     n_s = np.maximum(np.minimum(lens, prm.maxlen) - prm.trimfirst, 0)
     step2 = (n_s[passed] + 4 * n_win[passed]).sum()
+    if prm.flags & hiplib.F_STORE_RAW:
+        step2 += (P * n_win[passed]).sum()
     step3 = (4 * n_win[passed] + 12).sum()
     return int(step1 + step2 + step3), int(step1), int(step2), int(step3)
 
@@ -140,6 +147,30 @@ def cpu_baseline(seqs, motif, k, prm, budget_s=15.0):
                 reads_per_s=done / dt)
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (this process has not
+    touched a GPU and never will), one per GPU, rendezvous over 127.0.0.1; relay rank 0's output; non-zero exit if any
+    rank fails.  Replaces the reference's Pool over input files (Topsicle/main.py:232-235) as the unit of node-level
+    parallelism: one process + one context per GPU, no collective."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TPS_BENCH_SPAWNED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    if any(rcs):
+        raise SystemExit(f"bench.py: ranks exited with {rcs}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -153,10 +184,16 @@ def main():
     ap.add_argument("--resident-copies", type=int, default=0, help="copies of the batch kept in HBM (0 = enough for >1 GB)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus, sys.argv[1:])
+
+    lib = hiplib.load_library()                  # dlopen only (no GPU call): before torch.distributed brings its own HIP runtime in
     from topsicle_amd import dist
     grp = dist.Group()
     rank, world, local_rank = grp.rank, grp.world, grp.local_rank
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     cfg = dict(CONFIGS[args.workload])
@@ -182,12 +219,14 @@ def main():
     # launch costs ~3.5 us of host/queue work, which would otherwise sit inside every timed step)
     os.environ.setdefault("TPS_EVENT_STRIDE", "4")
     # one GPU per rank; TPS_BENCH_SHARE_GPU=1 (testing the launcher path on a box with fewer GPUs than ranks) wraps around
+    import ctypes
+    n_dev = ctypes.c_int(0)
+    lib.tps_device_count(ctypes.byref(n_dev))
     dev = local_rank
     if os.environ.get("TPS_BENCH_SHARE_GPU"):
-        import ctypes
-        n_dev = ctypes.c_int(0)
-        hiplib.load_library().tps_device_count(ctypes.byref(n_dev))
         dev = local_rank % max(n_dev.value, 1)
+    elif n_dev.value < world:
+        raise SystemExit(f"--gpus {world} but only {n_dev.value} GPU(s) visible ({lib.tps_last_error().decode()})")
     sc = hiplib.HipScanner(dev)
     sc.set_patterns(pats)
     copies = args.resident_copies or max(2, min(hiplib.MAX_SLOTS, -(-(1 << 30) // max(batch_bases, 1))))
@@ -214,8 +253,10 @@ def main():
     for i in range(args.steps):
         sc.scan(i % copies, prm)
     sc.sync()                      # device idle: every step's kernel and result copy has finished
-    dt = grp.max(time.perf_counter() - t0)
+    dt_rank = time.perf_counter() - t0
+    dt = grp.max(dt_rank)
     grp.barrier()
+    per_rank = grp.gather_objects(dict(rank=rank, device=dev, ms_per_step=dt_rank / args.steps * 1e3))
     n_launch, k_total_ms, k_mean_ms = sc.kernel_time_ms()
 
     res = sc.results((args.steps - 1) % copies)
@@ -236,7 +277,9 @@ def main():
             "value": value,
             "unit": "bases/s",
             "reads_per_sec": n_reads * world * args.steps / dt,
+            "scanned_bases_per_sec": scanned * world * args.steps / dt,
             "n_gpus": world,
+            "ranks": per_rank,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
@@ -267,6 +310,9 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
+                # physical HBM rate of the same launch (PMC bytes / event time): the fused kernel moves fewer bytes than the
+                # contract's algorithmic count (S_w is consumed from LDS, never re-read), so this is the lower figure
+                "traffic_frac": (traffic / (k_mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and k_mean_ms > 0) else None,
                 "algorithmic_bytes_per_launch": alg_total,
                 "algorithmic_bytes_split": {"step1": alg1, "windows": alg2, "binseg": alg3},
                 "kernel_ms_mean": k_mean_ms,

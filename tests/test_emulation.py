@@ -432,3 +432,31 @@ def test_planner_full_tiles_when_they_save_a_tile():
     assert plan("CCCTAA", 4, 6, 2467, hiplib.F_STORE_RAW)["tile_full"] == 0 and plan("CCCTAA", 5, 6, 2467)["tile_full"] == 0
     assert plan("AAACCCT", 5, 7, 2829)["tile_full"] == 1 and plan("TTAGG", 4, 5, 3000)["tile_full"] == 1
     assert plan("TTTTGGGG", 6, 8, 2000)["tile_full"] == 0
+
+
+@pytest.mark.parametrize("pats,W", [(["AC", "GT"], 600), (["ACGT", "TGCA"], 1100), (["AAAA", "CCCC"], 300)])
+def test_emulation_wide_windows_raw_capacity(pats, W):
+    """Raw rows (and their accumulators) are bytes: a window in which a pattern can occur more than 255 times is refused
+    with TPS_E_CAPACITY when raw counts are requested (it used to carry into the neighbouring pattern's byte); the same
+    scan without raw counts stays exact."""
+    rng = np.random.default_rng(W)
+    unit = pats[0]
+    seqs = [(unit * 900)[: 2 * W + 37], "".join("ACGT"[x] for x in rng.integers(0, 4, 3 * W)) + unit * 400]
+    prm = hiplib.make_params(window=W, slide=6, trimfirst=0, maxlen=20000,
+                             flags=hiplib.F_WINDOWS | hiplib.F_BINSEG | hiplib.F_TAILS_IN | hiplib.F_STORE_SUMS | hiplib.F_STORE_RAW)
+    with pytest.raises(RuntimeError, match="raw counts are bytes"):
+        emu.scan(pats, seqs, prm, tails=[0, 1])
+    prm.flags &= ~hiplib.F_STORE_RAW
+    out = emu.scan(pats, seqs, prm, tails=[0, 1])
+    for i, seq in enumerate(seqs):
+        _, counts = orc.window_count_matrix(seq, ["forward", "reverse"][i], pats, W, 6, 0, 20000)
+        lo, hi = out["win_off"][i], out["win_off"][i + 1]
+        assert np.array_equal(out["sums"][lo:hi], counts.sum(axis=1))
+
+
+def test_planner_refuses_sums_beyond_32_bits():
+    prm = hiplib.make_params(window=60000, slide=1, trimfirst=0, maxlen=600000, flags=hiplib.F_WINDOWS | hiplib.F_BINSEG)
+    with pytest.raises(RuntimeError, match="exceed"):
+        emu.plan(4, 12, prm, 500000)
+    prm = hiplib.make_params(window=255 * 4 + 4, slide=6, flags=hiplib.F_WINDOWS | hiplib.F_STORE_RAW)
+    emu.plan(4, 12, prm, 3000)                       # 255 occurrences at most: still fine

@@ -50,18 +50,3 @@ def test_plots_render(tmp_path, gold_dir):
     plt.close("all")
     assert list(df.columns) == ["Pattern", "Match", "read id"] and len(df) == 24200
     assert os.path.getsize(tmp_path / "d.png") > 1000 and os.path.getsize(tmp_path / "h.png") > 1000
-
-
-@pytest.mark.gpu
-def test_overview_cli_on_gpu(tmp_path, gold_dir):
-    """overview_plot end to end: the TRC filter runs on the GPU, the plots and the raw-count CSV on the 17 reads that pass."""
-    from topsicle_amd import overview_plot
-    out = tmp_path / "ov"
-    overview_plot.main(["--inputDir", os.path.join(gold_dir, "demo_col0.fastq.gz"), "--outputDir", str(out),
-                        "--pattern", "CCCTAAA", "--recfindingpattern", "--rawcount"])
-    assert (out / "descriptive_plot_1.png").exists() and (out / "heatmap_1.png").exists()
-    df = pd.read_csv(out / "heatmap_rawcount_1.csv")
-    assert list(df.columns) == ["Pattern", "Match", "read id"]
-    gold_ids = {r.split(",")[3] for r in open(os.path.join(gold_dir, "demo_telolengths_all.csv")).read().splitlines()[1:]}
-    assert {x.strip("[]'") for x in df["read id"].unique()} <= gold_ids and len(df) > 5000
-    assert not list(out.glob("temp_reads_in_heatmap*"))

@@ -616,6 +616,20 @@ int tps_binseg_l2(tps_ctx* c, const int32_t* sums, const int64_t* win_off, int64
     if (n == 0) return TPS_OK;
     const int64_t nw = win_off[n];
     if (nw > 0 && !sums) return fail(TPS_E_ARG, "null sums");
+    for (int64_t i = 0; i < n; ++i) {
+        // the kernel adds a read's sums up in 32 bits and compares d^2 * den in 128 bits (d <= len * total, den <= len^2 / 4)
+        const int64_t lo = win_off[i], len = win_off[i + 1] - lo;
+        if (len < 0 || lo < 0 || lo + len > nw) return fail(TPS_E_ARG, "win_off not monotone at %lld", (long long)i);
+        if (len > 500000) return fail(TPS_E_CAPACITY, "read %lld has %lld windows (max 500000)", (long long)i, (long long)len);
+        uint64_t tot = 0;
+        for (int64_t w = 0; w < len; ++w) {
+            if (sums[lo + w] < 0) return fail(TPS_E_ARG, "negative window sum at read %lld", (long long)i);
+            tot += (uint64_t)sums[lo + w];
+        }
+        if (tot >> 32 || (double)len * (double)len * (double)tot >= 18446744073709551616.0)
+            return fail(TPS_E_CAPACITY, "window sums of read %lld exceed the change-point arithmetic (total %llu over %lld windows)",
+                        (long long)i, (unsigned long long)tot, (long long)len);
+    }
     Slot& sl = c->slots[INTERNAL_SLOT];
     if ((rc = sl.sums.ensure((size_t)std::max<int64_t>(nw, 1) * 4))) return rc;
     if ((rc = sl.win_off.ensure((size_t)(n + 1) * 8))) return rc;

@@ -118,6 +118,24 @@ inline std::string plan_geometry(ScanArgs& a, const tps_params& prm, int k, int 
     a.q = a.lw / prm.slide;
     a.r = a.lw % prm.slide;
     if (max_nwin > 500000) return "too many windows per read (" + std::to_string(max_nwin) + ")";
+    {
+        // Arithmetic limits of the kernels (all far beyond the reference's defaults: window 100, <= 3301 windows per read):
+        //  * raw rows are bytes, and so are their accumulators (window_exact counts OCCURRENCES, overlapping ones included,
+        //    before the greedy recount of self-overlapping patterns): a pattern may occur at most 255 times in a window;
+        //  * the window sums of a read are added up in 32 bits (prefix sums, candidate sums, Binseg chunk sums);
+        //  * the exact change-point tournament compares d^2 * den in 128 bits with d <= n * T, T <= n * max S_w and
+        //    den <= n^2 / 4: n^6 * (max S_w)^2 / 4 < 2^128.
+        int min_per = k;
+        for (int i = 0; i < a.pat.n_periods; ++i) min_per = std::min(min_per, std::max(1, (int)a.pat.period[i]));
+        const int64_t occ_max = a.lw > 0 ? (a.lw - 1) / min_per + 1 : 0;
+        if ((prm.flags & TPS_F_STORE_RAW) && occ_max > 255)
+            return "raw counts are bytes: a pattern can occur " + std::to_string(occ_max) + " times in a window of " +
+                   std::to_string(prm.window) + " (max 255); use a smaller --windowSize with --rawcountpattern";
+        const int64_t sw_max = (int64_t)P * ((a.lw + k - 1) / k + 1);            // S_w <= P * (non-overlapping maximum + 1)
+        if (max_nwin * sw_max >= (1ll << 32)) return "window sums of one read exceed 32 bits (windows per read x window size too large)";
+        if ((double)max_nwin * (double)max_nwin * (double)max_nwin * (double)sw_max >= 18446744073709551616.0 /* 2^64 */)
+            return "change-point arithmetic would exceed 128 bits (windows per read x window size too large)";
+    }
     const int jump = std::max(prm.jump, 1);
     a.lc_cap = (int)(max_nwin / jump + 2);
     a.jump_magic = jump == 1 ? 0u : (uint32_t)(((1ull << 32) + (uint64_t)jump - 1) / (uint64_t)jump);   // 0: divide by 1
