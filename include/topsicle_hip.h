@@ -19,7 +19,16 @@
  *     fails with TPS_E_NO_DEVICE.
  *   - reads are passed as ONE concatenated ASCII byte string plus n+1 offsets (any case,
  *     any IUPAC letter; only A/C/G/T in either case can match, exactly like the reference's
- *     .upper() + literal regex).
+ *     .upper() + literal regex) -- or already 2-bit packed (tps_batch_upload_packed).  Either way a batch is
+ *     RESIDENT in HBM in the packed format below; the scan kernels read nothing else.
+ *
+ * Packed batch format (what the reference's Bio.SeqIO records, allsteps.py:127-149, become on this path)
+ *   seq2   uint32 words, 16 bases per word, base j of a word in bits [2j, 2j+1]; code = (ASCII >> 1) & 3:
+ *          A,a = 0   C,c = 1   T,t = 2   G,g = 3
+ *   inv    uint16 per word: bit j set = base j of the word is not one of acgtACGT (it never matches)
+ *   desc   one tps_read_desc per read; a read starts on a 16-byte boundary (word_off is a multiple of 4) and the words
+ *          up to the next such boundary after its last base are zero in seq2 and inv
+ *   3 bits per base instead of 8 across PCIe; libtopsicle_io.so's reader emits this format directly.
  */
 #ifndef TOPSICLE_HIP_H
 #define TOPSICLE_HIP_H
@@ -30,7 +39,7 @@
 extern "C" {
 #endif
 
-#define TPS_ABI_VERSION 1
+#define TPS_ABI_VERSION 2
 
 /* error codes */
 #define TPS_OK            0
@@ -55,6 +64,14 @@ extern "C" {
 #define TPS_F_TAILS_IN  32u   /* without STEP1: tails[] and pass come from the caller         */
 
 typedef struct tps_ctx tps_ctx;
+
+/* One read of a packed batch (16 bytes). */
+typedef struct tps_read_desc {
+    int64_t  word_off;    /* index of the read's first word in seq2 / inv; a multiple of 4            */
+    int32_t  len;         /* bases                                                                     */
+    uint32_t flags;       /* TPS_RD_*                                                                  */
+} tps_read_desc;
+#define TPS_RD_HAS_INVALID 1u   /* the read holds at least one base that is not acgtACGT (inv is consulted) */
 
 /* Parameters of one scan.  Names follow the reference CLI (Topsicle/main.py:319-334). */
 typedef struct tps_params {
@@ -104,6 +121,21 @@ int  tps_set_patterns(tps_ctx* ctx, const char* pats, int32_t n_patterns, int32_
 #define TPS_MAX_SLOTS 16
 int  tps_batch_upload(tps_ctx* ctx, int32_t slot, const uint8_t* bases, const int64_t* offsets,
                       int64_t n_reads);
+/* The same for a batch the host has already packed (format above): seq2[n_words], inv[n_words] (NULL = no read has an
+ * invalid base), desc[n_reads].  Three bits per base cross PCIe instead of eight.  Replaces allsteps.py:127-149 +
+ * main.py:68-86 (the parse that feeds every later step) together with libtopsicle_io.so's tps_reader_next_packed.
+ * Buffers obtained from tps_host_alloc are pinned: the copies then run asynchronously on the context's stream and the
+ * call returns at once -- the caller must keep those buffers unchanged until tps_sync (or any result download of the
+ * slot) has returned; ordinary memory is copied before the call returns. */
+int  tps_batch_upload_packed(tps_ctx* ctx, int32_t slot, const uint32_t* seq2, const uint16_t* inv,
+                             const tps_read_desc* desc, int64_t n_reads, int64_t n_words);
+/* Pinned host memory for upload staging buffers (double buffering: fill one while the other is in flight). */
+int  tps_host_alloc(tps_ctx* ctx, int64_t bytes, void** out);
+int  tps_host_free(tps_ctx* ctx, void* p);
+/* Download the resident packed batch of `slot` (tests: the device pack kernel vs the host packer; diagnostics).
+ * seq2 / inv hold n_words entries, desc n_reads; any of the three may be NULL.  n_words out via *n_words_out. */
+int  tps_batch_download_packed(tps_ctx* ctx, int32_t slot, uint32_t* seq2, uint16_t* inv, tps_read_desc* desc,
+                               int64_t n_reads, int64_t n_words, int64_t* n_words_out);
 /* Optional per-read tails (0/1) and pass flags for scans without TPS_F_STEP1. */
 int  tps_batch_set_tails(tps_ctx* ctx, int32_t slot, const uint8_t* tails);
 

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../topsicle_amd/csrc/tps_device.h"
+#include "../../topsicle_amd/csrc/tps_pack.h"
 #include "../../topsicle_amd/csrc/tps_plan.h"
 
 static std::string g_err;
@@ -47,18 +48,19 @@ extern "C" int emu_scan(const char* pats, int P, int k, const uint8_t* bases, co
     err = tps::plan_geometry(a, *prm, k, P, mx, lds_budget_bytes / 4, spans_pref, force_generic);
     if (!err.empty()) { g_err = err; return TPS_E_CAPACITY; }
 
-    const int64_t total = offsets[n];
-    const int64_t PAD = 64;
-    std::vector<uint8_t> buf((size_t)(total + 2 * PAD + 64), (uint8_t)'A');
-    uint8_t* al = (uint8_t*)(((uintptr_t)buf.data() + 15) & ~(uintptr_t)15);
-    uint8_t* data = al + 16 + (base_shift & 15);
-    // bytes around the data are deliberately non-ACGT garbage: the kernel must never let them count
-    memset(al, '#', (size_t)(16 + (base_shift & 15)));
-    if (total) memcpy(data, bases, (size_t)total);
-    memset(data + total, '#', 40);
-
-    a.bases = data;
-    a.offsets = offsets;
+    // the packed batch, exactly as the library keeps it in HBM (tps_pack.h).  Words the layout does not own are filled
+    // with garbage: the kernel must never let them count.  base_shift moves the batch inside its buffer by whole quads
+    // (the device only ever sees 16-byte aligned quads).
+    std::vector<tps_read_desc> desc((size_t)(n > 0 ? n : 1));
+    const int64_t n_words = tps::pack_layout(offsets, n, desc.data());
+    const int64_t lead = 4 * (int64_t)(base_shift & 3);
+    std::vector<uint32_t> seq2buf((size_t)(n_words + lead + 8), 0xDEADBEEFu);
+    std::vector<uint16_t> invbuf((size_t)(n_words + lead + 8), (uint16_t)0xFFFFu);
+    for (int64_t i = 0; i < n; ++i) desc[(size_t)i].word_off += lead;
+    tps::pack_range(bases, offsets, 0, n, desc.data(), seq2buf.data(), invbuf.data());
+    a.seq2 = seq2buf.data();
+    a.inv = invbuf.data();
+    a.desc = desc.data();
     a.tails_in = ((prm->flags & TPS_F_TAILS_IN) && !(prm->flags & TPS_F_STEP1)) ? tails : nullptr;
     a.lut = lut.data();
     a.results = results;
@@ -89,10 +91,7 @@ extern "C" int emu_scan(const char* pats, int P, int k, const uint8_t* bases, co
         const bool so = a.pat.so_mask != 0;
         switch (a.variant) {
             case 5: so ? tps::scan_read<5, true>(a, r, lds.data(), lut1) : a.pair_n ? tps::scan_read<5, false, true>(a, r, lds.data(), lut1) : tps::scan_read<5, false>(a, r, lds.data(), lut1); break;
-            case 6:
-                if (a.tile_full) a.pair_n ? tps::scan_read<6, false, true, true, true>(a, r, lds.data(), lut1) : tps::scan_read<6, false, false, true, true>(a, r, lds.data(), lut1);
-                else so ? tps::scan_read<6, true>(a, r, lds.data(), lut1) : a.pair_n ? tps::scan_read<6, false, true>(a, r, lds.data(), lut1) : tps::scan_read<6, false>(a, r, lds.data(), lut1);
-                break;
+            case 6: so ? tps::scan_read<6, true>(a, r, lds.data(), lut1) : a.pair_n ? tps::scan_read<6, false, true>(a, r, lds.data(), lut1) : tps::scan_read<6, false>(a, r, lds.data(), lut1); break;
             case 7: so ? tps::scan_read<7, true>(a, r, lds.data(), lut1) : a.pair_n ? tps::scan_read<7, false, true>(a, r, lds.data(), lut1) : tps::scan_read<7, false>(a, r, lds.data(), lut1); break;
             case 8: so ? tps::scan_read<8, true>(a, r, lds.data(), lut1) : a.pair_n ? tps::scan_read<8, false, true>(a, r, lds.data(), lut1) : tps::scan_read<8, false>(a, r, lds.data(), lut1); break;
             default: tps::scan_read<0, false>(a, r, lds.data(), lut1); break;

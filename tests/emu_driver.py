@@ -9,7 +9,7 @@ from topsicle_amd import hiplib
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "emu", "emu_scan.cpp")
-DEPS = [SRC] + [os.path.join(HERE, "..", "topsicle_amd", "csrc", f) for f in ("tps_device.h", "tps_plan.h")] + \
+DEPS = [SRC] + [os.path.join(HERE, "..", "topsicle_amd", "csrc", f) for f in ("tps_device.h", "tps_plan.h", "tps_pack.h")] + \
        [os.path.join(HERE, "..", "include", "topsicle_hip.h")]
 
 

@@ -419,19 +419,16 @@ def test_planner_picks_per_pattern_tiles():
         assert plan(motif, k, s)["lds_bytes"] <= 32000                                           # five workgroups per CU
 
 
-def test_planner_full_tiles_when_they_save_a_tile():
-    """Slide 6: tiles that use all 64 lanes (495 instead of 487 windows, a fourth staging chunk per lane) only when the
-    longest read then needs a tile less -- BASELINE config 2 (2467 windows) does, 25-30 kb reads (3301) do not; slides 5
-    and 7 get them for free; raw-count and self-overlap kernels keep the halo lane."""
+def test_planner_full_tiles_everywhere():
+    """With the packed batch a tile is staged as whole 64-base quads whatever the slide, so every fused tile uses all 64
+    lanes: 512 - q - 1 windows (495 at slide 6, window 100), for the sums-only, raw-count and self-overlap kernels alike."""
     def plan(motif, k, slide, nwin, flags=0):
         return emu.plan_table(orc.kmer_table(motif, k), hiplib.make_params(slide=slide, flags=hiplib.F_WINDOWS | flags), nwin)
-    p = plan("CCCTAA", 4, 6, 2467)
-    assert (p["tile_full"], p["tw"]) == (1, 494)          # 5 balanced tiles (at most 495 windows each)
-    p = plan("CCCTAA", 4, 6, 3301)
-    assert (p["tile_full"], p["tw"]) == (0, 487)          # 7 tiles either way: halo kernels, a short last tile
-    assert plan("CCCTAA", 4, 6, 2467, hiplib.F_STORE_RAW)["tile_full"] == 0 and plan("CCCTAA", 5, 6, 2467)["tile_full"] == 0
+    for nwin in (2467, 3301):
+        p = plan("CCCTAA", 4, 6, nwin)
+        assert (p["tile_full"], p["tw"]) == (1, 495)
+    assert plan("CCCTAA", 4, 6, 2467, hiplib.F_STORE_RAW)["tw"] == 495 and plan("CCCTAA", 5, 6, 2467)["tw"] == 496
     assert plan("AAACCCT", 5, 7, 2829)["tile_full"] == 1 and plan("TTAGG", 4, 5, 3000)["tile_full"] == 1
-    assert plan("TTTTGGGG", 6, 8, 2000)["tile_full"] == 0
 
 
 @pytest.mark.parametrize("pats,W", [(["AC", "GT"], 600), (["ACGT", "TGCA"], 1100), (["AAAA", "CCCC"], 300)])

@@ -9,10 +9,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <set>
 #include <string>
 #include <vector>
 
 #include "tps_device.h"
+#include "tps_pack.h"
 #include "tps_plan.h"
 
 // ======================================================================== kernels
@@ -54,8 +56,6 @@ TPS_SCAN_KERNEL(tps_scan_kernel_s5p, 5, false, true, false, 3)       // ... k <=
 TPS_SCAN_KERNEL(tps_scan_kernel_s6p, 6, false, true, false, 3)
 TPS_SCAN_KERNEL(tps_scan_kernel_s7p, 7, false, true, false, 3)
 TPS_SCAN_KERNEL(tps_scan_kernel_s8p, 8, false, true, false, 3)
-TPS_SCAN_KERNEL_F(tps_scan_kernel_s6f, 6, false, false, false, 3, true)   // ... slide 6 with FULL tiles (8 more windows per tile, a fourth staging chunk)
-TPS_SCAN_KERNEL_F(tps_scan_kernel_s6pf, 6, false, true, false, 3, true)
 TPS_SCAN_KERNEL(tps_scan_kernel_s5r, 5, false, false, true, 3)       // ... with the per-pattern raw counts (TPS_F_STORE_RAW)
 TPS_SCAN_KERNEL(tps_scan_kernel_s6r, 6, false, false, true, 3)
 TPS_SCAN_KERNEL(tps_scan_kernel_s7r, 7, false, false, true, 3)
@@ -71,6 +71,57 @@ extern "C" __global__ void __launch_bounds__(tps::NT * tps::WPG) tps_binseg_kern
     const int64_t r = (int64_t)blockIdx.x * tps::WPG + wave;
     if (r >= a.n_reads) return;
     tps::binseg_read(a, r, smem + wave * tps::BINSEG_SMEM_DW);
+}
+
+// ASCII -> packed batch (tps_pack.h), one workgroup per read, one thread per word of 16 bases.  Runs once per
+// tps_batch_upload, right behind the copy of the ASCII bytes; the scan kernels only ever see the packed batch.
+// bits 1-2 of an ASCII letter: A,C,T,G (either case) -> 0,1,2,3; one v_dot4_u32_u8 packs 4 bases; a v_perm rebuilds the
+// lower-case letter each code stands for and any byte that differs from it in more than the case bit is invalid.
+extern "C" __global__ void __launch_bounds__(256) tps_pack_kernel(const uint8_t* bases, const int64_t* offsets, tps_read_desc* desc,
+                                                                   uint32_t* seq2, uint16_t* inv, int64_t n_reads) {
+    const int64_t r = blockIdx.x;
+    if (r >= n_reads) return;
+    const int64_t off = offsets[r];
+    const int64_t L = desc[r].len;
+    const int64_t w0 = desc[r].word_off;
+    const int64_t nw = ((L + 63) / 64) * 4;
+    uint32_t any = 0;
+    for (int64_t w = threadIdx.x; w < nw; w += 256) {
+        const int64_t left = L - 16 * w;               // bases of this word (<= 0: padding up to the quad boundary)
+        uint32_t packed = 0, bad = 0;
+        if (left > 0) {
+            // the read starts at an arbitrary byte: five aligned dwords + byte funnel shifts
+            const uintptr_t p = (uintptr_t)(bases + off + 16 * w);
+            const uint32_t* q = (const uint32_t*)(p & ~(uintptr_t)3);
+            const uint32_t sh = (uint32_t)(p & 3u);
+            const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
+            uint32_t v[4] = {__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
+                             __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh)};
+            uint32_t any_bad = 0, b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t y = v[i] & 0x06060606u;
+                packed |= (tps::udot4(y, 0x40100401u) >> 1) << (8 * i);
+                b[i] = (v[i] ^ tps::perm(0x00670074u, 0x00630061u, y)) & 0xDFDFDFDFu;
+                any_bad |= b[i];
+            }
+            if (any_bad) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if ((b[i] >> (8 * j)) & 255u) bad |= 1u << (4 * i + j);
+            }
+            if (left < 16) {
+                packed &= (1u << (2 * (int)left)) - 1u;
+                bad &= (1u << (int)left) - 1u;
+            }
+        }
+        seq2[w0 + w] = packed;
+        inv[w0 + w] = (uint16_t)bad;
+        any |= bad;
+    }
+    if (any) atomicOr(&desc[r].flags, TPS_RD_HAS_INVALID);
 }
 
 // ======================================================================== host side
@@ -112,7 +163,9 @@ struct DevBuf {
 };
 
 struct Slot {
-    DevBuf bases, offsets, tails, results, c_start, c_end, win_off, sums, raw, stamps, lc;
+    DevBuf seq2, inv, desc, tails, results, c_start, c_end, win_off, sums, raw, stamps, lc;
+    int64_t n_words = 0;                 // words of seq2 / inv in use
+    bool inv_valid = true;               // false: the batch came packed without an inv array (no read is flagged)
     std::vector<int64_t> h_offsets;      // host copy of offsets (n+1)
     std::vector<int64_t> h_win_off;      // window layout of the last plan
     tps_read_result* h_results = nullptr;   // pinned
@@ -140,6 +193,9 @@ struct tps_ctx {
     hipStream_t stream = nullptr;
     hipDeviceProp_t prop{};
     DevBuf lut;
+    DevBuf ascii, ascii_off;          // staging of tps_batch_upload: ASCII bases + offsets, packed on the device right after the copy
+    std::set<void*> pinned;           // host buffers handed out by tps_host_alloc
+    std::vector<tps_read_desc> h_desc;   // scratch of the ASCII upload path
     tps::PatInfo pat{};
     bool have_pat = false;
     Slot slots[TPS_MAX_SLOTS + 1];
@@ -155,7 +211,7 @@ struct tps_ctx {
     int zero_copy = 1;       // per-read results are written by the kernel straight into mapped pinned host memory
     int force_generic = 0;
     int64_t lds_target_dw = 32 * 256;
-    size_t lds_set_v[19] = {0};
+    size_t lds_set_v[17] = {0};
 };
 
 namespace {
@@ -189,26 +245,80 @@ int check_params(const tps_params& p) {
     return TPS_OK;
 }
 
-int do_upload(tps_ctx* c, Slot& sl, const uint8_t* bases, const int64_t* offsets, int64_t n) {
-    if (n < 0 || !offsets || (n > 0 && !bases)) return fail(TPS_E_ARG, "bad batch pointers");
-    if (offsets[0] != 0) return fail(TPS_E_ARG, "offsets[0] must be 0");
-    for (int64_t i = 0; i < n; ++i)
-        if (offsets[i + 1] < offsets[i]) return fail(TPS_E_ARG, "offsets not monotone at %lld", (long long)i);
-    const int64_t total = offsets[n];
-    int rc;
-    if ((rc = sl.bases.ensure((size_t)(total + 2 * PAD + 32)))) return rc;
-    if ((rc = sl.offsets.ensure((size_t)(n + 1) * 8))) return rc;
-    uint8_t* d = (uint8_t*)sl.bases.p;
-    HIP_TRY(hipMemsetAsync(d, 'A', PAD, c->stream));
-    HIP_TRY(hipMemsetAsync(d + PAD + total, 'A', PAD + 32, c->stream));
-    if (total) HIP_TRY(hipMemcpyAsync(d + PAD, bases, (size_t)total, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(sl.offsets.p, offsets, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    sl.h_offsets.assign(offsets, offsets + n + 1);
+void reset_slot(Slot& sl, int64_t n, int64_t n_words) {
     sl.n = n;
+    sl.n_words = n_words;
     sl.has_tails = false;
     sl.planned = false;
     sl.scanned = false;
+}
+
+int ensure_packed(Slot& sl, int64_t n, int64_t n_words) {
+    int rc;
+    if ((rc = sl.seq2.ensure((size_t)std::max<int64_t>(n_words, 4) * 4))) return rc;
+    if ((rc = sl.inv.ensure((size_t)std::max<int64_t>(n_words, 4) * 2))) return rc;
+    if ((rc = sl.desc.ensure((size_t)std::max<int64_t>(n, 1) * sizeof(tps_read_desc)))) return rc;
+    return TPS_OK;
+}
+
+// ASCII batch -> HBM -> packed batch (tps_pack_kernel).  The ASCII copy only lives in the context's staging buffer.
+int do_upload(tps_ctx* c, Slot& sl, const uint8_t* bases, const int64_t* offsets, int64_t n) {
+    if (n < 0 || !offsets || (n > 0 && !bases)) return fail(TPS_E_ARG, "bad batch pointers");
+    if (offsets[0] != 0) return fail(TPS_E_ARG, "offsets[0] must be 0");
+    for (int64_t i = 0; i < n; ++i) {
+        if (offsets[i + 1] < offsets[i]) return fail(TPS_E_ARG, "offsets not monotone at %lld", (long long)i);
+        if (offsets[i + 1] - offsets[i] > 0x7FFFFFFFll) return fail(TPS_E_CAPACITY, "read %lld is longer than 2^31 - 1 bases", (long long)i);
+    }
+    const int64_t total = offsets[n];
+    c->h_desc.resize((size_t)std::max<int64_t>(n, 1));
+    const int64_t n_words = tps::pack_layout(offsets, n, c->h_desc.data());
+    int rc;
+    if ((rc = ensure_packed(sl, n, n_words))) return rc;
+    if ((rc = c->ascii.ensure((size_t)(total + 2 * PAD + 32)))) return rc;
+    if ((rc = c->ascii_off.ensure((size_t)(n + 1) * 8))) return rc;
+    uint8_t* d = (uint8_t*)c->ascii.p;
+    if (total) HIP_TRY(hipMemcpyAsync(d + PAD, bases, (size_t)total, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->ascii_off.p, offsets, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    if (n) HIP_TRY(hipMemcpyAsync(sl.desc.p, c->h_desc.data(), (size_t)n * sizeof(tps_read_desc), hipMemcpyHostToDevice, c->stream));
+    if (n) {
+        hipLaunchKernelGGL(tps_pack_kernel, dim3((unsigned)n), dim3(256), 0, c->stream, (const uint8_t*)d + PAD,
+                           (const int64_t*)c->ascii_off.p, (tps_read_desc*)sl.desc.p, (uint32_t*)sl.seq2.p, (uint16_t*)sl.inv.p, n);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));       // the caller's buffers and h_desc are free again
+    sl.h_offsets.assign(offsets, offsets + n + 1);
+    sl.inv_valid = true;
+    reset_slot(sl, n, n_words);
+    return TPS_OK;
+}
+
+// Host-packed batch: three plain copies.  Pinned sources (tps_host_alloc) are copied asynchronously.
+int do_upload_packed(tps_ctx* c, Slot& sl, const uint32_t* seq2, const uint16_t* inv, const tps_read_desc* desc, int64_t n, int64_t n_words) {
+    if (n < 0 || n_words < 0 || (n > 0 && !desc) || (n_words > 0 && !seq2)) return fail(TPS_E_ARG, "bad packed batch pointers");
+    sl.h_offsets.resize((size_t)n + 1);
+    int64_t acc = 0, need = 0;
+    bool flagged = false;
+    for (int64_t i = 0; i < n; ++i) {
+        const tps_read_desc& d = desc[i];
+        if (d.len < 0 || d.word_off < 0 || (d.word_off & 3) || d.word_off + tps::packed_words(d.len) > n_words)
+            return fail(TPS_E_ARG, "read %lld: descriptor outside the packed batch (word_off %lld, len %d, %lld words)", (long long)i,
+                        (long long)d.word_off, d.len, (long long)n_words);
+        sl.h_offsets[(size_t)i] = acc;
+        acc += d.len;
+        need = std::max(need, d.word_off + tps::packed_words(d.len));
+        flagged = flagged || (d.flags & TPS_RD_HAS_INVALID);
+    }
+    sl.h_offsets[(size_t)n] = acc;
+    if (flagged && !inv) return fail(TPS_E_ARG, "a read is flagged TPS_RD_HAS_INVALID but inv is NULL");
+    int rc;
+    if ((rc = ensure_packed(sl, n, n_words))) return rc;
+    if (n_words) HIP_TRY(hipMemcpyAsync(sl.seq2.p, seq2, (size_t)n_words * 4, hipMemcpyHostToDevice, c->stream));
+    if (n_words && inv) HIP_TRY(hipMemcpyAsync(sl.inv.p, inv, (size_t)n_words * 2, hipMemcpyHostToDevice, c->stream));
+    if (n) HIP_TRY(hipMemcpyAsync(sl.desc.p, desc, (size_t)n * sizeof(tps_read_desc), hipMemcpyHostToDevice, c->stream));
+    const bool all_pinned = (!n_words || c->pinned.count((void*)seq2)) && (!inv || c->pinned.count((void*)inv)) && (!n || c->pinned.count((void*)desc));
+    if (!all_pinned) HIP_TRY(hipStreamSynchronize(c->stream));     // ordinary memory: the copy is over when the call returns
+    sl.inv_valid = inv != nullptr;
+    reset_slot(sl, n, n_words);
     return TPS_OK;
 }
 
@@ -256,8 +366,9 @@ int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm) {
         sl.h_results_cap = want;
     }
     tps::ScanArgs& a = sl.args;
-    a.bases = (const uint8_t*)sl.bases.p + PAD;
-    a.offsets = (const int64_t*)sl.offsets.p;
+    a.seq2 = (const uint32_t*)sl.seq2.p;
+    a.inv = (const uint16_t*)sl.inv.p;
+    a.desc = (const tps_read_desc*)sl.desc.p;
     a.tails_in = ((prm.flags & TPS_F_TAILS_IN) && !(prm.flags & TPS_F_STEP1)) ? (const uint8_t*)sl.tails.p : nullptr;
     a.lut = (const uint32_t*)c->lut.p;
     a.results = c->zero_copy ? sl.h_results : (tps_read_result*)sl.results.p;
@@ -310,16 +421,11 @@ int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm) {
         case 8: kfn = so ? (const void*)tps_scan_kernel_s8so : rawk ? (const void*)tps_scan_kernel_s8r : pair ? (const void*)tps_scan_kernel_s8p : (const void*)tps_scan_kernel_s8; kidx = so ? 8 : rawk ? 16 : pair ? 12 : 4; break;
         default: kfn = (const void*)tps_scan_kernel; kidx = 0; break;
     }
-    if (a.variant == 6 && a.tile_full) {            // (the planner only asks for FULL tiles at slide 6 for these two)
-        kfn = pair ? (const void*)tps_scan_kernel_s6pf : (const void*)tps_scan_kernel_s6f;
-        kidx = pair ? 18 : 17;
-    }
     {
-        static const char* const names[19] = {"tps_scan_kernel", "tps_scan_kernel_s5", "tps_scan_kernel_s6", "tps_scan_kernel_s7",
+        static const char* const names[17] = {"tps_scan_kernel", "tps_scan_kernel_s5", "tps_scan_kernel_s6", "tps_scan_kernel_s7",
                                               "tps_scan_kernel_s8", "tps_scan_kernel_s5so", "tps_scan_kernel_s6so", "tps_scan_kernel_s7so",
                                               "tps_scan_kernel_s8so", "tps_scan_kernel_s5p", "tps_scan_kernel_s6p", "tps_scan_kernel_s7p",
-                                              "tps_scan_kernel_s8p", "tps_scan_kernel_s5r", "tps_scan_kernel_s6r", "tps_scan_kernel_s7r", "tps_scan_kernel_s8r",
-                                              "tps_scan_kernel_s6f", "tps_scan_kernel_s6pf"};
+                                              "tps_scan_kernel_s8p", "tps_scan_kernel_s5r", "tps_scan_kernel_s6r", "tps_scan_kernel_s7r", "tps_scan_kernel_s8r"};
         sl.kernel_name = names[kidx];
     }
     if (sl.lds_bytes > c->lds_set_v[kidx]) {
@@ -411,11 +517,15 @@ int tps_ctx_destroy(tps_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (auto& sl : c->slots) {
-        sl.bases.release(); sl.offsets.release(); sl.tails.release(); sl.results.release();
+        sl.seq2.release(); sl.inv.release(); sl.desc.release(); sl.tails.release(); sl.results.release();
         sl.c_start.release(); sl.c_end.release(); sl.win_off.release(); sl.sums.release(); sl.raw.release(); sl.stamps.release(); sl.lc.release();
         if (sl.h_results) (void)hipHostFree(sl.h_results);
     }
     c->lut.release();
+    c->ascii.release();
+    c->ascii_off.release();
+    for (void* hp : c->pinned) (void)hipHostFree(hp);
+    c->pinned.clear();
     for (auto& ep : c->ev_pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -473,6 +583,57 @@ int tps_batch_upload(tps_ctx* c, int32_t slot, const uint8_t* bases, const int64
     Slot* sl = get_slot(c, slot);
     if (!sl) return TPS_E_ARG;
     return do_upload(c, *sl, bases, offsets, n);
+}
+
+int tps_batch_upload_packed(tps_ctx* c, int32_t slot, const uint32_t* seq2, const uint16_t* inv, const tps_read_desc* desc,
+                            int64_t n, int64_t n_words) {
+    int rc;
+    if ((rc = bind(c))) return rc;
+    Slot* sl = get_slot(c, slot);
+    if (!sl) return TPS_E_ARG;
+    return do_upload_packed(c, *sl, seq2, inv, desc, n, n_words);
+}
+
+int tps_host_alloc(tps_ctx* c, int64_t bytes, void** out) {
+    int rc;
+    if ((rc = bind(c))) return rc;
+    if (!out || bytes < 0) return fail(TPS_E_ARG, "bad arguments");
+    *out = nullptr;
+    void* p = nullptr;
+    HIP_TRY(hipHostMalloc(&p, (size_t)std::max<int64_t>(bytes, 16), hipHostMallocDefault));
+    c->pinned.insert(p);
+    *out = p;
+    return TPS_OK;
+}
+
+int tps_host_free(tps_ctx* c, void* p) {
+    int rc;
+    if ((rc = bind(c))) return rc;
+    if (!p) return TPS_OK;
+    if (!c->pinned.erase(p)) return fail(TPS_E_ARG, "pointer was not allocated by tps_host_alloc of this context");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipHostFree(p));
+    return TPS_OK;
+}
+
+int tps_batch_download_packed(tps_ctx* c, int32_t slot, uint32_t* seq2, uint16_t* inv, tps_read_desc* desc, int64_t n, int64_t n_words,
+                              int64_t* n_words_out) {
+    int rc;
+    if ((rc = bind(c))) return rc;
+    Slot* sl = get_slot(c, slot);
+    if (!sl) return TPS_E_ARG;
+    if (sl->n < 0) return fail(TPS_E_STATE, "no batch uploaded in this slot");
+    if (n_words_out) *n_words_out = sl->n_words;
+    if ((seq2 || inv) && n_words != sl->n_words) return fail(TPS_E_ARG, "buffers must hold %lld words", (long long)sl->n_words);
+    if (desc && n != sl->n) return fail(TPS_E_ARG, "desc must hold %lld reads", (long long)sl->n);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (seq2 && n_words) HIP_TRY(hipMemcpy(seq2, sl->seq2.p, (size_t)n_words * 4, hipMemcpyDeviceToHost));
+    if (inv && n_words) {
+        if (!sl->inv_valid) memset(inv, 0, (size_t)n_words * 2);
+        else HIP_TRY(hipMemcpy(inv, sl->inv.p, (size_t)n_words * 2, hipMemcpyDeviceToHost));
+    }
+    if (desc && n) HIP_TRY(hipMemcpy(desc, sl->desc.p, (size_t)n * sizeof(tps_read_desc), hipMemcpyDeviceToHost));
+    return TPS_OK;
 }
 
 int tps_batch_set_tails(tps_ctx* c, int32_t slot, const uint8_t* tails) {

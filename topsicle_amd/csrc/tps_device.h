@@ -112,6 +112,13 @@ TPS_DEV void lds_max_i32(int32_t* p, int32_t v) { if (v > *p) *p = v; }
 struct u32x4 { uint32_t x, y, z, w; };
 struct u32x2 { uint32_t x, y; };
 TPS_DEV u32x4 load16(const uint8_t* p) { return *(const u32x4*)p; }
+TPS_DEV u32x2 load8(const uint8_t* p) { return *(const u32x2*)p; }
+TPS_DEV uint32_t bitrev32(uint32_t x) {
+    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+    x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+    return __builtin_bswap32(x);
+}
 #else
 TPS_DEV uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
 TPS_DEV uint32_t udot4(uint32_t a, uint32_t b) { return __builtin_amdgcn_udot4(a, b, 0u, false); }
@@ -138,6 +145,15 @@ TPS_DEV u32x4 load16(const uint8_t* p) {
     r.x = t.x; r.y = t.y; r.z = t.z; r.w = t.w;
     return r;
 }
+TPS_DEV u32x2 load8(const uint8_t* p) {
+    typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+    typedef const __attribute__((address_space(1))) v2u* gptr_t;
+    const v2u t = *(gptr_t)(uintptr_t)p;
+    u32x2 r;
+    r.x = t.x; r.y = t.y;
+    return r;
+}
+TPS_DEV uint32_t bitrev32(uint32_t x) { return __builtin_bitreverse32(x); }      // v_bfrev_b32
 #endif
 
 // table entry at byte offset `off` (already masked to the table size).  The table starts at the
@@ -209,8 +225,10 @@ struct PatInfo {
 };
 
 struct ScanArgs {
-    const uint8_t* bases;        // device; >= 64 readable bytes before and after the data
-    const int64_t* offsets;      // n+1
+    // the packed batch (tps_pack.h): 16 bases per word, reads start on 16-byte quads
+    const uint32_t* seq2;        // 2-bit codes
+    const uint16_t* inv;         // bit j of inv[w] = base j of word w is not acgtACGT; only read for reads flagged in desc
+    const tps_read_desc* desc;   // n: word offset, length, flags of every read
     const uint8_t* tails_in;     // n, or nullptr
     const uint32_t* lut;         // 4^k masks over the pattern list
     tps_read_result* results;    // n
@@ -306,7 +324,7 @@ TPS_HD int64_t blk_region_dw(const ScanArgs& a) {
     if (need < HIST_DW) need = HIST_DW;
     return (need + 3) & ~3ll;
 }
-TPS_HD int64_t val_dw(const ScanArgs& a) { return ((a.seq_dw + 4 + 3) / 4) * 2; }   // u16 per 16 positions (+ look-ahead), even
+TPS_HD int64_t val_dw(const ScanArgs& a) { return ((a.seq_dw + 4 + 3) / 4) * 2; }   // u16 per 16 positions (+ look-ahead), even (seq_dw is a multiple of 4)
 TPS_HD int64_t lc_dw(const ScanArgs& a) {          // even dword counts keep misc 8-byte aligned
     if (a.lc16) return (a.lc_global ? 0 : ((a.lc_cap + 3) / 4) * 2) + ((a.tile_cap + 1) / 2) * 2;
     return a.lc_global ? 0 : ((a.lc_cap + 1) / 2) * 2;        // generic kernel: absolute 32-bit sums, also off-chip by default
@@ -412,118 +430,102 @@ TPS_DEV uint32_t wave_max_u32(uint32_t v) {
 }
 #endif
 
-// ------------------------------------------------------------------ staging: HBM ASCII -> LDS 2-bit
-// Stages s-indices [i0, i0+n) of a tail string into LDS.  Forward tail: s[i] = seq[t + i];
-// reverse tail: s[i] = seq[L-1-t-i] (allsteps.py:267-271, 176-177).  LDS position of s-index
-// i0 is `delta` (0..15): global 16-byte chunks are loaded whole and aligned, chunk c -> dword c.
+// ------------------------------------------------------------------ staging: packed HBM -> LDS
+// The batch is resident in the packed format of tps_pack.h (2 bits per base, 16 bases per word, reads on 16-byte
+// boundaries), so staging is a copy: one aligned 16-byte "quad" (64 bases) per lane and load.  A staged range holds
+// s-indices [i0, i0+n) of a tail string.  Forward tail: s[i] = seq[t + i]; reverse tail: s[i] = seq[L-1-t-i]
+// (allsteps.py:267-271, 176-177) -- quads are then taken in descending address order and each word's sixteen 2-bit
+// fields are reversed on the way (v_bfrev_b32 + a swap of the two bits of every field: 5 VALU per 16 bases).  No
+// complementing: complement k-mers are already in the table.  Quad c of the range goes to LDS words 4c .. 4c+3 of the
+// destination; `delta` (0..63) is the position of s-index i0 inside quad 0.  Every quad touched lies inside the read's
+// own allocation (reads are padded to whole quads with zeros), so no bounds masking is needed.
 struct Stage {
-    const uint8_t* chunk0;   // address of chunk 0 (forward: ascending, reverse: descending by 16)
+    uint64_t q0;             // byte address of quad 0 in seq2 (forward: ascending by 16, reverse: descending)
+    uint64_t v0;             // byte address of quad 0's invalid words in inv (8 bytes per quad)
     int32_t delta;
-    int32_t nch;             // chunks that hold staged data
+    int32_t nq;              // quads that hold staged data
     int32_t n;               // staged s-indices
     bool reverse;
 };
-TPS_DEV Stage stage_plan(const uint8_t* seq, int64_t L, bool reverse, int64_t t, int64_t i0, int32_t n) {
+TPS_DEV Stage stage_plan(const ScanArgs& a, int64_t word_off, int64_t L, bool reverse, int64_t t, int64_t i0, int32_t n) {
     Stage st;
     st.reverse = reverse;
     st.n = n;
-    if (!reverse) {
-        uintptr_t a0 = (uintptr_t)(seq + t + i0);
-        uintptr_t lo = a0 & ~(uintptr_t)15;
-        st.delta = (int32_t)(a0 - lo);
-        st.chunk0 = (const uint8_t*)lo;
-    } else {
-        uintptr_t e = (uintptr_t)(seq + (L - 1 - t - i0));
-        uintptr_t top = e | (uintptr_t)15;
-        st.delta = (int32_t)(top - e);
-        st.chunk0 = (const uint8_t*)(top - 15);
-    }
-    st.nch = n > 0 ? (st.delta + n + 15) >> 4 : 0;
+    const int64_t pos = reverse ? (L - 1 - t - i0) : (t + i0);     // read position of s-index i0
+    const int64_t w = word_off + 4 * (pos >> 6);
+    st.delta = reverse ? 63 - (int32_t)(pos & 63) : (int32_t)(pos & 63);
+    st.q0 = (uint64_t)(uintptr_t)a.seq2 + (uint64_t)w * 4u;
+    st.v0 = (uint64_t)(uintptr_t)a.inv + (uint64_t)w * 2u;
+    st.nq = n > 0 ? (st.delta + n + 63) >> 6 : 0;
     return st;
 }
-
-TPS_DEV uint32_t bad_bits16(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, bool reverse) {
-    uint32_t w[4] = {b0, b1, b2, b3};
-    uint32_t m = 0;
-    for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 4; ++j)
-            if ((w[i] >> (8 * j)) & 255u) m |= 1u << (4 * i + j);
-    if (reverse) {      // position j <-> byte 15-j
-        uint32_t rv = 0;
-        for (int j = 0; j < 16; ++j) rv |= ((m >> j) & 1u) << (15 - j);
-        m = rv;
-    }
-    return m;
-}
-
-// address of chunk c of a staged range
-// = a wave-uniform base + an unsigned 32-bit per-lane offset: one scalar-base load address instead of 64-bit per-lane
-// arithmetic with a select for the direction (5 - 6 VALU instructions per chunk)
-constexpr int STAGE_KMAX = 1 << 16;              // > chunks of any staged range (everything staged fits the 160 KB of LDS)
+// address of quad c of a staged range = a wave-uniform base + an unsigned 32-bit per-lane offset (one scalar-base load
+// address instead of 64-bit per-lane arithmetic with a select for the direction)
+constexpr int STAGE_KMAX = 1 << 16;              // > quads of any staged range (everything staged fits the 160 KB of LDS)
 TPS_DEV const uint8_t* stage_addr(const Stage& st, int c) {
-    const uint8_t* base = st.reverse ? st.chunk0 - 16 * (intptr_t)STAGE_KMAX : st.chunk0;      // uniform
+    const uint8_t* base = (const uint8_t*)(uintptr_t)(st.reverse ? st.q0 - 16ull * STAGE_KMAX : st.q0);      // uniform
     const uint32_t off = st.reverse ? 16u * (uint32_t)(STAGE_KMAX - c) : 16u * (uint32_t)c;
     return base + off;
 }
-// 16 ASCII bytes of chunk c -> (packed 16 bases, 16 invalid bits)
-TPS_DEV void stage_pack(const Stage& st, int c, const u32x4& v, uint32_t& packed, uint32_t& bad) {
-    const uint32_t w = st.reverse ? 0x01041040u : 0x40100401u;
-    // bits 1-2 of an ASCII letter: A,C,T,G (either case) -> 0,1,2,3; one dot product packs 4 bases
-    uint32_t y0 = v.x & 0x06060606u, y1 = v.y & 0x06060606u, y2 = v.z & 0x06060606u, y3 = v.w & 0x06060606u;
-    uint32_t d0 = udot4(y0, w), d1 = udot4(y1, w), d2 = udot4(y2, w), d3 = udot4(y3, w);
-    // d_i = 2 * (8-bit packed codes of 4 bases); halve per 16-bit half so bit 32 is never needed.  A reversed range
-    // wants the four bytes in the opposite order: one byte permute with a uniform selector instead of a second
-    // assembly and two selects
-    const uint32_t lo2 = d0 + (d1 << 8), hi2 = d2 + (d3 << 8);
-    const uint32_t fwd = (lo2 >> 1) | ((hi2 >> 1) << 16);
-    packed = perm(fwd, fwd, st.reverse ? 0x00010203u : 0x03020100u);
-    // expected lower-case letter for each 2-bit code: selector 0,2,4,6 -> a,c,t,g.  A valid byte differs from it in the
-    // case bit at most; that bit is masked once, after the four words have been OR-ed (one op instead of four)
-    const uint32_t s1 = 0x00630061u, s0 = 0x00670074u;
-    uint32_t b0 = v.x ^ perm(s0, s1, y0);
-    uint32_t b1 = v.y ^ perm(s0, s1, y1);
-    uint32_t b2 = v.z ^ perm(s0, s1, y2);
-    uint32_t b3 = v.w ^ perm(s0, s1, y3);
-    bad = 0;
-    if ((b0 | b1 | b2 | b3) & 0xDFDFDFDFu) {
-        b0 &= 0xDFDFDFDFu; b1 &= 0xDFDFDFDFu; b2 &= 0xDFDFDFDFu; b3 &= 0xDFDFDFDFu;
-        bad = bad_bits16(b0, b1, b2, b3, st.reverse);
-        // keep only positions inside the staged range [delta, delta+n)
-        int lo = st.delta - 16 * c, hi = st.delta + st.n - 16 * c;
-        uint32_t keep = 0xFFFFu;
-        if (lo > 0) keep &= (lo >= 16) ? 0u : (0xFFFFu << lo);
-        if (hi < 16) keep &= (hi <= 0) ? 0u : ((1u << hi) - 1u);
-        bad &= keep & 0xFFFFu;
-    }
+TPS_DEV const uint8_t* stage_inv_addr(const Stage& st, int c) {
+    const uint8_t* base = (const uint8_t*)(uintptr_t)(st.reverse ? st.v0 - 8ull * STAGE_KMAX : st.v0);
+    const uint32_t off = st.reverse ? 8u * (uint32_t)(STAGE_KMAX - c) : 8u * (uint32_t)c;
+    return base + off;
 }
-// chunk c of a staged range -> (packed 16 bases, 16 invalid bits); zero beyond the staged chunks
-TPS_DEV void stage_chunk(const Stage& st, int c, uint32_t& packed, uint32_t& bad) {
-    packed = 0;
-    bad = 0;
-    if (c >= st.nch) return;
-    stage_pack(st, c, load16(stage_addr(st, c)), packed, bad);
+// the sixteen 2-bit fields of a word in reverse order
+TPS_DEV uint32_t rev2(uint32_t x) {
+    const uint32_t y = bitrev32(x);               // fields reversed, the two bits of each field swapped
+    return ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);
 }
+// a loaded quad in LDS order
+TPS_DEV u32x4 stage_orient(const Stage& st, const u32x4& v) {
+    if (!st.reverse) return v;
+    u32x4 r;
+    r.x = rev2(v.w); r.y = rev2(v.z); r.z = rev2(v.y); r.w = rev2(v.x);
+    return r;
+}
+// the four 16-bit invalid words of a quad (two per dword) in LDS order
+TPS_DEV u32x2 stage_orient_inv(const Stage& st, const u32x2& v) {
+    if (!st.reverse) return v;
+    u32x2 r;
+    r.x = bitrev32(v.y); r.y = bitrev32(v.x);
+    return r;
+}
+#ifdef TPS_EMU
+TPS_DEV void lds_store16(uint32_t* p, const u32x4& v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w; }
+TPS_DEV void lds_store8(uint32_t* p, const u32x2& v) { p[0] = v.x; p[1] = v.y; }
+#else
+TPS_DEV void lds_store16(uint32_t* p, const u32x4& v) { *(u32x4*)p = v; }        // ds_write_b128 (p is 16-byte aligned)
+TPS_DEV void lds_store8(uint32_t* p, const u32x2& v) { *(u32x2*)p = v; }
+#endif
 
-// one thread stages chunks tid, tid+NT, ... of `ndw` dwords at seq2/val; four 16-byte loads are in
-// flight per lane before the first one is consumed (HBM latency is paid once per four chunks)
-TPS_DEV void stage_thread(const Stage& st, uint32_t* seq2, uint16_t* val, int ndw, uint32_t* invalid_flag, int tid) {
-    for (int base = tid; base < ndw; base += 4 * NT) {
+// lane `tid` stages quads tid, tid+NT, ... of the `nqd` quads at seq2 / val (zeros past the staged range); up to four
+// 16-byte loads are in flight per lane before the first one is consumed.  The invalid words are only touched for reads
+// that have any (has_inv, wave-uniform).
+TPS_DEV void stage_thread(const Stage& st, bool has_inv, uint32_t* seq2, uint16_t* val, int nqd, uint32_t* invalid_flag, int tid) {
+    for (int base = tid; base < nqd; base += 4 * NT) {
         u32x4 v[4];
+        u32x2 b[4];
         TPS_UNROLL
         for (int u = 0; u < 4; ++u) {
             const int c = base + u * NT;
             v[u].x = v[u].y = v[u].z = v[u].w = 0;
-            if (c < ndw && c < st.nch) v[u] = load16(stage_addr(st, c));
+            b[u].x = b[u].y = 0;
+            if (c < nqd && c < st.nq) {
+                v[u] = load16(stage_addr(st, c));
+                if (has_inv) b[u] = load8(stage_inv_addr(st, c));
+            }
         }
         TPS_UNROLL
         for (int u = 0; u < 4; ++u) {
             const int c = base + u * NT;
-            if (c < ndw) {
-                uint32_t packed = 0, bad = 0;
-                if (c < st.nch) stage_pack(st, c, v[u], packed, bad);
-                if (bad) *invalid_flag = 1u;       // benign race: every writer stores 1
-                seq2[c] = packed;
-                val[c] = (uint16_t)bad;
+            if (c < nqd) {
+                lds_store16(seq2 + 4 * c, stage_orient(st, v[u]));
+                if (has_inv) {
+                    const u32x2 o = stage_orient_inv(st, b[u]);
+                    if (o.x | o.y) *invalid_flag = 1u;       // benign race: every writer stores 1
+                    lds_store8((uint32_t*)val + 2 * c, o);
+                }
             }
         }
     }
@@ -1059,19 +1061,20 @@ struct Geo {
     // positions plus the look-ahead of the last k-mer and of the overlap test (k + d <= 13 bases)
     static constexpr int WDW = (POS + 13 + 15) / 16;
 };
-// Staging geometry of a tile: NT lanes of positions (+ look-ahead and the sub-dword start offset), staged as PF 16-byte
-// chunks per lane.  HALO tiles leave the last lane unused (its blocks are never a window's); FULL tiles use all 64 lanes
-// and hold 8 more windows.  FULL is free at slides 5 and 7 (same chunks per lane); at slide 6, 64 lanes of bases are 3
-// chunks more than 3 per lane, so FULL costs a fourth chunk per lane to pack: separate kernels (_s6f, _s6pf) that the
-// planner takes when they save a tile (config 2: 2467 windows = 5 x 495 instead of 5 x 487 + 32); slide 8 is always HALO.
+// Staging geometry of a tile: NT lanes of positions (+ look-ahead and the sub-quad start offset), staged as whole
+// 16-byte quads (64 bases) of the packed batch, PF per lane (1 up to slide 7, a nearly empty second one at slide 8).
+// All 64 lanes hold window blocks (FULL tiles: 512 - q - 1 windows); HALO tiles (last lane unused) are kept as a
+// template option for experiments only -- with packed input a FULL tile costs no extra staging work at any slide.
+constexpr int SEQ_LEAD = 4;                       // LDS words in front of a staged tile: lanes read the base before their first, the per-pattern tiles 16 more
 template <int S, bool FULL>
 struct TileGeo {
     static constexpr int LANES = FULL ? NT : NT - 1;
-    static constexpr int TILE_DW = (LANES * Geo<S>::POS + 13 + 15 + 15) / 16 + 1;
-    static constexpr int PF = (TILE_DW + NT - 1) / NT;
-    static constexpr int SEQ = TILE_DW + 5;       // dwords of seq2: the dword before the tile, the tile, look-ahead reads of the last lane
+    static constexpr int BASES = LANES * Geo<S>::POS + 13 + 15;       // positions the lanes touch, look-ahead included
+    static constexpr int NQ = (63 + BASES + 63) / 64;                 // quads of a tile whatever its sub-quad start offset
+    static constexpr int PF = (NQ + NT - 1) / NT;
+    static constexpr int SEQ = SEQ_LEAD + 4 * NQ + 4;                 // dwords of seq2: lead, the tile, look-ahead reads of the last lane
 };
-constexpr bool tile_full_default(int s) { return s == 5 || s == 7; }
+constexpr bool tile_full_default(int s) { return s >= 1; }
 
 // LDS slice of a wave in the fused kernels: everything whose size is known at compile time comes first, at
 // compile-time offsets from the slice base (one SGPR for all of it, offsets folded into the DS instructions);
@@ -1079,6 +1082,7 @@ constexpr bool tile_full_default(int s) { return s == 5 || s == 7; }
 template <int S, bool FULL>
 TPS_DEV Lds carve_fused(uint32_t* base, uint32_t* lut, const ScanArgs& a) {
     constexpr int BLK = 9 * NT + 2 * XLANES, ROW = NT * Geo<S>::B + NT, SEQ = TileGeo<S, FULL>::SEQ, VAL = ((SEQ + 4 + 3) / 4) * 2;
+    static_assert(BLK % 4 == 0 && ROW % 4 == 0 && MISC_DW % 4 == 0 && SEQ % 4 == 0, "seq2 must be 16-byte aligned");
     Lds l;
     l.lut2 = lut - a.pair_n;
     l.lut = lut;
@@ -1091,7 +1095,7 @@ TPS_DEV Lds carve_fused(uint32_t* base, uint32_t* lut, const ScanArgs& a) {
     l.row = base + BLK;
     l.misc = l.row + ROW;
     l.Tot = l.misc + MISC_DW;
-    l.seq2 = l.Tot + 2;
+    l.seq2 = l.Tot + 4;                        // 16-byte aligned: BLK, ROW, MISC_DW are multiples of 4 dwords
     l.val = (uint16_t*)(l.seq2 + SEQ);
     uint32_t* p = l.seq2 + SEQ + VAL;
     l.Lc = p;
@@ -2368,14 +2372,15 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
     const Lds l = SV ? carve_fused<SV ? SV : 5, FULL>(lds_base, lut, a) : carve(lds_base, lut, a);
     const PatInfo& pat = a.pat;
     const tps_params& prm = a.prm;
-    const int64_t off = a.offsets[r];
-    const int64_t L = a.offsets[r + 1] - off;
-    const uint8_t* seq = a.bases + off;
+    // one 16-byte descriptor per read (wave-uniform: a scalar load)
+    const int64_t woff = a.desc[r].word_off;
+    const int64_t L = a.desc[r].len;
+    const bool has_inv = (a.desc[r].flags & TPS_RD_HAS_INVALID) != 0;
     const bool step1 = (prm.flags & TPS_F_STEP1) != 0;
 
     const int n1 = (int)(L < prm.no_bp ? L : prm.no_bp);
-    const Stage st_s = stage_plan(seq, L, false, 0, 0, n1);     // first n1 bases
-    const Stage st_e = stage_plan(seq, L, true, 0, 0, n1);      // last n1 bases, reversed
+    const Stage st_s = stage_plan(a, woff, L, false, 0, 0, n1);     // first n1 bases
+    const Stage st_e = stage_plan(a, woff, L, true, 0, 0, n1);      // last n1 bases, reversed
 
     TPS_STAMP(0);
     TPS_PHASE { for (int i = tid; i < MISC_DW; i += NT) l.misc[i] = 0; }
@@ -2383,24 +2388,29 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
     TPS_STAMP(1);
     TPS_PHASE {
         if (step1) {
-            // the heads are staged side by side: [0, head_dw) and [head_dw, 2 head_dw).  Lane t takes chunk t of BOTH
-            // heads first, the two 16-byte loads in flight together: 1000 bases are at most 64 chunks per head, so the
-            // common case pays the HBM latency once (a flat loop over 2 x 67 dwords paid it three times, the third round
-            // for six lanes); whatever lies beyond (the zeroed slack, longer heads) follows in the same pattern.
-            for (int c0 = tid; c0 < a.head_dw; c0 += NT) {
-                u32x4 vs, ve;
-                vs.x = vs.y = vs.z = vs.w = 0;
-                ve = vs;
-                if (c0 < st_s.nch) vs = load16(stage_addr(st_s, c0));
-                if (c0 < st_e.nch) ve = load16(stage_addr(st_e, c0));
-                uint32_t ps = 0, bs = 0, pe_ = 0, be = 0;
-                if (c0 < st_s.nch) stage_pack(st_s, c0, vs, ps, bs);
-                if (c0 < st_e.nch) stage_pack(st_e, c0, ve, pe_, be);
-                if (bs | be) l.misc[M_INVALID] = 1u;
-                l.seq2[c0] = ps;
-                l.val[c0] = (uint16_t)bs;
-                l.seq2[a.head_dw + c0] = pe_;
-                l.val[a.head_dw + c0] = (uint16_t)be;
+            // the heads are staged side by side: words [0, head_dw) and [head_dw, 2 head_dw), head_dw / 4 quads each.
+            // 1000 bases are at most 17 quads per head: lanes 0-31 take the first head, lanes 32-63 the reversed last
+            // one, every lane at most one 16-byte load in the common case -- one HBM round trip for both heads.
+            const int hq = a.head_dw >> 2;
+            const int side = tid >> 5;
+            const Stage& st = side ? st_e : st_s;
+            uint32_t* dst = l.seq2 + side * a.head_dw;
+            uint32_t* dstv = (uint32_t*)l.val + side * (a.head_dw >> 1);
+            for (int c = tid & 31; c < hq; c += 32) {
+                u32x4 v;
+                u32x2 b;
+                v.x = v.y = v.z = v.w = 0;
+                b.x = b.y = 0;
+                if (c < st.nq) {
+                    v = load16(stage_addr(st, c));
+                    if (has_inv) b = load8(stage_inv_addr(st, c));
+                }
+                lds_store16(dst + 4 * c, stage_orient(st, v));
+                if (has_inv) {
+                    const u32x2 o = stage_orient_inv(st, b);
+                    if (o.x | o.y) l.misc[M_INVALID] = 1u;
+                    lds_store8(dstv + 2 * c, o);
+                }
             }
         }
     }
@@ -2479,14 +2489,15 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
                 int64_t n_stage = n_s - i0;
                 const int64_t cap = (int64_t)blk_per_tile * prm.slide + 32;
                 if (n_stage > cap) n_stage = cap;
-                const Stage st = stage_plan(seq, L, tail == 1, prm.trimfirst, i0, (int)n_stage);
+                const Stage st = stage_plan(a, woff, L, tail == 1, prm.trimfirst, i0, (int)n_stage);
                 // spans needed for this tile's blocks 0 .. nw_tile-1+q (+ the partial block)
                 const int blk_need = nw_tile + a.q + 1;
                 const int spans = (blk_need + (1 << a.blk_log2) - 1) >> a.blk_log2;
-                const int ndw = spans * a.span_dw + 4 < a.seq_dw ? spans * a.span_dw + 4 : a.seq_dw;
+                // words the spans read: the tile starts up to 63 positions into its first quad, + the look-ahead words
+                const int ndw = spans * a.span_dw + 8 < a.seq_dw ? spans * a.span_dw + 8 : a.seq_dw;
                 TPS_PHASE { if (tid == 0) l.misc[M_INVALID] = 0; }
                 TPS_SYNC();
-                TPS_PHASE { stage_thread(st, l.seq2, l.val, ndw, &l.misc[M_INVALID], tid); }
+                TPS_PHASE { stage_thread(st, has_inv, l.seq2, l.val, (ndw + 3) >> 2, &l.misc[M_INVALID], tid); }
                 TPS_SYNC();
                 if (w0 == 0) TPS_STAMP(5);
                 TPS_PHASE {
@@ -2507,43 +2518,47 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
                 if (w0 == 0) TPS_STAMP(8);
             }
         } else {
-            // ---------------- fused tiles: NT lanes x 8 blocks, the last lane is halo only
+            // ---------------- fused tiles: NT lanes x 8 blocks
             typedef TileGeo<SV ? SV : 1, FULL> t_;
             constexpr int PF = t_::PF;
             const TileConst tc = tile_const(a, r);
-            // windows per tile: at most NT * B - q - 1 (- B with the halo lane); the planner balances the tiles of the longest
-            // read (2467 windows = 5 x 494) -- a tile then stages only what its windows need, which at slide 6 mostly spares
-            // FULL tiles their fourth chunk per lane
-            int tw = (int)uniform((uint32_t)a.tw);
+            int tw = (int)uniform((uint32_t)a.tw);     // windows per tile: NT * B - q - 1
             TPS_PIN_S(tw);
             bool pp = false;
             if constexpr (RAW) pp = a.pp_d >= 0 && (SO ? a.pp_d > 0 : (a.pp_d == 0 && a.raw != nullptr));
             auto tile_stage = [&](int w0_) {
                 const int64_t i0 = (int64_t)w0_ * prm.slide;
                 int64_t n_stage = n_s - i0;
-                int64_t cap = (int64_t)(t_::TILE_DW - 1) * 16;
+                int64_t cap = (int64_t)t_::BASES;
                 // the last window ends r positions into block tw - 1 + q; + its last k-mer, the pair lookup's extra base and
                 // the look-ahead of the self-overlap tests (<= 13 bases in all)
                 const int64_t need = (int64_t)(tw - 1 + tc.q) * prm.slide + tc.r + 13;
                 if (cap > need) cap = need;
                 if (n_stage > cap) n_stage = cap;
-                return stage_plan(seq, L, tail == 1, prm.trimfirst, i0, (int)n_stage);
+                return stage_plan(a, woff, L, tail == 1, prm.trimfirst, i0, (int)n_stage);
             };
-            // Software prefetch: the 16-byte loads of the NEXT tile are issued right after the current
-            // tile has been packed into LDS and complete while it is being scanned, so a wave pays
-            // the HBM latency once per read instead of once per tile.
+            // Software prefetch: the 16-byte load(s) of the NEXT tile are issued right after the current tile has been
+            // copied into LDS and complete while it is being scanned, so a wave pays the HBM latency once per read
+            // instead of once per tile.  One quad (64 bases) per lane covers a tile up to slide 7.
             u32x4 pf[PF];
+            u32x2 pv[PF];
 #ifdef TPS_EMU
             u32x4 pf_keep[NT][PF];
+            u32x2 pv_keep[NT][PF];
 #endif
             auto pf_load = [&](const Stage& stn, int tid_) {
                 TPS_UNROLL
                 for (int u = 0; u < PF; ++u) {
                     const int c = tid_ + u * NT;
                     pf[u].x = pf[u].y = pf[u].z = pf[u].w = 0;
-                    if (c < stn.nch) pf[u] = load16(stage_addr(stn, c));
+                    pv[u].x = pv[u].y = 0;
+                    if (c < stn.nq) {
+                        pf[u] = load16(stage_addr(stn, c));
+                        if (has_inv) pv[u] = load8(stage_inv_addr(stn, c));
+                    }
 #ifdef TPS_EMU
                     pf_keep[tid_][u] = pf[u];
+                    pv_keep[tid_][u] = pv[u];
 #endif
                 }
             };
@@ -2565,16 +2580,23 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
                         const int c = tid + u * NT;
 #ifdef TPS_EMU
                         pf[u] = pf_keep[tid][u];
+                        pv[u] = pv_keep[tid][u];
 #endif
-                        uint32_t packed = 0, bad = 0;
-                        if (c < st.nch) stage_pack(st, c, pf[u], packed, bad);
-                        if (bad) l.misc[M_INVALID] = 1u;
-                        if (c + 1 < t_::SEQ) {
-                            l.seq2[c + 1] = packed;    // one dword in: lanes also read the base before their first
-                            l.val[c + 1] = (uint16_t)bad;
+                        if (c < t_::NQ) {              // every quad of the tile buffer is written (zeros past the staged range)
+                            lds_store16(l.seq2 + SEQ_LEAD + 4 * c, stage_orient(st, pf[u]));
+                            if (has_inv) {
+                                const u32x2 o = stage_orient_inv(st, pv[u]);
+                                if (o.x | o.y) l.misc[M_INVALID] = 1u;
+                                lds_store8((uint32_t*)l.val + (SEQ_LEAD >> 1) + 2 * c, o);
+                            }
                         }
                     }
-                    if (tid == 0) { l.seq2[0] = 0; l.val[0] = 0; }
+                    if (tid == NT - 1) {               // the lead words: lanes read the base before their first one
+                        u32x4 z;
+                        z.x = z.y = z.z = z.w = 0;
+                        lds_store16(l.seq2, z);
+                        if (has_inv) { u32x2 z2; z2.x = z2.y = 0; lds_store8((uint32_t*)l.val, z2); }
+                    }
                 }
                 TPS_SYNC();
                 if (w0 + tw < n_win) {
@@ -2582,7 +2604,7 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
                     TPS_PHASE { pf_load(stn, tid); }
                 }
                 if (w0 == 0) TPS_STAMP(5);
-                const int fdelta = st.delta + 16;      // LDS position of the tile's first base
+                const int fdelta = st.delta + 16 * SEQ_LEAD;      // LDS position of the tile's first base
                 if constexpr (RAW) {
                     // per-pattern tiles: raw counts wanted, or a table with one self-overlap period (exact without recounts)
                     constexpr int SP = SV ? SV : 5;

@@ -104,6 +104,13 @@ inline std::string build_patterns(const char* pats, int P, int k, std::vector<ui
     return "";
 }
 
+// = TileGeo<S, true>::SEQ (tps_device.h): LDS words of a fused tile's packed bases
+inline int fused_seq_dw(int slide) {
+    const int bases = NT * 8 * slide + 13 + 15;
+    const int nq = (63 + bases + 63) / 64;
+    return SEQ_LEAD + 4 * nq + 4;
+}
+
 // Slides that have a specialised kernel instantiation (tps_scan_kernel_s<S>).
 inline bool has_specialised_slide(int s) { return s == 5 || s == 6 || s == 7 || s == 8; }
 
@@ -139,7 +146,7 @@ inline std::string plan_geometry(ScanArgs& a, const tps_params& prm, int k, int 
     const int jump = std::max(prm.jump, 1);
     a.lc_cap = (int)(max_nwin / jump + 2);
     a.jump_magic = jump == 1 ? 0u : (uint32_t)(((1ull << 32) + (uint64_t)jump - 1) / (uint64_t)jump);   // 0: divide by 1
-    a.head_dw = (prm.no_bp + 30) / 16 + 3;
+    a.head_dw = 4 * ((prm.no_bp + 63 + 63) / 64) + 4;      // whole quads of a step-1 head whatever its start offset, + look-ahead words
     (void)target_dw;
     // fused kernels: compile-time slide, 16-bit masks (<= 15 patterns), a window spans at least one
     // 8-block chunk and its far end lies within the exchange halo (XLANES - NT lanes)
@@ -147,7 +154,7 @@ inline std::string plan_geometry(ScanArgs& a, const tps_params& prm, int k, int 
     for (int i = 0; i < a.pat.n_periods; ++i) max_period = std::max(max_period, a.pat.period[i]);
     const bool fused = !force_generic && spans_pref <= 0 && k <= TPS_DIRECT_K && has_specialised_slide(prm.slide) && P <= 15 && a.q >= 8 &&
                        a.q / 8 + 2 < (XLANES - NT) && max_period <= std::min(prm.slide, 6) &&
-                       2 * a.head_dw <= (((int)NT - 1) * 8 * prm.slide + 43) / 16 + 1 + 5;   // heads fit the (smaller, HALO) tile buffer (TileGeo::SEQ)
+                       2 * a.head_dw <= fused_seq_dw(prm.slide);   // the two step-1 heads fit the tile buffer (TileGeo::SEQ)
     a.lc16 = 0; a.tile_cap = 0; a.tw = 0; a.tw_magic = 0; a.pair_n = 0; a.lc_global = 0; a.lc_stride = 0; a.pp_d = -1; a.tile_full = 0;
     if (fused) {
         // per-pattern tiles (tile_pp_s): one-hot 2-bit fields per pattern need distinct k-mers; a lane's 8 blocks hold at
@@ -163,31 +170,12 @@ inline std::string plan_geometry(ScanArgs& a, const tps_params& prm, int k, int 
         a.spans_per_tile = NT;
         a.nblk_cap = NT * 8;
         a.rec_rs = 0;
-        a.tot_dw = 2;
-        const int pos = 8 * prm.slide;
-        // FULL tiles (all 64 lanes hold window blocks: 8 more windows per tile) are free at slides 5 and 7; at slide 6 they
-        // cost a fourth staging chunk per lane (kernels _s6f / _s6pf), so they are taken when the longest read then needs
-        // a tile less -- and only by the sums-only kernels of tables without self-overlap
-        {
-            const int64_t tw_halo = (int64_t)NT * 8 - a.q - 1 - 8, tw_full = tw_halo + 8;
-            a.tile_full = 0;
-            if (prm.slide == 5 || prm.slide == 7) a.tile_full = 1;
-            else if (prm.slide == 6 && a.pat.so_mask == 0 && !(prm.flags & TPS_F_STORE_RAW) && tw_halo > 0 && !getenv("TPS_NO_TILE_FULL") &&
-                     ((max_nwin + tw_full - 1) / tw_full < (max_nwin + tw_halo - 1) / tw_halo || getenv("TPS_FORCE_TILE_FULL"))) a.tile_full = 1;
-        }
-        const int lanes = a.tile_full ? (int)NT : (int)NT - 1;             // = TileGeo<S, FULL>::LANES
-        const int tile_dw = (lanes * pos + 13 + 15 + 15) / 16 + 1;         // = TileGeo::TILE_DW
-        a.seq_dw = tile_dw + 5;                    // = TileGeo::SEQ: compile-time size in the kernel (carve_fused); the heads fit (see `fused`)
-        // candidate left sums as u16 relative to their tile when a tile's window sums cannot reach 2^16
-        // (every position matches at most one list pattern: S_w <= lw + P)
-        a.tw = (int)NT * 8 - a.q - 1 - (a.tile_full ? 0 : 8);
-        // FULL tiles at slide 6: equal tiles for the longest read (2467 windows = 5 x 494 instead of 4 x 495 + 487) -- a tile
-        // stages only what its windows need, which then mostly fits three chunks per lane.  (Elsewhere a short last tile is
-        // cheaper than equal ones: fewer window iterations.)
-        if (max_nwin > 0 && a.tile_full && prm.slide == 6 && !getenv("TPS_NO_TILE_BALANCE")) {
-            const int64_t tiles = (max_nwin + a.tw - 1) / a.tw;
-            a.tw = (int)std::max<int64_t>(1, std::min<int64_t>(a.tw, (max_nwin + tiles - 1) / tiles));
-        }
+        a.tot_dw = 4;                              // (keeps seq2 16-byte aligned behind it: carve_fused)
+        // all 64 lanes hold window blocks (FULL tiles): with the packed batch a tile is staged as whole 64-base quads, one
+        // per lane, whatever the slide -- the halo-lane variant of the ASCII days has no cheaper staging any more
+        a.tile_full = 1;
+        a.seq_dw = fused_seq_dw(prm.slide);        // = TileGeo<S, true>::SEQ: compile-time size in the kernel (carve_fused)
+        a.tw = (int)NT * 8 - a.q - 1;
         a.tw_magic = (uint32_t)(((1ull << 32) + (uint64_t)a.tw - 1) / (uint64_t)a.tw);
         a.tile_cap = (int)((max_nwin + a.tw - 1) / a.tw) + 1;
         a.lc16 = (a.pat.dup_mask == 0 && (int64_t)a.tw * (a.lw + P) < 65536) ? 1 : 0;
@@ -233,7 +221,7 @@ inline std::string plan_geometry(ScanArgs& a, const tps_params& prm, int k, int 
         a.nblk_cap = sp * bps;
         a.rec_rs = 0;
         a.tot_dw = std::max(((sp + 2) / 2) * 2, (int)NT);
-        a.seq_dw = std::max(sp * a.span_dw + 4, 2 * a.head_dw);
+        a.seq_dw = (std::max(sp * a.span_dw + 8, 2 * a.head_dw) + 3) & ~3;     // whole quads; a tile starts up to 63 positions into its first one
         a.blk_dw = (int32_t)blk_region_dw(a);
         return wg_lds_dwords(a);
     };

@@ -20,7 +20,8 @@ MAX_K, MAX_PATTERNS, MAX_SLOTS = 15, 31, 16
 
 EXPORTS = [
     "tps_abi_version", "tps_device_count", "tps_ctx_create", "tps_ctx_destroy", "tps_last_error",
-    "tps_set_patterns", "tps_batch_upload", "tps_batch_set_tails", "tps_batch_scan", "tps_sync",
+    "tps_set_patterns", "tps_batch_upload", "tps_batch_upload_packed", "tps_host_alloc", "tps_host_free",
+    "tps_batch_download_packed", "tps_batch_set_tails", "tps_batch_scan", "tps_sync",
     "tps_batch_results", "tps_batch_window_offsets", "tps_batch_window_sums", "tps_batch_window_raw",
     "tps_batch_trc_counts", "tps_trc_counts", "tps_window_counts", "tps_binseg_l2", "tps_window_count",
     "tps_kernel_time_ms", "tps_kernel_time_reset", "tps_device_info", "tps_batch_kernel_info",
@@ -38,6 +39,10 @@ class Params(C.Structure):
                 ("maxlen", C.c_int32), ("jump", C.c_int32), ("min_size", C.c_int32),
                 ("flags", C.c_uint32)]
 
+
+DESC_DTYPE = np.dtype([("word_off", "<i8"), ("len", "<i4"), ("flags", "<u4")], align=True)      # struct tps_read_desc
+assert DESC_DTYPE.itemsize == 16
+RD_HAS_INVALID = 1
 
 RESULT_DTYPE = np.dtype([("best_start", "<i4"), ("best_start_idx", "<i4"), ("best_end", "<i4"),
                          ("best_end_idx", "<i4"), ("tail", "<i4"), ("pass", "<i4"), ("n_win", "<i4"),
@@ -75,6 +80,10 @@ def load_library(path: str | None = None) -> C.CDLL:
         "tps_last_error": (C.c_char_p, []),
         "tps_set_patterns": (C.c_int, [vp, C.c_char_p, i32, i32]),
         "tps_batch_upload": (C.c_int, [vp, i32, vp, vp, i64]),
+        "tps_batch_upload_packed": (C.c_int, [vp, i32, vp, vp, vp, i64, i64]),
+        "tps_host_alloc": (C.c_int, [vp, i64, C.POINTER(vp)]),
+        "tps_host_free": (C.c_int, [vp, vp]),
+        "tps_batch_download_packed": (C.c_int, [vp, i32, vp, vp, vp, i64, i64, C.POINTER(i64)]),
         "tps_batch_set_tails": (C.c_int, [vp, i32, vp]),
         "tps_batch_scan": (C.c_int, [vp, i32, C.POINTER(Params)]),
         "tps_sync": (C.c_int, [vp]),
@@ -196,6 +205,41 @@ class HipScanner:
         n = len(offsets) - 1
         self._check(self.lib.tps_batch_upload(self._h, slot, _ptr(bases), _ptr(offsets), n))
         self._n[slot] = n
+
+    def upload_packed(self, slot: int, seq2: np.ndarray, inv, desc: np.ndarray):
+        """A batch the host has packed already (2 bits per base; include/topsicle_hip.h).  Arrays that live in buffers
+        from `host_alloc` are copied asynchronously: keep them unchanged until `sync()` / a result download."""
+        assert seq2.dtype == np.uint32 and desc.dtype == DESC_DTYPE and (inv is None or inv.dtype == np.uint16)
+        n, nw = len(desc), len(seq2)
+        assert inv is None or len(inv) == nw
+        self._check(self.lib.tps_batch_upload_packed(self._h, slot, _ptr(seq2), _ptr(inv), _ptr(desc), n, nw))
+        self._n[slot] = n
+
+    def host_alloc(self, nbytes: int) -> np.ndarray:
+        """Pinned host memory as a uint8 array (freed with the context or by `host_free`)."""
+        p = C.c_void_p()
+        self._check(self.lib.tps_host_alloc(self._h, int(nbytes), C.byref(p)))
+        buf = (C.c_uint8 * max(int(nbytes), 1)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=np.uint8, count=int(nbytes))
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p.value
+        return arr
+
+    def host_free(self, arr: np.ndarray):
+        p = getattr(self, "_pinned", {}).pop(arr.ctypes.data, None)
+        if p is not None:
+            self._check(self.lib.tps_host_free(self._h, C.c_void_p(p)))
+
+    def download_packed(self, slot: int):
+        """(seq2, inv, desc) of the slot's resident packed batch (tests / diagnostics)."""
+        n = self._n[slot]
+        nw = C.c_int64(0)
+        self._check(self.lib.tps_batch_download_packed(self._h, slot, None, None, None, n, 0, C.byref(nw)))
+        seq2 = np.zeros(nw.value, np.uint32)
+        inv = np.zeros(nw.value, np.uint16)
+        desc = np.zeros(n, DESC_DTYPE)
+        self._check(self.lib.tps_batch_download_packed(self._h, slot, _ptr(seq2), _ptr(inv), _ptr(desc), n, nw.value, None))
+        return seq2, inv, desc
 
     def set_tails(self, slot: int, tails: np.ndarray):
         tails = np.ascontiguousarray(tails, dtype=np.uint8)
