@@ -178,6 +178,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="config2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end legs (FASTQ file on disk -> results / -> CLI outputs)")
     ap.add_argument("--no-store-sums", action="store_true", help="do not write S_w to HBM (boundary-only run)")
     ap.add_argument("--n-reads", type=int, default=0, help="diagnostic: override the batch size (NOT the metric's workload)")
     ap.add_argument("--flags", type=int, default=0, help="diagnostic: override the scan flags (partial pipelines are NOT the metric)")
@@ -323,6 +324,13 @@ def main():
             seqs = synth.split_reads(bases[: offsets[min(n_reads, 4096)]], offsets[: min(n_reads, 4096) + 1])
             out["cpu_baseline"] = cpu_baseline(seqs, motif, k, prm)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        if not args.no_e2e and world == 1 and not (args.flags or args.n_reads):
+            # PCIe- and parse-inclusive rates on a FASTQ file of the same reads: never `value` (topsicle_amd/e2e.py)
+            from topsicle_amd import e2e
+            try:
+                out["e2e"] = e2e.measure(bases, offsets, motif, k, cfg["slide"], device=dev)
+            except Exception as e:                  # a full /tmp must not cost the bench line
+                out["e2e"] = {"error": repr(e)}
         print(json.dumps(out))
     sc.close()
     grp.close()

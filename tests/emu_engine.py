@@ -29,6 +29,24 @@ class EmuEngine:
     def upload(self, slot, bases, offsets):
         self.slots[slot] = dict(bases=np.array(bases, np.uint8), offsets=np.array(offsets, np.int64), tails=None, out=None)
 
+    def upload_packed(self, slot, seq2, inv, desc):
+        """Unpack to ASCII (the emulation packs again itself): codes 0..3 = A, C, T, G; flagged positions become N."""
+        letters = np.frombuffer(b"ACTG", np.uint8)
+        seqs = []
+        for d in desc:
+            w0, L = int(d["word_off"]), int(d["len"])
+            nw = (L + 15) // 16
+            w = np.asarray(seq2[w0:w0 + nw], np.uint32)
+            codes = ((w[:, None] >> (2 * np.arange(16, dtype=np.uint32))) & 3).reshape(-1)[:L]
+            s = letters[codes].copy()
+            if inv is not None and (int(d["flags"]) & 1):
+                v = np.asarray(inv[w0:w0 + nw], np.uint16)
+                bad = ((v[:, None] >> np.arange(16, dtype=np.uint16)) & 1).reshape(-1)[:L].astype(bool)
+                s[bad] = ord("N")
+            seqs.append(s.tobytes())
+        bases, offsets = hiplib.pack_reads(seqs)
+        self.upload(slot, bases, offsets)
+
     def set_tails(self, slot, tails):
         self.slots[slot]["tails"] = np.array(tails, np.uint8)
 

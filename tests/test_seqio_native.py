@@ -148,3 +148,118 @@ def test_native_bgzf_blocks_inflate_in_parallel(tmp_path, monkeypatch, caplog, t
     caplog.set_level(logging.ERROR)
     assert all_records(str(p3)) == []                   # errors are logged, nothing is returned (the reference's convention)
     assert any("Error parsing file" in r.getMessage() for r in caplog.records)
+
+
+# ---------------------------------------------------------------------------- packed batches (the upload format)
+def _packed_records(path, words_cap=1 << 20, reads_cap=4096, n_sets=3):
+    """(records, flat packed arrays re-packed per batch) through read_batches_packed."""
+    from packfmt import np_pack
+    pool = seqio.BufferPool(n_sets, words_cap, reads_cap)
+    recs, n_batches = [], 0
+    for pb in seqio.read_batches_packed(path, pool, max_records=reads_cap):
+        rb = [pb.record(i) for i in range(pb.n)]
+        bases = np.frombuffer("".join(r.seq for r in rb).encode("latin1"), np.uint8)
+        offsets = np.zeros(pb.n + 1, np.int64)
+        np.cumsum([len(r.seq) for r in rb], out=offsets[1:])
+        seq2, inv, desc = np_pack(bases, offsets)
+        assert np.array_equal(pb.seq2, seq2) and np.array_equal(pb.inv, inv) and np.array_equal(pb.desc, desc)
+        assert pb.any_invalid == bool(inv.any())
+        pb.release()
+        assert [pb.record(i).seq for i in range(pb.n)] == [r.seq for r in rb]      # still readable after the buffers went back
+        recs += rb
+        n_batches += 1
+    return recs, n_batches
+
+
+@pytest.mark.skipif(seqio._load_io() is None, reason="libtopsicle_io.so not built")
+def test_packed_reader_equals_python_parser(tmp_path, gold_dir):
+    demo = os.path.join(gold_dir, "demo_col0.fastq.gz")
+    py = list(seqio.read_records(demo))
+    plain = tmp_path / "demo.fastq"
+    with gzip.open(demo, "rb") as g:
+        plain.write_bytes(g.read())
+    crlf = tmp_path / "crlf.fastq"
+    crlf.write_bytes(plain.read_bytes().replace(b"\n", b"\r\n"))
+    for path, min_batches in ((str(plain), 1), (demo, 1), (str(crlf), 1)):
+        recs, _ = _packed_records(path)
+        assert [(r.id, r.description, r.seq, r.qual) for r in recs] == [(r.id, r.description, r.seq, r.qual) for r in py], path
+    recs, nb = _packed_records(str(plain), words_cap=8192, reads_cap=16)          # many small batches (<= 131 kb each)
+    assert nb > 5 and [r.seq for r in recs] == [r.seq for r in py]
+    with pytest.raises(RuntimeError, match="does not fit"):
+        _packed_records(str(plain), words_cap=512, reads_cap=16)                  # a 48 kb read cannot fit 8 kb of bases
+
+
+@pytest.mark.skipif(seqio._load_io() is None, reason="libtopsicle_io.so not built")
+def test_packed_reader_switches_to_ascii_decoder_on_odd_records(tmp_path):
+    """Plain FASTQ whose records stop being 4-line records half way (wrapped sequence, '+name' lines, lower case, N):
+    the packed mmap path hands over to the streaming decoder at that record; nothing is lost or duplicated."""
+    fq = tmp_path / "odd.fastq"
+    body = b""
+    for i in range(40):
+        body += b"@r%d\n" % i + b"ACGTNacgtn"[: 4 + i % 6] * 37 + b"\n+\n" + b"I" * (37 * (4 + i % 6)) + b"\n"
+    body += b"@wrapped x y\nACGTAC\nGTTT\n+wrapped\nIIIIII\nIIII\n"
+    for i in range(40, 60):
+        body += b"@r%d\n" % i + b"GATTACA" * 11 + b"\n+r%d\n" % i + b"#" * 77 + b"\n"
+    fq.write_bytes(body)
+    recs, _ = _packed_records(str(fq))
+    py = list(seqio.read_records(str(fq)))
+    assert len(recs) == 61 and [(r.id, r.seq, r.qual) for r in recs] == [(r.id, r.seq, r.qual) for r in py]
+    fa = tmp_path / "x.fa"
+    fa.write_text(">a 1\nACGT\nAC\n>b\nNNNNTTTT\n")
+    recs, _ = _packed_records(str(fa))
+    assert [(r.id, r.seq, r.qual) for r in recs] == [("a", "ACGTAC", None), ("b", "NNNNTTTT", None)]
+
+
+@pytest.mark.skipif(seqio._load_io() is None, reason="libtopsicle_io.so not built")
+def test_packed_batch_writes_records_like_biopython(tmp_path, gold_dir):
+    import io
+    demo = os.path.join(gold_dir, "demo_col0.fastq.gz")
+    plain = tmp_path / "demo.fastq"
+    with gzip.open(demo, "rb") as g:
+        plain.write_bytes(g.read())
+    want = io.StringIO()
+    py = list(seqio.read_records(demo))
+    for r in py[3:9]:
+        seqio.write_record(want, r, "fastq")
+    for path in (str(plain), demo):
+        pool = seqio.BufferPool(2, 1 << 20, 4096)
+        got = io.BytesIO()
+        for pb in seqio.read_batches_packed(path, pool):
+            pb.release()
+            pb.write_records(got, range(3, 9), "fastq")
+        assert got.getvalue().decode() == want.getvalue()
+    want = io.StringIO()
+    seqio.write_record(want, py[0], "fasta")
+    got = io.BytesIO()
+    for pb in seqio.read_batches_packed(demo, seqio.BufferPool(2, 1 << 20, 4096)):
+        pb.write_records(got, [0], "fasta")
+        pb.release()
+    assert got.getvalue().decode() == want.getvalue()
+
+
+def test_engine_pool_keeps_input_order_with_several_contexts(tmp_path):
+    """Several contexts pull batches from one queue (dynamic balancing); results come back in file order."""
+    from emu_engine import EmuEngine
+    import topsicle_oracle as orc
+    from topsicle_amd import batch, hiplib, synth
+    bases, offsets, _ = synth.make_reads(90, 1500, "CCCTAA", seed=4, tract_min=200, tract_max=900)
+    fq = tmp_path / "r.fastq"
+    with open(fq, "wb") as h:
+        for i in range(90):
+            s = bytes(bases[offsets[i]:offsets[i + 1]])
+            h.write(b"@read%d\n" % i + s + b"\n+\n" + b"I" * len(s) + b"\n")
+    pats = orc.kmer_table("CCCTAA", 4)
+    pool = batch.EnginePool([EmuEngine(), EmuEngine(), EmuEngine()], pats)
+    prm = hiplib.make_params(min_len=0, min_count=-1)
+    ids, bkps, nb = [], [], 0
+    for pb, res, _s, _r, _w in pool.scan_file(str(fq), prm, max_bases=16384):
+        ids += pb.ids
+        bkps += res["bkp"].tolist()
+        nb += 1
+    assert nb >= 9 and ids == [f"read{i}" for i in range(90)]
+    for i in (0, 17, 89):
+        seq = bytes(bases[offsets[i]:offsets[i + 1]]).decode()
+        cs, ce = orc.trc_counts(seq, pats)
+        tail = "forward" if max(cs) > max(ce) else "reverse"
+        _, counts = orc.window_count_matrix(seq, tail, pats, 100, 6, 100, 20000)
+        assert bkps[i] == orc.binseg_l2_exact(counts.sum(axis=1))

@@ -1,17 +1,23 @@
-"""Batched driver: parse a file once, cut the record stream into batches balanced by bases,
+"""Batched driver: parse a file once, cut the record stream into batches balanced by bases, pack them (2 bits per base),
 run the fused scan (one launch per batch) and hand back per-read rows.
 
-Replaces the O(R_pass^2) structure of the reference's process_file loop, which re-parses the
-filtered file once per passing read (main.py:125-152 -> allsteps.py:257-259).
+Replaces the O(R_pass^2) structure of the reference's process_file loop, which re-parses the filtered file once per
+passing read (main.py:125-152 -> allsteps.py:257-259), and its `Pool` over input files (main.py:232-235) as the unit of
+parallelism: here a reader thread decodes + packs batches into pinned staging buffers while worker threads -- one per
+context, two contexts per GPU -- pull batches from ONE shared queue (dynamic balancing over all GPUs, SURVEY.md section
+8e), upload, scan and download; the caller consumes results in input order.  No collective, no device-to-device traffic.
 """
 from __future__ import annotations
+
+import queue
+import threading
 
 import numpy as np
 
 from . import hiplib
 
-BATCH_BASES = 256 << 20          # ~256 MB of bases per upload
-BATCH_READS = 1 << 20
+BATCH_BASES = 64 << 20           # bases per upload: 16 MB of packed words + 8 MB of invalid masks across PCIe
+BATCH_READS = 1 << 18
 
 
 def record_batches(records, max_bases: int = BATCH_BASES, max_reads: int = BATCH_READS):
@@ -28,17 +34,21 @@ def record_batches(records, max_bases: int = BATCH_BASES, max_reads: int = BATCH
 
 
 def scan_records(engine, recs, prm: hiplib.Params, slot: int = 0, want_sums=False, want_raw=False):
-    """Fused scan of one batch (a list of records or a seqio.RecordBatch).  Returns (results, sums, raw, win_off)."""
-    if hasattr(recs, "bases"):
-        bases, offsets = recs.bases, recs.offsets
+    """Fused scan of one batch: a seqio.PackedBatch (uploaded as it is), a seqio.RecordBatch or a list of records (ASCII
+    upload, packed on the device).  Returns (results, sums, raw, win_off)."""
+    if hasattr(recs, "seq2"):
+        engine.upload_packed(slot, recs.seq2, recs.inv if recs.any_invalid else None, recs.desc)
+    elif hasattr(recs, "bases"):
+        engine.upload(slot, recs.bases, recs.offsets)
     else:
-        bases, offsets = hiplib.pack_reads([r.seq for r in recs])
-    engine.upload(slot, bases, offsets)
+        engine.upload(slot, *hiplib.pack_reads([r.seq for r in recs]))
     flags = prm.flags | (hiplib.F_STORE_SUMS if want_sums else 0) | (hiplib.F_STORE_RAW if want_raw else 0)
     p = hiplib.Params.from_buffer_copy(prm)
     p.flags = flags
     engine.scan(slot, p)
     engine.sync()
+    if hasattr(recs, "release"):
+        recs.release()                 # the staging buffers are free again: the reader may refill them
     res = engine.results(slot)
     sums = raw = win_off = None
     if want_sums:
@@ -49,9 +59,9 @@ def scan_records(engine, recs, prm: hiplib.Params, slot: int = 0, want_sums=Fals
 
 
 class EnginePool:
-    """Read-sharding over the GPUs of one node: one engine (context) per
-    GPU, each driven by its own host thread; batches of ~equal bases are dealt round-robin and
-    results are handed back in input order.  No collective, no device-to-device traffic."""
+    """Read sharding over the contexts of one node: `engines` holds one or more contexts per GPU (two per GPU overlap the
+    upload / launch ramp / result download of one batch with the scan of another).  Batches go to whichever context is
+    free next; results come back in input order."""
 
     def __init__(self, engines, patterns):
         self.engines = list(engines)
@@ -60,40 +70,87 @@ class EnginePool:
         for e in self.engines:
             e.set_patterns(patterns)
 
+    # -- sources
     def scan_file(self, filepath, prm, want_sums=False, want_raw=False, max_bases=None):
-        """Like scan_stream over the records of a FASTA/FASTQ(.gz) file, decoded natively into batch
-        buffers (seqio.read_batches); yields (RecordBatch, results, sums, raw, win_off)."""
+        """Records of a FASTA/FASTQ(.gz) file, decoded and packed natively (seqio.read_batches_packed); yields
+        (PackedBatch, results, sums, raw, win_off) in file order."""
         from . import seqio
-        n = len(self.engines)
-        if max_bases is None:
-            max_bases = BATCH_BASES if n == 1 else BATCH_BASES // 4
-        return self._scan_batches(seqio.read_batches(filepath, max_bases=max_bases), prm, want_sums, want_raw)
+        max_bases = max_bases or BATCH_BASES
+        words_cap = max(max_bases // 16, 1024)                 # (a read's padding to whole 64-base quads counts too)
+        reads_cap = min(BATCH_READS, max(64, max_bases // 64))
+        alloc = getattr(self.engines[0], "host_alloc", None)
+        pool = seqio.BufferPool(len(self.engines) + 2, words_cap, reads_cap, alloc)
+        return self._run(seqio.read_batches_packed(filepath, pool, max_records=reads_cap), prm, want_sums, want_raw)
 
     def scan_stream(self, records, prm, want_sums=False, want_raw=False, max_bases=None):
-        n = len(self.engines)
-        if max_bases is None:
-            max_bases = BATCH_BASES if n == 1 else BATCH_BASES // 4
-        return self._scan_batches(record_batches(records, max_bases=max_bases), prm, want_sums, want_raw)
+        return self._run(record_batches(records, max_bases=max_bases or BATCH_BASES), prm, want_sums, want_raw)
 
-    def _scan_batches(self, batches, prm, want_sums, want_raw):
-        # one worker thread per engine, two batches in flight each: the host decodes / packs batch i+1 (native code, the
-        # GIL is released) while the GPU scans batch i and the caller writes the results of batch i-1 -- also with ONE GPU
+    # -- the pipeline
+    def _run(self, batches, prm, want_sums, want_raw):
         n = len(self.engines)
-        from collections import deque
-        from concurrent.futures import ThreadPoolExecutor
-        workers = [ThreadPoolExecutor(max_workers=1) for _ in range(n)]
-        pending = deque()
+        q_in: queue.Queue = queue.Queue(maxsize=n + 1)
+        q_out: queue.Queue = queue.Queue()
+        stop = threading.Event()
+
+        def reader():
+            count = 0
+            try:
+                for b in batches:
+                    while not stop.is_set():
+                        try:
+                            q_in.put((count, b), timeout=0.2)
+                            break
+                        except queue.Full:
+                            continue
+                    if stop.is_set():
+                        break
+                    count += 1
+                q_out.put(("eof", count, None))
+            except BaseException as e:          # parse errors surface in the consumer
+                q_out.put(("error", None, e))
+            finally:
+                for _ in range(n):
+                    q_in.put(None)
+
+        def worker(eng):
+            try:
+                while True:
+                    item = q_in.get()
+                    if item is None:
+                        return
+                    i, b = item
+                    q_out.put(("batch", i, (b,) + scan_records(eng, b, prm, 0, want_sums, want_raw)))
+            except BaseException as e:
+                stop.set()
+                q_out.put(("error", None, e))
+
+        threads = [threading.Thread(target=reader, daemon=True)] + [threading.Thread(target=worker, args=(e,), daemon=True) for e in self.engines]
+        for t in threads:
+            t.start()
+        pending, nxt, total = {}, 0, None
         try:
-            for i, recs in enumerate(batches):
-                eng = self.engines[i % n]
-                fut = workers[i % n].submit(scan_records, eng, recs, prm, 0, want_sums, want_raw)
-                pending.append((recs, fut))
-                while len(pending) >= 2 * n:
-                    r, f = pending.popleft()
-                    yield (r,) + f.result()
-            while pending:
-                r, f = pending.popleft()
-                yield (r,) + f.result()
+            while total is None or nxt < total:
+                kind, i, payload = q_out.get()
+                if kind == "error":
+                    raise payload
+                if kind == "eof":
+                    total = i
+                    continue
+                pending[i] = payload
+                while nxt in pending:
+                    yield pending.pop(nxt)
+                    nxt += 1
         finally:
-            for w in workers:
-                w.shutdown(wait=True)
+            stop.set()
+            try:
+                while True:
+                    q_in.get_nowait()
+            except queue.Empty:
+                pass
+            for _ in range(n):
+                try:
+                    q_in.put_nowait(None)
+                except queue.Full:
+                    pass
+            for t in threads:
+                t.join(timeout=5)

@@ -199,6 +199,14 @@ TPS_DEV uint32_t g32_load(uint64_t base, uint32_t i) {
 }
 #endif
 
+// high half of a 32 x 32-bit product (v_mul_hi_u32, full rate) and the sum of the four bytes of a word (v_sad_u8)
+TPS_DEV uint32_t mulhi32(uint32_t x, uint32_t y) { return (uint32_t)(((uint64_t)x * (uint64_t)y) >> 32); }
+#ifdef TPS_EMU
+TPS_DEV uint32_t add_bytes(uint32_t v, uint32_t acc) { return acc + (v & 255u) + ((v >> 8) & 255u) + ((v >> 16) & 255u) + (v >> 24); }
+#else
+TPS_DEV uint32_t add_bytes(uint32_t v, uint32_t acc) { return __builtin_amdgcn_sad_u8(v, 0u, acc); }
+#endif
+
 constexpr int cgcd(int a, int b) { return b == 0 ? a : cgcd(b, a % b); }
 constexpr int clog2(int x) { return x <= 1 ? 0 : 1 + clog2(x / 2); }
 
@@ -639,12 +647,13 @@ TPS_DEV void trc_count_thread(const ScanArgs& a, const Lds& l, const Stage& st_s
 }
 // Step 1, packed path (fused kernels, PLAIN case: every position matches at most one pattern and
 // occurrences of one pattern never overlap).  Lane (side, t) scans the 16-position chunks t, t+32, ...
-// of its side and counts in sixteen 4-bit fields of one 64-bit register: a table entry is
-// mask << 16 | popcount with the mask in bits 16..30, so clz(entry | 0x8000) - 1 = 14 - pattern for a
-// match and 15 for none (the top field: its overflow leaves the register); no predication, no LDS
-// atomics.  A lane sees `iters` chunks = at most iters * ceil(16 / k) <= 15 non-overlapping occurrences.
-// The lane then widens its fields to bytes (side totals <= npos / k <= 255) and parks them in LDS:
-// 16 bytes per lane = [even fields 0-6 | odd 1-7 | even 8-14 | odd 9-15].
+// of its side.  A table entry is e = 1 << (16 + p) | 1 for a position where pattern p starts (no duplicate
+// k-mers), so mulhi(e, e) = 1 << 2p: a one-hot 2-bit field per pattern (v_mul_hi_u32 + one add per position; no
+// predication, no LDS atomics).  Eight consecutive positions hold at most ceil(8 / min period) <= 3 occurrences of a
+// pattern, so two half-chunks are added up in 2-bit fields each and then widened to nibbles (even / odd patterns:
+// two words); a lane sees `iters` chunks = at most iters * ceil(16 / k) <= 15 occurrences per pattern.
+// The lane then widens its nibbles to bytes (side totals <= npos / k <= 255) and parks them in LDS:
+// 16 bytes per lane = [patterns 0,4,8,12 | 2,6,10,14 | 1,5,9,13 | 3,7,11,15].
 // Tables with self-overlapping k-mers (no invalid letter, no duplicate) take the same path: occurrences are
 // counted as they are, and a pattern that matches at p and again d < k bases later (d one of its periods;
 // one AND per position and period on the table entries, six look-ahead entries per chunk) is reported in
@@ -662,7 +671,7 @@ TPS_DEV bool trc_packed_ok(const ScanArgs& a, int npos) {
     int maxd = 0;
     TPS_NOVEC
     for (int i = 0; i < a.pat.n_periods; ++i) maxd = a.pat.period[i] > maxd ? a.pat.period[i] : maxd;
-    return a.pat.P <= 15 && maxd <= 6 && npos <= 255 * mp && iters * ((16 + mp - 1) / mp) <= 15;
+    return a.pat.P <= 15 && maxd <= 6 && mp >= 3 && npos <= 255 * mp && iters * ((16 + mp - 1) / mp) <= 15;
 }
 template <bool SO_>
 TPS_DEV void trc_count_packed(const ScanArgs& a, const Lds& l, const Stage& st_s, const Stage& st_e, int tid) {
@@ -685,7 +694,7 @@ TPS_DEV void trc_count_packed(const ScanArgs& a, const Lds& l, const Stage& st_s
                 if (pat.period[i] == d) ppd[d] |= pat.period_pat[i] << 16;
         }
     }
-    uint64_t acc = 0;
+    uint32_t ne = 0, no = 0;                        // per-pattern counts of this lane, nibbles: even / odd patterns
     uint32_t cf = 0;
     for (int c0 = 0; c0 < nchunks; c0 += 32) {      // uniform trip count
         const int c = c0 + t;
@@ -717,15 +726,20 @@ TPS_DEV void trc_count_packed(const ScanArgs& a, const Lds& l, const Stage& st_s
             }
         }
         TPS_UNROLL
-        for (int j = 0; j < 16; ++j) acc += 1ull << ((4u * (uint32_t)__builtin_clz(h[j] | 0x8000u) - 4u) & 63u);
+        for (int half = 0; half < 2; ++half) {
+            uint32_t x2 = 0;                         // 2-bit fields: <= 3 occurrences of a pattern in 8 positions
+            TPS_UNROLL
+            for (int j = 8 * half; j < 8 * half + 8; ++j) x2 += mulhi32(h[j], h[j]);
+            ne += x2 & 0x33333333u;
+            no += (x2 >> 2) & 0x33333333u;
+        }
     }
     if (SO_ && cf) lds_or(&l.misc[M_CMASK + side], cf >> 16);
-    const uint32_t lo = (uint32_t)acc, hi = (uint32_t)(acc >> 32);
     uint32_t* dst = l.blk + 4 * tid;
-    dst[0] = lo & 0x0F0F0F0Fu;
-    dst[1] = (lo >> 4) & 0x0F0F0F0Fu;
-    dst[2] = hi & 0x0F0F0F0Fu;
-    dst[3] = (hi >> 4) & 0x0F0F0F0Fu;
+    dst[0] = ne & 0x0F0F0F0Fu;
+    dst[1] = (ne >> 4) & 0x0F0F0F0Fu;
+    dst[2] = no & 0x0F0F0F0Fu;
+    dst[3] = (no >> 4) & 0x0F0F0F0Fu;
 }
 // Recount of the (few) patterns with overlapping occurrences, cooperatively: every lane looks its chunks up
 // again and publishes, per conflicting pattern, the 16 occurrence bits of each chunk (u16 per chunk: a
@@ -793,8 +807,8 @@ TPS_DEV int trc_walk_occ(const Lds& l, int side, int slot, int k) {
 TPS_DEV void trc_sum_packed(const ScanArgs& a, const Lds& l, const Stage& st_s, const Stage& st_e, int64_t r, int tid) {
     const int side = tid >> 5, p = tid & 31;
     if (p < a.pat.P) {
-        const int f = 14 - p;
-        const uint8_t* src = (const uint8_t*)(l.blk + 4 * 32 * side) + 4 * ((f & 1) + 2 * (f >> 3)) + ((f & 7) >> 1);
+        // byte of pattern p in a lane's 16 parked bytes: word [0, 2, 1, 3][p & 3], byte p >> 2
+        const uint8_t* src = (const uint8_t*)(l.blk + 4 * 32 * side) + 4 * (((p & 1) << 1) | ((p >> 1) & 1)) + (p >> 2);
         uint32_t sm = 0;
         TPS_UNROLL
         for (int t = 0; t < 32; ++t) sm += src[16 * t];
@@ -999,14 +1013,6 @@ TPS_DEV void windows_group(const ScanArgs& a, const Lds& l, int delta, int w0, i
         l.row[u * NT + tid] = sw;
     }
 }
-
-// high half of a 32 x 32-bit product (v_mul_hi_u32, full rate) and the sum of the four bytes of a word (v_sad_u8)
-TPS_DEV uint32_t mulhi32(uint32_t x, uint32_t y) { return (uint32_t)(((uint64_t)x * (uint64_t)y) >> 32); }
-#ifdef TPS_EMU
-TPS_DEV uint32_t add_bytes(uint32_t v, uint32_t acc) { return acc + (v & 255u) + ((v >> 8) & 255u) + ((v >> 16) & 255u) + (v >> 24); }
-#else
-TPS_DEV uint32_t add_bytes(uint32_t v, uint32_t acc) { return __builtin_amdgcn_sad_u8(v, 0u, acc); }
-#endif
 
 // w / jump by the host-supplied magic multiplier (jump == 1 has no 32-bit magic: ceil(2^32 / 1) = 2^32)
 TPS_DEV uint32_t div_jump(uint32_t w, uint32_t magic) { return magic ? (uint32_t)(((uint64_t)w * magic) >> 32) : w; }
@@ -2275,6 +2281,71 @@ TPS_DEV void binseg_from_lc(const ScanArgs& a, const Lds& l, uint64_t lc_g, cons
     // fused geometry's window sizes); otherwise through int64 like the standalone path
     const bool exact53 = (double)n * 4294967296.0 < 9007199254740992.0 && (double)tot * (double)n < 9007199254740992.0;
     const double nf = (double)n, totf = (double)tot;
+    // Float32 prefilter (off-chip 16-bit sums, the fused kernels' normal case): the score D^2 / (b (n - b)) of every
+    // candidate in single precision from the EXACT D (float64 fma, then rounded once), the wave maximum, and only
+    // candidates within 1e-4 of it -- two orders of magnitude more than single precision can be off -- go through the
+    // float64 fraction comparison below (41 instructions per candidate; the prefilter costs about a third of that).
+    constexpr int LCV = 16;
+    const bool prefilter = a.lc16 && lc_g && exact53 && c_max - c_min < LCV * NT;
+    int nslot = c_max >= c_min ? (c_max - c_min + NT) / NT : 0;          // candidate slots per lane that any lane uses
+    TPS_PIN_S(nslot);
+    auto tile_sum = [&](int c) { return l.Tc[(uint32_t)(((uint64_t)(uint32_t)(c * jump) * a.tw_magic) >> 32)]; };
+    uint32_t lcv[LCV];
+    float sc[LCV];
+    float thr32 = -1.0f;
+#ifdef TPS_EMU
+    static thread_local uint32_t lcv_keep[NT][LCV];
+    static thread_local float sc_keep[NT][LCV];
+    float emu_m32 = 0.0f;
+#endif
+    if (prefilter) {
+        float best32 = 0.0f;
+        TPS_PHASE {
+            // all of the lane's values are requested before the first one is used
+            TPS_UNROLL
+            for (int i = 0; i < LCV; ++i) {
+                const int c = c_min + tid + i * NT;
+                lcv[i] = c <= c_max ? g16_load(lc_g, (uint32_t)c) : 0u;
+            }
+            best32 = 0.0f;
+            TPS_UNROLL
+            for (int i = 0; i < LCV; ++i) {
+                const int c = c_min + tid + i * NT;
+                sc[i] = -1.0f;
+                if (i >= nslot) continue;            // uniform: no lane has a candidate in this slot
+                if (c <= c_max) {
+                    const uint32_t lc = tile_sum(c) + lcv[i];
+                    lcv[i] = lc;
+                    const int b = c * jump;
+                    const double bf = (double)b;
+                    const float d32 = (float)__builtin_fma(-totf, bf, nf * (double)lc);
+                    const float den32 = (float)b * (float)(n - b);
+#ifdef TPS_EMU
+                    sc[i] = d32 * d32 * (1.0f / den32);
+#else
+                    sc[i] = d32 * d32 * __builtin_amdgcn_rcpf(den32);
+#endif
+                    best32 = sc[i] > best32 ? sc[i] : best32;
+                }
+            }
+#ifdef TPS_EMU
+            for (int i = 0; i < LCV; ++i) { lcv_keep[tid][i] = lcv[i]; sc_keep[tid][i] = sc[i]; }
+            emu_m32 = best32 > emu_m32 ? best32 : emu_m32;
+#endif
+        }
+        float m32;
+#ifdef TPS_EMU
+        m32 = emu_m32;
+#else
+        {
+            uint32_t mb;
+            __builtin_memcpy(&mb, &best32, 4);       // non-negative floats order like integers
+            mb = wave_max_u32(mb);
+            __builtin_memcpy(&m32, &mb, 4);
+        }
+#endif
+        thr32 = m32 * (1.0f - 1e-4f);
+    }
     TPS_PHASE {
         double bn = -1.0, bd = 1.0;
         best_b = -1;
@@ -2293,11 +2364,18 @@ TPS_DEV void binseg_from_lc(const ScanArgs& a, const Lds& l, uint64_t lc_g, cons
             amb = near || (amb && !take);
             if (take) { bn = num; bd = den; best_b = b; }
         };
-        auto tile_sum = [&](int c) { return l.Tc[(uint32_t)(((uint64_t)(uint32_t)(c * jump) * a.tw_magic) >> 32)]; };
-        constexpr int LCV = 16;
-        if (a.lc16 && lc_g && c_max - c_min < LCV * NT) {
+        if (prefilter) {
+#ifdef TPS_EMU
+            for (int i = 0; i < LCV; ++i) { lcv[i] = lcv_keep[tid][i]; sc[i] = sc_keep[tid][i]; }
+#endif
+            TPS_UNROLL
+            for (int i = 0; i < LCV; ++i) {
+                const int c = c_min + tid + i * NT;
+                if (i >= nslot) continue;            // uniform
+                if (c <= c_max && sc[i] >= thr32) offer(c, lcv[i]);
+            }
+        } else if (a.lc16 && lc_g && c_max - c_min < LCV * NT) {
             // off-chip 16-bit sums: all of the lane's values are requested before the first one is used
-            uint32_t lcv[LCV];
             TPS_UNROLL
             for (int i = 0; i < LCV; ++i) {
                 const int c = c_min + tid + i * NT;

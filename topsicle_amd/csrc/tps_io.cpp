@@ -14,12 +14,19 @@
 //     Anything unexpected (wrapped lines, blank lines, length mismatch) hands the rest of the file to
 //   * the streaming decoder on zlib (gz or plain, FASTA or FASTQ, wrapped lines), single-threaded.
 //
+// Packed mode (tps_reader_next_packed): plain FASTQ records are 2-bit packed straight from the mmap'ed file into the
+// caller's (pinned) upload buffers in the layout of tps_pack.h -- no ASCII copy of the bases, the qualities are never
+// touched; the caller gets each record's spans in the file so that the few reads that pass the TRC filter can be written
+// back out from the mapping.  tps_pack_reads packs an ASCII batch (the .gz / BGZF / FASTA paths) with the same team.
+//
 // Plain C ABI (ctypes-loadable).  Build: g++ -O2 -shared -fPIC tps_io.cpp -lz -lpthread
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
+
+#include "tps_pack.h"
 
 #include <algorithm>
 #include <cstdint>
@@ -337,6 +344,78 @@ struct Fast {
         }
         return (int64_t)finish(bases, offsets, heads, head_off, quals, p);
     }
+    // Packed variant of next() for mmap'ed plain FASTQ: records are packed (tps_pack.h) into seq2 / inv / desc, no ASCII
+    // copy.  spans gets 4 entries per record: header offset and length, sequence offset, quality offset (text offsets).
+    // -3: not plain 4-line FASTQ here; -2: a single record does not fit.
+    int64_t next_packed(uint32_t* seq2, uint16_t* inv, int64_t words_cap, tps_read_desc* desc, int64_t max_records, char* heads,
+                        int64_t heads_cap, int64_t* head_off, int64_t* spans) {
+        recs.clear();
+        int64_t nw = 0, nh = 0;
+        head_off[0] = 0;
+        size_t p = pos;
+        while ((int64_t)recs.size() < max_records) {
+            if (nl_i + 4 > nl.size()) {
+                if (!whole) {
+                    if (!recs.empty()) break;
+                    if (p >= size) break;
+                    pos = p;
+                    index_window();
+                    p = pos;
+                    if (nl.size() >= 4) continue;
+                    if (!whole) return -3;
+                }
+                if (only_blank(p)) break;
+                if (recs.empty()) return -3;
+                break;
+            }
+            const uint64_t e0 = nl[nl_i], e1 = nl[nl_i + 1], e2 = nl[nl_i + 2], e3 = nl[nl_i + 3];
+            auto trim = [&](uint64_t a, uint64_t e) { return (e > a && data[e - 1] == '\r') ? e - 1 : e; };
+            const uint64_t h0 = p, h1 = trim(p, e0), s0 = e0 + 1, s1 = trim(s0, e1), q0 = e2 + 1, q1 = trim(q0, e3);
+            const bool ok = h1 > h0 && data[h0] == '@' && e1 + 1 < size && data[e1 + 1] == '+' && (s1 - s0) == (q1 - q0) &&
+                            (s1 == s0 || (data[s0] != ' ' && data[s0] != '\t' && data[s1 - 1] != ' ' && data[s1 - 1] != '\t'));
+            if (!ok) {
+                if (recs.empty()) return -3;
+                break;
+            }
+            const int64_t sl = (int64_t)(s1 - s0), hl = (int64_t)(h1 - h0 - 1);
+            if (sl > 0x7FFFFFFFll) return -3;
+            const int64_t w = tps::packed_words(sl);
+            if (nw + w > words_cap || nh + hl > heads_cap) {
+                if (recs.empty()) return -2;
+                break;
+            }
+            const size_t i = recs.size();
+            recs.push_back(Rec{h0 + 1, (uint64_t)hl, s0, (uint64_t)sl, q0});
+            desc[i].word_off = nw;
+            desc[i].len = (int32_t)sl;
+            desc[i].flags = 0;
+            nw += w;
+            nh += hl;
+            head_off[i + 1] = nh;
+            nl_i += 4;
+            p = std::min<size_t>((size_t)e3 + 1, size);
+        }
+        const size_t n = recs.size();
+        const int T = nw < (1 << 18) ? 1 : threads;
+        team(T, [&](int t, int nt) {
+            // ranges of ~equal words, not of equal record counts: reads vary in length
+            const int64_t wa = nw * (int64_t)t / nt, wb = nw * (int64_t)(t + 1) / nt;
+            size_t a = std::lower_bound(desc, desc + n, wa, [](const tps_read_desc& d, int64_t v) { return d.word_off < v; }) - desc;
+            size_t b = t + 1 == nt ? n : std::lower_bound(desc, desc + n, wb, [](const tps_read_desc& d, int64_t v) { return d.word_off < v; }) - desc;
+            for (size_t i = a; i < b; ++i) {
+                const Rec& r = recs[i];
+                if (tps::pack_one((const uint8_t*)data + r.s0, (int64_t)r.sl, seq2 + desc[i].word_off, inv ? inv + desc[i].word_off : nullptr))
+                    desc[i].flags |= TPS_RD_HAS_INVALID;
+                memcpy(heads + head_off[i], data + r.h0, (size_t)r.hl);
+                if (spans) {
+                    spans[4 * i] = (int64_t)r.h0; spans[4 * i + 1] = (int64_t)r.hl;
+                    spans[4 * i + 2] = (int64_t)r.s0; spans[4 * i + 3] = (int64_t)r.q0;
+                }
+            }
+        });
+        pos = p;
+        return (int64_t)n;
+    }
     bool only_blank(size_t from) const {
         for (size_t i = from; i < size; ++i)
             if (data[i] != '\n' && data[i] != '\r' && data[i] != ' ') return false;
@@ -532,6 +611,48 @@ int64_t tps_reader_next(void* hv, uint8_t* bases, int64_t bases_cap, int64_t* of
         r->have_pending = false;
     }
     return n;
+}
+
+// Packed mode for plain (uncompressed, mmap'ed) 4-line FASTQ: see Fast::next_packed.  Returns the number of records (0 at
+// the end of the input), -1 on an error, -2 if one record does not fit into empty buffers, -4 if this input cannot be read
+// in packed mode (compressed, FASTA, wrapped or odd records from here on): the caller continues with tps_reader_next at
+// the same record and packs with tps_pack_reads.  *n_words receives the words used in seq2 / inv.
+int64_t tps_reader_next_packed(void* hv, uint32_t* seq2, uint16_t* inv, int64_t words_cap, tps_read_desc* desc, int64_t max_records,
+                               char* heads, int64_t heads_cap, int64_t* head_off, int64_t* spans, int64_t* n_words) {
+    Handle* h = (Handle*)hv;
+    if (!h || !seq2 || !desc || !heads || !head_off || !n_words) { g_err = "null argument"; return -1; }
+    *n_words = 0;
+    head_off[0] = 0;
+    if (!h->format) return 0;
+    if (!h->fast || h->fast->src) return -4;
+    const int64_t n = h->fast->next_packed(seq2, inv, words_cap, desc, max_records, heads, heads_cap, head_off, spans);
+    if (n == -3) return -4;                 // (the position is unchanged: tps_reader_next re-reads this record its own way)
+    if (n > 0) *n_words = desc[n - 1].word_off + tps::packed_words(desc[n - 1].len);
+    return n;
+}
+
+// Packs an ASCII batch (concatenated bases + n+1 offsets) into the layout of tps_pack.h with the reader's thread team.
+// seq2 / inv must hold tps_packed_words_total(offsets, n) entries; inv may be NULL.  Returns the words written.
+int64_t tps_packed_words_total(const int64_t* offsets, int64_t n) {
+    int64_t w = 0;
+    for (int64_t i = 0; i < n; ++i) w += tps::packed_words(offsets[i + 1] - offsets[i]);
+    return w;
+}
+int64_t tps_pack_reads(const uint8_t* bases, const int64_t* offsets, int64_t n, uint32_t* seq2, uint16_t* inv, tps_read_desc* desc,
+                       int32_t nthreads) {
+    if (n < 0 || !offsets || !seq2 || !desc || (n > 0 && !bases)) { g_err = "null argument"; return -1; }
+    for (int64_t i = 0; i < n; ++i)
+        if (offsets[i + 1] < offsets[i] || offsets[i + 1] - offsets[i] > 0x7FFFFFFFll) { g_err = "bad offsets"; return -1; }
+    const int64_t nw = tps::pack_layout(offsets, n, desc);
+    int T = nthreads > 0 ? nthreads : io_threads();
+    if (offsets[n] < (4 << 20)) T = 1;
+    team(T, [&](int t, int nt) {
+        const int64_t wa = nw * (int64_t)t / nt, wb = nw * (int64_t)(t + 1) / nt;
+        int64_t a = std::lower_bound(desc, desc + n, wa, [](const tps_read_desc& d, int64_t v) { return d.word_off < v; }) - desc;
+        int64_t b = t + 1 == nt ? n : std::lower_bound(desc, desc + n, wb, [](const tps_read_desc& d, int64_t v) { return d.word_off < v; }) - desc;
+        tps::pack_range(bases, offsets, a, b, desc, seq2, inv);
+    });
+    return nw;
 }
 
 }  // extern "C"

@@ -22,6 +22,7 @@ from . import allsteps, batch, hiplib, seqio
 
 version_number = "1.0.0"
 Topsicle_output_prefix = "Topsicle"
+CONTEXTS_PER_GPU = 2
 
 
 def get_log_path(args):
@@ -54,7 +55,8 @@ _CSV_LOCK = __import__("threading").Lock()      # telolengths_all.csv is appende
 
 
 def process_file(args, seq_loc, telo_phrase, pattern, sliding_val, engines):
-    """One input file: step 1 + filtered file + step 2 rows (main.py:52-154), batched.
+    """One input file: step 1 + filtered file + step 2 rows (main.py:52-154), batch by batch: the per-read work of a batch
+    is numpy arithmetic on the kernel's result records, one bulk write of the passing records and one bulk CSV append.
     Returns [(file_name, telo_phrase, [[readID, telolen]], trc), ...] in read order."""
     tprint("subsetting raw dataset based on TRC cutoff")
     base_name = os.path.basename(seq_loc)
@@ -76,7 +78,7 @@ def process_file(args, seq_loc, telo_phrase, pattern, sliding_val, engines):
         tprint(f"Temporary fasta file already exists: {fasta_temp}. Using existing file.")
     else:
         fasta_temp = os.path.join(args.outputDir, f"{file_name}_trc_over_{min_cutoff}.{fmt}")
-        out_handle = open(fasta_temp, "w")
+        out_handle = open(fasta_temp, "wb")
 
     rows = []
     image_num = 1
@@ -84,41 +86,49 @@ def process_file(args, seq_loc, telo_phrase, pattern, sliding_val, engines):
     csv_path = f"{args.outputDir}/telolengths_all.csv"
     pool = batch.EnginePool(engines, pattern)
     try:
-        for rb, res, sums, raw, win_off in pool.scan_file(seq_loc, prm, want_sums, want_raw):
+        for pb, res, sums, raw, win_off in pool.scan_file(seq_loc, prm, want_sums, want_raw):
+            idx = np.nonzero(res["pass"])[0]
+            if out_handle is not None and len(idx):
+                pb.write_records(out_handle, idx, fmt)                       # every passing record (main.py:83-86)
+            ids = [pb.read_id(int(i)) for i in idx]
+            if args.read_check:
+                keep = [j for j, rid in enumerate(ids) if rid == args.read_check]
+                idx, ids = idx[keep], [ids[j] for j in keep]
+            if not len(idx):
+                continue
+            r = res[idx]
+            fwd = r["tail"] == 0
+            trc = np.where(fwd, r["best_start"], r["best_end"]) / ratio      # float64, like int / float upstream
+            lens = pb.desc["len"][idx].astype(np.int64)
+            m = np.minimum(args.maxlengthtelo, lens)
+            bkp = r["bkp"].astype(np.int64)
+            point = np.where(bkp >= 0, bkp * sliding_val + args.trimfirst, 0)
+            telolen = np.where((point <= m) & (point != 0), point, 0)        # allsteps.py:330-333
+            for j in np.nonzero(bkp < 0)[0]:
+                tprint(f"read {ids[j]}: {int(r['n_win'][j])} windows, no admissible change point; reporting 0")
+            telo_l, trc_l = telolen.tolist(), trc.tolist()
             with _CSV_LOCK, open(csv_path, mode="a", newline="") as fh:
-                writer = csv.writer(fh)
-                for i in np.nonzero(res["pass"])[0]:
-                    r = res[i]
-                    rec = rb.record(int(i))
-                    if out_handle is not None:
-                        seqio.write_record(out_handle, rec, fmt)
-                    if args.read_check and rec.id != args.read_check:
-                        continue
-                    fwd = r["tail"] == 0
-                    trc_val = int(r["best_start"] if fwd else r["best_end"]) / ratio
-                    m = min(args.maxlengthtelo, len(rec.seq))
-                    point = int(r["bkp"]) * sliding_val + args.trimfirst if r["bkp"] >= 0 else 0
-                    telolen = point if (point <= m and point != 0) else 0
-                    if r["bkp"] < 0:
-                        tprint(f"read {rec.id}: {int(r['n_win'])} windows, no admissible change point; reporting 0")
-                    writer.writerow([file_name, telo_phrase, f"{trc_val:.3f}", rec.id, telolen])
-                    rows.append((file_name, telo_phrase, [[rec.id, telolen]], trc_val))
-                    if args.plot and r["n_win"] > 0:
+                csv.writer(fh).writerows(zip([file_name] * len(ids), [telo_phrase] * len(ids), ["%.3f" % t for t in trc_l], ids, telo_l))
+            rows += [(file_name, telo_phrase, [[rid, tl]], t) for rid, tl, t in zip(ids, telo_l, trc_l)]
+            if args.plot or args.rawcountpattern:                            # per-read artefacts (main.py:140-150)
+                for j, i in enumerate(idx):
+                    tail = "forward" if fwd[j] else "reverse"
+                    if args.plot and r["n_win"][j] > 0:
                         import matplotlib.pyplot as plt
                         y = sums[win_off[i]:win_off[i + 1]] / len(pattern)
-                        allsteps._plot_changepoint(rec.id, y, sliding_val, args.trimfirst, point, args.rangecp or m)
-                        plt.savefig(f"{args.outputDir}/plot_{telo_phrase}_{image_num}.png", format="png", dpi=300)
+                        allsteps._plot_changepoint(ids[j], y, sliding_val, args.trimfirst, int(point[j]), args.rangecp or int(m[j]))
+                        plt.savefig(f"{args.outputDir}/plot_{telo_phrase}_{image_num + j}.png", format="png", dpi=300)
                         plt.close()
                     if args.rawcountpattern:
                         block = raw[win_off[i]:win_off[i + 1]]
                         if raw_npz is not None:
-                            raw_npz["read_id"].append(rec.id)
-                            raw_npz["tail"].append("forward" if fwd else "reverse")
+                            raw_npz["read_id"].append(ids[j])
+                            raw_npz["tail"].append(tail)
                             raw_npz["n_win"].append(block.shape[0])
                             raw_npz["counts"].append(np.array(block, dtype=np.uint8))
                         else:
-                            _write_rawcount(args, telo_phrase, image_num, pattern, sliding_val, block, "forward" if fwd else "reverse")
-                    image_num += 1
+                            _write_rawcount(args, telo_phrase, image_num + j, pattern, sliding_val, block, tail)
+            image_num += len(idx)
     finally:
         if out_handle is not None:
             out_handle.close()
@@ -198,7 +208,8 @@ def analysis_run(args, engines=None, engine_factory=None):
         first = getattr(args, "device", 0) or 0
         if engine_factory is None:
             def engine_factory():
-                return [hiplib.HipScanner(first + i) for i in range(n_gpus)]
+                # two contexts (launch queues) per GPU: the upload / launch ramp / download of one batch overlaps the scan of another
+                return [hiplib.HipScanner(first + i // CONTEXTS_PER_GPU) for i in range(n_gpus * CONTEXTS_PER_GPU)]
         engines = engine_factory()
         tprint(f"GPU engines: {[e.device_info() for e in engines]}")
 
@@ -262,42 +273,50 @@ def _process_files(args, filenames, telo_phrase, pattern, sliding_val, engines, 
                 e.close()
 
 
+def recommend_cutoff(vertex_x, max_trc, median_trc, inputtrc):
+    """The cutoff advice of main.py:276-293 as a pure function: (recommended cutoff, log lines).  The fit's vertex is
+    accepted unless it lies beyond the data (then the median TRC, or 0.9 if that is >= 1) or is implausibly low (< 0.4:
+    the input cutoff takes over when it is higher)."""
+    notes = []
+    if vertex_x > max_trc:
+        notes.append(f"Asymptotic TRC {vertex_x:.3f} is greater than max TRC, which is not expected. See plot.")
+        use_median = median_trc < 1.0
+        notes.append(f"Using median TRC value ({median_trc:.3f}) as asymptotic TRC instead." if use_median
+                     else "Using 0.9 as asymptotic TRC instead, since asymptotic is greater than 1.0.")
+        vertex_x = median_trc if use_median else 0.9
+    if vertex_x < 0.4:
+        notes.append("Quadratic fit suggests asymptotic TRC less than 0.4. See plot with fit line")
+        if max_trc < 0.4:
+            notes.append(f"Maximum TRC value in data is {max_trc:.3f}, which is less than 0.4, indicating low confidence in telomere detection.")
+        if vertex_x < inputtrc:
+            notes.append(f"Asymptotic TRC {vertex_x:.3f} is less than input cutoff {inputtrc:.3f}. Topsicle declares input TRC (={inputtrc}) as asymptotic TRC.")
+            vertex_x = inputtrc
+    return vertex_x, notes
+
+
 def summarize(args, phrase_to_telo, phrase_to_trc):
     """Per-k medians and the quadratic-fit cutoff advice (main.py:248-306)."""
     inputtrc = args.cutoff[0] if isinstance(args.cutoff, (list, tuple)) else args.cutoff
     for phrase in sorted(phrase_to_telo):
-        median_telo = np.median(phrase_to_telo[phrase])
-        median_trc = np.median(phrase_to_trc[phrase])
-        tprint(f"k-mer: {phrase}, with TRC >= {inputtrc}, median telomere length is {median_telo:.2f} bp")
-        if len(phrase_to_telo[phrase]) >= 3:
-            max_trc = max(phrase_to_trc[phrase])
-            plot_path = os.path.join(args.outputDir, f"quadfit_{phrase}mer_{args.pattern}.png")
-            vertex_x, _vertex_y, _coeffs = allsteps.fit_quadratic_and_find_vertex(
-                phrase_to_trc[phrase], phrase_to_telo[phrase], inputtrc=inputtrc, median_trc=median_trc,
-                save_path=plot_path)
-            if vertex_x > max_trc:
-                tprint(f"Asymptotic TRC {vertex_x:.3f} is greater than max TRC, which is not expected. See plot.")
-                if median_trc < 1.0:
-                    tprint(f"Using median TRC value ({median_trc:.3f}) as asymptotic TRC instead.")
-                    vertex_x = median_trc
-                else:
-                    tprint("Using 0.9 as asymptotic TRC instead, since asymptotic is greater than 1.0.")
-                    vertex_x = 0.9
-            if vertex_x < 0.4:
-                tprint("Quadratic fit suggests asymptotic TRC less than 0.4. See plot with fit line")
-                if max_trc < 0.4:
-                    tprint(f"Maximum TRC value in data is {max_trc:.3f}, which is less than 0.4, indicating low confidence in telomere detection.")
-                if vertex_x < inputtrc:
-                    tprint(f"Asymptotic TRC {vertex_x:.3f} is less than input cutoff {inputtrc:.3f}. Topsicle declares input TRC (={inputtrc}) as asymptotic TRC.")
-                    vertex_x = inputtrc
-            tprint(f"asymptotic TRC, or recommended cutoff: {vertex_x:.3f}")
-            kept = [t for c, t in zip(phrase_to_trc[phrase], phrase_to_telo[phrase]) if c >= vertex_x]
-            if kept:
-                tprint(f"Median telomere length for reads with TRC cutoff >= {vertex_x:.3f}: {np.median(kept):.2f} bp")
-            else:
-                tprint(f"No read has TRC >= {vertex_x:.3f}, please double check the data or submit log to GitHub.")
-        else:
+        telo = np.asarray(phrase_to_telo[phrase], dtype=np.float64)
+        trc = np.asarray(phrase_to_trc[phrase], dtype=np.float64)
+        tprint(f"k-mer: {phrase}, with TRC >= {inputtrc}, median telomere length is {np.median(telo):.2f} bp")
+        if len(telo) < 3:
             tprint("Not enough data points to recommend TRC cutoff.")
+            continue
+        median_trc = np.median(trc)
+        fit_x, _fit_y, _coeffs = allsteps.fit_quadratic_and_find_vertex(
+            list(trc), list(telo), inputtrc=inputtrc, median_trc=median_trc,
+            save_path=os.path.join(args.outputDir, f"quadfit_{phrase}mer_{args.pattern}.png"))
+        cutoff, notes = recommend_cutoff(fit_x, float(trc.max()), median_trc, inputtrc)
+        for line in notes:
+            tprint(line)
+        tprint(f"asymptotic TRC, or recommended cutoff: {cutoff:.3f}")
+        kept = telo[trc >= cutoff]
+        if len(kept):
+            tprint(f"Median telomere length for reads with TRC cutoff >= {cutoff:.3f}: {np.median(kept):.2f} bp")
+        else:
+            tprint(f"No read has TRC >= {cutoff:.3f}, please double check the data or submit log to GitHub.")
 
 
 def build_parser():

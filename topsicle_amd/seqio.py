@@ -189,6 +189,13 @@ def _load_io():
         lib.tps_reader_next.restype = C.c_int64
         lib.tps_reader_next.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                         C.c_void_p, C.c_void_p]
+        lib.tps_reader_next_packed.restype = C.c_int64
+        lib.tps_reader_next_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+                                               C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+        lib.tps_pack_reads.restype = C.c_int64
+        lib.tps_pack_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+        lib.tps_packed_words_total.restype = C.c_int64
+        lib.tps_packed_words_total.argtypes = [C.c_void_p, C.c_int64]
         _io_lib = lib
     return _io_lib or None
 
@@ -240,3 +247,218 @@ def read_batches(filepath: str, max_bases: int = 256 << 20, max_records: int = 1
                               quals[:nb] if quals is not None else None, fmt)
     finally:
         lib.tps_reader_close(h)
+
+
+# ---------------------------------------------------------------------------- packed batches (upload format)
+def pack_reads_host(bases, offsets, out=None, threads: int = 0):
+    """ASCII batch -> the packed upload format of include/topsicle_hip.h (2 bits per base + invalid mask + read
+    descriptors) with the native thread team.  `out` = (seq2, inv, desc) buffers to fill (e.g. pinned); returns
+    (seq2[:n_words], inv[:n_words], desc[:n])."""
+    import ctypes as C
+    import numpy as np
+    from . import hiplib
+    lib = _load_io()
+    if lib is None:
+        raise RuntimeError("libtopsicle_io.so is not built")
+    bases = np.ascontiguousarray(bases, np.uint8)
+    offsets = np.ascontiguousarray(offsets, np.int64)
+    n = len(offsets) - 1
+    nw = int(lib.tps_packed_words_total(offsets.ctypes.data, n))
+    if out is None:
+        out = (np.empty(max(nw, 4), np.uint32), np.empty(max(nw, 4), np.uint16), np.empty(max(n, 1), hiplib.DESC_DTYPE))
+    seq2, inv, desc = out
+    if len(seq2) < nw or len(inv) < nw or len(desc) < n:
+        raise ValueError("packed buffers too small")
+    got = lib.tps_pack_reads(bases.ctypes.data, offsets.ctypes.data, n, seq2.ctypes.data, inv.ctypes.data, desc.ctypes.data, threads)
+    if got < 0:
+        raise RuntimeError(lib.tps_io_last_error().decode())
+    return seq2[:nw], inv[:nw], desc[:n]
+
+
+class BufferSet:
+    """One set of upload staging buffers (seq2, inv, desc), typically pinned (HipScanner.host_alloc)."""
+
+    def __init__(self, words_cap: int, reads_cap: int, alloc=None):
+        import numpy as np
+        from . import hiplib
+        self.words_cap, self.reads_cap = int(words_cap), int(reads_cap)
+        if alloc is None:
+            def alloc(nbytes):
+                return np.empty(nbytes, np.uint8)
+        self.seq2 = alloc(4 * self.words_cap).view(np.uint32)
+        self.inv = alloc(2 * self.words_cap).view(np.uint16)
+        self.desc = alloc(16 * self.reads_cap).view(hiplib.DESC_DTYPE)
+
+
+class BufferPool:
+    """A few BufferSets handed round between the reader thread and the upload workers (double buffering: the reader fills
+    one set while others are in flight)."""
+
+    def __init__(self, n_sets: int, words_cap: int, reads_cap: int, alloc=None):
+        import queue
+        self.words_cap, self.reads_cap = int(words_cap), int(reads_cap)
+        self._free = queue.Queue()
+        self._alloc = alloc
+        for _ in range(n_sets):
+            self._free.put(BufferSet(words_cap, reads_cap, alloc))
+
+    def get(self) -> BufferSet:
+        return self._free.get()
+
+    def put(self, bs: BufferSet):
+        self._free.put(bs)
+
+
+class PackedBatch:
+    """A batch of reads in the packed upload format, plus what is needed to write single records back out: either the
+    records' spans in the mmap'ed input file (plain FASTQ, nothing was copied) or the ASCII RecordBatch it was packed from."""
+
+    def __init__(self, seq2, inv, desc, heads, head_off, fmt, spans=None, text=None, ascii_batch=None, bufset=None, pool=None):
+        self.seq2, self.inv, self.desc, self.heads, self.head_off, self.fmt = seq2, inv, desc, heads, head_off, fmt
+        self.spans, self.text, self.ascii_batch = spans, text, ascii_batch
+        self.n = len(desc)
+        self.n_bases = int(desc["len"].sum(dtype="int64")) if self.n else 0
+        self._bufset, self._pool = bufset, pool
+        self._ids = None
+
+    def __len__(self):
+        return self.n
+
+    @property
+    def any_invalid(self) -> bool:
+        return bool((self.desc["flags"] & 1).any())
+
+    def release(self):
+        """Hand the staging buffers back (after the upload has completed).  seq2 / inv / desc must not be used afterwards."""
+        if self._pool is not None and self._bufset is not None:
+            import numpy as np
+            self.desc = np.array(self.desc)               # lengths stay available for the writers
+            self.seq2 = self.inv = None
+            self._pool.put(self._bufset)
+            self._bufset = None
+
+    def head(self, i: int) -> str:
+        return bytes(self.heads[self.head_off[i]:self.head_off[i + 1]]).decode("utf-8", "replace")
+
+    @property
+    def ids(self):
+        if self._ids is None:
+            self._ids = [_first_token(self.head(i)) for i in range(self.n)]
+        return self._ids
+
+    def read_id(self, i: int) -> str:
+        return self._ids[i] if self._ids is not None else _first_token(self.head(i))
+
+    def seq_bytes(self, i: int) -> bytes:
+        if self.spans is not None:
+            s0 = int(self.spans[i, 2])
+            return self.text[s0:s0 + int(self.desc["len"][i])]
+        b = self.ascii_batch
+        return b.bases[int(b.offsets[i]):int(b.offsets[i + 1])].tobytes()
+
+    def qual_bytes(self, i: int):
+        if self.spans is not None:
+            q0 = int(self.spans[i, 3])
+            return self.text[q0:q0 + int(self.desc["len"][i])]
+        b = self.ascii_batch
+        return None if b.quals is None else b.quals[int(b.offsets[i]):int(b.offsets[i + 1])].tobytes()
+
+    def record(self, i: int) -> Record:
+        d = self.head(i)
+        q = self.qual_bytes(i)
+        return Record(_first_token(d), d, self.seq_bytes(i).decode("ascii", "replace"), None if q is None else q.decode("ascii", "replace"))
+
+    def write_records(self, handle, indices, fmt: str):
+        """Write the given records to a BINARY handle in the layout Biopython's SeqIO.write produces (main.py:84-86)."""
+        out = []
+        for i in indices:
+            i = int(i)
+            head = bytes(self.heads[self.head_off[i]:self.head_off[i + 1]])
+            seq = self.seq_bytes(i)
+            if fmt == "fastq":
+                q = self.qual_bytes(i)
+                if q is None:
+                    raise ValueError("no qualities for FASTQ output")
+                out += [b"@", head, b"\n", seq, b"\n+\n", q, b"\n"]
+            else:
+                out += [b">", head, b"\n"]
+                out += [seq[j:j + 60] + b"\n" for j in range(0, len(seq), 60)]
+            if len(out) > 4096:
+                handle.write(b"".join(out))
+                out = []
+        if out:
+            handle.write(b"".join(out))
+
+
+def read_batches_packed(filepath: str, pool: BufferPool, max_records: int = 1 << 20):
+    """Generator of PackedBatch over a FASTA/FASTQ(.gz) file.  Plain FASTQ is packed straight from the mmap'ed file by
+    the native thread team (no ASCII copy, qualities untouched); other inputs are decoded to ASCII batches first
+    (read_batches) and packed by the same team.  Every batch owns one BufferSet of `pool` until `release()`."""
+    import ctypes as C
+    import mmap
+    import numpy as np
+    lib = _load_io()
+    if lib is None:
+        raise RuntimeError("libtopsicle_io.so is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    h = C.c_void_p()
+    if lib.tps_reader_open(filepath.encode(), C.byref(h)) != 0:
+        logging.error("Error parsing file: %s", lib.tps_io_last_error().decode())
+        return
+    fh = mm = None
+    try:
+        fmt = {1: "fasta", 2: "fastq"}.get(lib.tps_reader_format(h), "fasta")
+        packed_mode = True
+        nrec_cap = min(max_records, pool.reads_cap)
+        heads_cap = max(pool.words_cap * 2, 1 << 20)
+        while packed_mode:
+            bs = pool.get()
+            heads = np.empty(heads_cap, np.uint8)
+            head_off = np.empty(nrec_cap + 1, np.int64)
+            spans = np.empty((nrec_cap, 4), np.int64)
+            nw = C.c_int64(0)
+            n = lib.tps_reader_next_packed(h, bs.seq2.ctypes.data, bs.inv.ctypes.data, bs.words_cap, bs.desc.ctypes.data, nrec_cap,
+                                           heads.ctypes.data, heads_cap, head_off.ctypes.data, spans.ctypes.data, C.byref(nw))
+            if n > 0:
+                if mm is None:
+                    fh = open(filepath, "rb")
+                    mm = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
+                yield PackedBatch(bs.seq2[:nw.value], bs.inv[:nw.value], bs.desc[:n], heads[:int(head_off[n])], head_off[:n + 1].copy(),
+                                  fmt, spans=spans[:n].copy(), text=mm, bufset=bs, pool=pool)
+                continue
+            pool.put(bs)
+            if n == 0:
+                return
+            if n == -4:
+                packed_mode = False          # compressed / FASTA / odd records: ASCII batches from here on
+            elif n == -2:
+                raise RuntimeError("a single read does not fit the upload buffers; raise the batch size")
+            else:
+                logging.error("Error parsing file: %s", lib.tps_io_last_error().decode())
+                return
+        # ASCII path: decode with tps_reader_next into plain arrays, then pack into a pool buffer
+        cap = pool.words_cap * 16 - 64 * nrec_cap if pool.words_cap * 16 > 128 * nrec_cap else pool.words_cap * 8
+        while True:
+            bases = np.empty(cap, np.uint8)
+            quals = np.empty(cap, np.uint8) if fmt == "fastq" else None
+            nrec = min(nrec_cap, cap // 64 + 1024)
+            offsets = np.empty(nrec + 1, np.int64)
+            head_off = np.empty(nrec + 1, np.int64)
+            heads = np.empty(max(cap // 8, 1 << 20), np.uint8)
+            n = lib.tps_reader_next(h, bases.ctypes.data, cap, offsets.ctypes.data, nrec, heads.ctypes.data, len(heads),
+                                    head_off.ctypes.data, quals.ctypes.data if quals is not None else None)
+            if n == -2:
+                raise RuntimeError("a single read does not fit the upload buffers; raise the batch size")
+            if n < 0:
+                logging.error("Error parsing file: %s", lib.tps_io_last_error().decode())
+                return
+            if n == 0:
+                return
+            nb = int(offsets[n])
+            rb = RecordBatch(bases[:nb], offsets[:n + 1].copy(), heads[:int(head_off[n])].tobytes(), head_off[:n + 1].copy(),
+                             quals[:nb] if quals is not None else None, fmt)
+            bs = pool.get()
+            seq2, inv, desc = pack_reads_host(rb.bases, rb.offsets, out=(bs.seq2, bs.inv, bs.desc))
+            yield PackedBatch(seq2, inv, desc, np.frombuffer(rb.heads, np.uint8), rb.head_off, fmt, ascii_batch=rb, bufset=bs, pool=pool)
+    finally:
+        lib.tps_reader_close(h)
+        # (the mapping stays alive as long as a yielded batch references it)
