@@ -177,6 +177,21 @@ int  tps_binseg_l2(tps_ctx* ctx, const int32_t* sums, const int64_t* win_off, in
 /* Number of windows seq_cut_windows yields for a read of length L (allsteps.py:219, 263-271). */
 int64_t tps_window_count(int64_t read_len, int32_t window, int32_t slide, int32_t trimfirst, int32_t maxlen);
 
+/* ---- exploratory counts (overview plots) ------------------------------------------------- */
+/* patterns_vs_match_heatmap's counting loop (descriptive_plot.py:259-291): for every read of the resident batch longer
+ * than min_len, in bases [lo, hi) of the read (strand 0) and of its reverse complement (strand 1), the leftmost
+ * non-overlapping matches of  kmer(.{follow})  for each of the first n_fwd patterns of the table -- the k-mers of the
+ * doubled motif; the table must hold their complements behind them, as patterns_to_search builds it (allsteps.py:104-120).
+ *   picks  uint32[n_reads][2][n_fwd][pw], pw = ceil((hi - lo) / 32): bit j of word w = a match starts at base lo + 32 w + j
+ *          of that strand's string (the reference's DataFrame rows: Pattern = the k-mer, Match = the `follow` letters
+ *          behind it, which the caller reads from its own copy of the read)
+ *   hist   int64[2][n_fwd][4^follow + 1] or NULL: the crosstab summed over the batch; the bin of a match is the 2-bit
+ *          code of the following bases (first base in the low bits, A C T G = 0 1 2 3, as the reference's upper-cased,
+ *          complemented strand-1 string spells them); the last bin counts matches followed by a non-ACGT letter.
+ * follow <= 8, hi - lo <= 4096, n_fwd <= 15. */
+int  tps_batch_kmer_followers(tps_ctx* ctx, int32_t slot, int32_t n_fwd, int32_t follow, int32_t lo, int32_t hi,
+                              int32_t min_len, uint32_t* picks, int64_t picks_words, int64_t* hist, int64_t hist_len);
+
 /* ---- measurement ----------------------------------------------------------------------- */
 /* hipEvent timings of the scan kernel launches since the last reset: number of launches,
  * total and mean milliseconds (events are recorded on the stream the kernel runs on). */

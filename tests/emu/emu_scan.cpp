@@ -100,6 +100,31 @@ extern "C" int emu_scan(const char* pats, int P, int k, const uint8_t* bases, co
     return TPS_OK;
 }
 
+// tps_batch_kmer_followers through the emulation: picks[n][2][n_fwd][pw], hist[2][n_fwd][4^follow + 1] (may be NULL)
+extern "C" int emu_followers(const char* pats, int P, int k, const uint8_t* bases, const int64_t* offsets, int64_t n, int n_fwd, int follow,
+                             int lo, int hi, int min_len, uint32_t* picks, unsigned long long* hist) {
+    std::vector<uint32_t> lut;
+    tps::FollowArgs a{};
+    std::string err = tps::build_patterns(pats, P, k, lut, a.pat);
+    if (!err.empty()) { g_err = err; return TPS_E_PATTERN; }
+    if (n_fwd < 1 || n_fwd > 15 || 2 * n_fwd > P || follow < 0 || follow > 8 || lo < 0 || hi <= lo || hi - lo > tps::FOLLOW_MAX_SPAN) { g_err = "bad arguments"; return TPS_E_ARG; }
+    std::vector<tps_read_desc> desc((size_t)(n > 0 ? n : 1));
+    const int64_t n_words = tps::pack_layout(offsets, n, desc.data());
+    std::vector<uint32_t> seq2buf((size_t)(n_words + 8), 0xDEADBEEFu);
+    std::vector<uint16_t> invbuf((size_t)(n_words + 8), (uint16_t)0xFFFFu);
+    tps::pack_range(bases, offsets, 0, n, desc.data(), seq2buf.data(), invbuf.data());
+    a.seq2 = seq2buf.data(); a.inv = invbuf.data(); a.desc = desc.data(); a.lut = lut.data();
+    a.picks = picks; a.hist = hist; a.n_reads = n;
+    a.n_fwd = n_fwd; a.follow = follow; a.lo = lo; a.hi = hi; a.min_len = min_len; a.pw = (hi - lo + 31) / 32; a.nbins = (1 << (2 * follow)) + 1;
+    std::vector<uint32_t> ldsbuf((size_t)tps::FOLLOW_LDS_DW + 16);
+    uint32_t* lds = (uint32_t*)(((uintptr_t)ldsbuf.data() + 15) & ~(uintptr_t)15);
+    for (int64_t r = 0; r < n; ++r) {
+        for (int i = 0; i < tps::FOLLOW_LDS_DW; ++i) lds[i] = 0xDEADBEEFu;
+        tps::followers_read(a, r, lds);
+    }
+    return TPS_OK;
+}
+
 extern "C" int emu_binseg(const int32_t* sums, const int64_t* win_off, int64_t n, int n_patterns, int jump,
                           int min_size, int32_t* bkp, double* gain) {
     tps::BinsegArgs a{sums, win_off, bkp, gain, n, n_patterns, jump, min_size};

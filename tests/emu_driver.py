@@ -20,7 +20,7 @@ def build(asan=False):
         return out
     cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas", "-shared", "-fPIC"]
     if asan:
-        cmd += ["-g", "-fsanitize=address,undefined"]
+        cmd += ["-O1", "-fno-omit-frame-pointer", "-fsanitize=address,undefined"]      # (-O2 -g takes three times as long to compile)
     subprocess.check_call(cmd + ["-o", out, SRC])
     return out
 
@@ -31,7 +31,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        _lib = C.CDLL(build())
+        _lib = C.CDLL(build(asan=bool(os.environ.get("TPS_EMU_ASAN"))))      # TPS_EMU_ASAN=1: the -fsanitize=address,undefined build
         _lib.emu_last_error.restype = C.c_char_p
         _lib.emu_scan.restype = C.c_int
         _lib.emu_binseg.restype = C.c_int
@@ -62,6 +62,20 @@ def scan(patterns, seqs, prm, tails=None, spans_pref=0, lds_budget=160 * 1024, b
     if rc != 0:
         raise RuntimeError(f"emu_scan rc={rc}: {L.emu_last_error().decode()}")
     return dict(results=res, c_start=cs, c_end=ce, win_off=win_off, sums=sums[:tot], raw=raw[:tot * P].reshape(-1, P))
+
+
+def followers(patterns, seqs, n_fwd, follow, lo=100, hi=2000, min_len=0):
+    """(picks uint32[n, 2, n_fwd, pw], hist int64[2, n_fwd, 4**follow + 1]) like HipScanner.kmer_followers."""
+    L = lib()
+    bases, offsets = hiplib.pack_reads(seqs)
+    n, P, k = len(seqs), len(patterns), len(patterns[0])
+    pw = (hi - lo + 31) // 32
+    picks = np.zeros((n, 2, n_fwd, pw), np.uint32)
+    hist = np.zeros((2, n_fwd, 4 ** follow + 1), np.uint64)
+    rc = L.emu_followers("".join(patterns).encode(), P, k, _p(bases), _p(offsets), C.c_int64(n), n_fwd, follow, lo, hi, min_len, _p(picks), _p(hist))
+    if rc != 0:
+        raise RuntimeError(f"emu_followers rc={rc}: {L.emu_last_error().decode()}")
+    return picks, hist.astype(np.int64)
 
 
 def binseg(sums, win_off, n_patterns, jump=5, min_size=2):

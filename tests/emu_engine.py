@@ -47,6 +47,10 @@ class EmuEngine:
         bases, offsets = hiplib.pack_reads(seqs)
         self.upload(slot, bases, offsets)
 
+    def kmer_followers(self, slot, n_fwd, follow, lo=100, hi=2000, min_len=0, want_hist=True):
+        picks, hist = emu.followers(self.patterns, self._seqs(self.slots[slot]), n_fwd, follow, lo, hi, min_len)
+        return picks, (hist if want_hist else None)
+
     def set_tails(self, slot, tails):
         self.slots[slot]["tails"] = np.array(tails, np.uint8)
 

@@ -77,10 +77,13 @@ class EnginePool:
         from . import seqio
         max_bases = max_bases or BATCH_BASES
         words_cap = max(max_bases // 16, 1024)                 # (a read's padding to whole 64-base quads counts too)
-        reads_cap = min(BATCH_READS, max(64, max_bases // 64))
-        alloc = getattr(self.engines[0], "host_alloc", None)
-        pool = seqio.BufferPool(len(self.engines) + 2, words_cap, reads_cap, alloc)
-        return self._run(seqio.read_batches_packed(filepath, pool, max_records=reads_cap), prm, want_sums, want_raw)
+        reads_cap = min(BATCH_READS, max(64, max_bases // 256))
+        key = (words_cap, reads_cap)
+        if getattr(self, "_pool_key", None) != key:            # pinned staging buffers are allocated once and reused file after file
+            alloc = getattr(self.engines[0], "host_alloc", None)
+            self._pool = seqio.BufferPool(len(self.engines) + 2, words_cap, reads_cap, alloc)
+            self._pool_key = key
+        return self._run(seqio.read_batches_packed(filepath, self._pool, max_records=reads_cap), prm, want_sums, want_raw)
 
     def scan_stream(self, records, prm, want_sums=False, want_raw=False, max_bases=None):
         return self._run(record_batches(records, max_bases=max_bases or BATCH_BASES), prm, want_sums, want_raw)

@@ -73,6 +73,14 @@ extern "C" __global__ void __launch_bounds__(tps::NT * tps::WPG) tps_binseg_kern
     tps::binseg_read(a, r, smem + wave * tps::BINSEG_SMEM_DW);
 }
 
+extern "C" __global__ void __launch_bounds__(tps::NT * tps::WPG) tps_followers_kernel(tps::FollowArgs a) {
+    __shared__ __attribute__((aligned(16))) uint32_t smem[tps::WPG * tps::FOLLOW_LDS_DW];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t r = (int64_t)blockIdx.x * tps::WPG + wave;
+    if (r >= a.n_reads) return;
+    tps::followers_read(a, r, smem + wave * tps::FOLLOW_LDS_DW);
+}
+
 // ASCII -> packed batch (tps_pack.h), one workgroup per read, one thread per word of 16 bases.  Runs once per
 // tps_batch_upload, right behind the copy of the ASCII bytes; the scan kernels only ever see the packed batch.
 // bits 1-2 of an ASCII letter: A,C,T,G (either case) -> 0,1,2,3; one v_dot4_u32_u8 packs 4 bases; a v_perm rebuilds the
@@ -193,6 +201,7 @@ struct tps_ctx {
     hipStream_t stream = nullptr;
     hipDeviceProp_t prop{};
     DevBuf lut;
+    DevBuf follow_picks, follow_hist; // outputs of tps_batch_kmer_followers
     DevBuf ascii, ascii_off;          // staging of tps_batch_upload: ASCII bases + offsets, packed on the device right after the copy
     std::set<void*> pinned;           // host buffers handed out by tps_host_alloc
     std::vector<tps_read_desc> h_desc;   // scratch of the ASCII upload path
@@ -524,6 +533,8 @@ int tps_ctx_destroy(tps_ctx* c) {
     c->lut.release();
     c->ascii.release();
     c->ascii_off.release();
+    c->follow_picks.release();
+    c->follow_hist.release();
     for (void* hp : c->pinned) (void)hipHostFree(hp);
     c->pinned.clear();
     for (auto& ep : c->ev_pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
@@ -633,6 +644,47 @@ int tps_batch_download_packed(tps_ctx* c, int32_t slot, uint32_t* seq2, uint16_t
         else HIP_TRY(hipMemcpy(inv, sl->inv.p, (size_t)n_words * 2, hipMemcpyDeviceToHost));
     }
     if (desc && n) HIP_TRY(hipMemcpy(desc, sl->desc.p, (size_t)n * sizeof(tps_read_desc), hipMemcpyDeviceToHost));
+    return TPS_OK;
+}
+
+int tps_batch_kmer_followers(tps_ctx* c, int32_t slot, int32_t n_fwd, int32_t follow, int32_t lo, int32_t hi, int32_t min_len,
+                             uint32_t* picks, int64_t picks_words, int64_t* hist, int64_t hist_len) {
+    int rc;
+    if ((rc = bind(c))) return rc;
+    Slot* sl = get_slot(c, slot);
+    if (!sl) return TPS_E_ARG;
+    if (!c->have_pat) return fail(TPS_E_PATTERN, "tps_set_patterns has not been called");
+    if (sl->n < 0) return fail(TPS_E_STATE, "no batch uploaded in this slot");
+    if (n_fwd < 1 || n_fwd > 15 || 2 * n_fwd > c->pat.P) return fail(TPS_E_ARG, "n_fwd must be 1..15 and the table must hold the complements behind the k-mers");
+    if (follow < 0 || follow > 8) return fail(TPS_E_CAPACITY, "follow must be 0..8 bases");
+    if (lo < 0 || hi <= lo || hi - lo > tps::FOLLOW_MAX_SPAN) return fail(TPS_E_CAPACITY, "the scanned range [lo, hi) must hold 1..%d bases", tps::FOLLOW_MAX_SPAN);
+    const int pw = (hi - lo + 31) / 32;
+    const int64_t n = sl->n;
+    const int64_t want = n * 2 * n_fwd * pw;
+    if (!picks || picks_words != want) return fail(TPS_E_ARG, "picks must hold %lld words", (long long)want);
+    const int nbins = (1 << (2 * follow)) + 1;
+    if (hist && hist_len != 2ll * n_fwd * nbins) return fail(TPS_E_ARG, "hist must hold %lld counters", 2ll * n_fwd * nbins);
+    if (n == 0) { if (hist) memset(hist, 0, (size_t)hist_len * 8); return TPS_OK; }
+    // scratch: the slot's raw / sums buffers are not touched; picks and counters get buffers of their own in the context
+    if ((rc = c->follow_picks.ensure((size_t)want * 4))) return rc;
+    if ((rc = c->follow_hist.ensure((size_t)2 * n_fwd * nbins * 8))) return rc;
+    HIP_TRY(hipMemsetAsync(c->follow_picks.p, 0, (size_t)want * 4, c->stream));
+    HIP_TRY(hipMemsetAsync(c->follow_hist.p, 0, (size_t)2 * n_fwd * nbins * 8, c->stream));
+    tps::FollowArgs a{};
+    a.seq2 = (const uint32_t*)sl->seq2.p;
+    a.inv = (const uint16_t*)sl->inv.p;
+    a.desc = (const tps_read_desc*)sl->desc.p;
+    a.lut = (const uint32_t*)c->lut.p;
+    a.picks = (uint32_t*)c->follow_picks.p;
+    a.hist = hist ? (unsigned long long*)c->follow_hist.p : nullptr;
+    a.n_reads = n;
+    a.pat = c->pat;
+    a.n_fwd = n_fwd; a.follow = follow; a.lo = lo; a.hi = hi; a.min_len = min_len; a.pw = pw; a.nbins = nbins;
+    hipLaunchKernelGGL(tps_followers_kernel, dim3((unsigned)((n + tps::WPG - 1) / tps::WPG)), dim3(tps::NT * tps::WPG), 0, c->stream, a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(picks, c->follow_picks.p, (size_t)want * 4, hipMemcpyDeviceToHost, c->stream));
+    if (hist) HIP_TRY(hipMemcpyAsync(hist, c->follow_hist.p, (size_t)hist_len * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return TPS_OK;
 }
 

@@ -455,15 +455,15 @@ struct Stage {
     int32_t n;               // staged s-indices
     bool reverse;
 };
-TPS_DEV Stage stage_plan(const ScanArgs& a, int64_t word_off, int64_t L, bool reverse, int64_t t, int64_t i0, int32_t n) {
+TPS_DEV Stage stage_plan(const uint32_t* seq2_base, const uint16_t* inv_base, int64_t word_off, int64_t L, bool reverse, int64_t t, int64_t i0, int32_t n) {
     Stage st;
     st.reverse = reverse;
     st.n = n;
     const int64_t pos = reverse ? (L - 1 - t - i0) : (t + i0);     // read position of s-index i0
     const int64_t w = word_off + 4 * (pos >> 6);
     st.delta = reverse ? 63 - (int32_t)(pos & 63) : (int32_t)(pos & 63);
-    st.q0 = (uint64_t)(uintptr_t)a.seq2 + (uint64_t)w * 4u;
-    st.v0 = (uint64_t)(uintptr_t)a.inv + (uint64_t)w * 2u;
+    st.q0 = (uint64_t)(uintptr_t)seq2_base + (uint64_t)w * 4u;
+    st.v0 = (uint64_t)(uintptr_t)inv_base + (uint64_t)w * 2u;
     st.nq = n > 0 ? (st.delta + n + 63) >> 6 : 0;
     return st;
 }
@@ -2457,8 +2457,8 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
     const bool step1 = (prm.flags & TPS_F_STEP1) != 0;
 
     const int n1 = (int)(L < prm.no_bp ? L : prm.no_bp);
-    const Stage st_s = stage_plan(a, woff, L, false, 0, 0, n1);     // first n1 bases
-    const Stage st_e = stage_plan(a, woff, L, true, 0, 0, n1);      // last n1 bases, reversed
+    const Stage st_s = stage_plan(a.seq2, a.inv, woff, L, false, 0, 0, n1);     // first n1 bases
+    const Stage st_e = stage_plan(a.seq2, a.inv, woff, L, true, 0, 0, n1);      // last n1 bases, reversed
 
     TPS_STAMP(0);
     TPS_PHASE { for (int i = tid; i < MISC_DW; i += NT) l.misc[i] = 0; }
@@ -2567,7 +2567,7 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
                 int64_t n_stage = n_s - i0;
                 const int64_t cap = (int64_t)blk_per_tile * prm.slide + 32;
                 if (n_stage > cap) n_stage = cap;
-                const Stage st = stage_plan(a, woff, L, tail == 1, prm.trimfirst, i0, (int)n_stage);
+                const Stage st = stage_plan(a.seq2, a.inv, woff, L, tail == 1, prm.trimfirst, i0, (int)n_stage);
                 // spans needed for this tile's blocks 0 .. nw_tile-1+q (+ the partial block)
                 const int blk_need = nw_tile + a.q + 1;
                 const int spans = (blk_need + (1 << a.blk_log2) - 1) >> a.blk_log2;
@@ -2613,7 +2613,7 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
                 const int64_t need = (int64_t)(tw - 1 + tc.q) * prm.slide + tc.r + 13;
                 if (cap > need) cap = need;
                 if (n_stage > cap) n_stage = cap;
-                return stage_plan(a, woff, L, tail == 1, prm.trimfirst, i0, (int)n_stage);
+                return stage_plan(a.seq2, a.inv, woff, L, tail == 1, prm.trimfirst, i0, (int)n_stage);
             };
             // Software prefetch: the 16-byte load(s) of the NEXT tile are issued right after the current tile has been
             // copied into LDS and complete while it is being scanned, so a wave pays the HBM latency once per read
@@ -2754,6 +2754,118 @@ TPS_DEV void binseg_read(const BinsegArgs& a, int64_t r, uint32_t* smem) {
         if (tid == 0) {
             a.bkp[r] = bkp;
             if (a.gain) a.gain[r] = gain;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ k-mer followers (overview heat map)
+// Topsicle/descriptive_plot.py:259-291 (patterns_vs_match_heatmap): in bases [lo, hi) of a read and of its reverse
+// complement, the non-overlapping matches of the regex  kmer(.{f})  for every k-mer of the doubled motif: which k-mer,
+// and which f bases follow it.  One wave per read.  The pattern table is the scan's own (k-mers, then their complements:
+// allsteps.py:104-120): on the read itself the first n_fwd patterns are looked for; on the reverse complement the
+// staged tail is the REVERSED read and a k-mer matches there iff its complement matches the reversed bases, i.e.
+// patterns n_fwd .. 2 n_fwd - 1 -- no complementing of the sequence, as in the scan.
+//   phase 1  every lane looks up positions lane, lane + 64, ... and sets the bit of (pattern, position)
+//   phase 2  lane p walks pattern p's bits leftmost-first, a match consumes k + f positions (re.finditer); the picks
+//            replace the occurrence bits and go to HBM (one bit per position: the host builds the reference's rows)
+//   phase 3  every pick adds one to hist[strand][pattern][code of the f following bases] (bin 4^f: a non-ACGT letter
+//            among them; on the reverse complement the codes are complemented: code ^ 2 per base)
+struct FollowArgs {
+    const uint32_t* seq2;
+    const uint16_t* inv;
+    const tps_read_desc* desc;
+    const uint32_t* lut;         // the table in global memory: masks over the pattern list (direct or hashed)
+    uint32_t* picks;             // [n_reads][2][n_fwd][pw]
+    unsigned long long* hist;    // [2][n_fwd][nbins] or nullptr
+    int64_t n_reads;
+    PatInfo pat;
+    int32_t n_fwd, follow, lo, hi, min_len, pw, nbins;
+};
+constexpr int FOLLOW_MAX_SPAN = 4096;                      // hi - lo
+constexpr int FOLLOW_SEQ_DW = 4 * ((63 + FOLLOW_MAX_SPAN + 63) / 64) + 8;
+constexpr int FOLLOW_PW = FOLLOW_MAX_SPAN / 32;
+constexpr int FOLLOW_LDS_DW = FOLLOW_SEQ_DW + FOLLOW_SEQ_DW / 2 + 4 + 15 * FOLLOW_PW + 4;   // seq2, val, flag, occurrence / pick bits
+#ifdef TPS_EMU
+TPS_DEV void hist_add(unsigned long long* p) { *p += 1ull; }
+#else
+TPS_DEV void hist_add(unsigned long long* p) { atomicAdd(p, 1ull); }
+#endif
+TPS_DEV void followers_read(const FollowArgs& a, int64_t r, uint32_t* lds) {
+    uint32_t* seq2 = lds;
+    uint16_t* val = (uint16_t*)(lds + FOLLOW_SEQ_DW);
+    uint32_t* flag = lds + FOLLOW_SEQ_DW + FOLLOW_SEQ_DW / 2 + 2;
+    uint32_t* occ = flag + 2;
+    const PatInfo& pat = a.pat;
+    const int64_t woff = a.desc[r].word_off;
+    const int64_t L = a.desc[r].len;
+    const bool has_inv = (a.desc[r].flags & TPS_RD_HAS_INVALID) != 0;
+    if (L <= a.min_len) return;                    // (the host zeroed the picks)
+    const int64_t m = L < a.hi ? L : a.hi;
+    const int n = (int)(m - a.lo);
+    const int need = pat.k + a.follow;
+    if (n < need) return;
+    const int npos = n - need + 1;
+    const int pw = a.pw;
+    const uint32_t fmask = a.follow >= 16 ? 0xFFFFFFFFu : ((1u << (2 * a.follow)) - 1u);
+    for (int strand = 0; strand < 2; ++strand) {
+        const Stage st = stage_plan(a.seq2, a.inv, woff, L, strand == 1, a.lo, 0, n);
+        TPS_PHASE {
+            for (int i = tid; i < a.n_fwd * pw; i += NT) occ[i] = 0;
+            if (tid == 0) flag[0] = 0;
+        }
+        TPS_SYNC();
+        TPS_PHASE { stage_thread(st, has_inv, seq2, val, (st.delta + n + 63 + 64) >> 6, flag, tid); }
+        TPS_SYNC();
+        const bool any_inv = has_inv && uniform(flag[0]) != 0;
+        const uint32_t sel = (1u << a.n_fwd) - 1u;
+        TPS_PHASE {
+            for (int p = tid; p < npos; p += NT) {
+                uint32_t h = h_at(a.lut, 0, seq2, val, pat, st.delta + p, any_inv);
+                h = (h >> (strand ? a.n_fwd : 0)) & sel;
+                while (h) {
+                    const int b = ffs0(h);
+                    h &= h - 1;
+                    lds_or(&occ[b * pw + (p >> 5)], 1u << (p & 31));
+                }
+            }
+        }
+        TPS_SYNC();
+        TPS_PHASE {
+            if (tid < a.n_fwd) {
+                uint32_t* bits = occ + tid * pw;
+                uint32_t* out = a.picks + ((r * 2 + strand) * a.n_fwd + tid) * (int64_t)pw;
+                int cursor = 0;
+                for (int w = 0; w < pw; ++w) {
+                    uint32_t mm = bits[w], picked = 0;
+                    while (mm) {
+                        const int bit = ffs0(mm);
+                        mm &= mm - 1;
+                        const int pos = 32 * w + bit;
+                        if (pos >= cursor) { picked |= 1u << bit; cursor = pos + need; }
+                    }
+                    bits[w] = picked;
+                    out[w] = picked;
+                }
+            }
+        }
+        TPS_SYNC();
+        if (a.hist) {
+            TPS_PHASE {
+                for (int i = tid; i < a.n_fwd * pw; i += NT) {
+                    uint32_t mm = occ[i];
+                    const int pj = i / pw, w = i - pj * pw;
+                    while (mm) {
+                        const int bit = ffs0(mm);
+                        mm &= mm - 1;
+                        const int q = st.delta + 32 * w + bit + pat.k;
+                        uint32_t code = v_at(seq2, q) & fmask;
+                        if (strand) code ^= 0xAAAAAAAAu & fmask;        // complement: A <-> T, C <-> G is code ^ 2
+                        const bool bad = any_inv && a.follow > 0 && invalid_at(val, q, a.follow);
+                        hist_add(&a.hist[((int64_t)strand * a.n_fwd + pj) * a.nbins + (bad ? (uint32_t)(a.nbins - 1) : code)]);
+                    }
+                }
+            }
+            TPS_SYNC();
         }
     }
 }

@@ -21,7 +21,7 @@ MAX_K, MAX_PATTERNS, MAX_SLOTS = 15, 31, 16
 EXPORTS = [
     "tps_abi_version", "tps_device_count", "tps_ctx_create", "tps_ctx_destroy", "tps_last_error",
     "tps_set_patterns", "tps_batch_upload", "tps_batch_upload_packed", "tps_host_alloc", "tps_host_free",
-    "tps_batch_download_packed", "tps_batch_set_tails", "tps_batch_scan", "tps_sync",
+    "tps_batch_download_packed", "tps_batch_kmer_followers", "tps_batch_set_tails", "tps_batch_scan", "tps_sync",
     "tps_batch_results", "tps_batch_window_offsets", "tps_batch_window_sums", "tps_batch_window_raw",
     "tps_batch_trc_counts", "tps_trc_counts", "tps_window_counts", "tps_binseg_l2", "tps_window_count",
     "tps_kernel_time_ms", "tps_kernel_time_reset", "tps_device_info", "tps_batch_kernel_info",
@@ -84,6 +84,7 @@ def load_library(path: str | None = None) -> C.CDLL:
         "tps_host_alloc": (C.c_int, [vp, i64, C.POINTER(vp)]),
         "tps_host_free": (C.c_int, [vp, vp]),
         "tps_batch_download_packed": (C.c_int, [vp, i32, vp, vp, vp, i64, i64, C.POINTER(i64)]),
+        "tps_batch_kmer_followers": (C.c_int, [vp, i32, i32, i32, i32, i32, i32, vp, i64, vp, i64]),
         "tps_batch_set_tails": (C.c_int, [vp, i32, vp]),
         "tps_batch_scan": (C.c_int, [vp, i32, C.POINTER(Params)]),
         "tps_sync": (C.c_int, [vp]),
@@ -240,6 +241,17 @@ class HipScanner:
         desc = np.zeros(n, DESC_DTYPE)
         self._check(self.lib.tps_batch_download_packed(self._h, slot, _ptr(seq2), _ptr(inv), _ptr(desc), n, nw.value, None))
         return seq2, inv, desc
+
+    def kmer_followers(self, slot: int, n_fwd: int, follow: int, lo: int = 100, hi: int = 2000, min_len: int = 0, want_hist: bool = True):
+        """patterns_vs_match_heatmap's counting (descriptive_plot.py:259-291) on the resident batch:
+        (picks uint32[n, 2, n_fwd, pw], hist int64[2, n_fwd, 4**follow + 1] or None)."""
+        n = self._n[slot]
+        pw = (hi - lo + 31) // 32
+        picks = np.zeros((n, 2, n_fwd, pw), dtype=np.uint32)
+        hist = np.zeros((2, n_fwd, 4 ** follow + 1), dtype=np.int64) if want_hist else None
+        self._check(self.lib.tps_batch_kmer_followers(self._h, slot, n_fwd, follow, lo, hi, min_len, _ptr(picks), picks.size,
+                                                      _ptr(hist), 0 if hist is None else hist.size))
+        return picks, hist
 
     def set_tails(self, slot: int, tails: np.ndarray):
         tails = np.ascontiguousarray(tails, dtype=np.uint8)

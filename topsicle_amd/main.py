@@ -23,6 +23,7 @@ from . import allsteps, batch, hiplib, seqio
 version_number = "1.0.0"
 Topsicle_output_prefix = "Topsicle"
 CONTEXTS_PER_GPU = 2
+LAST_TIMINGS = {}                 # seconds of the last analysis_run: reads (step 1 + 2 + outputs) / summary (fit + PNG); bench.py's e2e leg reads it
 
 
 def get_log_path(args):
@@ -169,6 +170,7 @@ def analysis_run(args, engines=None, engine_factory=None):
     """`engines`: contexts to use (tests inject theirs).  `engine_factory()` -> a fresh list of contexts: given (or by
     default on real GPUs), several input files are processed concurrently, one host thread + one set of contexts per
     file in flight -- the role of upstream's `Pool(num_cores)` over files (main.py:232-235)."""
+    LAST_TIMINGS.clear()
     print("---- Topsicle run parameters ---")
     for k, v in vars(args).items():
         tprint(f"{k}: {v}")
@@ -233,7 +235,9 @@ def analysis_run(args, engines=None, engine_factory=None):
             filenames.append(args.inputDir)
 
         tprint("begin processing reads")
+        t_reads = time.perf_counter()
         results = _process_files(args, filenames, telo_phrase, pattern, sliding_val, engines, engine_factory, num_cores)
+        LAST_TIMINGS["reads_s"] = LAST_TIMINGS.get("reads_s", 0.0) + time.perf_counter() - t_reads
         tprint("finished processing all reads")
         print("---------------------")
         for file_result in results:
@@ -241,7 +245,9 @@ def analysis_run(args, engines=None, engine_factory=None):
                 phrase_to_telo[entry[1]].append(float(entry[2][0][1]))
                 phrase_to_trc[entry[1]].append(float(entry[3]))
 
+    t_sum = time.perf_counter()
     summarize(args, phrase_to_telo, phrase_to_trc)
+    LAST_TIMINGS["summary_s"] = time.perf_counter() - t_sum
     return tprint("All telomere found, have a nice day.")
 
 

@@ -177,7 +177,8 @@ def _load_io():
     if _io_lib is None:
         import ctypes as C
         import os
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libtopsicle_io.so")
+        # TOPSICLE_IO_LIB: another build of csrc/tps_io.cpp (the sanitizer build of tests/test_sanitizers.py)
+        path = os.environ.get("TOPSICLE_IO_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libtopsicle_io.so")
         if not os.path.exists(path):
             _io_lib = False
             return None
