@@ -17,7 +17,7 @@
 
 static std::string g_err;
 static int g_variant_calls[9] = {0};
-extern "C" int emu_counter(int i) { return (i >= 0 && i < 4) ? tps::emu_counter(i) : -1; }
+extern "C" int emu_counter(int i) { return (i >= 0 && i < 8) ? tps::emu_counter(i) : -1; }
 extern "C" int emu_variant_calls(int v) { return (v >= 0 && v < 9) ? g_variant_calls[v] : -1; }
 
 extern "C" const char* emu_last_error() { return g_err.c_str(); }

@@ -48,14 +48,14 @@
     }
 #define TPS_SCAN_KERNEL(NAME, SV, SO, PAIR, RAW, MINW) TPS_SCAN_KERNEL_F(NAME, SV, SO, PAIR, RAW, MINW, tps::tile_full_default(SV))
 TPS_SCAN_KERNEL(tps_scan_kernel, 0, false, false, true, 4)          // generic: any slide, up to 31 patterns
-TPS_SCAN_KERNEL(tps_scan_kernel_s5, 5, false, false, false, 3)       // specialised: compile-time slide, <= 15 patterns
-TPS_SCAN_KERNEL(tps_scan_kernel_s6, 6, false, false, false, 3)
-TPS_SCAN_KERNEL(tps_scan_kernel_s7, 7, false, false, false, 3)
-TPS_SCAN_KERNEL(tps_scan_kernel_s8, 8, false, false, false, 3)
-TPS_SCAN_KERNEL(tps_scan_kernel_s5p, 5, false, true, false, 3)       // ... k <= 4: two positions per table lookup
-TPS_SCAN_KERNEL(tps_scan_kernel_s6p, 6, false, true, false, 3)
-TPS_SCAN_KERNEL(tps_scan_kernel_s7p, 7, false, true, false, 3)
-TPS_SCAN_KERNEL(tps_scan_kernel_s8p, 8, false, true, false, 3)
+TPS_SCAN_KERNEL(tps_scan_kernel_s5, 5, false, false, false, 5)       // specialised: compile-time slide, <= 15 patterns
+TPS_SCAN_KERNEL(tps_scan_kernel_s6, 6, false, false, false, 5)
+TPS_SCAN_KERNEL(tps_scan_kernel_s7, 7, false, false, false, 5)
+TPS_SCAN_KERNEL(tps_scan_kernel_s8, 8, false, false, false, 5)
+TPS_SCAN_KERNEL(tps_scan_kernel_s5p, 5, false, true, false, 5)       // ... k <= 4: two positions per table lookup
+TPS_SCAN_KERNEL(tps_scan_kernel_s6p, 6, false, true, false, 5)
+TPS_SCAN_KERNEL(tps_scan_kernel_s7p, 7, false, true, false, 5)
+TPS_SCAN_KERNEL(tps_scan_kernel_s8p, 8, false, true, false, 5)
 TPS_SCAN_KERNEL(tps_scan_kernel_s5r, 5, false, false, true, 3)       // ... with the per-pattern raw counts (TPS_F_STORE_RAW)
 TPS_SCAN_KERNEL(tps_scan_kernel_s6r, 6, false, false, true, 3)
 TPS_SCAN_KERNEL(tps_scan_kernel_s7r, 7, false, false, true, 3)

@@ -1044,11 +1044,11 @@ TPS_DEV void candidates_group(const ScanArgs& a, const Lds& l, uint64_t lc_g, in
 struct TileConst {
     int32_t q, r;
     uint32_t jump, jump_magic, lc_cap, lc16;
-    uint64_t lc_g;               // this read's off-chip Lc16 (0 = Lc16 lives in LDS)
+    uint64_t lc_g;               // this read's off-chip candidate sums: Lc16, or absolute 32-bit sums (0 = they live in LDS)
 };
 TPS_DEV TileConst tile_const(const ScanArgs& a, int64_t r) {
     TileConst t;
-    t.lc_g = (a.lc16 && a.lc_global) ? (uint64_t)(uintptr_t)(a.lc_scratch + r * (int64_t)a.lc_stride) : 0ull;
+    t.lc_g = a.lc_global ? (uint64_t)(uintptr_t)(a.lc_scratch + r * (int64_t)a.lc_stride) : 0ull;
     t.q = (int32_t)uniform((uint32_t)a.q); t.r = (int32_t)uniform((uint32_t)a.r);
     t.jump = uniform((uint32_t)a.prm.jump); t.jump_magic = uniform(a.jump_magic);
     t.lc_cap = uniform((uint32_t)a.lc_cap); t.lc16 = uniform((uint32_t)a.lc16);
@@ -1502,6 +1502,8 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const TileConst& tc, const Lds& l, 
                     if (tc.lc16) {
                         if (tc.lc_g) g16_store(tc.lc_g, c, pre);
                         else l.Lc16[c] = (uint16_t)pre;
+                    } else if (tc.lc_g) {
+                        g32_store(tc.lc_g, c, carry + pre);
                     } else {
                         l.Lc[c] = carry + pre;
                     }
@@ -1538,6 +1540,8 @@ TPS_DEV void tile_candidates(const TileConst& tc, const Lds& l, int w0, int tile
                 if (tc.lc16) {
                     if (tc.lc_g) g16_store(tc.lc_g, c, pre);
                     else l.Lc16[c] = (uint16_t)pre;
+                } else if (tc.lc_g) {
+                    g32_store(tc.lc_g, c, carry + pre);
                 } else {
                     l.Lc[c] = carry + pre;
                 }
@@ -1578,7 +1582,7 @@ TPS_DEV void tile_candidates(const TileConst& tc, const Lds& l, int w0, int tile
 //            bytes, floored to 1, summed (S_w), transposed into pattern order, stored
 //   phase 3  tile_candidates
 #ifdef TPS_EMU
-inline int& emu_counter(int i) { static int c[4] = {0, 0, 0, 0}; return c[i]; }   // tests: 0 = per-pattern tiles, 1 = windows recounted there
+inline int& emu_counter(int i) { static int c[8] = {0, 0, 0, 0, 0, 0, 0, 0}; return c[i]; }   // tests: 0 = per-pattern tiles, 1 = windows recounted there, 4 = exact change-point tournaments
 #endif
 template <int S>
 struct GeoPP {
@@ -2286,51 +2290,61 @@ TPS_DEV void binseg_from_lc(const ScanArgs& a, const Lds& l, uint64_t lc_g, cons
     // candidates within 1e-4 of it -- two orders of magnitude more than single precision can be off -- go through the
     // float64 fraction comparison below (41 instructions per candidate; the prefilter costs about a third of that).
     constexpr int LCV = 16;
-    const bool prefilter = a.lc16 && lc_g && exact53 && c_max - c_min < LCV * NT;
+    const bool prefilter = !a.lc16 && lc_g && exact53 && c_max - c_min < LCV * NT;
     int nslot = c_max >= c_min ? (c_max - c_min + NT) / NT : 0;          // candidate slots per lane that any lane uses
     TPS_PIN_S(nslot);
     auto tile_sum = [&](int c) { return l.Tc[(uint32_t)(((uint64_t)(uint32_t)(c * jump) * a.tw_magic) >> 32)]; };
-    uint32_t lcv[LCV];
-    float sc[LCV];
-    float thr32 = -1.0f;
+    // per lane: its best single-precision score with that candidate's index and left sum, and its second-best score
+    float p_s1 = -1.0f, p_s2 = -1.0f, thr32 = -1.0f;
+    uint32_t p_lc = 0;
+    int p_c = -1;
+    bool crowded = false;                          // some lane holds a second candidate within the prefilter's margin
 #ifdef TPS_EMU
-    static thread_local uint32_t lcv_keep[NT][LCV];
-    static thread_local float sc_keep[NT][LCV];
+    static thread_local float ps1_keep[NT], ps2_keep[NT];
+    static thread_local uint32_t plc_keep[NT];
+    static thread_local int pc_keep[NT];
     float emu_m32 = 0.0f;
 #endif
     if (prefilter) {
-        float best32 = 0.0f;
         TPS_PHASE {
-            // all of the lane's values are requested before the first one is used
-            TPS_UNROLL
-            for (int i = 0; i < LCV; ++i) {
-                const int c = c_min + tid + i * NT;
-                lcv[i] = c <= c_max ? g16_load(lc_g, (uint32_t)c) : 0u;
-            }
-            best32 = 0.0f;
-            TPS_UNROLL
-            for (int i = 0; i < LCV; ++i) {
-                const int c = c_min + tid + i * NT;
-                sc[i] = -1.0f;
-                if (i >= nslot) continue;            // uniform: no lane has a candidate in this slot
-                if (c <= c_max) {
-                    const uint32_t lc = tile_sum(c) + lcv[i];
-                    lcv[i] = lc;
+            p_s1 = -1.0f; p_s2 = -1.0f; p_lc = 0; p_c = -1;
+            // four slots at a time behind ONE uniform test (nslot lives in an SGPR): slots no lane uses cost nothing;
+            // the four loads of a group are requested before the first one is used
+            auto group = [&](int g) {
+                uint32_t lcv[4];
+                TPS_UNROLL
+                for (int i = 0; i < 4; ++i) {
+                    const int c = c_min + tid + (4 * g + i) * NT;
+                    lcv[i] = c <= c_max ? g32_load(lc_g, (uint32_t)c) : 0u;
+                }
+                TPS_UNROLL
+                for (int i = 0; i < 4; ++i) {
+                    const int c = c_min + tid + (4 * g + i) * NT;
                     const int b = c * jump;
                     const double bf = (double)b;
-                    const float d32 = (float)__builtin_fma(-totf, bf, nf * (double)lc);
+                    const float d32 = (float)__builtin_fma(-totf, bf, nf * (double)lcv[i]);
                     const float den32 = (float)b * (float)(n - b);
 #ifdef TPS_EMU
-                    sc[i] = d32 * d32 * (1.0f / den32);
+                    float s_ = d32 * d32 * (1.0f / den32);
 #else
-                    sc[i] = d32 * d32 * __builtin_amdgcn_rcpf(den32);
+                    float s_ = d32 * d32 * __builtin_amdgcn_rcpf(den32);
 #endif
-                    best32 = sc[i] > best32 ? sc[i] : best32;
+                    s_ = c <= c_max ? s_ : -1.0f;
+                    const bool gt = s_ > p_s1;                    // (an exact tie becomes the runner-up: conservative)
+                    const float lose = gt ? p_s1 : s_;
+                    p_s2 = lose > p_s2 ? lose : p_s2;
+                    p_lc = gt ? lcv[i] : p_lc;
+                    p_c = gt ? c : p_c;
+                    p_s1 = gt ? s_ : p_s1;
                 }
-            }
+            };
+            if (nslot > 0) group(0);
+            if (nslot > 4) group(1);
+            if (nslot > 8) group(2);
+            if (nslot > 12) group(3);
 #ifdef TPS_EMU
-            for (int i = 0; i < LCV; ++i) { lcv_keep[tid][i] = lcv[i]; sc_keep[tid][i] = sc[i]; }
-            emu_m32 = best32 > emu_m32 ? best32 : emu_m32;
+            ps1_keep[tid] = p_s1; ps2_keep[tid] = p_s2; plc_keep[tid] = p_lc; pc_keep[tid] = p_c;
+            emu_m32 = p_s1 > emu_m32 ? p_s1 : emu_m32;
 #endif
         }
         float m32;
@@ -2338,13 +2352,19 @@ TPS_DEV void binseg_from_lc(const ScanArgs& a, const Lds& l, uint64_t lc_g, cons
         m32 = emu_m32;
 #else
         {
+            const float nn = p_s1 > 0.0f ? p_s1 : 0.0f;
             uint32_t mb;
-            __builtin_memcpy(&mb, &best32, 4);       // non-negative floats order like integers
+            __builtin_memcpy(&mb, &nn, 4);          // non-negative floats order like integers
             mb = wave_max_u32(mb);
             __builtin_memcpy(&m32, &mb, 4);
         }
 #endif
         thr32 = m32 * (1.0f - 1e-4f);
+#ifdef TPS_EMU
+        for (int t = 0; t < NT; ++t) crowded = crowded || (ps2_keep[t] >= thr32 && ps2_keep[t] >= 0.0f);
+#else
+        crowded = __builtin_amdgcn_ballot_w64(p_s2 >= thr32 && p_s2 >= 0.0f) != 0;
+#endif
     }
     TPS_PHASE {
         double bn = -1.0, bd = 1.0;
@@ -2366,16 +2386,12 @@ TPS_DEV void binseg_from_lc(const ScanArgs& a, const Lds& l, uint64_t lc_g, cons
         };
         if (prefilter) {
 #ifdef TPS_EMU
-            for (int i = 0; i < LCV; ++i) { lcv[i] = lcv_keep[tid][i]; sc[i] = sc_keep[tid][i]; }
+            p_s1 = ps1_keep[tid]; p_lc = plc_keep[tid]; p_c = pc_keep[tid];
 #endif
-            TPS_UNROLL
-            for (int i = 0; i < LCV; ++i) {
-                const int c = c_min + tid + i * NT;
-                if (i >= nslot) continue;            // uniform
-                if (c <= c_max && sc[i] >= thr32) offer(c, lcv[i]);
-            }
+            if (p_c >= 0 && p_s1 >= thr32) offer(p_c, p_lc);
         } else if (a.lc16 && lc_g && c_max - c_min < LCV * NT) {
             // off-chip 16-bit sums: all of the lane's values are requested before the first one is used
+            uint32_t lcv[LCV];
             TPS_UNROLL
             for (int i = 0; i < LCV; ++i) {
                 const int c = c_min + tid + i * NT;
@@ -2428,7 +2444,11 @@ TPS_DEV void binseg_from_lc(const ScanArgs& a, const Lds& l, uint64_t lc_g, cons
     }
 #endif
     (void)misc;
+    if (crowded) ntie = 2u;                        // the prefilter kept one candidate per lane: a second one that close needs the full comparison
     if (ntie > 1u) {                               // float noise cannot separate them: exact integers decide
+#ifdef TPS_EMU
+        ++emu_counter(4);
+#endif
         Cand ex = binseg_exact_wg(S_global, n, jump, min_size, xs);
         bkp = ex.b;
         gain = ex.b < 0 ? 0.0 : gain_from((int64_t)ex.d, ex.den, n, n_patterns);

@@ -178,10 +178,13 @@ inline std::string plan_geometry(ScanArgs& a, const tps_params& prm, int k, int 
         a.tw = (int)NT * 8 - a.q - 1;
         a.tw_magic = (uint32_t)(((1ull << 32) + (uint64_t)a.tw - 1) / (uint64_t)a.tw);
         a.tile_cap = (int)((max_nwin + a.tw - 1) / a.tw) + 1;
-        a.lc16 = (a.pat.dup_mask == 0 && (int64_t)a.tw * (a.lw + P) < 65536) ? 1 : 0;
-        // the 16-bit sums go off-chip (L2-resident scratch, 2 bytes per candidate): LDS per wave drops by ~1 kB
-        a.lc_global = (a.lc16 && !getenv("TPS_LC_IN_LDS")) ? 1 : 0;
-        a.lc_stride = (a.lc_cap + 1) & ~1;
+        // The candidates' left sums live off-chip (L2-resident scratch, written once and read once by the same wave) as
+        // absolute 32-bit sums: 4 bytes per candidate instead of the 2 of the tile-relative 16-bit form, but the
+        // change-point step then needs no per-candidate tile lookup (mul, mulhi, LDS read, add) and no Tc array in LDS.
+        // TPS_LC16 / TPS_LC_IN_LDS select the older layouts (experiments).
+        a.lc16 = (getenv("TPS_LC16") || getenv("TPS_LC_IN_LDS")) && a.pat.dup_mask == 0 && (int64_t)a.tw * (a.lw + P) < 65536 ? 1 : 0;
+        a.lc_global = getenv("TPS_LC_IN_LDS") ? 0 : 1;
+        a.lc_stride = a.lc16 ? ((a.lc_cap + 1) & ~1) : 2 * ((a.lc_cap + 1) & ~1);        // in 16-bit units
         // pair table (two positions per lookup) while it is small: k <= 4 -> at most 4 KB per workgroup
         a.pair_n = (a.pat.so_mask == 0 && k <= 4 && !(prm.flags & TPS_F_STORE_RAW) && !getenv("TPS_NO_PAIR")) ? (1 << (2 * (k + 1))) : 0;   // (the raw-count kernels use single lookups)
         a.blk_dw = (int32_t)blk_region_dw(a);
