@@ -89,13 +89,21 @@ extern "C" int emu_scan(const char* pats, int P, int k, const uint8_t* bases, co
     for (int64_t r = 0; r < n; ++r) {
         for (auto& w : lds) w = 0xDEADBEEFu;          // LDS content is undefined at workgroup start
         const bool so = a.pat.so_mask != 0;
+        const bool want_raw = a.raw != nullptr;
+        // the library's kernel families: plain, pair table, raw rows, self-overlap sums, self-overlap raw
+#define EMU_CASE(S)                                                                                              \
+        case S:                                                                                                  \
+            if (so && want_raw) tps::scan_read<S, true, false, true>(a, r, lds.data(), lut1);                    \
+            else if (so) tps::scan_read<S, true, false, false>(a, r, lds.data(), lut1);                          \
+            else if (want_raw) tps::scan_read<S, false, false, true>(a, r, lds.data(), lut1);                    \
+            else if (a.pair_n) tps::scan_read<S, false, true, false>(a, r, lds.data(), lut1);                    \
+            else tps::scan_read<S, false, false, false>(a, r, lds.data(), lut1);                                 \
+            break;
         switch (a.variant) {
-            case 5: so ? tps::scan_read<5, true>(a, r, lds.data(), lut1) : a.pair_n ? tps::scan_read<5, false, true>(a, r, lds.data(), lut1) : tps::scan_read<5, false>(a, r, lds.data(), lut1); break;
-            case 6: so ? tps::scan_read<6, true>(a, r, lds.data(), lut1) : a.pair_n ? tps::scan_read<6, false, true>(a, r, lds.data(), lut1) : tps::scan_read<6, false>(a, r, lds.data(), lut1); break;
-            case 7: so ? tps::scan_read<7, true>(a, r, lds.data(), lut1) : a.pair_n ? tps::scan_read<7, false, true>(a, r, lds.data(), lut1) : tps::scan_read<7, false>(a, r, lds.data(), lut1); break;
-            case 8: so ? tps::scan_read<8, true>(a, r, lds.data(), lut1) : a.pair_n ? tps::scan_read<8, false, true>(a, r, lds.data(), lut1) : tps::scan_read<8, false>(a, r, lds.data(), lut1); break;
+            EMU_CASE(5) EMU_CASE(6) EMU_CASE(7) EMU_CASE(8)
             default: tps::scan_read<0, false>(a, r, lds.data(), lut1); break;
         }
+#undef EMU_CASE
     }
     return TPS_OK;
 }

@@ -371,7 +371,7 @@ def _pp_reads(rng, motif, k, n, L, chain_units):
     ("AAACCCT", 5, 7, []),
 ])
 def test_emulation_per_pattern_tiles(motif, k, slide, units):
-    """tile_pp_s: exact per-pattern counts without recounting (canonical picks + start skips), raw and sums-only,
+    """tile_pp_s (raw rows) and tile_so_s (sums only): exact counts without recounting (canonical picks + start skips),
     both tails, several tiles per read, reads with and without non-ACGT letters."""
     rng = np.random.default_rng(sum(map(ord, motif)) * 1000 + 10 * k + slide)
     pats, seqs = _pp_reads(rng, motif, k, 4, 9000, units)
@@ -384,10 +384,11 @@ def test_emulation_per_pattern_tiles(motif, k, slide, units):
             continue
         flags = hiplib.F_WINDOWS | hiplib.F_BINSEG | hiplib.F_TAILS_IN | hiplib.F_STORE_SUMS | (hiplib.F_STORE_RAW if raw else 0)
         prm = hiplib.make_params(window=100, slide=slide, trimfirst=100, maxlen=20000, flags=flags)
-        t0, r0 = L.emu_counter(0), L.emu_counter(1)
+        which = 0 if raw else 5          # raw rows: per-pattern tiles (tile_pp_s); sums only, self-overlap table: tile_so_s
+        t0, r0 = L.emu_counter(which), L.emu_counter(1)
         out = emu.scan(pats, seqs, prm, tails=tails, base_shift=int(rng.integers(16)))
-        tiles, redone = L.emu_counter(0) - t0, L.emu_counter(1) - r0
-        assert tiles >= 8, "per-pattern tiles were not used"
+        tiles, redone = L.emu_counter(which) - t0, L.emu_counter(1) - r0
+        assert tiles >= 8, "the canonical-pick tiles were not used"
         nwin_total = 0
         for i, seq in enumerate(seqs):
             _, counts = orc.window_count_matrix(seq, ["forward", "reverse"][tails[i]], pats, 100, slide, 100, 20000)

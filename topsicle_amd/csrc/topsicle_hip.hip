@@ -46,6 +46,9 @@
         const int64_t r = (int64_t)blockIdx.x * tps::WPG + wave;                                           \
         if (r < a.n_reads) tps::scan_read<SV, SO, PAIR, RAW, FULL>(a, r, slice, lut);                           \
     }
+#ifndef TPS_SO_MINW
+#define TPS_SO_MINW 4     // waves per SIMD the sums-only self-overlap kernels are compiled for (tile_so_s wants ~128 VGPRs: 5 would spill ~120)
+#endif
 #define TPS_SCAN_KERNEL(NAME, SV, SO, PAIR, RAW, MINW) TPS_SCAN_KERNEL_F(NAME, SV, SO, PAIR, RAW, MINW, tps::tile_full_default(SV))
 TPS_SCAN_KERNEL(tps_scan_kernel, 0, false, false, true, 4)          // generic: any slide, up to 31 patterns
 TPS_SCAN_KERNEL(tps_scan_kernel_s5, 5, false, false, false, 5)       // specialised: compile-time slide, <= 15 patterns
@@ -60,10 +63,14 @@ TPS_SCAN_KERNEL(tps_scan_kernel_s5r, 5, false, false, true, 3)       // ... with
 TPS_SCAN_KERNEL(tps_scan_kernel_s6r, 6, false, false, true, 3)
 TPS_SCAN_KERNEL(tps_scan_kernel_s7r, 7, false, false, true, 3)
 TPS_SCAN_KERNEL(tps_scan_kernel_s8r, 8, false, false, true, 3)
-TPS_SCAN_KERNEL(tps_scan_kernel_s5so, 5, true, false, true, 5)       // ... with self-overlapping k-mers in the table
-TPS_SCAN_KERNEL(tps_scan_kernel_s6so, 6, true, false, true, 5)
-TPS_SCAN_KERNEL(tps_scan_kernel_s7so, 7, true, false, true, 5)
-TPS_SCAN_KERNEL(tps_scan_kernel_s8so, 8, true, false, true, 5)
+TPS_SCAN_KERNEL(tps_scan_kernel_s5so, 5, true, false, false, TPS_SO_MINW)      // ... self-overlapping k-mers in the table, sums only (tile_so_s)
+TPS_SCAN_KERNEL(tps_scan_kernel_s6so, 6, true, false, false, TPS_SO_MINW)
+TPS_SCAN_KERNEL(tps_scan_kernel_s7so, 7, true, false, false, TPS_SO_MINW)
+TPS_SCAN_KERNEL(tps_scan_kernel_s8so, 8, true, false, false, TPS_SO_MINW)
+TPS_SCAN_KERNEL(tps_scan_kernel_s5sor, 5, true, false, true, 5)      // ... the same with the per-pattern raw counts (tile_pp_s)
+TPS_SCAN_KERNEL(tps_scan_kernel_s6sor, 6, true, false, true, 5)
+TPS_SCAN_KERNEL(tps_scan_kernel_s7sor, 7, true, false, true, 5)
+TPS_SCAN_KERNEL(tps_scan_kernel_s8sor, 8, true, false, true, 5)
 
 extern "C" __global__ void __launch_bounds__(tps::NT * tps::WPG) tps_binseg_kernel(tps::BinsegArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t smem[tps::WPG * tps::BINSEG_SMEM_DW];
@@ -220,7 +227,7 @@ struct tps_ctx {
     int zero_copy = 1;       // per-read results are written by the kernel straight into mapped pinned host memory
     int force_generic = 0;
     int64_t lds_target_dw = 32 * 256;
-    size_t lds_set_v[17] = {0};
+    size_t lds_set_v[21] = {0};
 };
 
 namespace {
@@ -422,20 +429,32 @@ int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm) {
     int kidx;
     const bool so = a.pat.so_mask != 0;
     const bool pair = a.pair_n != 0;
-    const bool rawk = !so && a.raw != nullptr;           // the raw-count variants (single lookups; the plan drops the pair table)
-    switch (a.variant) {
-        case 5: kfn = so ? (const void*)tps_scan_kernel_s5so : rawk ? (const void*)tps_scan_kernel_s5r : pair ? (const void*)tps_scan_kernel_s5p : (const void*)tps_scan_kernel_s5; kidx = so ? 5 : rawk ? 13 : pair ? 9 : 1; break;
-        case 6: kfn = so ? (const void*)tps_scan_kernel_s6so : rawk ? (const void*)tps_scan_kernel_s6r : pair ? (const void*)tps_scan_kernel_s6p : (const void*)tps_scan_kernel_s6; kidx = so ? 6 : rawk ? 14 : pair ? 10 : 2; break;
-        case 7: kfn = so ? (const void*)tps_scan_kernel_s7so : rawk ? (const void*)tps_scan_kernel_s7r : pair ? (const void*)tps_scan_kernel_s7p : (const void*)tps_scan_kernel_s7; kidx = so ? 7 : rawk ? 15 : pair ? 11 : 3; break;
-        case 8: kfn = so ? (const void*)tps_scan_kernel_s8so : rawk ? (const void*)tps_scan_kernel_s8r : pair ? (const void*)tps_scan_kernel_s8p : (const void*)tps_scan_kernel_s8; kidx = so ? 8 : rawk ? 16 : pair ? 12 : 4; break;
-        default: kfn = (const void*)tps_scan_kernel; kidx = 0; break;
-    }
+    const bool want_raw = a.raw != nullptr;
     {
-        static const char* const names[17] = {"tps_scan_kernel", "tps_scan_kernel_s5", "tps_scan_kernel_s6", "tps_scan_kernel_s7",
-                                              "tps_scan_kernel_s8", "tps_scan_kernel_s5so", "tps_scan_kernel_s6so", "tps_scan_kernel_s7so",
-                                              "tps_scan_kernel_s8so", "tps_scan_kernel_s5p", "tps_scan_kernel_s6p", "tps_scan_kernel_s7p",
-                                              "tps_scan_kernel_s8p", "tps_scan_kernel_s5r", "tps_scan_kernel_s6r", "tps_scan_kernel_s7r", "tps_scan_kernel_s8r"};
-        sl.kernel_name = names[kidx];
+        // kernel family by table and outputs: [slide 5..8] x {plain, pair table, raw rows, self-overlap sums, self-overlap raw}
+        struct K { const void* fn; const char* name; };
+        static const K plain[4] = {{(const void*)tps_scan_kernel_s5, "tps_scan_kernel_s5"}, {(const void*)tps_scan_kernel_s6, "tps_scan_kernel_s6"},
+                                   {(const void*)tps_scan_kernel_s7, "tps_scan_kernel_s7"}, {(const void*)tps_scan_kernel_s8, "tps_scan_kernel_s8"}};
+        static const K pairk[4] = {{(const void*)tps_scan_kernel_s5p, "tps_scan_kernel_s5p"}, {(const void*)tps_scan_kernel_s6p, "tps_scan_kernel_s6p"},
+                                   {(const void*)tps_scan_kernel_s7p, "tps_scan_kernel_s7p"}, {(const void*)tps_scan_kernel_s8p, "tps_scan_kernel_s8p"}};
+        static const K rawk[4] = {{(const void*)tps_scan_kernel_s5r, "tps_scan_kernel_s5r"}, {(const void*)tps_scan_kernel_s6r, "tps_scan_kernel_s6r"},
+                                  {(const void*)tps_scan_kernel_s7r, "tps_scan_kernel_s7r"}, {(const void*)tps_scan_kernel_s8r, "tps_scan_kernel_s8r"}};
+        static const K sok[4] = {{(const void*)tps_scan_kernel_s5so, "tps_scan_kernel_s5so"}, {(const void*)tps_scan_kernel_s6so, "tps_scan_kernel_s6so"},
+                                 {(const void*)tps_scan_kernel_s7so, "tps_scan_kernel_s7so"}, {(const void*)tps_scan_kernel_s8so, "tps_scan_kernel_s8so"}};
+        static const K sork[4] = {{(const void*)tps_scan_kernel_s5sor, "tps_scan_kernel_s5sor"}, {(const void*)tps_scan_kernel_s6sor, "tps_scan_kernel_s6sor"},
+                                  {(const void*)tps_scan_kernel_s7sor, "tps_scan_kernel_s7sor"}, {(const void*)tps_scan_kernel_s8sor, "tps_scan_kernel_s8sor"}};
+        if (a.variant >= 5 && a.variant <= 8) {
+            const int fam = so ? (want_raw ? 4 : 3) : want_raw ? 2 : pair ? 1 : 0;
+            const K* tab[5] = {plain, pairk, rawk, sok, sork};
+            const K& k = tab[fam][a.variant - 5];
+            kfn = k.fn;
+            sl.kernel_name = k.name;
+            kidx = 1 + fam * 4 + (a.variant - 5);
+        } else {
+            kfn = (const void*)tps_scan_kernel;
+            sl.kernel_name = "tps_scan_kernel";
+            kidx = 0;
+        }
     }
     if (sl.lds_bytes > c->lds_set_v[kidx]) {
         HIP_TRY(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sl.lds_bytes));

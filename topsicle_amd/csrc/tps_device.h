@@ -2052,6 +2052,304 @@ TPS_DEV void tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
     tile_candidates(tc, l, w0, tile, nw_tile, s_total);
 }
 
+// ------------------------------------------------------------------ step 2, self-overlap tables, sums only
+// S_w alone (no raw rows) for a table whose k-mers have ONE self-overlap period D (2 D >= k), without the per-pattern
+// fields of tile_pp_s: the CANONICAL PICKS of tile_pp_s (pick(p) = occ(p) & ~pick(p - D), greedy from the head of every
+// chain of overlapping occurrences) computed on the table's one-bit-per-pattern masks, inside the published words of
+// tile_fused_s.  Per position: one lookup, t = h & pick[p - D] (the canonically skipped occurrence), pick = h ^ t,
+// count += popcount(pick), presence |= h.  A window's count is then the prefix-count difference of tile_fused_s, plus its
+// START SKIPS (occurrences in its first D positions that are skipped only because of a pick before the window: their
+// number is folded into the count a block publishes for windows that start there), and only a window whose start skip
+// heads a chain that goes on (>= 3 chained occurrences) is repaired afterwards by walking that chain (as in tile_pp_s).
+//   phase 1  (lane-contiguous) look-back over the previous lane's last 16 positions, picks of the lane's 8 blocks; per
+//            block XS = suffix-OR | count before the block - start skips, XPC = prefix-OR | count r positions in
+//   phase 1b / 2  exactly tile_fused_s: lane-strided windows from three LDS reads, S_w to HBM and row[]
+//   repairs  (lane-contiguous: lane L owns windows 8 L .. 8 L + 7) chain-parity walks, exact recount where a lane's
+//            incoming state is unknown
+//   phase 3  tile_candidates
+template <int S, int D>
+TPS_DEV void tile_so_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int delta, int w0, int tile, int nw_tile,
+                       int64_t out_base, uint64_t& s_total) {
+    // look-back over the previous lane's last LBK positions: enough for a chain that starts inside it (two links); a chain
+    // through the whole look-back takes the walk below
+    constexpr int B = 8, LOG2B = 3, POS = B * S, LBK = 2 * D + 2;
+    constexpr int WDW = (1 + LBK + POS + 6 + 7 + 15) / 16;
+    constexpr int RS = NT + NT / B;
+    constexpr int AHEAD = (2 * D > S) ? 2 * D - S : 0;
+    constexpr uint32_t MH = 0xFFFF0000u;              // the mask half of a table entry (mask << 16 | 1)
+    static_assert(D >= 2 && D <= 6, "one self-overlap period, 2 .. 6 (2 D >= k >= 4)");
+    const PatInfo& pat = a.pat;
+    int rp = tc.r, q = tc.q;
+    TPS_PIN_S(rp); TPS_PIN_S(q);
+    const uint32_t amask = pat.kmask << 2;
+    uint32_t* carry = l.misc + M_SCAN;            // [0, 6): picks (mask half) of the D positions before the next tile's first; [6]: uncertain
+    const int cblk = a.tw & (B - 1), clane = a.tw >> 3;
+    uint32_t cold[7];
+    TPS_UNROLL
+    for (int i = 0; i < 7; ++i) cold[i] = uniform(carry[i]);
+    auto picked_before_tile = [&](int pos, int pidx) -> bool {
+        uint32_t cv = 0;
+        TPS_UNROLL
+        for (int i = 0; i < D; ++i) cv = (pos - (delta - D) == i) ? cold[i] : cv;
+        return w0 != 0 && ((cv >> (16 + pidx)) & 1u) != 0;
+    };
+#ifdef TPS_EMU
+    uint32_t keep[NT][3];
+#endif
+    uint32_t chm = 0, chw = 0, unc = 0;
+    TPS_PHASE {
+        const int span = tid;
+        const int p0 = delta + span * POS;
+        const uint32_t sh2 = (uint32_t)((p0 - 1 - LBK) & 15) * 2u;
+        // the lane's registers start LBK positions before its first one (p0 >= 64: fused tiles are staged behind SEQ_LEAD words)
+        const int d0 = (p0 - 1 - LBK) >> 4;
+        uint32_t w[WDW];
+        {
+            uint32_t prev = l.seq2[d0];
+            TPS_UNROLL
+            for (int i = 0; i < WDW; ++i) {
+                uint32_t nx = l.seq2[d0 + i + 1];
+                w[i] = alignbit(nx, prev, sh2);
+                prev = nx;
+            }
+        }
+        auto look = [&](int p) -> uint32_t {          // table entry of the k-mer at position p (relative to the lane's first, -LBK <= p)
+            const int idx = p + LBK, dw = idx >> 4, bit = idx & 15;
+            const uint32_t v4 = bit ? alignbit(dw + 1 < WDW ? w[dw + 1] : 0u, w[dw], 2u * bit) : w[dw];
+            return lut_at(l.lut, v4, amask);
+        };
+        uint32_t pk[LBK + POS + AHEAD + 1];           // picks (mask half only), index p + LBK
+        uint32_t tv[POS + 1];                         // canonically skipped occurrences
+        {
+            uint32_t ca[LBK];
+            TPS_UNROLL
+            for (int i = 0; i < LBK; ++i) {
+                const uint32_t h = look(i - LBK);
+                if (i >= D) {
+                    pk[i] = (h ^ (h & pk[i - D])) & MH;
+                    ca[i] = h & ca[i - D];
+                } else {
+                    pk[i] = h & MH;
+                    ca[i] = h & MH;
+                }
+            }
+            TPS_UNROLL
+            for (int i = LBK - D; i < LBK; ++i) unc |= ca[i];
+            if (unc && span > 0) {
+                // one pattern chains through the whole look-back: walk the chain further back (rare)
+                unc = 0;
+                TPS_UNROLL
+                for (int i = LBK - D; i < LBK; ++i) {
+                    if (ca[i]) {
+                        const int pidx = ffs0(ca[i]) - 16;
+                        int n = 0, pw = p0 - LBK + (i % D) - D;
+                        while (pw >= delta && ((lut_mask(l.lut, l.lshift, pat, v_at(l.seq2, pw)) >> pidx) & 1u)) { ++n; pw -= D; }
+                        const bool blocked = pw < delta && picked_before_tile(pw, pidx);
+                        if (pw < delta && w0 != 0 && cold[6]) unc |= ca[i];
+                        else if (((n & 1) != 0) != blocked) pk[i] ^= ca[i];
+                    }
+                }
+            }
+            if (span == 0) {
+                TPS_UNROLL
+                for (int i = 0; i < D; ++i) pk[LBK - D + i] = cold[i];
+                unc = cold[6];
+            }
+        }
+        uint32_t cnt = 0, run_or = 0;
+        uint32_t gs[B], c0s[B], ch3[B];
+        uint32_t* xs = l.row + span * (B + 1);
+        uint32_t* xpc = l.XPC + span * (B + 1);
+        TPS_UNROLL
+        for (int blk = 0; blk < B; ++blk) ch3[blk] = 0;
+        TPS_UNROLL
+        for (int blk = 0; blk < B; ++blk) {
+            if (blk == cblk && span == clane) {       // this block is the next tile's first
+                TPS_UNROLL
+                for (int i = 0; i < D; ++i) carry[i] = pk[LBK + blk * S - D + i];
+                carry[6] = unc;
+            }
+            uint32_t g = 0, sfw = 0;
+            uint32_t c1 = cnt, pp_ = run_or;
+            const uint32_t c0 = cnt;
+            TPS_UNROLL
+            for (int i = 0; i < S; ++i) {
+                const int p = blk * S + i;
+                const uint32_t h = look(p);
+                const uint32_t t = h & pk[LBK + p - D];           // (pk holds mask bits only, so does t)
+                if (i < D) sfw |= t;
+                const int pm = p - D;
+                if (pm >= 0 && pm % S < D) ch3[pm / S] |= h & tv[pm];
+                tv[p] = t;
+                const uint32_t pick = (h ^ t) & MH;
+                pk[LBK + p] = pick;
+                cnt += (uint32_t)popc(pick);
+                g |= h;
+                if (i + 1 == rp) { c1 = cnt; pp_ = run_or | g; }
+            }
+            xpc[blk] = pack_hi_lo(pp_, c1);
+            gs[blk] = g;
+            run_or |= g;
+            c0s[blk] = c0 - (uint32_t)popc(sfw);      // windows that start here also pick their start skips
+            if (blk > 0) {
+                chm |= ch3[blk - 1] ? (1u << (blk - 1)) : 0u;
+                chw |= ch3[blk - 1];
+                TPS_PIN_V(chm); TPS_PIN_V(chw);
+            }
+        }
+        TPS_UNROLL
+        for (int i = 0; i < AHEAD; ++i) {
+            const int p = POS + i, pm = p - D;
+            if (pm % S < D) ch3[pm / S] |= look(p) & tv[pm];
+        }
+        chm |= ch3[B - 1] ? (1u << (B - 1)) : 0u;
+        chw |= ch3[B - 1];
+        uint32_t sfx = 0;
+        TPS_UNROLL
+        for (int j = B - 1; j >= 0; --j) {
+            sfx |= gs[j];
+            xs[j] = pack_hi_lo(sfx, c0s[j]);
+        }
+        l.XF[span] = pack_hi_lo(sfx, cnt);
+        TPS_PIN_V(chm); TPS_PIN_V(chw); TPS_PIN_V(unc);
+#ifdef TPS_EMU
+        keep[tid][0] = chm; keep[tid][1] = chw; keep[tid][2] = unc;
+        chm = 0; chw = 0; unc = 0;
+        ++emu_counter(5);
+#endif
+    }
+    TPS_SYNC();
+    uint64_t unc_mask = 0;
+#ifdef TPS_EMU
+    for (int t = 0; t < NT; ++t) unc_mask |= (uint64_t)(keep[t][2] != 0) << t;
+    emu_counter(2) += __builtin_popcountll(unc_mask);
+#else
+    unc_mask = __builtin_amdgcn_ballot_w64(unc != 0);
+#endif
+    const int rot = q & (B - 1), dl0 = q >> LOG2B;
+    uint32_t fo_a = 0, fo_b = 0;
+#ifdef TPS_EMU
+    uint32_t fo_keep[NT][2];
+#endif
+    TPS_PHASE {
+        uint32_t orw = 0, sumw = l.XF[tid];
+        TPS_NOVEC
+        for (int t = 1; t < dl0; ++t) {
+            const uint32_t v = l.XF[tid + t];
+            orw |= v;
+            sumw += v;
+        }
+        const uint32_t vb = l.XF[tid + dl0];
+        fo_a = pack_hi_lo(orw, sumw);
+        fo_b = pack_hi_lo(orw | vb, sumw + vb);
+#ifdef TPS_EMU
+        fo_keep[tid][0] = fo_a; fo_keep[tid][1] = fo_b;
+#endif
+    }
+    TPS_SYNC();
+    TPS_PHASE {
+#ifdef TPS_EMU
+        fo_a = fo_keep[tid][0]; fo_b = fo_keep[tid][1];
+#endif
+        l.XF[tid] = fo_a;
+        l.XT[tid] = fo_b;
+    }
+    TPS_SYNC();
+    TPS_PHASE {
+        const uint32_t lane = (uint32_t)tid;
+        const bool farl = (((lane & (B - 1)) + (uint32_t)rot) >> LOG2B) != 0;
+        uint32_t* ps = l.row + (lane + (lane >> LOG2B));
+        const uint32_t* pe = l.XPC + ((lane + (uint32_t)q) + ((lane + (uint32_t)q) >> LOG2B));
+        const uint32_t* pf = (farl ? l.XT : l.XF) + (lane >> LOG2B);
+        int32_t* outl = a.sums + (out_base + w0) + lane;
+        const uint32_t am = pat.all_mask << 16;
+        const int nfull = nw_tile >> 6;
+        const uint32_t npart = (uint32_t)(nw_tile & 63);
+        uint32_t xv[B], ev[B], fv[B];
+        TPS_UNROLL
+        for (int u = 0; u < B; ++u) { xv[u] = ps[u * RS]; ev[u] = pe[u * RS]; fv[u] = pf[u * (NT / B)]; }
+        TPS_UNROLL
+        for (int u = 0; u < B; ++u) {
+            uint32_t sw = 0;
+            if (u <= nfull) {
+                const bool valid = (u < nfull) || (lane < npart);
+                const uint32_t x = xv[u], e = ev[u], f = fv[u];
+                const uint32_t m = x | e | f;
+                const uint32_t s_ = ((e - x + f) & 0xFFFFu) + (uint32_t)popc(~m & am);
+                if (valid) {
+                    sw = s_;
+                    outl[u * NT] = (int32_t)sw;
+                }
+            }
+            ps[u * RS] = sw;
+        }
+    }
+    TPS_SYNC();
+    // Repairs (rare, lane-divergent): S_w is in row[] and in HBM by now.  Lane L owns windows 8 L .. 8 L + 7, the ones that
+    // start at its own blocks.
+#ifndef TPS_EMU
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+#endif
+    TPS_PHASE {
+#ifdef TPS_EMU
+        chm = keep[tid][0]; chw = keep[tid][1];
+#endif
+        const int lane = tid;
+        const bool redo_all = ((unc_mask >> lane) & ((2ull << (dl0 + 1)) - 1ull)) != 0;
+        uint32_t todo = redo_all ? 0xFFu : (chm << 8);
+        while (todo) {
+            const int bit = ffs0(todo);
+            todo &= todo - 1u;
+            const int j = bit & 7, wl = lane * B + j;
+            if (wl >= nw_tile) continue;
+            uint32_t sw = l.row[lane * (B + 1) + j];
+            if (bit < 8) {
+#ifdef TPS_EMU
+                ++emu_counter(1);
+#endif
+                sw = window_exact(a, l, delta, wl, pat.all_mask, 0u, nullptr, true);
+            } else {
+#ifdef TPS_EMU
+                ++emu_counter(3);
+#endif
+                // the window starts on a canonically skipped occurrence x whose chain goes on: it picks x, x + 2 D, ... = one
+                // more than canonical iff the chain has an odd number of elements from x; the start skip was added -- take
+                // it back for an even count
+                const int a0 = delta + wl * S;
+                uint32_t fw = chw;
+                bool lost = false;
+                while (fw) {
+                    const int pidx = ffs0(fw) - 16;
+                    fw &= fw - 1u;
+                    int x = -1;
+                    TPS_NOVEC
+                    for (int i = 0; i < D; ++i)
+                        if ((lut_mask(l.lut, l.lshift, pat, v_at(l.seq2, a0 + i)) >> pidx) & 1u) x = a0 + i;
+                    if (x >= 0) {
+                        int n = 0, pb = x - D;
+                        while (pb >= delta && ((lut_mask(l.lut, l.lshift, pat, v_at(l.seq2, pb)) >> pidx) & 1u)) { ++n; pb -= D; }
+                        const bool blocked = pb < delta && picked_before_tile(pb, pidx);
+                        if (pb < delta && w0 != 0 && cold[6]) lost = true;
+                        int m = 1;
+                        for (int pw = x + D; pw < a0 + a.lw && ((lut_mask(l.lut, l.lshift, pat, v_at(l.seq2, pw)) >> pidx) & 1u); pw += D) ++m;
+                        if ((((n & 1) != 0) != blocked) && (m & 1) == 0) sw -= 1u;
+                    }
+                }
+                if (lost) {
+#ifdef TPS_EMU
+                    ++emu_counter(1);
+#endif
+                    sw = window_exact(a, l, delta, wl, pat.all_mask, 0u, nullptr, true);
+                }
+            }
+            l.row[lane * (B + 1) + j] = sw;
+            a.sums[out_base + w0 + wl] = (int32_t)sw;
+        }
+    }
+    TPS_SYNC();
+    tile_candidates(tc, l, w0, tile, nw_tile, s_total);
+}
+
 // ------------------------------------------------------------------ step 3: single-split Binseg (l2)
 // gain(b) = cost(0,n) - cost(0,b) - cost(b,n) = (n L_b - T b)^2 / (n b (n-b))   [y = S / P]
 // so the arg-max over b in {0, jump, 2 jump, ...}, b >= min_size, n-b >= min_size is that of
@@ -2721,6 +3019,24 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
                         continue;
                     }
                     if (pp && SO) {                    // a tile with non-ACGT letters takes the recount path: the next tile starts blind
+                        TPS_PHASE { if (tid == 0) l.misc[M_SCAN + 6] = 1u; }
+                        TPS_SYNC();
+                    }
+                }
+                if constexpr (SO && !RAW) {
+                    // sums only, a table with one self-overlap period: canonical picks on the mask words (tile_so_s)
+                    constexpr int SP = SV ? SV : 5;
+                    if (a.pp_d > 0 && uniform(l.misc[M_INVALID]) == 0) {
+                        switch (a.pp_d) {
+                            case 2: tile_so_s<SP, 2>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
+                            case 3: tile_so_s<SP, 3>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
+                            case 4: tile_so_s<SP, 4>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
+                            case 5: tile_so_s<SP, 5>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
+                            default: tile_so_s<SP, (SP < 6 ? SP : 6)>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
+                        }
+                        continue;
+                    }
+                    if (a.pp_d > 0) {                      // a tile with non-ACGT letters takes the recount path: the next tile starts blind
                         TPS_PHASE { if (tid == 0) l.misc[M_SCAN + 6] = 1u; }
                         TPS_SYNC();
                     }
