@@ -56,6 +56,10 @@ CONFIGS = {
                        desc="BASELINE configs[4] sample, k=5 pass: 10k synthetic ONT reads x 25 kb, --pattern CCCTAA"),
     "config5_k6": dict(n_reads=10000, read_len=25000, motif="CCCTAA", k=6, window=100, slide=6, errors=synth.ONT, seed=20250919 + 4,
                        desc="BASELINE configs[4] sample, k=6 pass: 10k synthetic ONT reads x 25 kb, --pattern CCCTAA"),
+    # all of BASELINE configs[4]'s k passes on one resident batch per step: upload once, three table scans with raw counts
+    "config5": dict(n_reads=10000, read_len=25000, motif="CCCTAA", k=4, ks=[4, 5, 6], raw=True, window=100, slide=6, errors=synth.ONT, seed=20250919 + 4,
+                    desc="BASELINE configs[4] sample: 10k synthetic ONT reads x 25 kb, --pattern CCCTAA --telophrase 4 5 6 --rawcountpattern "
+                         "(one step = the three k passes over one resident batch)"),
     "config3_per_gpu": dict(n_reads=25000, read_len=20000, motif="AAACCCT", k=5, window=100, slide=7,
                             errors=synth.HIFI, seed=20250919 + 2,
                             desc="BASELINE configs[2] shard: 25k synthetic HiFi reads x 20 kb per GPU, --pattern AAACCCT"),
@@ -202,7 +206,9 @@ def main():
         cfg["n_reads"] = args.n_reads
         cfg["desc"] += f" [diagnostic batch of {args.n_reads} reads]"
     motif, k = cfg["motif"], cfg["k"]
-    pats = kmer_table(motif, k)
+    ks = cfg.get("ks", [k])
+    tables = [kmer_table(motif, kk) for kk in ks]
+    pats = tables[0]
     P = len(pats)
     # every rank scans its own, differently seeded batch of the same shape (weak scaling)
     bases, offsets, truth = synth.make_reads(cfg["n_reads"], cfg["read_len"], motif, seed=cfg["seed"] + 1000 * rank,
@@ -214,6 +220,8 @@ def main():
                              flags=hiplib.F_STEP1 | hiplib.F_WINDOWS | hiplib.F_BINSEG |
                              (0 if args.no_store_sums else hiplib.F_STORE_SUMS))
 
+    if cfg.get("raw"):
+        prm.flags |= hiplib.F_STORE_RAW
     if args.flags:
         prm.flags = args.flags
     # kernel durations come from HIP events stamped by the dispatch itself; every 4th launch is timed (timing a
@@ -243,29 +251,47 @@ def main():
     # ... and enough further launches (~25 ms of GPU work) that the HIP runtime's one-off internal growth steps
     # (a ~6 ms hiccup observed once around the 20th-30th launch of a process) are over and the GPU has reached its
     # sustained clocks before the timed region: after only 64 launches a step measures 0.099 ms, after 256: 0.095 ms
-    for s in range(max(int(os.environ.get("TPS_BENCH_PRIME", "256")), 4 * copies)):
-        sc.scan(s % copies, prm)
+    def step(slot):
+        if len(tables) == 1:
+            sc.scan(slot, prm)
+        else:
+            for t in tables:                       # resident tables: switching is a pointer swap in the library
+                sc.set_patterns(t)
+                sc.scan(slot, prm)
+
+    for s in range(max(int(os.environ.get("TPS_BENCH_PRIME", "256")) // len(tables), 4 * copies)):
+        step(s % copies)
     sc.sync()
     for i in range(args.warmup):
-        sc.scan(i % copies, prm)
+        step(i % copies)
     barrier()
     sc.kernel_time_reset()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        sc.scan(i % copies, prm)
+        step(i % copies)
     sc.sync()                      # device idle: every step's kernel and result copy has finished
     dt_rank = time.perf_counter() - t0
     dt = grp.max(dt_rank)
     grp.barrier()
     per_rank = grp.gather_objects(dict(rank=rank, device=dev, ms_per_step=dt_rank / args.steps * 1e3))
     n_launch, k_total_ms, k_mean_ms = sc.kernel_time_ms()
-
-    res = sc.results((args.steps - 1) % copies)
-    kinfo = sc.kernel_info((args.steps - 1) % copies)
-    passed = res["pass"].astype(bool)
-    n_win = res["n_win"].astype(np.int64)
     lens = np.diff(offsets)
-    alg_total, alg1, alg2, alg3 = algorithmic_bytes(lens, passed, n_win, P, prm)
+    last = (args.steps - 1) % copies
+    alg_total = alg1 = alg2 = alg3 = 0
+    kinfos = []
+    for t in tables:                               # algorithmic bytes of every table pass of a step (one pass: the usual case)
+        if len(tables) > 1:
+            sc.set_patterns(t)
+            sc.scan(last, prm)
+            sc.sync()
+        res = sc.results(last)
+        passed = res["pass"].astype(bool)
+        n_win = res["n_win"].astype(np.int64)
+        a_t, a_1, a_2, a_3 = algorithmic_bytes(lens, passed, n_win, len(t), prm)
+        alg_total += a_t; alg1 += a_1; alg2 += a_2; alg3 += a_3
+        kinfos.append(sc.kernel_info(last))
+    kinfo = kinfos[0] if len(kinfos) == 1 else " | ".join(kinfos)
+    k_mean_ms *= len(tables)                       # per step: the table passes' kernels together
     scanned = int((2 * np.minimum(lens, prm.no_bp)).sum() + np.maximum(np.minimum(lens, prm.maxlen) - prm.trimfirst, 0)[passed].sum())
 
     if rank == 0:
@@ -293,7 +319,7 @@ def main():
                 "workload": cfg["desc"],
                 "reads_per_step_per_gpu": n_reads,
                 "read_len": cfg["read_len"],
-                "pattern": motif, "k": k, "n_patterns": P,
+                "pattern": motif, "k": k if len(ks) == 1 else ks, "n_patterns": P,
                 "window": cfg["window"], "slide": cfg["slide"], "trimfirst": 100, "maxlengthtelo": 20000, "cutoff": 0.7,
                 "resident_copies": copies,
                 "store_window_sums": not args.no_store_sums,

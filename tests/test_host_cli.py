@@ -196,3 +196,26 @@ def test_cli_processes_several_files_concurrently(tmp_path, gold_dir):
         assert mine == [w.split(",", 1)[1] for w in want], n    # same rows, same order within the file
         assert os.path.exists(out / f"{n}.fastq_trc_over_0.7.fastq")
     assert "processing 3 files, 3 at a time" in open(out / "topsicle_run.log").read()
+
+
+def test_cli_several_k_in_one_pass_equals_separate_runs(engine, demo_fastq, tmp_path):
+    """`--telophrase 4 5 6`: every batch is uploaded once and scanned once per k; telolengths_all.csv, the raw-count
+    files and the filtered fastq are what three separate single-k runs leave behind (rows of one k before the next,
+    main.py:206-235)."""
+    single_rows = []
+    for k in (4, 5, 6):
+        out = tmp_path / f"k{k}"
+        run_cli(engine, ["-i", demo_fastq, "-o", str(out), "--pattern", "CCCTAAA", "--slide", "6", "--telophrase", str(k), "--rawcountpattern"])
+        single_rows += open(out / "telolengths_all.csv").read().splitlines()[1:]
+    out = tmp_path / "all"
+    run_cli(engine, ["-i", demo_fastq, "-o", str(out), "--pattern", "CCCTAAA", "--slide", "6", "--telophrase", "4", "5", "6", "--rawcountpattern"])
+    got = open(out / "telolengths_all.csv").read().splitlines()
+    assert got[0] == "file_number,phrase,trc,readID,telo_length" and got[1:] == single_rows
+    for k in (4, 5, 6):
+        for f in sorted(os.listdir(tmp_path / f"k{k}")):
+            if f.startswith("rawcount_"):
+                assert open(tmp_path / f"k{k}" / f).read() == open(out / f).read(), f
+    last = [f for f in os.listdir(tmp_path / "k6") if "_trc_over_" in f][0]
+    assert open(tmp_path / "k6" / last).read() == open(out / last).read()
+    log = open(out / "topsicle_run.log").read()
+    assert all(f"k-mer: {k}, with TRC >= 0.7" in log for k in (4, 5, 6))

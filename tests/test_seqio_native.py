@@ -82,11 +82,20 @@ def test_native_plain_fastq_thread_team(tmp_path, monkeypatch, threads):
     got = all_records(str(q), max_bases=30000)
     exp = list(want[:50]) + [("w1", "w1", "ACGTACGT", "IIIIIIII"), ("w2", "w2 x", "AAAA", "IIII")] + list(want[50:60])
     assert [(r.id, r.description, r.seq, r.qual) for r in got] == exp
-    # (c) a record larger than the batch buffers grows them; leading blank lines are skipped
+    # (c) a record larger than the batch buffers grows them
     big = tmp_path / "big.fastq"
-    big.write_text("\n\n@big\n" + "ACGT" * 5000 + "\n+\n" + "I" * 20000 + "\n@s\nAC\n+\nII\n")
+    big.write_text("@big\n" + "ACGT" * 5000 + "\n+\n" + "I" * 20000 + "\n@s\nAC\n+\nII\n")
     got = all_records(str(big), max_bases=1000)
     assert [(r.id, len(r.seq)) for r in got] == [("big", 20000), ("s", 2)]
+    # (d) both readers agree on odd input: a file that starts with a blank line has no identifiable format
+    # (check_file_type, allsteps.py:36-50), and a quality string of the wrong length is an error, not a silent mis-framing
+    blank = tmp_path / "blank.fastq"
+    blank.write_text("\n@a\nACGT\n+\nIIII\n")
+    assert all_records(str(blank)) == [] and list(seqio.read_records(str(blank))) == []
+    short = tmp_path / "short.fastq"
+    short.write_text("@a\nACGT\n+\nIIII\n@b\nACGTA\n+\nIIII\n@c\nAC\n+\nII\n")
+    assert [r.id for r in all_records(str(short))] == ["a"]                 # the native reader stops at the bad record ...
+    assert [r.id for r in seqio.read_records(str(short))] == ["a"]          # ... and so does the Python parser (both log the error)
 
 
 def _write_bgzf(path, payload: bytes, block=60000, splits=None):

@@ -33,29 +33,52 @@ def record_batches(records, max_bases: int = BATCH_BASES, max_reads: int = BATCH
         yield cur
 
 
-def scan_records(engine, recs, prm: hiplib.Params, slot: int = 0, want_sums=False, want_raw=False):
-    """Fused scan of one batch: a seqio.PackedBatch (uploaded as it is), a seqio.RecordBatch or a list of records (ASCII
-    upload, packed on the device).  Returns (results, sums, raw, win_off)."""
+class Job:
+    """One scan of a resident batch: a pattern table + parameters + which window outputs to download.  Several jobs per
+    batch = `--telophrase 4 5 6`: the batch is parsed, packed and uploaded ONCE and scanned once per k (the reference
+    re-parses the input for every k, main.py:206-235)."""
+
+    def __init__(self, patterns, prm: hiplib.Params, want_sums=False, want_raw=False):
+        self.patterns, self.prm, self.want_sums, self.want_raw = list(patterns), prm, bool(want_sums), bool(want_raw)
+
+
+def upload_batch(engine, recs, slot: int = 0):
+    """A seqio.PackedBatch is uploaded as it is (3 bits per base); a seqio.RecordBatch or a list of records goes up as
+    ASCII and is packed on the device."""
     if hasattr(recs, "seq2"):
         engine.upload_packed(slot, recs.seq2, recs.inv if recs.any_invalid else None, recs.desc)
     elif hasattr(recs, "bases"):
         engine.upload(slot, recs.bases, recs.offsets)
     else:
         engine.upload(slot, *hiplib.pack_reads([r.seq for r in recs]))
-    flags = prm.flags | (hiplib.F_STORE_SUMS if want_sums else 0) | (hiplib.F_STORE_RAW if want_raw else 0)
-    p = hiplib.Params.from_buffer_copy(prm)
-    p.flags = flags
-    engine.scan(slot, p)
-    engine.sync()
-    if hasattr(recs, "release"):
-        recs.release()                 # the staging buffers are free again: the reader may refill them
-    res = engine.results(slot)
-    sums = raw = win_off = None
-    if want_sums:
-        sums, win_off = engine.window_sums(slot)
-    if want_raw:
-        raw, win_off = engine.window_raw(slot)
-    return res, sums, raw, win_off
+
+
+def scan_jobs(engine, recs, jobs, slot: int = 0):
+    """Upload once, then one fused scan per job.  Returns [(results, sums, raw, win_off), ...] in job order."""
+    upload_batch(engine, recs, slot)
+    out = []
+    for n, job in enumerate(jobs):
+        if len(jobs) > 1 or getattr(engine, "patterns", None) != job.patterns:
+            engine.set_patterns(job.patterns)
+        p = hiplib.Params.from_buffer_copy(job.prm)
+        p.flags = job.prm.flags | (hiplib.F_STORE_SUMS if job.want_sums else 0) | (hiplib.F_STORE_RAW if job.want_raw else 0)
+        engine.scan(slot, p)
+        engine.sync()
+        if n == 0 and hasattr(recs, "release"):
+            recs.release()             # the upload has completed: the staging buffers go back to the reader
+        res = engine.results(slot)
+        sums = raw = win_off = None
+        if job.want_sums:
+            sums, win_off = engine.window_sums(slot)
+        if job.want_raw:
+            raw, win_off = engine.window_raw(slot)
+        out.append((res, sums, raw, win_off))
+    return out
+
+
+def scan_records(engine, recs, prm: hiplib.Params, slot: int = 0, want_sums=False, want_raw=False):
+    """Fused scan of one batch with the engine's current pattern table.  Returns (results, sums, raw, win_off)."""
+    return scan_jobs(engine, recs, [Job(engine.patterns, prm, want_sums, want_raw)], slot)[0]
 
 
 class EnginePool:
@@ -63,12 +86,14 @@ class EnginePool:
     upload / launch ramp / result download of one batch with the scan of another).  Batches go to whichever context is
     free next; results come back in input order."""
 
-    def __init__(self, engines, patterns):
+    def __init__(self, engines, patterns=None):
         self.engines = list(engines)
         if not self.engines:
             raise ValueError("no engines")
-        for e in self.engines:
-            e.set_patterns(patterns)
+        self.patterns = None if patterns is None else list(patterns)
+        if self.patterns is not None:
+            for e in self.engines:
+                e.set_patterns(self.patterns)
 
     # -- sources
     def scan_file(self, filepath, prm, want_sums=False, want_raw=False, max_bases=None):
@@ -83,13 +108,32 @@ class EnginePool:
             alloc = getattr(self.engines[0], "host_alloc", None)
             self._pool = seqio.BufferPool(len(self.engines) + 2, words_cap, reads_cap, alloc)
             self._pool_key = key
-        return self._run(seqio.read_batches_packed(filepath, self._pool, max_records=reads_cap), prm, want_sums, want_raw)
+        return self._single(self._run(seqio.read_batches_packed(filepath, self._pool, max_records=reads_cap),
+                                      [Job(self.patterns, prm, want_sums, want_raw)]))
+
+    def scan_file_jobs(self, filepath, jobs, max_bases=None):
+        """One pass over the file for several jobs (pattern tables): yields (PackedBatch, [(results, sums, raw, win_off) per job])."""
+        from . import seqio
+        max_bases = max_bases or BATCH_BASES
+        words_cap = max(max_bases // 16, 1024)
+        reads_cap = min(BATCH_READS, max(64, max_bases // 256))
+        key = (words_cap, reads_cap)
+        if getattr(self, "_pool_key", None) != key:
+            alloc = getattr(self.engines[0], "host_alloc", None)
+            self._pool = seqio.BufferPool(len(self.engines) + 2, words_cap, reads_cap, alloc)
+            self._pool_key = key
+        return self._run(seqio.read_batches_packed(filepath, self._pool, max_records=reads_cap), list(jobs))
 
     def scan_stream(self, records, prm, want_sums=False, want_raw=False, max_bases=None):
-        return self._run(record_batches(records, max_bases=max_bases or BATCH_BASES), prm, want_sums, want_raw)
+        return self._single(self._run(record_batches(records, max_bases=max_bases or BATCH_BASES), [Job(self.patterns, prm, want_sums, want_raw)]))
+
+    @staticmethod
+    def _single(it):
+        for b, outs in it:
+            yield (b,) + outs[0]
 
     # -- the pipeline
-    def _run(self, batches, prm, want_sums, want_raw):
+    def _run(self, batches, jobs):
         n = len(self.engines)
         q_in: queue.Queue = queue.Queue(maxsize=n + 1)
         q_out: queue.Queue = queue.Queue()
@@ -122,7 +166,7 @@ class EnginePool:
                     if item is None:
                         return
                     i, b = item
-                    q_out.put(("batch", i, (b,) + scan_records(eng, b, prm, 0, want_sums, want_raw)))
+                    q_out.put(("batch", i, (b, scan_jobs(eng, b, jobs, 0))))
             except BaseException as e:
                 stop.set()
                 q_out.put(("error", None, e))

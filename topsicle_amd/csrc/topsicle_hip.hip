@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <set>
 #include <string>
 #include <vector>
@@ -207,7 +208,10 @@ struct tps_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipDeviceProp_t prop{};
-    DevBuf lut;
+    struct Table { DevBuf dev; int P = 0, k = 0; std::string key; tps::PatInfo pat{}; };
+    std::deque<Table> tables;         // resident pattern tables (deque: pointers to elements stay valid)
+    Table* lut_cur = nullptr;
+    size_t table_rr = 0;
     DevBuf follow_picks, follow_hist; // outputs of tps_batch_kmer_followers
     DevBuf ascii, ascii_off;          // staging of tps_batch_upload: ASCII bases + offsets, packed on the device right after the copy
     std::set<void*> pinned;           // host buffers handed out by tps_host_alloc
@@ -386,7 +390,7 @@ int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm) {
     a.inv = (const uint16_t*)sl.inv.p;
     a.desc = (const tps_read_desc*)sl.desc.p;
     a.tails_in = ((prm.flags & TPS_F_TAILS_IN) && !(prm.flags & TPS_F_STEP1)) ? (const uint8_t*)sl.tails.p : nullptr;
-    a.lut = (const uint32_t*)c->lut.p;
+    a.lut = (const uint32_t*)c->lut_cur->dev.p;
     a.results = c->zero_copy ? sl.h_results : (tps_read_result*)sl.results.p;
     a.c_start = a.c_end = nullptr;
     if (prm.flags & TPS_F_STEP1) {
@@ -549,7 +553,7 @@ int tps_ctx_destroy(tps_ctx* c) {
         sl.c_start.release(); sl.c_end.release(); sl.win_off.release(); sl.sums.release(); sl.raw.release(); sl.stamps.release(); sl.lc.release();
         if (sl.h_results) (void)hipHostFree(sl.h_results);
     }
-    c->lut.release();
+    for (auto& t : c->tables) t.dev.release();
     c->ascii.release();
     c->ascii_off.release();
     c->follow_picks.release();
@@ -583,6 +587,17 @@ int tps_set_patterns(tps_ctx* c, const char* pats, int32_t P, int32_t k) {
     int rc;
     if ((rc = bind(c))) return rc;
     if (!pats) return fail(TPS_E_ARG, "null pattern table");
+    if (P < 1 || k < 1 || P > TPS_MAX_PATTERNS || k > TPS_MAX_K) return fail(TPS_E_PATTERN, "%d patterns of %d letters not supported", P, k);
+    // a few tables stay resident (a multi-k run switches between them once per batch and k: no copy, no sync)
+    const std::string key(pats, (size_t)P * (size_t)k);
+    for (auto& t : c->tables)
+        if (t.P == P && t.k == k && t.key == key) {
+            c->lut_cur = &t;
+            c->pat = t.pat;
+            c->have_pat = true;
+            for (auto& sl : c->slots) sl.planned = false;
+            return TPS_OK;
+        }
     std::vector<uint32_t> lut;
     tps::PatInfo pi{};
     std::string err = tps::build_patterns(pats, P, k, lut, pi);
@@ -598,9 +613,15 @@ int tps_set_patterns(tps_ctx* c, const char* pats, int32_t P, int32_t k) {
             lut[n1 + cc] = ((m1 | m2) << 16) | (uint32_t)(__builtin_popcount(m1) + __builtin_popcount(m2));
         }
     }
-    if ((rc = c->lut.ensure(lut.size() * 4))) return rc;
-    HIP_TRY(hipMemcpyAsync(c->lut.p, lut.data(), lut.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));          // no launch may still be reading the table that gets recycled
+    tps_ctx::Table* slot = nullptr;
+    if (c->tables.size() < 6) { c->tables.emplace_back(); slot = &c->tables.back(); }
+    else { slot = &c->tables[c->table_rr++ % c->tables.size()]; }
+    if ((rc = slot->dev.ensure(lut.size() * 4))) return rc;
+    HIP_TRY(hipMemcpyAsync(slot->dev.p, lut.data(), lut.size() * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    slot->P = P; slot->k = k; slot->key = key; slot->pat = pi;
+    c->lut_cur = slot;
     c->pat = pi;
     c->have_pat = true;
     for (auto& sl : c->slots) sl.planned = false;     // kernel choice and LDS plan depend on the table (periods, duplicates, k)
@@ -693,7 +714,7 @@ int tps_batch_kmer_followers(tps_ctx* c, int32_t slot, int32_t n_fwd, int32_t fo
     a.seq2 = (const uint32_t*)sl->seq2.p;
     a.inv = (const uint16_t*)sl->inv.p;
     a.desc = (const tps_read_desc*)sl->desc.p;
-    a.lut = (const uint32_t*)c->lut.p;
+    a.lut = (const uint32_t*)c->lut_cur->dev.p;
     a.picks = (uint32_t*)c->follow_picks.p;
     a.hist = hist ? (unsigned long long*)c->follow_hist.p : nullptr;
     a.n_reads = n;

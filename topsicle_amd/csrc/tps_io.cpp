@@ -110,6 +110,11 @@ struct Reader {
                 if (!getline(line)) break;
                 p_qual += line;
             }
+            if (p_qual.size() != p_seq.size()) {       // mis-framed from here on: an error, like the Python parser and Biopython
+                g_err = "FASTQ record '" + p_head.substr(0, p_head.find_first_of(" \t")) + "': " + std::to_string(p_qual.size()) +
+                        " quality characters for " + std::to_string(p_seq.size()) + " bases";
+                return false;
+            }
             return true;
         }
         // FASTA
@@ -492,8 +497,9 @@ int tps_reader_open(const char* path, void** out) {
         if (!g_err.empty()) { delete h; return -1; }                             // unreadable (corrupt gzip), not empty
         h->format = 0; *out = h; return 0;                                       // empty file: no records
     }
+    // the format comes from the first character of the FIRST line, like check_file_type (allsteps.py:36-50): a file that
+    // starts with a blank line is "format cannot be identified" there, so it is here
     size_t i = 0;
-    while (i < r->len && (r->buf[i] == '\n' || r->buf[i] == '\r' || r->buf[i] == ' ')) ++i;
     char c = i < r->len ? r->buf[i] : 0;
     r->format = h->format = c == '>' ? 1 : c == '@' ? 2 : 0;
     if (!h->format) {

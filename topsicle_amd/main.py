@@ -56,21 +56,30 @@ _CSV_LOCK = __import__("threading").Lock()      # telolengths_all.csv is appende
 
 
 def process_file(args, seq_loc, telo_phrase, pattern, sliding_val, engines):
-    """One input file: step 1 + filtered file + step 2 rows (main.py:52-154), batch by batch: the per-read work of a batch
-    is numpy arithmetic on the kernel's result records, one bulk write of the passing records and one bulk CSV append.
-    Returns [(file_name, telo_phrase, [[readID, telolen]], trc), ...] in read order."""
+    """One input file, one k (main.py:52-154).  Returns [(file_name, telo_phrase, [[readID, telolen]], trc), ...] in read order."""
+    return process_file_multi(args, seq_loc, [(telo_phrase, pattern, sliding_val)], engines)[0]
+
+
+def process_file_multi(args, seq_loc, phrases, engines):
+    """One input file, every requested k in ONE pass: each batch is parsed, packed and uploaded once and scanned once per
+    k-mer table (`phrases` = [(telo_phrase, pattern list, slide), ...]).  Per k it does what the reference's process_file
+    does (main.py:52-154): step 1 + filtered file + step 2 rows; the per-read work of a batch is numpy arithmetic on the
+    kernel's result records, one bulk write of the passing records and one bulk CSV append.  Rows of the first k are
+    appended to telolengths_all.csv batch by batch; the other k's rows are returned for the caller to append behind them
+    (the reference writes all rows of one k before the next).  Returns one row list per k:
+    [(file_name, telo_phrase, [[readID, telolen]], trc), ...] in read order."""
     tprint("subsetting raw dataset based on TRC cutoff")
     base_name = os.path.basename(seq_loc)
     file_name = os.path.splitext(base_name)[0]
     min_cutoff = min(args.cutoff) if isinstance(args.cutoff, (list, tuple)) else args.cutoff
     no_bp = 1000
     ratio = no_bp / len(args.pattern)
-    prm = hiplib.make_params(
-        no_bp=no_bp, min_len=args.minSeqLength, min_count=allsteps.min_count_for_cutoff(min_cutoff, ratio, no_bp),
-        window=args.windowSize, slide=sliding_val, trimfirst=args.trimfirst, maxlen=args.maxlengthtelo,
-        flags=hiplib.F_STEP1 | hiplib.F_WINDOWS | hiplib.F_BINSEG)
     want_sums = bool(args.plot)
     want_raw = bool(args.rawcountpattern)
+    jobs = [batch.Job(pattern, hiplib.make_params(
+        no_bp=no_bp, min_len=args.minSeqLength, min_count=allsteps.min_count_for_cutoff(min_cutoff, ratio, no_bp),
+        window=args.windowSize, slide=slide, trimfirst=args.trimfirst, maxlen=args.maxlengthtelo,
+        flags=hiplib.F_STEP1 | hiplib.F_WINDOWS | hiplib.F_BINSEG), want_sums, want_raw) for _k, pattern, slide in phrases]
 
     fmt = _formats(seq_loc)
     fasta_temp = os.path.join(args.outputDir, f"{file_name}_trc_over_{min_cutoff}.fasta")
@@ -79,62 +88,66 @@ def process_file(args, seq_loc, telo_phrase, pattern, sliding_val, engines):
         tprint(f"Temporary fasta file already exists: {fasta_temp}. Using existing file.")
     else:
         fasta_temp = os.path.join(args.outputDir, f"{file_name}_trc_over_{min_cutoff}.{fmt}")
-        out_handle = open(fasta_temp, "wb")
+        out_handle = open(fasta_temp, "wb")        # holds the passing records of the LAST k, as after upstream's k loop
 
-    rows = []
-    image_num = 1
-    raw_npz = {"read_id": [], "tail": [], "n_win": [], "counts": []} if getattr(args, "rawcountformat", "csv") == "npz" else None
+    rows = [[] for _ in phrases]
+    image_num = [1] * len(phrases)
+    npz = getattr(args, "rawcountformat", "csv") == "npz"
+    raw_npz = [{"read_id": [], "tail": [], "n_win": [], "counts": []} if npz else None for _ in phrases]
     csv_path = f"{args.outputDir}/telolengths_all.csv"
-    pool = batch.EnginePool(engines, pattern)
+    pool = batch.EnginePool(engines)
     try:
-        for pb, res, sums, raw, win_off in pool.scan_file(seq_loc, prm, want_sums, want_raw):
-            idx = np.nonzero(res["pass"])[0]
-            if out_handle is not None and len(idx):
-                pb.write_records(out_handle, idx, fmt)                       # every passing record (main.py:83-86)
-            ids = [pb.read_id(int(i)) for i in idx]
-            if args.read_check:
-                keep = [j for j, rid in enumerate(ids) if rid == args.read_check]
-                idx, ids = idx[keep], [ids[j] for j in keep]
-            if not len(idx):
-                continue
-            r = res[idx]
-            fwd = r["tail"] == 0
-            trc = np.where(fwd, r["best_start"], r["best_end"]) / ratio      # float64, like int / float upstream
-            lens = pb.desc["len"][idx].astype(np.int64)
-            m = np.minimum(args.maxlengthtelo, lens)
-            bkp = r["bkp"].astype(np.int64)
-            point = np.where(bkp >= 0, bkp * sliding_val + args.trimfirst, 0)
-            telolen = np.where((point <= m) & (point != 0), point, 0)        # allsteps.py:330-333
-            for j in np.nonzero(bkp < 0)[0]:
-                tprint(f"read {ids[j]}: {int(r['n_win'][j])} windows, no admissible change point; reporting 0")
-            telo_l, trc_l = telolen.tolist(), trc.tolist()
-            with _CSV_LOCK, open(csv_path, mode="a", newline="") as fh:
-                csv.writer(fh).writerows(zip([file_name] * len(ids), [telo_phrase] * len(ids), ["%.3f" % t for t in trc_l], ids, telo_l))
-            rows += [(file_name, telo_phrase, [[rid, tl]], t) for rid, tl, t in zip(ids, telo_l, trc_l)]
-            if args.plot or args.rawcountpattern:                            # per-read artefacts (main.py:140-150)
-                for j, i in enumerate(idx):
-                    tail = "forward" if fwd[j] else "reverse"
-                    if args.plot and r["n_win"][j] > 0:
-                        import matplotlib.pyplot as plt
-                        y = sums[win_off[i]:win_off[i + 1]] / len(pattern)
-                        allsteps._plot_changepoint(ids[j], y, sliding_val, args.trimfirst, int(point[j]), args.rangecp or int(m[j]))
-                        plt.savefig(f"{args.outputDir}/plot_{telo_phrase}_{image_num + j}.png", format="png", dpi=300)
-                        plt.close()
-                    if args.rawcountpattern:
-                        block = raw[win_off[i]:win_off[i + 1]]
-                        if raw_npz is not None:
-                            raw_npz["read_id"].append(ids[j])
-                            raw_npz["tail"].append(tail)
-                            raw_npz["n_win"].append(block.shape[0])
-                            raw_npz["counts"].append(np.array(block, dtype=np.uint8))
-                        else:
-                            _write_rawcount(args, telo_phrase, image_num + j, pattern, sliding_val, block, tail)
-            image_num += len(idx)
+        for pb, outs in pool.scan_file_jobs(seq_loc, jobs):
+            for n, ((telo_phrase, pattern, sliding_val), (res, sums, raw, win_off)) in enumerate(zip(phrases, outs)):
+                idx = np.nonzero(res["pass"])[0]
+                if out_handle is not None and len(idx) and n == len(phrases) - 1:
+                    pb.write_records(out_handle, idx, fmt)                   # every passing record (main.py:83-86)
+                ids = [pb.read_id(int(i)) for i in idx]
+                if args.read_check:
+                    keep = [j for j, rid in enumerate(ids) if rid == args.read_check]
+                    idx, ids = idx[keep], [ids[j] for j in keep]
+                if not len(idx):
+                    continue
+                r = res[idx]
+                fwd = r["tail"] == 0
+                trc = np.where(fwd, r["best_start"], r["best_end"]) / ratio  # float64, like int / float upstream
+                lens = pb.desc["len"][idx].astype(np.int64)
+                m = np.minimum(args.maxlengthtelo, lens)
+                bkp = r["bkp"].astype(np.int64)
+                point = np.where(bkp >= 0, bkp * sliding_val + args.trimfirst, 0)
+                telolen = np.where((point <= m) & (point != 0), point, 0)    # allsteps.py:330-333
+                for j in np.nonzero(bkp < 0)[0]:
+                    tprint(f"read {ids[j]}: {int(r['n_win'][j])} windows, no admissible change point; reporting 0")
+                telo_l, trc_l = telolen.tolist(), trc.tolist()
+                if n == 0:
+                    with _CSV_LOCK, open(csv_path, mode="a", newline="") as fh:
+                        csv.writer(fh).writerows(zip([file_name] * len(ids), [telo_phrase] * len(ids), ["%.3f" % t for t in trc_l], ids, telo_l))
+                rows[n] += [(file_name, telo_phrase, [[rid, tl]], t) for rid, tl, t in zip(ids, telo_l, trc_l)]
+                if args.plot or args.rawcountpattern:                        # per-read artefacts (main.py:140-150)
+                    for j, i in enumerate(idx):
+                        tail = "forward" if fwd[j] else "reverse"
+                        if args.plot and r["n_win"][j] > 0:
+                            import matplotlib.pyplot as plt
+                            y = sums[win_off[i]:win_off[i + 1]] / len(pattern)
+                            allsteps._plot_changepoint(ids[j], y, sliding_val, args.trimfirst, int(point[j]), args.rangecp or int(m[j]))
+                            plt.savefig(f"{args.outputDir}/plot_{telo_phrase}_{image_num[n] + j}.png", format="png", dpi=300)
+                            plt.close()
+                        if args.rawcountpattern:
+                            block = raw[win_off[i]:win_off[i + 1]]
+                            if raw_npz[n] is not None:
+                                raw_npz[n]["read_id"].append(ids[j])
+                                raw_npz[n]["tail"].append(tail)
+                                raw_npz[n]["n_win"].append(block.shape[0])
+                                raw_npz[n]["counts"].append(np.array(block, dtype=np.uint8))
+                            else:
+                                _write_rawcount(args, telo_phrase, image_num[n] + j, pattern, sliding_val, block, tail)
+                image_num[n] += len(idx)
     finally:
         if out_handle is not None:
             out_handle.close()
-    if raw_npz is not None and raw_npz["read_id"]:
-        _write_rawcount_npz(args, file_name, telo_phrase, pattern, sliding_val, raw_npz)
+    for n, (telo_phrase, pattern, sliding_val) in enumerate(phrases):
+        if raw_npz[n] is not None and raw_npz[n]["read_id"]:
+            _write_rawcount_npz(args, file_name, telo_phrase, pattern, sliding_val, raw_npz[n])
     if out_handle is not None:
         tprint(f"Temporary fasta file with TRC more than {min_cutoff}:", fasta_temp)
     return rows
@@ -217,6 +230,7 @@ def analysis_run(args, engines=None, engine_factory=None):
 
     phrase_to_telo = defaultdict(list)
     phrase_to_trc = defaultdict(list)
+    phrases = []
     for telo_phrase in telo_phrases:
         if telo_phrase > len(args.pattern):
             tprint("Cannot have length of subset larger than length of pattern")
@@ -225,25 +239,35 @@ def analysis_run(args, engines=None, engine_factory=None):
         sliding_val = args.slide if args.slide else len(args.pattern)
         pattern = allsteps.patterns_to_search(telopattern=args.pattern, cut_length=telo_phrase)
         tprint("patterns to search:", pattern)
+        phrases.append((telo_phrase, pattern, sliding_val))
 
-        filenames = []
-        if os.path.isdir(args.inputDir):
-            for root, _dirs, files in os.walk(args.inputDir):
-                for filename in files:
-                    filenames.append(os.path.join(root, filename))
-        else:
-            filenames.append(args.inputDir)
+    filenames = []
+    if os.path.isdir(args.inputDir):
+        for root, _dirs, files in os.walk(args.inputDir):
+            for filename in files:
+                filenames.append(os.path.join(root, filename))
+    else:
+        filenames.append(args.inputDir)
 
-        tprint("begin processing reads")
-        t_reads = time.perf_counter()
-        results = _process_files(args, filenames, telo_phrase, pattern, sliding_val, engines, engine_factory, num_cores)
-        LAST_TIMINGS["reads_s"] = LAST_TIMINGS.get("reads_s", 0.0) + time.perf_counter() - t_reads
-        tprint("finished processing all reads")
-        print("---------------------")
-        for file_result in results:
-            for entry in file_result:
+    # every k in ONE pass over the input (the reference loops over k outermost and re-parses every file per k,
+    # main.py:206-235): per file a list of row lists, one per k
+    tprint("begin processing reads")
+    t_reads = time.perf_counter()
+    per_file = _process_files(args, filenames, phrases, engines, engine_factory, num_cores)
+    LAST_TIMINGS["reads_s"] = time.perf_counter() - t_reads
+    tprint("finished processing all reads")
+    print("---------------------")
+    for n, (telo_phrase, _pattern, _slide) in enumerate(phrases):
+        late = []
+        for file_rows in per_file:
+            for entry in file_rows[n]:
                 phrase_to_telo[entry[1]].append(float(entry[2][0][1]))
                 phrase_to_trc[entry[1]].append(float(entry[3]))
+                if n > 0:
+                    late.append([entry[0], entry[1], "%.3f" % entry[3], entry[2][0][0], entry[2][0][1]])
+        if late:                                   # rows of the later k's follow the first k's, in upstream's order
+            with _CSV_LOCK, open(output_csv, mode="a", newline="") as fh:
+                csv.writer(fh).writerows(late)
 
     t_sum = time.perf_counter()
     summarize(args, phrase_to_telo, phrase_to_trc)
@@ -251,13 +275,13 @@ def analysis_run(args, engines=None, engine_factory=None):
     return tprint("All telomere found, have a nice day.")
 
 
-def _process_files(args, filenames, telo_phrase, pattern, sliding_val, engines, engine_factory, num_cores):
-    """All input files of one k: sequentially on the given contexts, or -- several files, a factory for more
-    contexts, no per-read plots (pyplot is not thread-safe) -- up to min(num_cores, 8) files at a time, each on
-    its own thread and contexts (parsing / gunzip is the bottleneck, the GPUs are shared).  Results keep file order."""
+def _process_files(args, filenames, phrases, engines, engine_factory, num_cores):
+    """All input files: sequentially on the given contexts, or -- several files, a factory for more contexts, no per-read
+    plots (pyplot is not thread-safe) -- up to min(num_cores, 8) files at a time, each on its own thread and contexts
+    (parsing / gunzip is the bottleneck, the GPUs are shared).  Results keep file order: one list of per-k row lists per file."""
     workers = min(len(filenames), max(1, num_cores), 8)
     if workers <= 1 or engine_factory is None or args.plot or args.rawcountpattern:
-        return [process_file(args, seq_loc, telo_phrase, pattern, sliding_val, engines) for seq_loc in filenames]
+        return [process_file_multi(args, seq_loc, phrases, engines) for seq_loc in filenames]
     import threading
     from concurrent.futures import ThreadPoolExecutor
     local = threading.local()
@@ -267,7 +291,7 @@ def _process_files(args, filenames, telo_phrase, pattern, sliding_val, engines, 
         if not hasattr(local, "engines"):
             local.engines = engine_factory()
             made.append(local.engines)
-        return process_file(args, seq_loc, telo_phrase, pattern, sliding_val, local.engines)
+        return process_file_multi(args, seq_loc, phrases, local.engines)
 
     tprint(f"processing {len(filenames)} files, {workers} at a time")
     try:

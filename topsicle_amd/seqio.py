@@ -85,6 +85,11 @@ def parse(handle, fmt: str):
                 if not q:
                     break
                 qual += q.rstrip("\r\n")
+            if len(qual) != len(seq):
+                # a quality string that is too short swallowed the next header; one that is too long leaves its tail
+                # where a header should be: either way the file is mis-framed from here on (Biopython raises as well)
+                raise ValueError(f"FASTQ record {head[1:].split()[0] if head[1:].split() else ''!r}: "
+                                 f"{len(qual)} quality characters for {len(seq)} bases")
             desc = head[1:]
             yield Record(_first_token(desc), desc, seq, qual)
     else:
