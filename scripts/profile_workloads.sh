@@ -4,7 +4,7 @@
 # usage: scripts/profile_workloads.sh <tag> "<workload>[:flags] ..."      -> gpurun_out/profw_<tag>/<workload>_f<flags>/
 set -u
 TAG=${1:-r02}
-LIST=${2:-"config3_per_gpu config4_sample config5_k4:31 config5_k5 config5_k5:31 config5_k6 config5_k6:31"}
+LIST=${2:-"config3_per_gpu config4_sample config5_k4:31 config5_k5 config5_k5:31 config5_k6 config5_k6:31 config5"}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 for item in $LIST; do

@@ -1601,8 +1601,10 @@ TPS_DEV void pp_expand(uint32_t ne, uint32_t no, uint32_t* b) {   // nibble word
 template <int S, int D>
 TPS_DEV void tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int delta, int w0, int tile, int nw_tile,
                        int64_t out_base, uint64_t& s_total) {
-    typedef GeoPP<S> g_;
-    constexpr int WDW = g_::WDW, B = g_::B, POS = g_::POS, LBK = g_::LBK;
+    // look-back over the previous lane's last LBK positions (tables with a self-overlap period only): enough for a chain that
+    // starts inside it; a chain through the whole look-back takes the walk below
+    constexpr int B = 8, POS = B * S, LBK = D > 0 ? 2 * D + 2 : 0;
+    constexpr int WDW = (1 + LBK + POS + 6 + 7 + 15) / 16;
     constexpr int DH = D > 0 ? D : 1;
     constexpr int AHEAD = (D > 0 && 2 * D > S) ? 2 * D - S : 0;   // positions past the lane whose occurrences close a start-skip chain
     constexpr uint32_t M3 = 0x33333333u;
@@ -1635,8 +1637,8 @@ TPS_DEV void tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
     TPS_PHASE {
         const int span = tid;
         const int p0 = delta + span * POS;        // >= 16
-        const uint32_t sh2 = (uint32_t)((p0 - 1) & 15) * 2u;
-        const int d0 = ((p0 - 1) >> 4) - 1;       // >= -1: lane 0 may read one dword before seq2 (its look-back is discarded)
+        const uint32_t sh2 = (uint32_t)((p0 - 1 - LBK) & 15) * 2u;
+        const int d0 = (p0 - 1 - LBK) >> 4;       // the lane's registers start LBK positions before its first one (p0 >= 64)
         uint32_t w[WDW];
         {
             uint32_t prev = l.seq2[d0];
@@ -1647,7 +1649,7 @@ TPS_DEV void tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
                 prev = nx;
             }
         }
-        // one-hot field of the pattern that starts at position p (relative to the lane's first, -16 <= p)
+        // one-hot field of the pattern that starts at position p (relative to the lane's first, -LBK <= p)
         auto look = [&](int p) -> uint32_t {
             const int idx = p + LBK, dw = idx >> 4, bit = idx & 15;
             const uint32_t v4 = bit ? alignbit(dw + 1 < WDW ? w[dw + 1] : 0u, w[dw], 2u * bit) : w[dw];
