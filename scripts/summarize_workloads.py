@@ -22,10 +22,17 @@ for d in sorted(glob.glob(os.path.join(src, "*_f*"))):
     stats = glob.glob(os.path.join(d, "trace", "*", "*_kernel_stats.csv"))
     kern = calls = mean_ns = None
     if stats:
-        for r in csv.DictReader(open(stats[0])):
-            if r["Name"].startswith("tps_"):
-                kern, calls, mean_ns = r["Name"], int(r["Calls"]), float(r["AverageNs"])
-                break
+        ks = [(r["Name"], int(r["Calls"]), float(r["AverageNs"])) for r in csv.DictReader(open(stats[0])) if r["Name"].startswith("tps_scan")]
+        ks = [k for k in ks if k[1] * 4 >= max(x[1] for x in ks)]          # (drop stray launches of the set-up phase)
+        if len(ks) == 1:
+            kern, calls, mean_ns = ks[0]
+        elif ks:
+            # several scan kernels per step (the three k passes of config5): one step = one launch of each, so the step's
+            # kernel time is the sum of the means weighted by launches per step
+            per_step = min(k[1] for k in ks)
+            kern = " + ".join(f"{k[0]}x{round(k[1] / per_step)}" for k in ks)
+            calls = per_step
+            mean_ns = sum(k[1] * k[2] for k in ks) / per_step
         if dst:
             shutil.copyfile(stats[0], os.path.join(dst, f"{name}_kernel_stats.csv"))
     pmc = collections.defaultdict(list)

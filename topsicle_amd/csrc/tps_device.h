@@ -1658,8 +1658,8 @@ TPS_DEV void tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
         };
         uint32_t pk[LBK + POS + AHEAD + 1];       // picks, index p + LBK (registers: only the last D are live)
         uint32_t tv[POS + 1];                     // skips
-        if (D > 0) {
-            uint32_t ca[LBK];                     // same pattern at p, p - D, p - 2 D, ... down to the look-back's start
+        if constexpr (D > 0) {
+            uint32_t ca[LBK > 0 ? LBK : 1];       // same pattern at p, p - D, p - 2 D, ... down to the look-back's start
             TPS_UNROLL
             for (int i = 0; i < LBK; ++i) {
                 const uint32_t h = look(i - LBK);
