@@ -23,16 +23,17 @@
 // (the only workgroup barrier in the kernel); after that every wave runs its own read with
 // wave-level synchronisation only.
 #define TPS_SCAN_KERNEL_F(NAME, SV, SO, PAIR, RAW, MINW, FULL)                                                           \
-    extern "C" __global__ void __launch_bounds__(tps::NT * tps::WPG, MINW) NAME(tps::ScanArgs a) {         \
+    extern "C" __global__ void __launch_bounds__(tps::NT * tps::WPG_MAX, MINW) NAME(tps::ScanArgs a) {     \
         extern __shared__ __attribute__((aligned(16))) uint32_t lds[];                                     \
         /* workgroup-shared tables: [pair table (PAIR kernels)][single table], both aligned to their size */ \
         uint32_t* lut = lds + ((PAIR) ? a.pair_n : 0);                                                     \
-        for (int i = (int)threadIdx.x; i < a.lut_n; i += tps::NT * tps::WPG) {                             \
+        const int nthr_ = tps::NT * a.wpg;            /* = blockDim.x */                                   \
+        for (int i = (int)threadIdx.x; i < a.lut_n; i += nthr_) {                                          \
             const uint32_t m_ = a.lut[i];                                                                  \
             lut[i] = (SV) ? ((m_ << 16) | (uint32_t)__builtin_popcount(m_)) : m_;                          \
         }                                                                                                  \
         if (PAIR) {   /* host-built pair table, stored right behind the plain table */                      \
-            for (int c = 4 * (int)threadIdx.x; c < a.pair_n; c += 4 * tps::NT * tps::WPG)                  \
+            for (int c = 4 * (int)threadIdx.x; c < a.pair_n; c += 4 * nthr_)                               \
                 *(uint4*)(lds + c) = *(const uint4*)(a.lut + a.lut_n + c);                                 \
         }                                                                                                  \
         __syncthreads();                                                                                   \
@@ -44,7 +45,7 @@
         const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));                          \
         const int64_t wave_dw = (tps::lds_dwords(a) + 3) & ~3ll;                                           \
         uint32_t* slice = lut + ((a.lut_n + 3) & ~3) + wave * wave_dw;                                     \
-        const int64_t r = (int64_t)blockIdx.x * tps::WPG + wave;                                           \
+        const int64_t r = (int64_t)blockIdx.x * a.wpg + wave;                                              \
         if (r < a.n_reads) tps::scan_read<SV, SO, PAIR, RAW, FULL>(a, r, slice, lut);                           \
     }
 #ifndef TPS_SO_MINW
@@ -484,9 +485,9 @@ int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm) {
         // hipExtLaunchKernel stamps the pair of events from the dispatch packet's own start / end timestamps:
         // no separate barrier packets around the kernel (two hipEventRecord calls cost ~6 us per launch and
         // kept consecutive launches from running back to back)
-        const int64_t grid = (n + tps::WPG - 1) / tps::WPG;
+        const int64_t grid = (n + a.wpg - 1) / a.wpg;
         void* kargs[] = {(void*)&a};
-        HIP_TRY(hipExtLaunchKernel(kfn, dim3((unsigned)grid), dim3(tps::NT * tps::WPG), kargs, sl.lds_bytes, c->stream,
+        HIP_TRY(hipExtLaunchKernel(kfn, dim3((unsigned)grid), dim3(tps::NT * a.wpg), kargs, sl.lds_bytes, c->stream,
                                    timed ? ep.a : nullptr, timed ? ep.b : nullptr, 0));
     }
     if (!c->no_copy && !c->zero_copy) HIP_TRY(hipMemcpyAsync(sl.h_results, sl.results.p, (size_t)n * sizeof(tps_read_result), hipMemcpyDeviceToHost, c->stream));
@@ -579,7 +580,8 @@ int tps_batch_kernel_info(tps_ctx* c, int32_t slot, char* buf, int32_t buf_len) 
     if (!sl) return TPS_E_ARG;
     if (!sl->scanned) return fail(TPS_E_STATE, "slot %d has not been scanned", slot);
     const size_t gran = (sl->lds_bytes + 1279) / 1280;
-    snprintf(buf, (size_t)buf_len, "%s lds=%zu wgs_per_cu=%d", sl->kernel_name, sl->lds_bytes, gran ? (int)std::min<size_t>(128 / gran, 8) : 8);
+    const int wgs = gran ? (int)std::min<size_t>(128 / gran, 8) : 8;
+    snprintf(buf, (size_t)buf_len, "%s lds=%zu wgs_per_cu=%d waves_per_wg=%d", sl->kernel_name, sl->lds_bytes, wgs, sl->args.wpg);
     return TPS_OK;
 }
 

@@ -71,7 +71,8 @@ __device__ __forceinline__ int tps_fresh_lane() {
 namespace tps {
 
 constexpr int NT = 64;                            // lanes that cooperate on one read: one wave
-constexpr int WPG = 4;                            // independent waves (reads) per workgroup
+constexpr int WPG = 4;                            // independent waves (reads) per workgroup: the default, and the fixed size of the small kernels
+constexpr int WPG_MAX = 8;                        // the scan kernels take 4 .. 8 waves per workgroup (ScanArgs::wpg): a big table (k >= 6) is shared by more waves
 constexpr uint32_t FLAG_CONFLICT = 0x80000000u;   // generic path: bit 31 of a block mask
 constexpr uint32_t FLAG16 = 0x8000u;              // specialised path: bit 15 of a 16-bit mask
 constexpr int HIST_COPIES = 8;                    // private step-1 histograms (lane % 8)
@@ -275,6 +276,7 @@ struct ScanArgs {
     int32_t tw;                  // windows per fused tile
     uint32_t tw_magic;           // ceil(2^32 / tw)
     int32_t tile_full;           // fused tiles: 1 = all 64 lanes hold windows' blocks (8 more windows per tile), 0 = the last lane is halo
+    int32_t wpg;                 // waves (reads) per workgroup of this launch, 4 .. WPG_MAX
     int32_t pp_d;                // per-pattern tiles (tile_pp_s): -1 = not eligible, 0 = no self-overlapping k-mer,
                                  // d > 0 = the one self-overlap period of the table
 };
@@ -370,7 +372,7 @@ TPS_HD int64_t lds_dwords(const ScanArgs& a) {
     return (int64_t)a.blk_dw + a.seq_dw + val_dw(a) + a.tot_dw + lc_dw(a) + row_dw(a) + MISC_DW;   // per wave; + lut_n per workgroup
 }
 // LDS dwords of a whole workgroup: the shared table + WPG wave slices (each rounded to 16 bytes)
-TPS_HD int64_t wg_lds_dwords(const ScanArgs& a) { return a.pair_n + ((a.lut_n + 3) & ~3) + (int64_t)WPG * ((lds_dwords(a) + 3) & ~3ll); }
+TPS_HD int64_t wg_lds_dwords(const ScanArgs& a) { return a.pair_n + ((a.lut_n + 3) & ~3) + (int64_t)(a.wpg > 0 ? a.wpg : WPG) * ((lds_dwords(a) + 3) & ~3ll); }
 // misc layout (dwords)
 constexpr int M_BEST = 0;        // 2: step-1 arg-max keys (count << 5 | 31 - pattern) of the two sides
 constexpr int M_CMASK = 2;       // 2: conflict masks of step 1 (start, end)

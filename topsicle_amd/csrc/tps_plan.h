@@ -111,6 +111,30 @@ inline int fused_seq_dw(int slide) {
     return SEQ_LEAD + 4 * nq + 4;
 }
 
+// Waves per workgroup: 4, unless the table is big (k >= 6: 16 KB and more per workgroup) and sharing it among more waves
+// puts more waves on a CU.  LDS is handed out in 1280-byte granules, 128 per CU; at most 8 workgroups per CU.
+inline void plan_wpg(ScanArgs& a, int64_t budget_dw) {
+    auto waves_per_cu = [&](int w) {
+        a.wpg = w;
+        const int64_t dw = wg_lds_dwords(a);
+        if (dw > budget_dw) return 0;
+        const int64_t gran = std::max<int64_t>(1, (dw * 4 + 1279) / 1280);
+        return (int)std::min<int64_t>(32, std::min<int64_t>(8, 128 / gran) * w);
+    };
+    int best = WPG, best_w = waves_per_cu(WPG);
+    if (const char* e = getenv("TPS_WPG")) {
+        const int w = atoi(e);
+        if (w >= 1 && w <= WPG_MAX && waves_per_cu(w) > 0) { a.wpg = w; return; }
+    }
+    // only multiples of four: a workgroup's waves go round the four SIMDs, and five waves would put two on one of them
+    // (measured at k = 6, 10 000 x 25 kb reads: 4 waves per workgroup 0.256 ms, 5: 0.306, 7: 0.251, 8: 0.222)
+    if (a.lut_n * 4 >= 16384) {
+        const int v = waves_per_cu(WPG_MAX);
+        if (v > best_w) { best = WPG_MAX; best_w = v; }
+    }
+    a.wpg = best;
+}
+
 // Slides that have a specialised kernel instantiation (tps_scan_kernel_s<S>).
 inline bool has_specialised_slide(int s) { return s == 5 || s == 6 || s == 7 || s == 8; }
 
@@ -118,8 +142,17 @@ inline bool has_specialised_slide(int s) { return s == 5 || s == 6 || s == 7 || 
 // rec_rs, seq_dw, head_dw, tot_dw, blk_dw, lc_cap, jump_magic.  budget_dw = LDS dwords one workgroup (WPG waves +
 // the shared table) may use; target_dw = preferred workgroup LDS size (occupancy); spans_pref > 0
 // forces the spans per tile.
+inline std::string plan_geometry_core(ScanArgs& a, const tps_params& prm, int k, int P, int64_t max_nwin, int64_t budget_dw,
+                                      int spans_pref, int force_generic, int64_t target_dw);
 inline std::string plan_geometry(ScanArgs& a, const tps_params& prm, int k, int P, int64_t max_nwin, int64_t budget_dw,
                                  int spans_pref, int force_generic = 0, int64_t target_dw = 32 * 256) {
+    a.wpg = WPG;
+    std::string err = plan_geometry_core(a, prm, k, P, max_nwin, budget_dw, spans_pref, force_generic, target_dw);
+    if (err.empty()) plan_wpg(a, budget_dw);
+    return err;
+}
+inline std::string plan_geometry_core(ScanArgs& a, const tps_params& prm, int k, int P, int64_t max_nwin, int64_t budget_dw,
+                                      int spans_pref, int force_generic, int64_t target_dw) {
     a.lut_n = a.pat.hash_shift ? 2 * 256 : 1 << (2 * k);     // hashed table: 256 (key, mask) pairs
     a.lw = std::max(0, prm.window - k);            // k-mer start positions in a (W-1)-char window
     a.q = a.lw / prm.slide;
