@@ -1130,15 +1130,20 @@ TPS_DEV uint32_t pack_hi_lo(uint32_t hi_src, uint32_t lo_src) { return perm(hi_s
 
 // RAW: this instantiation can also produce the per-pattern counts (TPS_F_STORE_RAW); the kernels without it carry
 // no recount code at all unless the table has self-overlapping k-mers.
-template <int S, bool SO, bool INV, bool RZ, bool PAIR, bool RAW>
+// RPT: the window's partial block (r = (W - k) % slide positions) as a COMPILE-TIME constant, or -1 = read it at run time.
+// A window ends r positions into a block, so every block publishes its prefix words at that position; with r known at
+// compile time the capture is a plain copy at one unrolled position instead of two selects at every position (measured on
+// the slide-7 kernel, r = 4: 112 of ~565 instructions per tile).  scan_read switches on r once per tile.
+template <int S, bool SO, bool INV, int RPT, bool PAIR, bool RAW>
 TPS_DEV void tile_fused_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int delta, int w0, int tile, int nw_tile,
                           int64_t out_base, uint64_t& s_total, int64_t r) {
     // RZ: the window has no partial block (W - k divisible by the slide), so nothing is captured mid-block
+    constexpr bool RZ = RPT == 0;
     typedef Geo<S> g_;
     constexpr int WDW = g_::WDW, B = g_::B, LOG2B = g_::LOG2B, POS = g_::POS;
     constexpr int RS = NT + NT / B;               // row stride of the padded layout between u and u + 1
     const PatInfo& pat = a.pat;
-    const int rp = tc.r, q = tc.q;                // rp: positions of the partial block (a.r)
+    const int rp = RPT >= 0 ? RPT : tc.r, q = tc.q;   // rp: positions of the partial block (a.r)
     const uint32_t amask = pat.kmask << 2;        // k-mer code as a byte offset into the 4-byte table
     TPS_PHASE {
         const int span = tid;
@@ -3045,12 +3050,21 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
                         TPS_SYNC();
                     }
                 }
-                if (uniform(l.misc[M_INVALID]) != 0)
-                    tile_fused_s<SV ? SV : 1, SO, true, false, false, RAW>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r);
-                else if (tc.r == 0)
-                    tile_fused_s<SV ? SV : 1, SO, false, true, PAIR, RAW>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r);
-                else
-                    tile_fused_s<SV ? SV : 1, SO, false, false, PAIR, RAW>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r);
+                constexpr int SF = SV ? SV : 1;
+                if (uniform(l.misc[M_INVALID]) != 0) {
+                    tile_fused_s<SF, SO, true, -1, false, RAW>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r);
+                } else if constexpr (SO || RAW) {
+                    // (these kernels reach the plain tile only as a fallback: one instantiation with r read at run time)
+                    if (tc.r == 0) tile_fused_s<SF, SO, false, 0, PAIR, RAW>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r);
+                    else tile_fused_s<SF, SO, false, -1, PAIR, RAW>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r);
+                } else {
+#define TPS_TILE_RP(N) case N: if constexpr (N < SF) tile_fused_s<SF, SO, false, (N < SF ? N : 0), PAIR, RAW>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r); break;
+                    switch (tc.r) {
+                        TPS_TILE_RP(0) TPS_TILE_RP(1) TPS_TILE_RP(2) TPS_TILE_RP(3) TPS_TILE_RP(4) TPS_TILE_RP(5) TPS_TILE_RP(6) TPS_TILE_RP(7)
+                        default: break;
+                    }
+#undef TPS_TILE_RP
+                }
                 if (w0 == 0) TPS_STAMP(8);
             }
         }
