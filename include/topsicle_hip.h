@@ -13,7 +13,10 @@
  *   - every function returns 0 on success or a negative TPS_E_* code; tps_last_error() gives
  *     the message of the last failure on the calling thread.
  *   - the caller allocates and owns every host buffer; the library keeps no host pointer
- *     after a call returns.  Device memory is owned by the context.
+ *     after a call returns -- with ONE exception: uploads from buffers obtained with tps_host_alloc
+ *     (pinned memory) are asynchronous on the context's stream, and those buffers must not be
+ *     rewritten or freed before the next tps_sync (or blocking download) on that context.
+ *     Device memory is owned by the context.
  *   - one context per (host thread, device); a context is not thread-safe, distinct contexts
  *     are independent.  There is NO CPU fallback: creating a context without a usable GPU
  *     fails with TPS_E_NO_DEVICE.
