@@ -23,6 +23,18 @@ for case in range(n_cases):
     W = int(rng.choice([100, 100, 100, 80, 120, 150]))
     t = int(rng.choice([100, 0, 37]))
     pats, seqs = _pp_reads(rng, motif, k, int(rng.integers(3, 12)), int(rng.integers(3000, 24000)), units)
+    if case % 2:
+        # mostly random sequence with short chain-ridden stretches: most tiles take the chain-free path, the stretches land
+        # anywhere relative to the tile boundaries (the hand-over between the plain and the canonical-pick tiles)
+        mixed = []
+        for sq in seqs:
+            out, pos = [], 0
+            while pos < len(sq):
+                n = int(rng.integers(100, 1500))
+                out.append(sq[pos:pos + n]); pos += n
+                out.append("".join("ACGT"[x] for x in rng.integers(0, 4, int(rng.integers(1500, 9000)))))
+            mixed.append("".join(out)[:int(rng.integers(6000, 30000))])
+        seqs = mixed
     if rng.random() < 0.3:
         i = int(rng.integers(len(seqs))); p = int(rng.integers(len(seqs[i])))
         seqs[i] = seqs[i][:p] + "N" + seqs[i][p + 1:]

@@ -384,11 +384,15 @@ def test_emulation_per_pattern_tiles(motif, k, slide, units):
             continue
         flags = hiplib.F_WINDOWS | hiplib.F_BINSEG | hiplib.F_TAILS_IN | hiplib.F_STORE_SUMS | (hiplib.F_STORE_RAW if raw else 0)
         prm = hiplib.make_params(window=100, slide=slide, trimfirst=100, maxlen=20000, flags=flags)
-        which = 0 if raw else 5          # raw rows: per-pattern tiles (tile_pp_s); sums only, self-overlap table: tile_so_s
-        t0, r0 = L.emu_counter(which), L.emu_counter(1)
+        # raw rows: per-pattern tiles (tile_pp_s, counter 0); sums only, self-overlap table: tile_so_s (5) for tiles with a
+        # chained occurrence, the chain-detecting plain tile (6) for the others
+        count = (lambda: L.emu_counter(0)) if raw else (lambda: L.emu_counter(5) + L.emu_counter(6))
+        t0, r0, f0 = count(), L.emu_counter(1), L.emu_counter(6)
         out = emu.scan(pats, seqs, prm, tails=tails, base_shift=int(rng.integers(16)))
-        tiles, redone = L.emu_counter(which) - t0, L.emu_counter(1) - r0
+        tiles, redone, fast = count() - t0, L.emu_counter(1) - r0, L.emu_counter(6) - f0
         assert tiles >= 8, "the canonical-pick tiles were not used"
+        if not raw:
+            assert 0 < fast < tiles, ("both the chain-free and the chained tile path should have run", fast, tiles)
         nwin_total = 0
         for i, seq in enumerate(seqs):
             _, counts = orc.window_count_matrix(seq, ["forward", "reverse"][tails[i]], pats, 100, slide, 100, 20000)
@@ -403,6 +407,47 @@ def test_emulation_per_pattern_tiles(motif, k, slide, units):
         assert redone < nwin_total // 2, (redone, nwin_total)
         if not units:
             assert redone == 0
+
+
+@pytest.mark.parametrize("motif,k,slide,unit", [
+    ("CCCTAA", 5, 6, "CTAA"),                     # CTAAC: period 4
+    ("CCCTAA", 6, 6, "CCTAA"),                    # CCTAAC: period 5
+    ("TTTAGGG", 7, 7, "TTTAGG"),                  # period 6
+])
+def test_emulation_chain_free_tiles_hand_over(motif, k, slide, unit):
+    """Sums only, self-overlap table: tiles without a chained occurrence complete as plain tiles (tile_fused_s<.., CD>), the
+    others go through tile_so_s.  Chains planted around every tile boundary (before, across, after; 2 to 6 links; both
+    tails) check the hand-over in both directions: what a plain tile leaves for a chained successor, and a chained tile
+    followed by a plain one."""
+    rng = np.random.default_rng(7 * k + slide)
+    pats = orc.kmer_table(motif, k)
+    flags = hiplib.F_WINDOWS | hiplib.F_BINSEG | hiplib.F_TAILS_IN | hiplib.F_STORE_SUMS
+    prm = hiplib.make_params(window=100, slide=slide, trimfirst=100, maxlen=20000, flags=flags)
+    tw = emu.plan_table(pats, prm, 3301)["tw"]
+    L = 100 + 2 * tw * slide + 1500
+    d = len(unit)
+    seqs, tails = [], []
+    for off in range(-3 * d - 2, 3 * d + 3):
+        body = ["ACGT"[x] for x in rng.integers(0, 4, L)]
+        for t in (1, 2):
+            run = list(unit * int(rng.integers(2, 7)) + unit[:k - d])
+            at = 100 + t * tw * slide + off
+            body[at:at + len(run)] = run
+        tail = int(rng.integers(2))
+        seqs.append("".join(body if tail == 0 else body[::-1]))
+        tails.append(tail)
+    lib = emu.lib()
+    f0, s0, r0 = lib.emu_counter(6), lib.emu_counter(5), lib.emu_counter(1)
+    out = emu.scan(pats, seqs, prm, tails=tails, base_shift=int(rng.integers(16)))
+    fast, slow, redone = lib.emu_counter(6) - f0, lib.emu_counter(5) - s0, lib.emu_counter(1) - r0
+    assert fast > 0 and slow > 0, (fast, slow)
+    for i, seq in enumerate(seqs):
+        _, counts = orc.window_count_matrix(seq, ["forward", "reverse"][tails[i]], pats, 100, slide, 100, 20000)
+        lo, hi = out["win_off"][i], out["win_off"][i + 1]
+        assert hi - lo == counts.shape[0]
+        bad = np.flatnonzero(out["sums"][lo:hi] != counts.sum(axis=1))
+        assert bad.size == 0, (i, tails[i], bad[:8], tw)
+    assert redone < 40 * len(seqs)
 
 
 def test_planner_picks_per_pattern_tiles():

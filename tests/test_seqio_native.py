@@ -199,6 +199,50 @@ def test_packed_reader_equals_python_parser(tmp_path, gold_dir):
 
 
 @pytest.mark.skipif(seqio._load_io() is None, reason="libtopsicle_io.so not built")
+def test_packed_reader_thread_team_resynchronises_at_any_byte(tmp_path):
+    """The packed reader cuts the text into one stretch per thread; every thread but the first has to find the first
+    record that starts in its stretch.  Reads of 0 .. 700 bases, quality lines that begin with '@' or '+', CRLF records,
+    no newline at the end / blank lines at the end, many batch sizes (stretch boundaries land everywhere), a batch cut
+    short by the buffer caps in the middle of a thread's stretch, and an irregular record that hands the rest to the
+    streaming decoder.  Runs in a child process: the team size and threshold are read once per process."""
+    import subprocess
+    import sys
+    import textwrap
+    code = textwrap.dedent(r"""
+        import os, sys
+        import numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        from test_seqio_native import _packed_records
+        from topsicle_amd import seqio
+        rng = np.random.default_rng(5)
+        def rec(i, n, crlf):
+            s = "".join("ACGTNacgt"[x] for x in rng.integers(0, 9, n))
+            q = "".join(chr(33 + int(x)) for x in rng.integers(0, 60, n))
+            if n and i %% 3 == 0: q = "@" + q[1:]
+            if n and i %% 5 == 0: q = "+" + q[1:]
+            nl = "\r\n" if crlf else "\n"
+            return f"@r{i} d{nl}{s}{nl}+{nl}{q}{nl}", (f"r{i}", s, q)
+        parts, want = zip(*[rec(i, int(rng.integers(0, 700)), i %% 11 == 0) for i in range(900)])
+        tmp = %r
+        for name, text, exp in (("a.fastq", "".join(parts).rstrip("\n"), list(want)),
+                                ("b.fastq", "".join(parts) + "\n\n \n", list(want)),
+                                ("c.fastq", "".join(parts[:500]) + "@w\nAC\nGT\n+\nII\nII\n" + "".join(parts[500:]),
+                                 list(want[:500]) + [("w", "ACGT", "IIII")] + list(want[500:]))):
+            path = os.path.join(tmp, name)
+            with open(path, "w", newline="") as h:
+                h.write(text)
+            for words_cap, reads_cap in ((1 << 20, 4096), (9000, 4096), (3000, 64), (1 << 20, 37), (1100, 4096)):
+                recs, nb = _packed_records(path, words_cap=words_cap, reads_cap=reads_cap)
+                assert [(r.id, r.seq, r.qual) for r in recs] == exp, (name, words_cap, reads_cap)
+        print("ok")
+    """) % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path))
+    for threads in ("2", "7", "16"):
+        env = dict(os.environ, TPS_IO_THREADS=threads, TPS_IO_PACK_MIN_SPAN="1")
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (threads, r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.mark.skipif(seqio._load_io() is None, reason="libtopsicle_io.so not built")
 def test_packed_reader_switches_to_ascii_decoder_on_odd_records(tmp_path):
     """Plain FASTQ whose records stop being 4-line records half way (wrapped sequence, '+name' lines, lower case, N):
     the packed mmap path hands over to the streaming decoder at that record; nothing is lost or duplicated."""

@@ -279,6 +279,7 @@ struct ScanArgs {
     int32_t wpg;                 // waves (reads) per workgroup of this launch, 4 .. WPG_MAX
     int32_t pp_d;                // per-pattern tiles (tile_pp_s): -1 = not eligible, 0 = no self-overlapping k-mer,
                                  // d > 0 = the one self-overlap period of the table
+    int32_t so_fast;             // sums only, pp_d > 0: tiles without a chained occurrence take the plain tile (chain test inside it)
 };
 
 struct BinsegArgs {
@@ -1126,6 +1127,9 @@ TPS_DEV Lds carve_fused(uint32_t* base, uint32_t* lut, const ScanArgs& a) {
 //   phase 3  (after the exclusive scan of row[]) candidate-strided: Lc[c] = left sum of window c * jump.
 // XS aliases row[]: the only reader of XS[w] is the lane that then writes row[w].
 // Windows beyond nw_tile (they need blocks of the next tile) are not produced.
+#ifdef TPS_EMU
+inline int& emu_counter(int i) { static int c[8] = {0, 0, 0, 0, 0, 0, 0, 0}; return c[i]; }   // tests: 0 = per-pattern tiles, 1 = windows recounted there, 4 = exact change-point tournaments, 5 = tile_so_s tiles, 6 = chain-free tiles of a self-overlap table completed as plain tiles
+#endif
 TPS_DEV uint32_t pack_hi_lo(uint32_t hi_src, uint32_t lo_src) { return perm(hi_src, lo_src, 0x07060100u); }
 
 // RAW: this instantiation can also produce the per-pattern counts (TPS_F_STORE_RAW); the kernels without it carry
@@ -1134,9 +1138,17 @@ TPS_DEV uint32_t pack_hi_lo(uint32_t hi_src, uint32_t lo_src) { return perm(hi_s
 // A window ends r positions into a block, so every block publishes its prefix words at that position; with r known at
 // compile time the capture is a plain copy at one unrolled position instead of two selects at every position (measured on
 // the slide-7 kernel, r = 4: 112 of ~565 instructions per tile).  scan_read switches on r once per tile.
-template <int S, bool SO, bool INV, int RPT, bool PAIR, bool RAW>
-TPS_DEV void tile_fused_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int delta, int w0, int tile, int nw_tile,
+// CD > 0: CHAIN DETECTION for a table whose self-overlapping k-mers share the one period CD (sums only).  Occurrences of
+// such a k-mer D apart are counted once by the reference's non-overlapping search; a tile in which NO pattern occurs at
+// p and again at p + CD (both inside the tile) needs none of that: every window's count is the plain prefix difference.
+// Phase 1 ANDs the table entries CD positions apart (one v_and_or per position); if any lane saw a chain the tile returns
+// true right after phase 1, nothing but its own exchange words written, and the caller runs tile_so_s on it.  Otherwise
+// it completes as a plain tile and leaves tile_so_s's carry (the picks of the CD positions before the next tile's first
+// = plain occurrences there) for a following chained tile.
+template <int S, bool SO, bool INV, int RPT, bool PAIR, bool RAW, int CD = 0>
+TPS_DEV bool tile_fused_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int delta, int w0, int tile, int nw_tile,
                           int64_t out_base, uint64_t& s_total, int64_t r) {
+    static_assert(CD == 0 || (!SO && !INV && !PAIR && CD <= S), "chain detection: single lookups on clean tiles, period <= slide");
     // RZ: the window has no partial block (W - k divisible by the slide), so nothing is captured mid-block
     constexpr bool RZ = RPT == 0;
     typedef Geo<S> g_;
@@ -1145,6 +1157,7 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const TileConst& tc, const Lds& l, 
     const PatInfo& pat = a.pat;
     const int rp = RPT >= 0 ? RPT : tc.r, q = tc.q;   // rp: positions of the partial block (a.r)
     const uint32_t amask = pat.kmask << 2;        // k-mer code as a byte offset into the 4-byte table
+    uint32_t chain_any = 0;                       // CD: mask half of (entry at p) & (entry at p + CD), OR over the lane's positions
     TPS_PHASE {
         const int span = tid;
         // The lane's bases start at an arbitrary bit offset; one per-lane funnel shift aligns the base
@@ -1216,6 +1229,7 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const TileConst& tc, const Lds& l, 
         } else {
             // table lookups run one block ahead of their use (software pipeline, 2 S values in flight)
             uint32_t hc[S], hn[S];
+            uint32_t cf = 0;
             auto fetch = [&](int blk, uint32_t* hh, int cnt_) {
                 TPS_UNROLL
                 for (int i = 0; i < S; ++i) {
@@ -1254,6 +1268,11 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const TileConst& tc, const Lds& l, 
             for (int blk = 0; blk < B; ++blk) {
                 if (blk + 1 < B) fetch(blk + 1, hn, S);
                 else if (SO) fetch(B, hn, MAXD);          // look-ahead past the lane's last block (w[] holds 13 extra bases)
+                else if (CD > 0) fetch(B, hn, CD);
+                if constexpr (CD > 0) {
+                    TPS_UNROLL
+                    for (int i = 0; i < S; ++i) cf |= hc[i] & (i + CD < S ? hc[i + CD] : hn[i + CD - S]);
+                }
                 uint32_t g = 0;
                 c0s[blk] = cnt;
                 uint32_t c1 = cnt, pp = run_or;
@@ -1283,6 +1302,7 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const TileConst& tc, const Lds& l, 
                 TPS_UNROLL
                 for (int i = 0; i < S; ++i) hc[i] = hn[i];
             }
+            if constexpr (CD > 0) chain_any |= cf & 0xFFFF0000u;
         }
         uint32_t sfx = 0;
         TPS_UNROLL
@@ -1293,6 +1313,17 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const TileConst& tc, const Lds& l, 
         l.XF[span] = pack_hi_lo(sfx, cnt);        // the lane's OR | the lane's matches
     }
     TPS_SYNC();
+    if constexpr (CD > 0) {
+#ifdef TPS_EMU
+        const bool chained = chain_any != 0;      // (the emulation's phase loop has OR-ed every lane into the one variable)
+#else
+        const bool chained = __builtin_amdgcn_ballot_w64(chain_any != 0) != 0;
+#endif
+        if (chained) return true;
+#ifdef TPS_EMU
+        ++emu_counter(6);
+#endif
+    }
     if (w0 == 0) TPS_STAMP(6);
     if (w0 == 0) TPS_STAMP(7);
     const int rot = q & (B - 1), dl0 = q >> LOG2B;
@@ -1326,6 +1357,17 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const TileConst& tc, const Lds& l, 
 #endif
         l.XF[tid] = fo_a;
         l.XT[tid] = fo_b;
+        if constexpr (CD > 0) {
+            // what tile_so_s wants to know about the positions before the NEXT tile's first one: no chain here, so the
+            // picks there are the plain occurrences, and nothing is uncertain
+            if (tid == (a.tw >> LOG2B)) {
+                uint32_t* carry = l.misc + M_SCAN;
+                const int pn = delta + a.tw * S - CD;
+                TPS_UNROLL
+                for (int i = 0; i < CD; ++i) carry[i] = lut_mask(l.lut, l.lshift, pat, v_at(l.seq2, pn + i)) << 16;
+                carry[6] = 0;
+            }
+        }
     }
     TPS_SYNC();
 #ifdef TPS_EMU
@@ -1522,6 +1564,7 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const TileConst& tc, const Lds& l, 
     }
     s_total += gsum;
     TPS_SYNC();
+    return false;
 }
 
 // After the window phase of a fused tile (row[] = S_w of the tile's windows, padded layout, 0 beyond nw_tile):
@@ -1588,9 +1631,6 @@ TPS_DEV void tile_candidates(const TileConst& tc, const Lds& l, int w0, int tile
 //   phase 2  (lane-contiguous) window 8 L + j = own lane from block j on + whole lanes in between + END[8 L + j + q]:
 //            bytes, floored to 1, summed (S_w), transposed into pattern order, stored
 //   phase 3  tile_candidates
-#ifdef TPS_EMU
-inline int& emu_counter(int i) { static int c[8] = {0, 0, 0, 0, 0, 0, 0, 0}; return c[i]; }   // tests: 0 = per-pattern tiles, 1 = windows recounted there, 4 = exact change-point tournaments
-#endif
 template <int S>
 struct GeoPP {
     static constexpr int B = 8, POS = B * S, LBK = 16;
@@ -3036,6 +3076,16 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
                     // sums only, a table with one self-overlap period: canonical picks on the mask words (tile_so_s)
                     constexpr int SP = SV ? SV : 5;
                     if (a.pp_d > 0 && uniform(l.misc[M_INVALID]) == 0) {
+                        // tiles without a chained occurrence (most tiles outside the telomere) complete as plain tiles
+                        bool chained = true;
+                        if (a.so_fast) {
+#define TPS_CD_RP(D_, N) case N: if constexpr (N < SP && D_ <= SP) chained = tile_fused_s<SP, false, false, (N < SP ? N : 0), false, false, (D_ <= SP ? D_ : 0)>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r); break;
+#define TPS_CD(D_) case D_: switch (tc.r) { TPS_CD_RP(D_, 0) TPS_CD_RP(D_, 1) TPS_CD_RP(D_, 2) TPS_CD_RP(D_, 3) TPS_CD_RP(D_, 4) TPS_CD_RP(D_, 5) TPS_CD_RP(D_, 6) TPS_CD_RP(D_, 7) default: break; } break;
+                            switch (a.pp_d) { TPS_CD(2) TPS_CD(3) TPS_CD(4) TPS_CD(5) TPS_CD(6) default: break; }
+#undef TPS_CD
+#undef TPS_CD_RP
+                        }
+                        if (!chained) continue;
                         switch (a.pp_d) {
                             case 2: tile_so_s<SP, 2>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
                             case 3: tile_so_s<SP, 3>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;

@@ -33,6 +33,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <pthread.h>
+#include <ctime>
 #include <string>
 #include <thread>
 #include <vector>
@@ -160,14 +165,72 @@ int io_threads() {
     }
     return (int)std::max(1u, n);
 }
+// TPS_IO_TIMING=1: phase times of the fast reader on stderr (diagnostics)
+inline bool io_timing() { static const bool on = getenv("TPS_IO_TIMING") != nullptr; return on; }
+inline double now_s() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+// The thread team: f(thread index, thread count) on `nthreads` threads, the caller being thread 0.  The workers are
+// created once and parked on a condition variable between calls (a team call per batch used to create and join its
+// threads: on a busy or quota-limited host that cost more than the decoding).  One team runs at a time; readers of
+// several files take turns.  A forked child starts with a fresh pool (threads do not survive fork).
+struct Pool {
+    std::mutex run_mu;                         // one team at a time
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::function<void(int, int)> job;
+    int nt = 0, remaining = 0, spawned = 0;
+    uint64_t gen = 0;
+    void worker(int w) {
+        uint64_t seen = 0;
+        for (;;) {
+            std::function<void(int, int)> fn;
+            int n;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return gen != seen; });
+                seen = gen;
+                if (w >= nt) continue;
+                fn = job;
+                n = nt;
+            }
+            fn(w, n);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (--remaining == 0) cv_done.notify_one();
+            }
+        }
+    }
+    void run(int nthreads, const std::function<void(int, int)>& f) {
+        std::lock_guard<std::mutex> run_lk(run_mu);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            while (spawned < nthreads - 1) {
+                ++spawned;
+                std::thread(&Pool::worker, this, spawned).detach();
+            }
+            job = f;
+            nt = nthreads;
+            remaining = nthreads - 1;
+            ++gen;
+        }
+        cv_work.notify_all();
+        f(0, nthreads);
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return remaining == 0; });
+    }
+};
+Pool* g_pool = nullptr;
+std::once_flag g_pool_once;
+inline Pool& pool() {
+    std::call_once(g_pool_once, [] {
+        g_pool = new Pool();                   // never destroyed: its threads are detached and end with the process
+        pthread_atfork(nullptr, nullptr, [] { g_pool = new Pool(); });
+    });
+    return *g_pool;
+}
 template <typename F>
 void team(int nthreads, F f) {                 // f(thread index, thread count); runs inline for one thread
     if (nthreads <= 1) { f(0, 1); return; }
-    std::vector<std::thread> th;
-    th.reserve((size_t)nthreads - 1);
-    for (int t = 1; t < nthreads; ++t) th.emplace_back([=] { f(t, nthreads); });
-    f(0, nthreads);
-    for (auto& x : th) x.join();
+    pool().run(nthreads, std::function<void(int, int)>(f));
 }
 
 // BGZF (bgzip): a gzip file made of independent <= 64 KiB members whose size is in the header's "BC" extra field
@@ -260,6 +323,7 @@ struct Fast {
     std::vector<Rec> recs;
 
     ~Fast() {
+        give_spare();
         if (src) delete src;
         else if (data) munmap((void*)data, size);
         if (fd >= 0) close(fd);
@@ -278,6 +342,7 @@ struct Fast {
             data = mem.data();
             size = mem.size();
         }
+        const double t_ix = io_timing() ? now_s() : 0.0;
         const size_t lo = pos, span = src ? size - lo : std::min<size_t>(size - lo, (size_t)512 << 20);
         win_hi = lo + span;
         whole = src ? src->eof() : win_hi == size;
@@ -300,6 +365,7 @@ struct Fast {
         for (auto& v : part) nl.insert(nl.end(), v.begin(), v.end());
         if (whole && size && data[size - 1] != '\n') nl.push_back(size);      // last line without a newline
         nl_i = 0;
+        if (io_timing()) fprintf(stderr, "[tps_io] index %.2f ms: %zu bytes, %zu lines, %d threads\n", 1e3 * (now_s() - t_ix), span, nl.size(), T);
     }
     // >= 0: records decoded; -3: not plain 4-line FASTQ here -> caller switches to the streaming decoder at `pos`
     int64_t next(uint8_t* bases, int64_t bases_cap, int64_t* offsets, int64_t max_records, char* heads, int64_t heads_cap,
@@ -352,74 +418,176 @@ struct Fast {
     // Packed variant of next() for mmap'ed plain FASTQ: records are packed (tps_pack.h) into seq2 / inv / desc, no ASCII
     // copy.  spans gets 4 entries per record: header offset and length, sequence offset, quality offset (text offsets).
     // -3: not plain 4-line FASTQ here; -2: a single record does not fit.
+    // One 4-line FASTQ record at text offset s: 0 = well formed (r filled, next = start of the following record), 1 = not a
+    // plain 4-line record here (or the text ends inside it).  The quality line is located by the sequence length and only
+    // its end is looked at -- its bytes are never read.
+    int parse_at(size_t s, Rec& r, size_t& next) const {
+        if (s >= size || data[s] != '@') return 1;
+        const char* e0p = (const char*)memchr(data + s, '\n', size - s);
+        if (!e0p) return 1;
+        const size_t e0 = (size_t)(e0p - data);
+        const size_t h1 = (e0 > s && data[e0 - 1] == '\r') ? e0 - 1 : e0;
+        if (h1 <= s) return 1;
+        const size_t s0 = e0 + 1;
+        if (s0 >= size) return 1;
+        const char* e1p = (const char*)memchr(data + s0, '\n', size - s0);
+        if (!e1p) return 1;
+        const size_t e1 = (size_t)(e1p - data);
+        const size_t s1 = (e1 > s0 && data[e1 - 1] == '\r') ? e1 - 1 : e1;
+        if (e1 + 1 >= size || data[e1 + 1] != '+') return 1;
+        const char* e2p = (const char*)memchr(data + e1 + 1, '\n', size - (e1 + 1));
+        if (!e2p) return 1;
+        const size_t q0 = (size_t)(e2p - data) + 1, sl = s1 - s0;
+        size_t q1 = q0 + sl;                                    // where the quality line has to end
+        if (q1 > size) return 1;
+        if (q1 < size) {
+            if (data[q1] == '\r' && q1 + 1 < size && data[q1 + 1] == '\n') next = q1 + 2;
+            else if (data[q1] == '\n') next = q1 + 1;
+            else return 1;                                      // more (or fewer) quality characters than bases
+        } else {
+            next = size;                                        // last line without a newline
+        }
+        if (sl && memchr(data + q0, '\n', sl)) return 1;        // a shorter quality line followed by something else
+        if (sl > 0x7FFFFFFFull) return 1;
+        if (sl && (data[s0] == ' ' || data[s0] == '\t' || data[s1 - 1] == ' ' || data[s1 - 1] == '\t')) return 1;
+        r = Rec{s + 1, (uint64_t)(h1 - s - 1), s0, (uint64_t)sl, q0};
+        return 0;
+    }
+    // What one thread of the team found in its stretch of the text: the records that START there, already packed into
+    // position-independent staging (every read begins on a quad boundary, so a run of reads is copied as one block).
+    struct Chunk {
+        std::vector<Rec> recs;
+        std::vector<uint32_t> seq2;
+        std::vector<uint16_t> inv;
+        std::vector<uint8_t> bad;                  // per record: has an invalid base
+        std::vector<int64_t> woff;                 // per record: word offset inside the staging
+        size_t first = 0, end = 0;                 // start of the first record, start of the record after the last
+        bool odd = false;                          // stopped at something that is not a plain 4-line record (at `end`)
+        int64_t base_rec = 0, base_word = 0, base_head = 0, take = 0;
+    };
+    std::vector<Chunk> chunks;
+    // the staging of a finished reader is kept for the next one (a few tens of MB that would otherwise be allocated, faulted
+    // in and freed again for every input file)
+    static std::mutex& spare_mu() { static std::mutex m; return m; }
+    static std::vector<std::vector<Chunk>>& spare() { static std::vector<std::vector<Chunk>> v; return v; }
+    void take_spare() {
+        std::lock_guard<std::mutex> lk(spare_mu());
+        if (!spare().empty()) { chunks.swap(spare().back()); spare().pop_back(); }
+    }
+    void give_spare() {
+        if (chunks.empty()) return;
+        std::lock_guard<std::mutex> lk(spare_mu());
+        if (spare().size() < 2) { spare().emplace_back(); spare().back().swap(chunks); }
+    }
     int64_t next_packed(uint32_t* seq2, uint16_t* inv, int64_t words_cap, tps_read_desc* desc, int64_t max_records, char* heads,
                         int64_t heads_cap, int64_t* head_off, int64_t* spans) {
-        recs.clear();
-        int64_t nw = 0, nh = 0;
+        // The text from the first unconsumed record on is cut into one stretch per thread; a thread finds the first record
+        // that starts in its stretch (a line that begins with '@', is followed by a sequence line, a '+' line and a quality
+        // line of the sequence's length -- a quality line that happens to begin with '@' fails that test), then decodes
+        // record after record: two memchr for the header and the sequence, the quality line skipped by length, the bases
+        // packed (AVX2) into the thread's staging while they are still in cache.  The stretches are then joined in order
+        // (each has to begin exactly where the previous one ended), capped at what the caller's buffers hold, and copied out.
+        // Text read: headers + sequence lines once.  Not read: the quality lines (half of the file).
         head_off[0] = 0;
-        size_t p = pos;
-        while ((int64_t)recs.size() < max_records) {
-            if (nl_i + 4 > nl.size()) {
-                if (!whole) {
-                    if (!recs.empty()) break;
-                    if (p >= size) break;
-                    pos = p;
-                    index_window();
-                    p = pos;
-                    if (nl.size() >= 4) continue;
-                    if (!whole) return -3;
-                }
-                if (only_blank(p)) break;
-                if (recs.empty()) return -3;
-                break;
-            }
-            const uint64_t e0 = nl[nl_i], e1 = nl[nl_i + 1], e2 = nl[nl_i + 2], e3 = nl[nl_i + 3];
-            auto trim = [&](uint64_t a, uint64_t e) { return (e > a && data[e - 1] == '\r') ? e - 1 : e; };
-            const uint64_t h0 = p, h1 = trim(p, e0), s0 = e0 + 1, s1 = trim(s0, e1), q0 = e2 + 1, q1 = trim(q0, e3);
-            const bool ok = h1 > h0 && data[h0] == '@' && e1 + 1 < size && data[e1 + 1] == '+' && (s1 - s0) == (q1 - q0) &&
-                            (s1 == s0 || (data[s0] != ' ' && data[s0] != '\t' && data[s1 - 1] != ' ' && data[s1 - 1] != '\t'));
-            if (!ok) {
-                if (recs.empty()) return -3;
-                break;
-            }
-            const int64_t sl = (int64_t)(s1 - s0), hl = (int64_t)(h1 - h0 - 1);
-            if (sl > 0x7FFFFFFFll) return -3;
-            const int64_t w = tps::packed_words(sl);
-            if (nw + w > words_cap || nh + hl > heads_cap) {
-                if (recs.empty()) return -2;
-                break;
-            }
-            const size_t i = recs.size();
-            recs.push_back(Rec{h0 + 1, (uint64_t)hl, s0, (uint64_t)sl, q0});
-            desc[i].word_off = nw;
-            desc[i].len = (int32_t)sl;
-            desc[i].flags = 0;
-            nw += w;
-            nh += hl;
-            head_off[i + 1] = nh;
-            nl_i += 4;
-            p = std::min<size_t>((size_t)e3 + 1, size);
-        }
-        const size_t n = recs.size();
-        const int T = nw < (1 << 18) ? 1 : threads;
+        nl.clear(); nl_i = 0; whole = false;       // (the line index of next() is not used here and is stale afterwards)
+        const double t_a = io_timing() ? now_s() : 0.0;
+        const size_t p = pos;
+        if (p >= size || only_blank(p)) return 0;
+        // text that yields at most words_cap words if it were nothing but sequence + quality lines
+        size_t span = std::min<size_t>(size - p, (size_t)std::max<int64_t>(words_cap, 1024) * 32);
+        static const size_t min_span = getenv("TPS_IO_PACK_MIN_SPAN") ? (size_t)atoll(getenv("TPS_IO_PACK_MIN_SPAN")) : (size_t)4 << 20;   // (tests: team on small files)
+        const int T = span < min_span ? 1 : threads;
+        if (chunks.empty()) take_spare();
+        if ((int)chunks.size() < T) chunks.resize((size_t)T);
         team(T, [&](int t, int nt) {
-            // ranges of ~equal words, not of equal record counts: reads vary in length
-            const int64_t wa = nw * (int64_t)t / nt, wb = nw * (int64_t)(t + 1) / nt;
-            size_t a = std::lower_bound(desc, desc + n, wa, [](const tps_read_desc& d, int64_t v) { return d.word_off < v; }) - desc;
-            size_t b = t + 1 == nt ? n : std::lower_bound(desc, desc + n, wb, [](const tps_read_desc& d, int64_t v) { return d.word_off < v; }) - desc;
-            for (size_t i = a; i < b; ++i) {
-                const Rec& r = recs[i];
-                if (tps::pack_one((const uint8_t*)data + r.s0, (int64_t)r.sl, seq2 + desc[i].word_off, inv ? inv + desc[i].word_off : nullptr))
-                    desc[i].flags |= TPS_RD_HAS_INVALID;
-                memcpy(heads + head_off[i], data + r.h0, (size_t)r.hl);
+            Chunk& c = chunks[(size_t)t];
+            c.recs.clear(); c.seq2.clear(); c.inv.clear(); c.bad.clear(); c.woff.clear();
+            c.odd = false; c.take = 0;
+            const size_t a = p + span * (size_t)t / (size_t)nt, b = p + span * (size_t)(t + 1) / (size_t)nt;
+            size_t s = a;
+            Rec r;
+            size_t nx = 0;
+            if (t > 0) {
+                // first line start >= a that opens a well-formed record (a itself counts if the previous byte ends a line)
+                s = b;
+                const char* q = (const char*)memchr(data + a - 1, '\n', b - (a - 1));
+                while (q) {
+                    const size_t cand = (size_t)(q - data) + 1;
+                    if (cand >= b) break;
+                    if (data[cand] == '@' && parse_at(cand, r, nx) == 0) { s = cand; break; }
+                    q = (const char*)memchr(data + cand, '\n', b - cand);
+                }
+            }
+            c.first = c.end = s;
+            c.seq2.reserve((b - a) / 28 + 1024);
+            if (inv) c.inv.reserve((b - a) / 28 + 1024);
+            while (s < b) {
+                if (parse_at(s, r, nx) != 0) { c.odd = true; break; }
+                const int64_t w = tps::packed_words((int64_t)r.sl), at = (int64_t)c.seq2.size();
+                c.seq2.resize((size_t)(at + w));
+                if (inv) c.inv.resize((size_t)(at + w));
+                const bool bad = tps::pack_one((const uint8_t*)data + r.s0, (int64_t)r.sl, c.seq2.data() + at, inv ? c.inv.data() + at : nullptr);
+                c.recs.push_back(r);
+                c.bad.push_back(bad ? 1 : 0);
+                c.woff.push_back(at);
+                s = nx;
+                c.end = s;
+            }
+        });
+        const double t_b = io_timing() ? now_s() : 0.0;
+        // join: stretch t has to begin where the records before it ended (a stretch in which no record starts is empty)
+        int64_t n = 0, nw = 0, nh = 0;
+        size_t cur = p;
+        bool stop = false, too_big = false;
+        for (int t = 0; t < T && !stop; ++t) {
+            Chunk& c = chunks[(size_t)t];
+            c.base_rec = n; c.base_word = nw; c.base_head = nh;
+            if (c.recs.empty()) {
+                if (c.odd && c.first == cur) stop = true;     // the very next record is not a plain one
+                continue;
+            }
+            if (c.first != cur) break;                        // mis-framed stretch: the next call starts at `cur`, a known record start
+            for (size_t i = 0; i < c.recs.size(); ++i) {
+                const int64_t w = tps::packed_words((int64_t)c.recs[i].sl), hl = (int64_t)c.recs[i].hl;
+                if (n >= max_records || nw + w > words_cap || nh + hl > heads_cap) {
+                    too_big = n == 0 && (w > words_cap || hl > heads_cap);
+                    stop = true;
+                    break;
+                }
+                desc[n].word_off = nw;
+                desc[n].len = (int32_t)c.recs[i].sl;
+                desc[n].flags = c.bad[i] ? TPS_RD_HAS_INVALID : 0;
+                nw += w; nh += hl; ++n;
+                head_off[n] = nh;
+                ++c.take;
+                cur = i + 1 < c.recs.size() ? (size_t)(c.recs[i + 1].h0 - 1) : c.end;
+            }
+            if (c.odd) stop = true;
+        }
+        if (n == 0) {
+            if (too_big) return -2;
+            return -3;                                        // not plain 4-line FASTQ at `pos`: the streaming decoder judges it
+        }
+        team(T, [&](int t, int) {
+            const Chunk& c = chunks[(size_t)t];
+            if (!c.take) return;
+            const int64_t words = (c.take < (int64_t)c.recs.size()) ? c.woff[(size_t)c.take] : (int64_t)c.seq2.size();
+            memcpy(seq2 + c.base_word, c.seq2.data(), (size_t)words * sizeof(uint32_t));
+            if (inv) memcpy(inv + c.base_word, c.inv.data(), (size_t)words * sizeof(uint16_t));
+            for (int64_t i = 0; i < c.take; ++i) {
+                const Rec& r = c.recs[(size_t)i];
+                const int64_t g = c.base_rec + i;
+                memcpy(heads + head_off[g], data + r.h0, (size_t)r.hl);
                 if (spans) {
-                    spans[4 * i] = (int64_t)r.h0; spans[4 * i + 1] = (int64_t)r.hl;
-                    spans[4 * i + 2] = (int64_t)r.s0; spans[4 * i + 3] = (int64_t)r.q0;
+                    spans[4 * g] = (int64_t)r.h0; spans[4 * g + 1] = (int64_t)r.hl;
+                    spans[4 * g + 2] = (int64_t)r.s0; spans[4 * g + 3] = (int64_t)r.q0;
                 }
             }
         });
-        pos = p;
-        return (int64_t)n;
+        if (io_timing()) fprintf(stderr, "[tps_io] batch of %lld records: decode+pack %.2f ms, join+copy %.2f ms (%lld words, %d threads, %zu bytes of text)\n",
+                                 (long long)n, 1e3 * (t_b - t_a), 1e3 * (now_s() - t_b), (long long)nw, T, cur - p);
+        pos = cur;
+        return n;
     }
     bool only_blank(size_t from) const {
         for (size_t i = from; i < size; ++i)
@@ -462,14 +630,14 @@ const char* tps_io_last_error(void) { return g_err.c_str(); }
 
 // Opens a FASTA/FASTQ file (plain or .gz).  The format comes from the first byte, like check_file_type
 // (allsteps.py:36-50).  Plain FASTQ files are mmap'ed for the thread-team decoder.  Returns 0 or -1.
-static Reader* open_stream(const char* path, int64_t seek_to, int format) {
+static Reader* open_stream(const char* path, int64_t seek_to, int format, size_t buf_bytes = (size_t)4 << 20) {
     gzFile gz = gzopen(path, "rb");
     if (!gz) { g_err = std::string("cannot open ") + path; return nullptr; }
-    gzbuffer(gz, 1 << 20);
+    gzbuffer(gz, buf_bytes < (1u << 20) ? (unsigned)buf_bytes : 1u << 20);
     if (seek_to > 0 && gzseek(gz, (z_off_t)seek_to, SEEK_SET) < 0) { g_err = "seek failed"; gzclose(gz); return nullptr; }
     Reader* r = new Reader();
     r->gz = gz;
-    r->buf.resize(4 << 20);
+    r->buf.resize(buf_bytes);
     r->format = format;
     return r;
 }
@@ -489,7 +657,9 @@ int tps_reader_open(const char* path, void** out) {
         fclose(f);
         plain = !(got == 2 && m[0] == 0x1f && m[1] == 0x8b);
     }
-    Reader* r = open_stream(path, 0, 0);
+    // (a plain file only needs its first bytes here -- the thread-team decoder works on the mapping; the streaming
+    // decoder's buffer grows to its working size when it is really used)
+    Reader* r = open_stream(path, 0, 0, plain ? (size_t)64 << 10 : (size_t)4 << 20);
     if (!r) { delete h; return -1; }
     h->slow = r;
     g_err.clear();
@@ -587,6 +757,7 @@ int64_t tps_reader_next(void* hv, uint8_t* bases, int64_t bases_cap, int64_t* of
         if (!h->slow) return -1;
     }
     Reader* r = h->slow;
+    if (r->buf.size() < ((size_t)4 << 20)) r->buf.resize((size_t)4 << 20);      // (opened with the small sniffing buffer)
     int64_t n = 0, nb = 0, nh = 0;
     g_err.clear();
     while (n < max_records) {

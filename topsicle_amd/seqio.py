@@ -294,6 +294,11 @@ class BufferSet:
         self.seq2 = alloc(4 * self.words_cap).view(np.uint32)
         self.inv = alloc(2 * self.words_cap).view(np.uint16)
         self.desc = alloc(16 * self.reads_cap).view(hiplib.DESC_DTYPE)
+        # scratch the packed reader fills per batch (the used parts are copied into the PackedBatch: they outlive release())
+        self.heads_cap = max(self.words_cap * 2, 1 << 20)
+        self.heads = np.empty(self.heads_cap, np.uint8)
+        self.head_off = np.empty(self.reads_cap + 1, np.int64)
+        self.spans = np.empty((self.reads_cap, 4), np.int64)
 
 
 class BufferPool:
@@ -415,20 +420,17 @@ def read_batches_packed(filepath: str, pool: BufferPool, max_records: int = 1 <<
         fmt = {1: "fasta", 2: "fastq"}.get(lib.tps_reader_format(h), "fasta")
         packed_mode = True
         nrec_cap = min(max_records, pool.reads_cap)
-        heads_cap = max(pool.words_cap * 2, 1 << 20)
         while packed_mode:
             bs = pool.get()
-            heads = np.empty(heads_cap, np.uint8)
-            head_off = np.empty(nrec_cap + 1, np.int64)
-            spans = np.empty((nrec_cap, 4), np.int64)
+            heads, head_off, spans = bs.heads, bs.head_off, bs.spans
             nw = C.c_int64(0)
             n = lib.tps_reader_next_packed(h, bs.seq2.ctypes.data, bs.inv.ctypes.data, bs.words_cap, bs.desc.ctypes.data, nrec_cap,
-                                           heads.ctypes.data, heads_cap, head_off.ctypes.data, spans.ctypes.data, C.byref(nw))
+                                           heads.ctypes.data, bs.heads_cap, head_off.ctypes.data, spans.ctypes.data, C.byref(nw))
             if n > 0:
                 if mm is None:
                     fh = open(filepath, "rb")
                     mm = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
-                yield PackedBatch(bs.seq2[:nw.value], bs.inv[:nw.value], bs.desc[:n], heads[:int(head_off[n])], head_off[:n + 1].copy(),
+                yield PackedBatch(bs.seq2[:nw.value], bs.inv[:nw.value], bs.desc[:n], heads[:int(head_off[n])].copy(), head_off[:n + 1].copy(),
                                   fmt, spans=spans[:n].copy(), text=mm, bufset=bs, pool=pool)
                 continue
             pool.put(bs)
