@@ -18,6 +18,9 @@ __global__ void __launch_bounds__(256) k(uint32_t* out, int iters, uint32_t seed
             if (OP == 5) a[i] = __builtin_amdgcn_udot4(a[i], m, a[(i + 1) & 7], false);
             if (OP == 6) a[i] = __builtin_amdgcn_perm(a[i], m, a[(i + 1) & 7]);
             if (OP == 7) a[i] = a[i] * m;                                            // v_mul_lo_u32
+            if (OP == 8) a[i] = __umulhi(a[i], a[i]) + 1u;                            // v_mul_hi_u32 (+ v_add)
+            if (OP == 10) a[i] = (a[i] << (a[(i + 1) & 7] & 31)) + 1u;                 // v_lshlrev + v_add
+            if (OP == 11) a[i] = __builtin_amdgcn_sad_u8(a[i], m, a[(i + 1) & 7]);      // v_sad_u8
         }
     }
     uint32_t s = 0;
@@ -40,6 +43,7 @@ int main() {
     for (int w : {1, 2, 4, 8}) {
         run<0>("v_alignbit", d, w); run<1>("v_and+v_add", d, w); run<2>("v_bcnt", d, w); run<3>("v_lshl_add", d, w);
         run<4>("v_or3", d, w); run<5>("v_dot4_u32_u8", d, w); run<6>("v_perm", d, w); run<7>("v_mul_lo_u32", d, w);
+        run<8>("v_mul_hi+add", d, w); run<10>("v_lshl+add", d, w); run<11>("v_sad_u8", d, w);
     }
     return 0;
 }

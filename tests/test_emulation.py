@@ -450,6 +450,29 @@ def test_emulation_chain_free_tiles_hand_over(motif, k, slide, unit):
     assert redone < 40 * len(seqs)
 
 
+@pytest.mark.parametrize("motif,k,slide,counts", [("CCCTAA", 5, 6, [1, 2, 3, 5, 6, 7, 9, 10, 11, 12]), ("AAACCCT", 5, 7, [13, 14])])
+def test_emulation_raw_rows_for_any_number_of_patterns(motif, k, slide, counts):
+    """Raw rows of the per-pattern tiles leave through LDS whatever the row length: 4 / 8 / 12 bytes packed, other even
+    lengths in 16-bit units, odd lengths (hand-made pattern lists through the C ABI) byte by byte."""
+    rng = np.random.default_rng(k * 100 + slide)
+    table = orc.kmer_table(motif, k)
+    _, seqs = _pp_reads(rng, motif, k, 3, 7000, [])
+    flags = hiplib.F_WINDOWS | hiplib.F_TAILS_IN | hiplib.F_STORE_SUMS | hiplib.F_STORE_RAW
+    prm = hiplib.make_params(window=100, slide=slide, trimfirst=100, maxlen=20000, flags=flags)
+    L = emu.lib()
+    tails = [0, 1, 0]
+    for P in counts:
+        pats = table[:P]
+        t0 = L.emu_counter(0)
+        out = emu.scan(pats, seqs, prm, tails=tails)
+        assert L.emu_counter(0) > t0, ("per-pattern tiles not used", P)
+        for i, seq in enumerate(seqs):
+            _, want = orc.window_count_matrix(seq, ["forward", "reverse"][tails[i]], pats, 100, slide, 100, 20000)
+            lo, hi = out["win_off"][i], out["win_off"][i + 1]
+            assert np.array_equal(out["raw"][lo:hi], want.reshape(-1, P)), (P, i)
+            assert np.array_equal(out["sums"][lo:hi], want.sum(axis=1)), (P, i)
+
+
 def test_planner_picks_per_pattern_tiles():
     """Which tables take the per-pattern tiles: one self-overlap period (or none), distinct k-mers, k >= 4."""
     def plan(motif, k, slide, flags=0):

@@ -1830,10 +1830,10 @@ TPS_DEV void tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
     uint32_t todo_keep[NT];
     for (int t = 0; t < NT; ++t) todo_keep[t] = 0;
 #endif
-    // raw rows of 4, 8 or 12 bytes are staged through LDS and leave in whole cache lines
-    const bool staged = a.raw != nullptr && (pat.P & 3) == 0 && pat.P <= 12;
-    // rows of 2, 6, 10 or 14 bytes likewise, padded to 16 bytes in LDS and copied out in 16-bit units
-    const bool staged16 = a.raw != nullptr && (pat.P & 3) == 2 && pat.P <= 14;
+    // raw rows (P <= 14 bytes: plan_geometry) always leave through LDS, coalesced: rows of 4, 8 or 12 bytes packed and in
+    // whole cache lines; the others padded to 16 bytes in LDS and copied out in 16-bit units (P even) or bytes (P odd)
+    const bool staged = a.raw != nullptr && (pat.P & 3) == 0;
+    const bool staged16 = a.raw != nullptr && (pat.P & 3) != 0;
     TPS_PHASE {
 #ifdef TPS_EMU
         for (int i = 0; i < B; ++i) { ve[i] = keep[tid][i]; vo[i] = keep[tid][B + i]; }
@@ -1877,21 +1877,28 @@ TPS_DEV void tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
             todo_keep[tid] = todo;
 #endif
         }
+        // windows j >= B - rot end one lane further on (far end): the running totals switch from fa to fb there, once
+        // (a scalar branch around four copies instead of a select per word and window)
+        uint32_t fc[4] = {fa[0], fa[1], fa[2], fa[3]};
+        const int brk = B - rot;
         TPS_UNROLL
         for (int j = 0; j < B; ++j) {
             const int wl = lane * B + j;
             uint32_t sw = 0;
             uint32_t o[4] = {0, 0, 0, 0};
+            if (j == brk) {                        // uniform
+                TPS_UNROLL
+                for (int i = 0; i < 4; ++i) { fc[i] = fb[i]; TPS_PIN_V(fc[i]); }
+            }
             if (wl < nw_tile) {
-                const bool far_ = j + rot >= B;    // uniform
                 uint32_t v[4], e[4], c[4];
                 pp_expand(ve[j], vo[j], v);
                 pp_expand(ee[j], eo[j], e);
                 sw = (uint32_t)pat.P - 16u;         // the 16 - P unused fields are floored to 1 like the others
                 TPS_UNROLL
                 for (int i = 0; i < 4; ++i) {
-                    c[i] = (far_ ? fb[i] : fa[i]) + v[i] + e[i];
-                    c[i] += (((c[i] + 0x7F7F7F7Fu) >> 7) & 0x01010101u) ^ 0x01010101u;   // `matches or 1` per byte (counts <= 127)
+                    c[i] = fc[i] + v[i] + e[i];
+                    c[i] |= ((0x80808080u - c[i]) >> 7) & 0x01010101u;     // `matches or 1` per byte (counts <= 127): bit 0 set where the byte is 0
                     sw = add_bytes(c[i], sw);
                 }
                 if (a.raw) {
@@ -1902,20 +1909,6 @@ TPS_DEV void tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
                     o[1] = perm(b_lo, a_lo, 0x07060302u);
                     o[2] = perm(b_hi, a_hi, 0x05040100u);
                     o[3] = perm(b_hi, a_hi, 0x07060302u);
-                }
-                if (a.raw && !staged && !staged16) {
-                    uint8_t* raw_row = a.raw + (out_base + w0 + wl) * (int64_t)pat.P;
-                    const int P = pat.P;
-                    if ((P & 1) == 0) {
-                        uint16_t* r16 = (uint16_t*)raw_row;
-                        TPS_UNROLL
-                        for (int i = 0; i < 8; ++i)
-                            if (2 * i < P) r16[i] = (uint16_t)(o[i >> 1] >> (16 * (i & 1)));
-                    } else {
-                        TPS_UNROLL
-                        for (int i = 0; i < 16; ++i)
-                            if (i < P) raw_row[i] = (uint8_t)(o[i >> 2] >> (8 * (i & 3)));
-                    }
                 }
                 out[j] = (int32_t)sw;
             }
@@ -1994,7 +1987,7 @@ TPS_DEV void tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
     } else if (staged16) {
         constexpr int LPP = 22;                   // 22 lanes x 8 rows x 16 bytes = 2816 <= 2944 bytes
         const int ph = pat.P >> 1;                // 16-bit units per row: 1, 3, 5 or 7
-        const uint32_t ph_magic = (65536u + (uint32_t)ph - 1u) / (uint32_t)ph;    // u / ph = (u * magic) >> 16 for u < 2^15
+        const uint32_t ph_magic = ph ? (65536u + (uint32_t)ph - 1u) / (uint32_t)ph : 0u;    // u / ph = (u * magic) >> 16 for u < 2^15
         uint32_t* buf = l.XPC;
         uint16_t* gout = (uint16_t*)(a.raw + (out_base + w0) * (int64_t)pat.P);
         for (int l0 = 0; l0 < NT; l0 += LPP) {
@@ -2014,15 +2007,31 @@ TPS_DEV void tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
                 }
             }
             TPS_SYNC();
-            TPS_PHASE {
-                int nvalid = (nw_tile - l0 * B) * ph;          // 16-bit units of this pass that belong to the tile's windows
-                const int ncap = LPP * B * ph;
-                if (nvalid > ncap) nvalid = ncap;
-                uint16_t* g = gout + (int64_t)l0 * B * ph;
-                const uint16_t* b16 = (const uint16_t*)buf;
-                for (int u = tid; u < nvalid; u += NT) {
-                    const uint32_t row = ((uint32_t)u * ph_magic) >> 16;
-                    g[u] = b16[row * 8u + ((uint32_t)u - row * (uint32_t)ph)];
+            if ((pat.P & 1) == 0) {
+                TPS_PHASE {
+                    int nvalid = (nw_tile - l0 * B) * ph;          // 16-bit units of this pass that belong to the tile's windows
+                    const int ncap = LPP * B * ph;
+                    if (nvalid > ncap) nvalid = ncap;
+                    uint16_t* g = gout + (int64_t)l0 * B * ph;
+                    const uint16_t* b16 = (const uint16_t*)buf;
+                    for (int u = tid; u < nvalid; u += NT) {
+                        const uint32_t row = ((uint32_t)u * ph_magic) >> 16;
+                        g[u] = b16[row * 8u + ((uint32_t)u - row * (uint32_t)ph)];
+                    }
+                }
+            } else {
+                // odd row length (a hand-made pattern list): the same, byte by byte
+                const uint32_t pb = (uint32_t)pat.P, pb_magic = (65536u + pb - 1u) / pb;      // u / P = (u * magic) >> 16 for u < 2^15
+                TPS_PHASE {
+                    int nvalid = (nw_tile - l0 * B) * (int)pb;
+                    const int ncap = LPP * B * (int)pb;
+                    if (nvalid > ncap) nvalid = ncap;
+                    uint8_t* g = (uint8_t*)gout + (int64_t)l0 * B * pb;
+                    const uint8_t* b8 = (const uint8_t*)buf;
+                    for (int u = tid; u < nvalid; u += NT) {
+                        const uint32_t row = ((uint32_t)u * pb_magic) >> 16;
+                        g[u] = b8[row * 16u + ((uint32_t)u - row * pb)];
+                    }
                 }
             }
             TPS_SYNC();

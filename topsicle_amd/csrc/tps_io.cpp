@@ -420,7 +420,7 @@ struct Fast {
     // -3: not plain 4-line FASTQ here; -2: a single record does not fit.
     // One 4-line FASTQ record at text offset s: 0 = well formed (r filled, next = start of the following record), 1 = not a
     // plain 4-line record here (or the text ends inside it).  The quality line is located by the sequence length and only
-    // its end is looked at -- its bytes are never read.
+    // the byte behind it is looked at -- its own bytes are never read.
     int parse_at(size_t s, Rec& r, size_t& next) const {
         if (s >= size || data[s] != '@') return 1;
         const char* e0p = (const char*)memchr(data + s, '\n', size - s);
@@ -447,7 +447,10 @@ struct Fast {
         } else {
             next = size;                                        // last line without a newline
         }
-        if (sl && memchr(data + q0, '\n', sl)) return 1;        // a shorter quality line followed by something else
+        // (A quality line SHORTER than the sequence would put q1 inside the next record; that is only mistaken for a line end
+        // if that record's header happens to end exactly there, and then the next "record" starts with a base instead of '@'
+        // and the file is rejected one record later than Biopython would.  Scanning the quality bytes to rule that out
+        // cost a third of the decoding time.)
         if (sl > 0x7FFFFFFFull) return 1;
         if (sl && (data[s0] == ' ' || data[s0] == '\t' || data[s1 - 1] == ' ' || data[s1 - 1] == '\t')) return 1;
         r = Rec{s + 1, (uint64_t)(h1 - s - 1), s0, (uint64_t)sl, q0};

@@ -190,10 +190,11 @@ inline std::string plan_geometry_core(ScanArgs& a, const tps_params& prm, int k,
                        2 * a.head_dw <= fused_seq_dw(prm.slide);   // the two step-1 heads fit the tile buffer (TileGeo::SEQ)
     a.lc16 = 0; a.tile_cap = 0; a.tw = 0; a.tw_magic = 0; a.pair_n = 0; a.lc_global = 0; a.lc_stride = 0; a.pp_d = -1; a.so_fast = 0; a.tile_full = 0;
     if (fused) {
-        // per-pattern tiles (tile_pp_s): one-hot 2-bit fields per pattern need distinct k-mers; a lane's 8 blocks hold at
+        // per-pattern tiles (tile_pp_s): one-hot 2-bit fields per pattern need distinct k-mers, raw rows of at most 14 bytes
+        // (they are staged through 16-byte LDS rows); a lane's 8 blocks hold at
         // most 14 non-overlapping occurrences of a pattern (nibbles), a block at most 2, a window at most 127 (bytes);
         // self-overlap only with ONE period d (then 2 d >= k: picks alternate along a chain)
-        const bool pp_counts = a.pat.dup_mask == 0 && k >= 4 && (8 * prm.slide + k - 1) / k <= 14 && (prm.slide + k - 1) / k <= 2 &&
+        const bool pp_counts = a.pat.dup_mask == 0 && k >= 4 && P <= 14 && (8 * prm.slide + k - 1) / k <= 14 && (prm.slide + k - 1) / k <= 2 &&
                                a.lw / k + 2 <= 127 && !getenv("TPS_NO_PP");
         if (pp_counts && a.pat.n_periods == 0) a.pp_d = 0;
         if (pp_counts && a.pat.n_periods == 1 && a.pat.period[0] >= 2 && 2 * a.pat.period[0] >= k) a.pp_d = a.pat.period[0];
