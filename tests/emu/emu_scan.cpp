@@ -33,6 +33,7 @@ extern "C" int emu_scan(const char* pats, int P, int k, const uint8_t* bases, co
                         int64_t* win_off_out, int32_t* sums, uint8_t* raw) {
     std::vector<uint32_t> lut;
     tps::ScanArgs a{};
+    a.val_on = 1;                                  // (the emulation always keeps the invalid-mask staging area)
     std::string err = tps::build_patterns(pats, P, k, lut, a.pat);
     if (!err.empty()) { g_err = err; return TPS_E_PATTERN; }
     std::vector<int64_t> win_off((size_t)n + 1);
@@ -147,6 +148,7 @@ extern "C" int emu_binseg(const int32_t* sums, const int64_t* win_off, int64_t n
 
 extern "C" int emu_plan(int k, int P, const tps_params* prm, int64_t max_nwin, int spans_pref, int lds_budget_bytes, int force_generic, int32_t* out10) {
     tps::ScanArgs a{};
+    a.val_on = 1;                                  // (the emulation always keeps the invalid-mask staging area)
     std::string err = tps::plan_geometry(a, *prm, k, P, max_nwin, lds_budget_bytes / 4, spans_pref, force_generic);
     if (!err.empty()) { g_err = err; return TPS_E_CAPACITY; }
     out10[0] = a.spans_per_tile; out10[1] = a.span_dw; out10[2] = a.blk_log2; out10[3] = a.q; out10[4] = a.r;
@@ -157,6 +159,7 @@ extern "C" int emu_plan(int k, int P, const tps_params* prm, int64_t max_nwin, i
 // plan for a real pattern table: out = {variant, pp_d, workgroup LDS bytes, pair_n, tile_full, tw}
 extern "C" int emu_plan_table(const char* pats, int P, int k, const tps_params* prm, int64_t max_nwin, int32_t* out4) {
     tps::ScanArgs a{};
+    a.val_on = 1;                                  // (the emulation always keeps the invalid-mask staging area)
     std::vector<uint32_t> lut;
     std::string err = tps::build_patterns(pats, P, k, lut, a.pat);
     if (err.empty()) err = tps::plan_geometry(a, *prm, k, P, max_nwin, 160 * 1024 / 4, 0, 0);

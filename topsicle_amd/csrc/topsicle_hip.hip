@@ -95,7 +95,7 @@ extern "C" __global__ void __launch_bounds__(tps::NT * tps::WPG) tps_followers_k
 // bits 1-2 of an ASCII letter: A,C,T,G (either case) -> 0,1,2,3; one v_dot4_u32_u8 packs 4 bases; a v_perm rebuilds the
 // lower-case letter each code stands for and any byte that differs from it in more than the case bit is invalid.
 extern "C" __global__ void __launch_bounds__(256) tps_pack_kernel(const uint8_t* bases, const int64_t* offsets, tps_read_desc* desc,
-                                                                   uint32_t* seq2, uint16_t* inv, int64_t n_reads) {
+                                                                   uint32_t* seq2, uint16_t* inv, int64_t n_reads, uint32_t* any_flag) {
     const int64_t r = blockIdx.x;
     if (r >= n_reads) return;
     const int64_t off = offsets[r];
@@ -138,7 +138,10 @@ extern "C" __global__ void __launch_bounds__(256) tps_pack_kernel(const uint8_t*
         inv[w0 + w] = (uint16_t)bad;
         any |= bad;
     }
-    if (any) atomicOr(&desc[r].flags, TPS_RD_HAS_INVALID);
+    if (any) {
+        atomicOr(&desc[r].flags, TPS_RD_HAS_INVALID);
+        *any_flag = 1u;                            // (mapped host word: the batch has a read with a non-ACGT letter)
+    }
 }
 
 // ======================================================================== host side
@@ -183,6 +186,7 @@ struct Slot {
     DevBuf seq2, inv, desc, tails, results, c_start, c_end, win_off, sums, raw, stamps, lc;
     int64_t n_words = 0;                 // words of seq2 / inv in use
     bool inv_valid = true;               // false: the batch came packed without an inv array (no read is flagged)
+    bool any_invalid = true;             // some read of the batch is flagged TPS_RD_HAS_INVALID (the kernels then stage the invalid masks)
     std::vector<int64_t> h_offsets;      // host copy of offsets (n+1)
     std::vector<int64_t> h_win_off;      // window layout of the last plan
     tps_read_result* h_results = nullptr;   // pinned
@@ -233,6 +237,7 @@ struct tps_ctx {
     int force_generic = 0;
     int64_t lds_target_dw = 32 * 256;
     size_t lds_set_v[21] = {0};
+    uint32_t* h_flag = nullptr;      // mapped host word the pack kernel raises when a read has a non-ACGT letter
 };
 
 namespace {
@@ -302,13 +307,16 @@ int do_upload(tps_ctx* c, Slot& sl, const uint8_t* bases, const int64_t* offsets
     HIP_TRY(hipMemcpyAsync(c->ascii_off.p, offsets, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream));
     if (n) HIP_TRY(hipMemcpyAsync(sl.desc.p, c->h_desc.data(), (size_t)n * sizeof(tps_read_desc), hipMemcpyHostToDevice, c->stream));
     if (n) {
+        if (!c->h_flag) HIP_TRY(hipHostMalloc((void**)&c->h_flag, 64, hipHostMallocMapped));
+        *c->h_flag = 0u;
         hipLaunchKernelGGL(tps_pack_kernel, dim3((unsigned)n), dim3(256), 0, c->stream, (const uint8_t*)d + PAD,
-                           (const int64_t*)c->ascii_off.p, (tps_read_desc*)sl.desc.p, (uint32_t*)sl.seq2.p, (uint16_t*)sl.inv.p, n);
+                           (const int64_t*)c->ascii_off.p, (tps_read_desc*)sl.desc.p, (uint32_t*)sl.seq2.p, (uint16_t*)sl.inv.p, n, c->h_flag);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipStreamSynchronize(c->stream));       // the caller's buffers and h_desc are free again
     sl.h_offsets.assign(offsets, offsets + n + 1);
     sl.inv_valid = true;
+    sl.any_invalid = n > 0 && *(volatile uint32_t*)c->h_flag != 0u;
     reset_slot(sl, n, n_words);
     return TPS_OK;
 }
@@ -339,6 +347,7 @@ int do_upload_packed(tps_ctx* c, Slot& sl, const uint32_t* seq2, const uint16_t*
     const bool all_pinned = (!n_words || c->pinned.count((void*)seq2)) && (!inv || c->pinned.count((void*)inv)) && (!n || c->pinned.count((void*)desc));
     if (!all_pinned) HIP_TRY(hipStreamSynchronize(c->stream));     // ordinary memory: the copy is over when the call returns
     sl.inv_valid = inv != nullptr;
+    sl.any_invalid = flagged;
     reset_slot(sl, n, n_words);
     return TPS_OK;
 }
@@ -366,6 +375,7 @@ int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm) {
         }
         sl.h_win_off[(size_t)n] = acc;
         sl.args = tps::ScanArgs{};
+        sl.args.val_on = sl.any_invalid ? 1 : 0;
         if ((rc = plan_lds(c, sl, prm, mx))) return rc;
         if ((rc = sl.win_off.ensure((size_t)(n + 1) * 8))) return rc;
         HIP_TRY(hipMemcpyAsync(sl.win_off.p, sl.h_win_off.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream));
@@ -560,6 +570,7 @@ int tps_ctx_destroy(tps_ctx* c) {
     c->follow_picks.release();
     c->follow_hist.release();
     for (void* hp : c->pinned) (void)hipHostFree(hp);
+    if (c->h_flag) (void)hipHostFree(c->h_flag);
     c->pinned.clear();
     for (auto& ep : c->ev_pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     (void)hipStreamDestroy(c->stream);

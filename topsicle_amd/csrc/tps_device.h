@@ -280,6 +280,8 @@ struct ScanArgs {
     int32_t pp_d;                // per-pattern tiles (tile_pp_s): -1 = not eligible, 0 = no self-overlapping k-mer,
                                  // d > 0 = the one self-overlap period of the table
     int32_t so_fast;             // sums only, pp_d > 0: tiles without a chained occurrence take the plain tile (chain test inside it)
+    int32_t val_on;              // 1 = some read of the batch has a non-ACGT letter: the invalid masks get their LDS staging area
+    int32_t seq_alias;           // fused sums-only kernels without self-overlap: the staged bases share LDS with the tail of row[]
 };
 
 struct BinsegArgs {
@@ -335,7 +337,7 @@ TPS_HD int64_t blk_region_dw(const ScanArgs& a) {
     if (need < HIST_DW) need = HIST_DW;
     return (need + 3) & ~3ll;
 }
-TPS_HD int64_t val_dw(const ScanArgs& a) { return ((a.seq_dw + 4 + 3) / 4) * 2; }   // u16 per 16 positions (+ look-ahead), even (seq_dw is a multiple of 4)
+TPS_HD int64_t val_dw(const ScanArgs& a) { return a.val_on ? ((a.seq_dw + 4 + 3) / 4) * 2 : 0; }   // u16 per 16 positions (+ look-ahead), even (seq_dw is a multiple of 4); none for a batch without invalid letters
 TPS_HD int64_t lc_dw(const ScanArgs& a) {          // even dword counts keep misc 8-byte aligned
     if (a.lc16) return (a.lc_global ? 0 : ((a.lc_cap + 3) / 4) * 2) + ((a.tile_cap + 1) / 2) * 2;
     return a.lc_global ? 0 : ((a.lc_cap + 1) / 2) * 2;        // generic kernel: absolute 32-bit sums, also off-chip by default
@@ -370,7 +372,7 @@ TPS_DEV Lds carve(uint32_t* base, uint32_t* lut, const ScanArgs& a) {
     return l;
 }
 TPS_HD int64_t lds_dwords(const ScanArgs& a) {
-    return (int64_t)a.blk_dw + a.seq_dw + val_dw(a) + a.tot_dw + lc_dw(a) + row_dw(a) + MISC_DW;   // per wave; + lut_n per workgroup
+    return (int64_t)a.blk_dw + (a.seq_alias ? 0 : a.seq_dw) + val_dw(a) + a.tot_dw + lc_dw(a) + row_dw(a) + MISC_DW;   // per wave; + lut_n per workgroup
 }
 // LDS dwords of a whole workgroup: the shared table + WPG wave slices (each rounded to 16 bytes)
 TPS_HD int64_t wg_lds_dwords(const ScanArgs& a) { return a.pair_n + ((a.lut_n + 3) & ~3) + (int64_t)(a.wpg > 0 ? a.wpg : WPG) * ((lds_dwords(a) + 3) & ~3ll); }
@@ -1090,8 +1092,15 @@ constexpr bool tile_full_default(int s) { return s >= 1; }
 // only the candidate / tile sums, whose size depends on the longest read, follow.  Sizes = plan_geometry's.
 template <int S, bool FULL>
 TPS_DEV Lds carve_fused(uint32_t* base, uint32_t* lut, const ScanArgs& a) {
-    constexpr int BLK = 9 * NT + 2 * XLANES, ROW = NT * Geo<S>::B + NT, SEQ = TileGeo<S, FULL>::SEQ, VAL = ((SEQ + 4 + 3) / 4) * 2;
+    constexpr int BLK = 9 * NT + 2 * XLANES, ROW = NT * Geo<S>::B + NT, SEQ = TileGeo<S, FULL>::SEQ;
+    const int VAL = a.val_on ? ((SEQ + 4 + 3) / 4) * 2 : 0;
     static_assert(BLK % 4 == 0 && ROW % 4 == 0 && MISC_DW % 4 == 0 && SEQ % 4 == 0, "seq2 must be 16-byte aligned");
+    // seq_alias: the staged bases live in the LAST SEQ dwords of row[].  A tile's lanes read them into registers at the very
+    // start of phase 1 (and step 1 reads its heads there while it counts into the block region in front); everything a tile
+    // writes to row[] afterwards (XS, then S_w and its scan) comes later in program order, and a wave's LDS operations
+    // execute in order -- the next tile's staging overwrites a row[] that is no longer needed.  Only for the kernels that
+    // never go back to the bases after phase 1 (no self-overlap recounts, no raw counts).
+    static_assert(BLK + ROW - SEQ >= HIST_DW && BLK + ROW - SEQ >= 4 * NT, "step 1 counts in front of the aliased bases");
     Lds l;
     l.lut2 = lut - a.pair_n;
     l.lut = lut;
@@ -1104,9 +1113,15 @@ TPS_DEV Lds carve_fused(uint32_t* base, uint32_t* lut, const ScanArgs& a) {
     l.row = base + BLK;
     l.misc = l.row + ROW;
     l.Tot = l.misc + MISC_DW;
-    l.seq2 = l.Tot + 4;                        // 16-byte aligned: BLK, ROW, MISC_DW are multiples of 4 dwords
-    l.val = (uint16_t*)(l.seq2 + SEQ);
-    uint32_t* p = l.seq2 + SEQ + VAL;
+    uint32_t* p = l.Tot + 4;                   // 16-byte aligned: BLK, ROW, MISC_DW are multiples of 4 dwords
+    if (a.seq_alias) {
+        l.seq2 = base + (BLK + ROW - SEQ);
+    } else {
+        l.seq2 = p;
+        p += SEQ;
+    }
+    l.val = (uint16_t*)p;
+    p += VAL;
     l.Lc = p;
     l.Lc16 = (uint16_t*)p;
     l.Tc = p + ((a.lc16 && a.lc_global) ? 0 : ((a.lc_cap + 3) / 4) * 2);

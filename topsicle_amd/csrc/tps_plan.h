@@ -188,7 +188,7 @@ inline std::string plan_geometry_core(ScanArgs& a, const tps_params& prm, int k,
     const bool fused = !force_generic && spans_pref <= 0 && k <= TPS_DIRECT_K && has_specialised_slide(prm.slide) && P <= 15 && a.q >= 8 &&
                        a.q / 8 + 2 < (XLANES - NT) && max_period <= std::min(prm.slide, 6) &&
                        2 * a.head_dw <= fused_seq_dw(prm.slide);   // the two step-1 heads fit the tile buffer (TileGeo::SEQ)
-    a.lc16 = 0; a.tile_cap = 0; a.tw = 0; a.tw_magic = 0; a.pair_n = 0; a.lc_global = 0; a.lc_stride = 0; a.pp_d = -1; a.so_fast = 0; a.tile_full = 0;
+    a.lc16 = 0; a.tile_cap = 0; a.tw = 0; a.tw_magic = 0; a.pair_n = 0; a.lc_global = 0; a.lc_stride = 0; a.pp_d = -1; a.so_fast = 0; a.seq_alias = 0; a.tile_full = 0;
     if (fused) {
         // per-pattern tiles (tile_pp_s): one-hot 2-bit fields per pattern need distinct k-mers, raw rows of at most 14 bytes
         // (they are staged through 16-byte LDS rows); a lane's 8 blocks hold at
@@ -210,6 +210,12 @@ inline std::string plan_geometry_core(ScanArgs& a, const tps_params& prm, int k,
         // per lane, whatever the slide -- the halo-lane variant of the ASCII days has no cheaper staging any more
         a.tile_full = 1;
         a.seq_dw = fused_seq_dw(prm.slide);        // = TileGeo<S, true>::SEQ: compile-time size in the kernel (carve_fused)
+        // the kernels that never return to the bases after a tile's first phase (sums only, no self-overlapping k-mer) keep
+        // them in the tail of row[] (carve_fused): with no invalid letters in the batch that is the sixth workgroup per CU
+        a.seq_alias = 0;
+#ifndef TPS_EMU
+        if (a.pat.so_mask == 0 && !(prm.flags & TPS_F_STORE_RAW) && !getenv("TPS_NO_SEQ_ALIAS")) a.seq_alias = 1;
+#endif
         a.tw = (int)NT * 8 - a.q - 1;
         a.tw_magic = (uint32_t)(((1ull << 32) + (uint64_t)a.tw - 1) / (uint64_t)a.tw);
         a.tile_cap = (int)((max_nwin + a.tw - 1) / a.tw) + 1;
@@ -236,7 +242,7 @@ inline std::string plan_geometry_core(ScanArgs& a, const tps_params& prm, int k,
         if (wg_lds_dwords(a) <= budget_dw) return "";
         // does not fit (very long maxlengthtelo: the candidate sums of 4 reads outgrow LDS): the generic kernel,
         // whose tile size adapts, takes over
-        a.lc16 = 0; a.tile_cap = 0; a.tw = 0; a.tw_magic = 0; a.pair_n = 0; a.lc_global = 0; a.lc_stride = 0; a.pp_d = -1; a.so_fast = 0;
+        a.lc16 = 0; a.tile_cap = 0; a.tw = 0; a.tw_magic = 0; a.pair_n = 0; a.lc_global = 0; a.lc_stride = 0; a.pp_d = -1; a.so_fast = 0; a.seq_alias = 0;
     }
     a.variant = 0;
     // the generic kernel's 32-bit candidate sums go off-chip too (stride counted in 16-bit units)
