@@ -19,60 +19,10 @@
 #include "tps_plan.h"
 
 // ======================================================================== kernels
-// One wave per read, tps::WPG waves per workgroup.  The lookup table is loaded once per workgroup
-// (the only workgroup barrier in the kernel); after that every wave runs its own read with
-// wave-level synchronisation only.
-#define TPS_SCAN_KERNEL_F(NAME, SV, SO, PAIR, RAW, MINW, FULL)                                                           \
-    extern "C" __global__ void __launch_bounds__(tps::NT * tps::WPG_MAX, MINW) NAME(tps::ScanArgs a) {     \
-        extern __shared__ __attribute__((aligned(16))) uint32_t lds[];                                     \
-        /* workgroup-shared tables: [pair table (PAIR kernels)][single table], both aligned to their size */ \
-        uint32_t* lut = lds + ((PAIR) ? a.pair_n : 0);                                                     \
-        const int nthr_ = tps::NT * a.wpg;            /* = blockDim.x */                                   \
-        for (int i = (int)threadIdx.x; i < a.lut_n; i += nthr_) {                                          \
-            const uint32_t m_ = a.lut[i];                                                                  \
-            lut[i] = (SV) ? ((m_ << 16) | (uint32_t)__builtin_popcount(m_)) : m_;                          \
-        }                                                                                                  \
-        if (PAIR) {   /* host-built pair table, stored right behind the plain table */                      \
-            for (int c = 4 * (int)threadIdx.x; c < a.pair_n; c += 4 * nthr_)                               \
-                *(uint4*)(lds + c) = *(const uint4*)(a.lut + a.lut_n + c);                                 \
-        }                                                                                                  \
-        __syncthreads();                                                                                   \
-        /* One read per wave; the hardware dispatcher balances the workgroups.  (Persistent waves were      \
-           tried: a shared device counter sustains only ~50 M same-address atomics/s -- too slow for the  \
-           claim rate -- and a static stride loses the dispatcher's dynamic balancing: 10 % slower on    \
-           25k-read batches.)                                                                             \
-           readfirstlane: the wave index is uniform -> everything per read lives in SGPRs */              \
-        const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));                          \
-        const int64_t wave_dw = (tps::lds_dwords(a) + 3) & ~3ll;                                           \
-        uint32_t* slice = lut + ((a.lut_n + 3) & ~3) + wave * wave_dw;                                     \
-        const int64_t r = (int64_t)blockIdx.x * a.wpg + wave;                                              \
-        if (r < a.n_reads) tps::scan_read<SV, SO, PAIR, RAW, FULL>(a, r, slice, lut);                           \
-    }
-#ifndef TPS_SO_MINW
-#define TPS_SO_MINW 4     // waves per SIMD the sums-only self-overlap kernels are compiled for (tile_so_s wants ~128 VGPRs: 5 would spill ~120)
-#endif
-#define TPS_SCAN_KERNEL(NAME, SV, SO, PAIR, RAW, MINW) TPS_SCAN_KERNEL_F(NAME, SV, SO, PAIR, RAW, MINW, tps::tile_full_default(SV))
-TPS_SCAN_KERNEL(tps_scan_kernel, 0, false, false, true, 4)          // generic: any slide, up to 31 patterns
-TPS_SCAN_KERNEL(tps_scan_kernel_s5, 5, false, false, false, 5)       // specialised: compile-time slide, <= 15 patterns
-TPS_SCAN_KERNEL(tps_scan_kernel_s6, 6, false, false, false, 5)
-TPS_SCAN_KERNEL(tps_scan_kernel_s7, 7, false, false, false, 5)
-TPS_SCAN_KERNEL(tps_scan_kernel_s8, 8, false, false, false, 5)
-TPS_SCAN_KERNEL(tps_scan_kernel_s5p, 5, false, true, false, 5)       // ... k <= 4: two positions per table lookup
-TPS_SCAN_KERNEL(tps_scan_kernel_s6p, 6, false, true, false, 5)
-TPS_SCAN_KERNEL(tps_scan_kernel_s7p, 7, false, true, false, 5)
-TPS_SCAN_KERNEL(tps_scan_kernel_s8p, 8, false, true, false, 5)
-TPS_SCAN_KERNEL(tps_scan_kernel_s5r, 5, false, false, true, 3)       // ... with the per-pattern raw counts (TPS_F_STORE_RAW)
-TPS_SCAN_KERNEL(tps_scan_kernel_s6r, 6, false, false, true, 3)
-TPS_SCAN_KERNEL(tps_scan_kernel_s7r, 7, false, false, true, 3)
-TPS_SCAN_KERNEL(tps_scan_kernel_s8r, 8, false, false, true, 3)
-TPS_SCAN_KERNEL(tps_scan_kernel_s5so, 5, true, false, false, TPS_SO_MINW)      // ... self-overlapping k-mers in the table, sums only (tile_so_s)
-TPS_SCAN_KERNEL(tps_scan_kernel_s6so, 6, true, false, false, TPS_SO_MINW)
-TPS_SCAN_KERNEL(tps_scan_kernel_s7so, 7, true, false, false, TPS_SO_MINW)
-TPS_SCAN_KERNEL(tps_scan_kernel_s8so, 8, true, false, false, TPS_SO_MINW)
-TPS_SCAN_KERNEL(tps_scan_kernel_s5sor, 5, true, false, true, 5)      // ... the same with the per-pattern raw counts (tile_pp_s)
-TPS_SCAN_KERNEL(tps_scan_kernel_s6sor, 6, true, false, true, 5)
-TPS_SCAN_KERNEL(tps_scan_kernel_s7sor, 7, true, false, true, 5)
-TPS_SCAN_KERNEL(tps_scan_kernel_s8sor, 8, true, false, true, 5)
+// The scan kernels live in tps_kernels.h (one macro body, instantiated per slide / table kind / outputs).  Compiled alone,
+// this file holds all of them; in the split build (-DTPS_KGROUP=0) only the plain and pair kernels, the others come
+// from tps_kernels.hip objects.
+#include "tps_kernels.h"
 
 extern "C" __global__ void __launch_bounds__(tps::NT * tps::WPG) tps_binseg_kernel(tps::BinsegArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t smem[tps::WPG * tps::BINSEG_SMEM_DW];

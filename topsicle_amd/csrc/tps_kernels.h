@@ -1,0 +1,113 @@
+// tps_kernels.h -- the scan kernels of libtopsicle_hip.so: the kernel body (one macro) and the list of instantiations, in
+// GROUPS so that the library can be compiled as several translation units in parallel (the self-overlap kernels alone are
+// two thirds of the machine code).  topsicle_hip.hip includes this with TPS_KGROUP undefined (all kernels in one unit: the
+// scripts that dump resource usage or ISA do that) or = 0 (host code + the small kernels, the rest declared only);
+// tps_kernels.hip is compiled once per TPS_KGROUP = 1 .. TPS_KGROUPS - 1 (__graft_entry__.build_hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "tps_device.h"
+
+// One wave per read, tps::WPG waves per workgroup.  The lookup table is loaded once per workgroup
+// (the only workgroup barrier in the kernel); after that every wave runs its own read with
+// wave-level synchronisation only.
+#define TPS_SCAN_KERNEL_F(NAME, SV, SO, PAIR, RAW, MINW, FULL)                                                           \
+    extern "C" __global__ void __launch_bounds__(tps::NT * tps::WPG_MAX, MINW) NAME(tps::ScanArgs a) {     \
+        extern __shared__ __attribute__((aligned(16))) uint32_t lds[];                                     \
+        /* workgroup-shared tables: [pair table (PAIR kernels)][single table], both aligned to their size */ \
+        uint32_t* lut = lds + ((PAIR) ? a.pair_n : 0);                                                     \
+        const int nthr_ = tps::NT * a.wpg;            /* = blockDim.x */                                   \
+        for (int i = (int)threadIdx.x; i < a.lut_n; i += nthr_) {                                          \
+            const uint32_t m_ = a.lut[i];                                                                  \
+            lut[i] = (SV) ? ((m_ << 16) | (uint32_t)__builtin_popcount(m_)) : m_;                          \
+        }                                                                                                  \
+        if (PAIR) {   /* host-built pair table, stored right behind the plain table */                      \
+            for (int c = 4 * (int)threadIdx.x; c < a.pair_n; c += 4 * nthr_)                               \
+                *(uint4*)(lds + c) = *(const uint4*)(a.lut + a.lut_n + c);                                 \
+        }                                                                                                  \
+        __syncthreads();                                                                                   \
+        /* One read per wave; the hardware dispatcher balances the workgroups.  (Persistent waves were      \
+           tried: a shared device counter sustains only ~50 M same-address atomics/s -- too slow for the  \
+           claim rate -- and a static stride loses the dispatcher's dynamic balancing: 10 % slower on    \
+           25k-read batches.)                                                                             \
+           readfirstlane: the wave index is uniform -> everything per read lives in SGPRs */              \
+        const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));                          \
+        const int64_t wave_dw = (tps::lds_dwords(a) + 3) & ~3ll;                                           \
+        uint32_t* slice = lut + ((a.lut_n + 3) & ~3) + wave * wave_dw;                                     \
+        const int64_t r = (int64_t)blockIdx.x * a.wpg + wave;                                              \
+        if (r < a.n_reads) tps::scan_read<SV, SO, PAIR, RAW, FULL>(a, r, slice, lut);                           \
+    }
+#ifndef TPS_SO_MINW
+#define TPS_SO_MINW 4     // waves per SIMD the sums-only self-overlap kernels are compiled for (tile_so_s wants ~128 VGPRs: 5 would spill ~120)
+#endif
+#define TPS_SCAN_KERNEL(NAME, SV, SO, PAIR, RAW, MINW) TPS_SCAN_KERNEL_F(NAME, SV, SO, PAIR, RAW, MINW, tps::tile_full_default(SV))
+
+#define TPS_KGROUPS 9
+#ifdef TPS_KGROUP
+#define TPS_IN_GROUP(g) (TPS_KGROUP == (g))
+#else
+#define TPS_IN_GROUP(g) 1
+#endif
+#define TPS_SCAN_KERNEL_DECL(NAME) extern "C" __global__ void NAME(tps::ScanArgs a);
+
+TPS_SCAN_KERNEL_DECL(tps_scan_kernel)
+TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s5)
+TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s6)
+TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s7)
+TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s8)
+TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s5p)
+TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s6p)
+TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s7p)
+TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s8p)
+TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s5r)
+TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s6r)
+TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s7r)
+TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s8r)
+TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s5so)
+TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s6so)
+TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s7so)
+TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s8so)
+TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s5sor)
+TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s6sor)
+TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s7sor)
+TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s8sor)
+
+#if TPS_IN_GROUP(0)
+TPS_SCAN_KERNEL(tps_scan_kernel_s5, 5, false, false, false, 5)       // specialised: compile-time slide, <= 15 patterns
+TPS_SCAN_KERNEL(tps_scan_kernel_s6, 6, false, false, false, 5)
+TPS_SCAN_KERNEL(tps_scan_kernel_s7, 7, false, false, false, 5)
+TPS_SCAN_KERNEL(tps_scan_kernel_s8, 8, false, false, false, 5)
+#endif
+#if TPS_IN_GROUP(1)
+TPS_SCAN_KERNEL(tps_scan_kernel_s5p, 5, false, true, false, 5)       // ... k <= 4: two positions per table lookup
+TPS_SCAN_KERNEL(tps_scan_kernel_s6p, 6, false, true, false, 5)
+TPS_SCAN_KERNEL(tps_scan_kernel_s7p, 7, false, true, false, 5)
+TPS_SCAN_KERNEL(tps_scan_kernel_s8p, 8, false, true, false, 5)
+#endif
+#if TPS_IN_GROUP(2)
+TPS_SCAN_KERNEL(tps_scan_kernel, 0, false, false, true, 4)          // generic: any slide, up to 31 patterns
+TPS_SCAN_KERNEL(tps_scan_kernel_s5r, 5, false, false, true, 3)       // ... with the per-pattern raw counts (TPS_F_STORE_RAW)
+TPS_SCAN_KERNEL(tps_scan_kernel_s6r, 6, false, false, true, 3)
+TPS_SCAN_KERNEL(tps_scan_kernel_s7r, 7, false, false, true, 3)
+TPS_SCAN_KERNEL(tps_scan_kernel_s8r, 8, false, false, true, 3)
+#endif
+#if TPS_IN_GROUP(3)
+TPS_SCAN_KERNEL(tps_scan_kernel_s5so, 5, true, false, false, TPS_SO_MINW)      // ... self-overlapping k-mers in the table, sums only (tile_so_s)
+TPS_SCAN_KERNEL(tps_scan_kernel_s6so, 6, true, false, false, TPS_SO_MINW)
+#endif
+#if TPS_IN_GROUP(4)
+TPS_SCAN_KERNEL(tps_scan_kernel_s7so, 7, true, false, false, TPS_SO_MINW)
+TPS_SCAN_KERNEL(tps_scan_kernel_s8so, 8, true, false, false, TPS_SO_MINW)
+#endif
+#if TPS_IN_GROUP(5)
+TPS_SCAN_KERNEL(tps_scan_kernel_s5sor, 5, true, false, true, 5)      // ... the same with the per-pattern raw counts (tile_pp_s)
+#endif
+#if TPS_IN_GROUP(6)
+TPS_SCAN_KERNEL(tps_scan_kernel_s6sor, 6, true, false, true, 5)
+#endif
+#if TPS_IN_GROUP(7)
+TPS_SCAN_KERNEL(tps_scan_kernel_s7sor, 7, true, false, true, 5)
+#endif
+#if TPS_IN_GROUP(8)
+TPS_SCAN_KERNEL(tps_scan_kernel_s8sor, 8, true, false, true, 5)
+#endif
