@@ -324,8 +324,20 @@ struct Fast {
 
     ~Fast() {
         give_spare();
-        if (src) delete src;
-        else if (data) munmap((void*)data, size);
+        if (src) {
+            delete src;
+        } else if (data) {
+            // Unmapping a few hundred MB that 16 threads have touched takes milliseconds (page-table teardown, TLB shootdowns,
+            // and the GPU driver's MMU notifier when the process holds a device context: 7 ms for 300 MB on the GPU box, more
+            // than decoding the file) -- off the caller's path: a detached thread does it.
+            void* p = (void*)data;
+            const size_t n = size;
+            try {
+                std::thread([p, n] { munmap(p, n); }).detach();
+            } catch (...) {
+                munmap(p, n);
+            }
+        }
         if (fd >= 0) close(fd);
     }
     void index_window() {
