@@ -78,7 +78,8 @@ extern "C" int emu_scan(const char* pats, int P, int k, const uint8_t* bases, co
     std::vector<uint32_t> lutbuf((size_t)a.pair_n + lut.size());
     uint32_t* lut1 = lutbuf.data() + a.pair_n;
     for (size_t i = 0; i < lut.size(); ++i)
-        lut1[i] = a.variant ? ((lut[i] << 16) | (uint32_t)__builtin_popcount(lut[i])) : lut[i];   // fused kernels: mask << 16 | count
+        lut1[i] = !a.variant ? lut[i] : a.lut_fields ? tps::mask_to_fields(lut[i])                 // raw-count kernels on the per-pattern tiles: one-hot fields
+                                                     : ((lut[i] << 16) | (uint32_t)__builtin_popcount(lut[i]));   // fused kernels: mask << 16 | count
     for (int c = 0; c < a.pair_n; ++c) {
         const uint32_t e1 = lut1[c & a.pat.kmask], e2 = lut1[(c >> 2) & a.pat.kmask];
         lutbuf[(size_t)c] = ((e1 | e2) & 0xFFFF0000u) | ((e1 + e2) & 0xFFFFu);

@@ -282,6 +282,8 @@ struct ScanArgs {
     int32_t so_fast;             // sums only, pp_d > 0: tiles without a chained occurrence take the plain tile (chain test inside it)
     int32_t val_on;              // 1 = some read of the batch has a non-ACGT letter: the invalid masks get their LDS staging area
     int32_t seq_alias;           // fused sums-only kernels without self-overlap: the staged bases share LDS with the tail of row[]
+    int32_t lut_fields;          // raw-count kernels on a table the per-pattern tiles take: the LDS table holds ready-made one-hot
+                                 // 2-bit fields (1 << 2 p for pattern p) instead of mask << 16 | count
 };
 
 struct BinsegArgs {
@@ -301,7 +303,7 @@ constexpr int HIST_DW = 2 * HIST_COPIES * HIST_STRIDE;   // step-1 private histo
 struct Lds {
     uint32_t* lut;     // generic kernel: mask over the pattern list; fused kernels: mask << 16 | popcount(mask)
     uint32_t* lut2;    // pair kernels: entry of the (k+1)-mer at p = entries of the k-mers at p and p+1 combined (OR | sum)
-    int lshift;        // 0 or 16: lut[code] >> lshift is the mask
+    int lshift;        // 0 or 16: lut[code] >> lshift is the mask; LUT_FIELDS: one-hot 2-bit fields (lut_mask)
     uint32_t* seq2;    // 2-bit packed bases, 16 per dword
     uint16_t* val;     // bit j of val[c] set = position 16c+j is NOT one of acgtACGT
     uint32_t* blk;     // block region
@@ -555,6 +557,17 @@ TPS_DEV bool invalid_at(const uint16_t* val, int q, int k) {
     uint64_t v = (uint64_t)val[idx] | ((uint64_t)val[idx + 1] << 16) | ((uint64_t)val[idx + 2] << 32);
     return ((v >> (q & 15)) & ((1ull << k) - 1ull)) != 0;
 }
+// Table formats in LDS (Lds::lshift): 0 = mask over the pattern list (generic kernel), 16 = mask << 16 | popcount (fused
+// kernels), LUT_FIELDS = the one-hot 2-bit field 1 << 2 p of THE pattern p the k-mer belongs to (raw-count kernels on tables
+// without duplicate k-mers: what the per-pattern tiles and the packed step 1 add up, without the squaring).
+constexpr int LUT_FIELDS = 32;
+TPS_HD uint32_t mask_to_fields(uint32_t m) {          // pattern mask -> the same patterns as 2-bit fields (bit 2 p)
+    uint32_t f = 0;
+    for (int p = 0; p < 16; ++p) f |= ((m >> p) & 1u) << (2 * p);
+    return f;
+}
+TPS_DEV uint32_t field_to_mask(uint32_t f) { return f ? 1u << (ffs0(f) >> 1) : 0u; }                // one-hot field -> pattern mask
+TPS_DEV uint32_t field_to_entry(uint32_t f) { return f ? ((1u << (16 + (ffs0(f) >> 1))) | 1u) : 0u; } // ... -> mask << 16 | 1
 // mask of list patterns whose k-mer is the low 2k bits of v (direct table or perfect hash)
 TPS_DEV uint32_t lut_mask(const uint32_t* lut, int lshift, const PatInfo& pat, uint32_t v) {
     const uint32_t code = v & pat.kmask;
@@ -562,6 +575,7 @@ TPS_DEV uint32_t lut_mask(const uint32_t* lut, int lshift, const PatInfo& pat, u
         const uint32_t slot = (code * pat.hash_mul) >> pat.hash_shift;
         return lut[2 * slot] == code ? lut[2 * slot + 1] : 0u;
     }
+    if (lshift == LUT_FIELDS) return field_to_mask(lut[code]);
     return lut[code] >> lshift;
 }
 // mask of list patterns whose k-mer starts at position q
@@ -678,7 +692,8 @@ TPS_DEV bool trc_packed_ok(const ScanArgs& a, int npos) {
     for (int i = 0; i < a.pat.n_periods; ++i) maxd = a.pat.period[i] > maxd ? a.pat.period[i] : maxd;
     return a.pat.P <= 15 && maxd <= 6 && mp >= 3 && npos <= 255 * mp && iters * ((16 + mp - 1) / mp) <= 15;
 }
-template <bool SO_>
+// FLD: the table holds one-hot 2-bit fields (LUT_FIELDS): no squaring, and the overlap test runs on fields
+template <bool SO_, bool FLD = false>
 TPS_DEV void trc_count_packed(const ScanArgs& a, const Lds& l, const Stage& st_s, const Stage& st_e, int tid) {
     const PatInfo& pat = a.pat;
     const int side = tid >> 5, t = tid & 31;
@@ -696,7 +711,7 @@ TPS_DEV void trc_count_packed(const ScanArgs& a, const Lds& l, const Stage& st_s
         for (int i = 0; i < pat.n_periods; ++i) {
             TPS_UNROLL
             for (int d = 1; d < 7; ++d)
-                if (pat.period[i] == d) ppd[d] |= pat.period_pat[i] << 16;
+                if (pat.period[i] == d) ppd[d] |= FLD ? mask_to_fields(pat.period_pat[i]) : pat.period_pat[i] << 16;
         }
     }
     uint32_t ne = 0, no = 0;                        // per-pattern counts of this lane, nibbles: even / odd patterns
@@ -734,12 +749,19 @@ TPS_DEV void trc_count_packed(const ScanArgs& a, const Lds& l, const Stage& st_s
         for (int half = 0; half < 2; ++half) {
             uint32_t x2 = 0;                         // 2-bit fields: <= 3 occurrences of a pattern in 8 positions
             TPS_UNROLL
-            for (int j = 8 * half; j < 8 * half + 8; ++j) x2 += mulhi32(h[j], h[j]);
+            for (int j = 8 * half; j < 8 * half + 8; ++j) x2 += FLD ? h[j] : mulhi32(h[j], h[j]);
             ne += x2 & 0x33333333u;
             no += (x2 >> 2) & 0x33333333u;
         }
     }
-    if (SO_ && cf) lds_or(&l.misc[M_CMASK + side], cf >> 16);
+    if (SO_ && cf) {
+        uint32_t cm = cf >> 16;
+        if (FLD) {                                  // fields -> pattern mask (rare: only a lane that saw an overlapping pair)
+            cm = 0;
+            while (cf) { cm |= 1u << (ffs0(cf) >> 1); cf &= cf - 1u; }
+        }
+        lds_or(&l.misc[M_CMASK + side], cm);
+    }
     uint32_t* dst = l.blk + 4 * tid;
     dst[0] = ne & 0x0F0F0F0Fu;
     dst[1] = (ne >> 4) & 0x0F0F0F0Fu;
@@ -777,7 +799,8 @@ TPS_DEV void trc_publish_occ(const ScanArgs& a, const Lds& l, const Stage& st_s,
             const uint32_t w0 = alignbit(d1, d0, sh), w1 = alignbit(d2, d1, sh);
             TPS_UNROLL
             for (int j = 0; j < 16; ++j) {
-                uint32_t h = lut_at(l.lut, j ? alignbit(w1, w0, 2u * j) : w0, amask) >> 16;
+                uint32_t h = lut_at(l.lut, j ? alignbit(w1, w0, 2u * j) : w0, amask);
+                h = l.lshift == LUT_FIELDS ? field_to_mask(h) : h >> 16;
                 if (16 * c + j >= npos) h = 0;
                 h &= cmask;
                 while (h) {
@@ -1104,7 +1127,7 @@ TPS_DEV Lds carve_fused(uint32_t* base, uint32_t* lut, const ScanArgs& a) {
     Lds l;
     l.lut2 = lut - a.pair_n;
     l.lut = lut;
-    l.lshift = 16;
+    l.lshift = a.lut_fields ? LUT_FIELDS : 16;
     l.blk = base;
     l.XPC = base;
     l.XF = base + 9 * NT;
@@ -1253,6 +1276,9 @@ TPS_DEV bool tile_fused_s(const ScanArgs& a, const TileConst& tc, const Lds& l, 
                         const int dw = p >> 4, bit = p & 15;
                         uint32_t v4 = bit ? alignbit(dw + 1 < WDW ? w[dw + 1] : 0u, w[dw], 2u * bit) : w[dw];
                         uint32_t h = lut_at(l.lut, v4, amask);
+                        if constexpr (INV && RAW) {
+                            if (a.lut_fields) h = field_to_entry(h);    // (a tile with non-ACGT letters of a batch on the per-pattern tiles)
+                        }
                         if (INV) {
                             if (h && invalid_at(l.val, p0 + p, pat.k)) h = 0;   // tiles with non-ACGT letters only
                         }
@@ -1652,6 +1678,13 @@ struct GeoPP {
     // base before the look-back + look-back + positions + chain look-ahead (<= 6) + last k-mer (<= 7 bases)
     static constexpr int WDW = (1 + LBK + POS + 6 + 7 + 15) / 16;
 };
+#ifndef TPS_PP_FIELDS
+#define TPS_PP_FIELDS 1
+#endif
+// the raw-count kernels load their LDS table as one-hot 2-bit fields whenever the per-pattern tiles will run (plan_geometry
+// sets ScanArgs::lut_fields): a position then costs lookup + add, without the v_mul_hi_u32 that squares mask << 16 | 1 into
+// 1 << 2 p.  -DTPS_PP_FIELDS=0 keeps the squaring (A/B builds).
+constexpr bool PP_FIELDS = TPS_PP_FIELDS != 0;
 constexpr uint32_t PP_BIAS = 14;                  // V nibbles = PP_BIAS - prefix + start skips, all in 0..15
 TPS_DEV void pp_expand(uint32_t ne, uint32_t no, uint32_t* b) {   // nibble words (even / odd patterns) -> 4 byte words
     b[0] = ne & 0x0F0F0F0Fu;                      // patterns 0, 4, 8, 12
@@ -1716,7 +1749,7 @@ TPS_DEV void tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
             const int idx = p + LBK, dw = idx >> 4, bit = idx & 15;
             const uint32_t v4 = bit ? alignbit(dw + 1 < WDW ? w[dw + 1] : 0u, w[dw], 2u * bit) : w[dw];
             const uint32_t h = lut_at(l.lut, v4, amask);
-            return mulhi32(h, h);
+            return PP_FIELDS ? h : mulhi32(h, h);       // (the table of these kernels holds the fields ready-made)
         };
         uint32_t pk[LBK + POS + AHEAD + 1];       // picks, index p + LBK (registers: only the last D are live)
         uint32_t tv[POS + 1];                     // skips
@@ -2898,7 +2931,11 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
         bool packed1 = false;
         if constexpr (SV != 0) packed1 = clean && trc_packed_ok(a, st_s.n - pat.k + 1);
         if (packed1) {
-            if (SO) {
+            bool fld = false;
+            if constexpr (RAW) fld = a.lut_fields != 0;
+            if (fld) {
+                if constexpr (RAW) { TPS_PHASE { trc_count_packed<SO, true>(a, l, st_s, st_e, tid); } }
+            } else if (SO) {
                 TPS_PHASE { trc_count_packed<true>(a, l, st_s, st_e, tid); }
             } else {
                 TPS_PHASE { trc_count_packed<false>(a, l, st_s, st_e, tid); }

@@ -19,7 +19,8 @@
         const int nthr_ = tps::NT * a.wpg;            /* = blockDim.x */                                   \
         for (int i = (int)threadIdx.x; i < a.lut_n; i += nthr_) {                                          \
             const uint32_t m_ = a.lut[i];                                                                  \
-            lut[i] = (SV) ? ((m_ << 16) | (uint32_t)__builtin_popcount(m_)) : m_;                          \
+            lut[i] = !(SV) ? m_ : ((RAW) && a.lut_fields) ? tps::mask_to_fields(m_)                        \
+                                                          : ((m_ << 16) | (uint32_t)__builtin_popcount(m_));  \
         }                                                                                                  \
         if (PAIR) {   /* host-built pair table, stored right behind the plain table */                      \
             for (int c = 4 * (int)threadIdx.x; c < a.pair_n; c += 4 * nthr_)                               \

@@ -188,7 +188,7 @@ inline std::string plan_geometry_core(ScanArgs& a, const tps_params& prm, int k,
     const bool fused = !force_generic && spans_pref <= 0 && k <= TPS_DIRECT_K && has_specialised_slide(prm.slide) && P <= 15 && a.q >= 8 &&
                        a.q / 8 + 2 < (XLANES - NT) && max_period <= std::min(prm.slide, 6) &&
                        2 * a.head_dw <= fused_seq_dw(prm.slide);   // the two step-1 heads fit the tile buffer (TileGeo::SEQ)
-    a.lc16 = 0; a.tile_cap = 0; a.tw = 0; a.tw_magic = 0; a.pair_n = 0; a.lc_global = 0; a.lc_stride = 0; a.pp_d = -1; a.so_fast = 0; a.seq_alias = 0; a.tile_full = 0;
+    a.lc16 = 0; a.tile_cap = 0; a.tw = 0; a.tw_magic = 0; a.pair_n = 0; a.lc_global = 0; a.lc_stride = 0; a.pp_d = -1; a.so_fast = 0; a.seq_alias = 0; a.lut_fields = 0; a.tile_full = 0;
     if (fused) {
         // per-pattern tiles (tile_pp_s): one-hot 2-bit fields per pattern need distinct k-mers, raw rows of at most 14 bytes
         // (they are staged through 16-byte LDS rows); a lane's 8 blocks hold at
@@ -198,6 +198,7 @@ inline std::string plan_geometry_core(ScanArgs& a, const tps_params& prm, int k,
                                a.lw / k + 2 <= 127 && !getenv("TPS_NO_PP");
         if (pp_counts && a.pat.n_periods == 0) a.pp_d = 0;
         if (pp_counts && a.pat.n_periods == 1 && a.pat.period[0] >= 2 && 2 * a.pat.period[0] >= k) a.pp_d = a.pat.period[0];
+        a.lut_fields = (PP_FIELDS && a.pp_d >= 0 && (prm.flags & TPS_F_STORE_RAW)) ? 1 : 0;   // the per-pattern tiles will run: table of one-hot fields
         a.so_fast = getenv("TPS_NO_SO_FAST") ? 0 : 1;   // sums only, pp_d > 0: chain-free tiles complete as plain tiles (tile_fused_s<.., CD>)
         a.variant = prm.slide;
         a.blk_log2 = 3;                            // 8 blocks per lane for every slide
@@ -242,7 +243,7 @@ inline std::string plan_geometry_core(ScanArgs& a, const tps_params& prm, int k,
         if (wg_lds_dwords(a) <= budget_dw) return "";
         // does not fit (very long maxlengthtelo: the candidate sums of 4 reads outgrow LDS): the generic kernel,
         // whose tile size adapts, takes over
-        a.lc16 = 0; a.tile_cap = 0; a.tw = 0; a.tw_magic = 0; a.pair_n = 0; a.lc_global = 0; a.lc_stride = 0; a.pp_d = -1; a.so_fast = 0; a.seq_alias = 0;
+        a.lc16 = 0; a.tile_cap = 0; a.tw = 0; a.tw_magic = 0; a.pair_n = 0; a.lc_global = 0; a.lc_stride = 0; a.pp_d = -1; a.so_fast = 0; a.seq_alias = 0; a.lut_fields = 0;
     }
     a.variant = 0;
     // the generic kernel's 32-bit candidate sums go off-chip too (stride counted in 16-bit units)
