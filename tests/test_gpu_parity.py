@@ -426,6 +426,17 @@ def test_per_pattern_tiles_adversarial_sweep():
 
 
 @pytest.mark.gpu
+def test_raw_rows_for_any_number_of_patterns():
+    """scripts/raw_any_p_gpu.py: hand-made pattern lists of 1 .. 14 patterns (odd row lengths leave the per-pattern tiles byte by
+    byte, others in 16-bit units or packed), raw rows and sums against the oracle."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "raw_any_p_gpu.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("k", [4, 5, 6])
 def test_full_size_raw_count_properties(sc, k):
     """BASELINE config-5 shape (25 kb ONT reads, --telophrase 4 5 6 --rawcountpattern), 4000 reads per k, no oracle at this
