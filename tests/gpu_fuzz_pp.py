@@ -1,6 +1,6 @@
 """Adversarial GPU-vs-oracle sweep for the per-pattern tiles: telomere repeats full of deletions and long runs of the
 k-mers' own period (chains of overlapping occurrences), raw counts and sums, both tails.  The C oracle is the checker
-(test infrastructure only).  usage: fuzz_pp_gpu.py [N_CASES] [SEED0]"""
+(test infrastructure only).  usage: gpu_fuzz_pp.py [N_CASES] [SEED0]"""
 import os, sys, time
 ROOT = os.environ.get('GRAFT_REPO_ROOT', '/root/repo')
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'oracle')); sys.path.insert(0, os.path.join(ROOT, 'tests'))

@@ -310,7 +310,7 @@ def test_emulation_long_kmers_hashed_table(motif, k, slide):
 @pytest.mark.parametrize("jump,min_size,slide", [(1, 2, 6), (3, 2, 6), (8, 4, 7), (1, 1, 11), (13, 2, 6)])
 def test_emulation_other_jump_values(jump, min_size, slide):
     """The change-point candidates b = c * jump for jumps other than ruptures' default 5 (jump = 1 has no 32-bit
-    reciprocal: found by the GPU sweep scripts/fuzz_gpu.py)."""
+    reciprocal: found by the GPU sweep tests/gpu_fuzz.py)."""
     rng = np.random.default_rng(jump * 31 + slide)
     pats = orc.kmer_table("CCCTAA", 4)
     seqs = []

@@ -325,12 +325,12 @@ def test_long_kmers_hashed_table(sc, motif, k, slide):
 
 @pytest.mark.gpu
 def test_randomised_parameter_sweep():
-    """scripts/fuzz_gpu.py: random motifs / k / window / slide / trim / maxlen / jump / min_size / no_bp and reads
+    """tests/gpu_fuzz.py: random motifs / k / window / slide / trim / maxlen / jump / min_size / no_bp and reads
     with errors, N, lower case and both strands, checked against the C oracle (it found the jump = 1 bug)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_gpu.py"), "150", "11"], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_fuzz.py"), "150", "11"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
@@ -416,23 +416,23 @@ def test_per_pattern_tiles_chains_and_raw_rows(sc, motif, k, slide, units):
 
 @pytest.mark.gpu
 def test_per_pattern_tiles_adversarial_sweep():
-    """scripts/fuzz_pp_gpu.py: deletion-ridden repeats and runs of the k-mers' own period over 15 tables / slides, raw rows
+    """tests/gpu_fuzz_pp.py: deletion-ridden repeats and runs of the k-mers' own period over 15 tables / slides, raw rows
     and sums, both tails, against the C oracle."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_pp_gpu.py"), "90", "3"], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_fuzz_pp.py"), "90", "3"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 @pytest.mark.gpu
 def test_raw_rows_for_any_number_of_patterns():
-    """scripts/raw_any_p_gpu.py: hand-made pattern lists of 1 .. 14 patterns (odd row lengths leave the per-pattern tiles byte by
+    """tests/gpu_raw_any_p.py: hand-made pattern lists of 1 .. 14 patterns (odd row lengths leave the per-pattern tiles byte by
     byte, others in 16-bit units or packed), raw rows and sums against the oracle."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "raw_any_p_gpu.py")], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "gpu_raw_any_p.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
