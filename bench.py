@@ -178,7 +178,7 @@ def spawn_ranks(n, argv):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=1000, help="timed steps (default 1000: ~70 ms of GPU work at config 2, long enough for an outside utilisation probe to see the GPU busy)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="config2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
