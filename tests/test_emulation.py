@@ -415,8 +415,8 @@ def test_emulation_per_pattern_tiles(motif, k, slide, units):
     ("TTTAGGG", 7, 7, "TTTAGG"),                  # period 6
 ])
 def test_emulation_chain_free_tiles_hand_over(motif, k, slide, unit):
-    """Sums only, self-overlap table: tiles without a chained occurrence complete as plain tiles (tile_fused_s<.., CD>), the
-    others go through tile_so_s.  Chains planted around every tile boundary (before, across, after; 2 to 6 links; both
+    """Self-overlap table: tiles without a chained occurrence complete as plain tiles (sums only: tile_fused_s<.., CD>; raw rows:
+    tile_pp_s<S, 0, CD>), the others go through tile_so_s / tile_pp_s<S, D>.  Chains planted around every tile boundary (before, across, after; 2 to 6 links; both
     tails) check the hand-over in both directions: what a plain tile leaves for a chained successor, and a chained tile
     followed by a plain one."""
     rng = np.random.default_rng(7 * k + slide)
@@ -437,17 +437,25 @@ def test_emulation_chain_free_tiles_hand_over(motif, k, slide, unit):
         seqs.append("".join(body if tail == 0 else body[::-1]))
         tails.append(tail)
     lib = emu.lib()
-    f0, s0, r0 = lib.emu_counter(6), lib.emu_counter(5), lib.emu_counter(1)
-    out = emu.scan(pats, seqs, prm, tails=tails, base_shift=int(rng.integers(16)))
-    fast, slow, redone = lib.emu_counter(6) - f0, lib.emu_counter(5) - s0, lib.emu_counter(1) - r0
-    assert fast > 0 and slow > 0, (fast, slow)
-    for i, seq in enumerate(seqs):
-        _, counts = orc.window_count_matrix(seq, ["forward", "reverse"][tails[i]], pats, 100, slide, 100, 20000)
-        lo, hi = out["win_off"][i], out["win_off"][i + 1]
-        assert hi - lo == counts.shape[0]
-        bad = np.flatnonzero(out["sums"][lo:hi] != counts.sum(axis=1))
-        assert bad.size == 0, (i, tails[i], bad[:8], tw)
-    assert redone < 40 * len(seqs)
+    for raw in (0, 1):
+        # sums only: chain-free tiles (counter 6) vs tile_so_s (5); raw rows: chain-free per-pattern tiles (7) vs all of them (0)
+        p2 = hiplib.make_params(window=100, slide=slide, trimfirst=100, maxlen=20000, flags=flags | (hiplib.F_STORE_RAW if raw else 0))
+        fi, si = (7, 0) if raw else (6, 5)
+        f0, s0, r0 = lib.emu_counter(fi), lib.emu_counter(si), lib.emu_counter(1)
+        out = emu.scan(pats, seqs, p2, tails=tails, base_shift=int(rng.integers(16)))
+        fast, slow, redone = lib.emu_counter(fi) - f0, lib.emu_counter(si) - s0, lib.emu_counter(1) - r0
+        if raw:
+            slow -= fast                                # (counter 0 counts every completed per-pattern tile)
+        assert fast > 0 and slow > 0, (raw, fast, slow)
+        for i, seq in enumerate(seqs):
+            _, counts = orc.window_count_matrix(seq, ["forward", "reverse"][tails[i]], pats, 100, slide, 100, 20000)
+            lo, hi = out["win_off"][i], out["win_off"][i + 1]
+            assert hi - lo == counts.shape[0]
+            bad = np.flatnonzero(out["sums"][lo:hi] != counts.sum(axis=1))
+            assert bad.size == 0, (raw, i, tails[i], bad[:8], tw)
+            if raw:
+                assert np.array_equal(out["raw"][lo:hi], counts.reshape(-1, len(pats))), (i, tails[i])
+        assert redone < 40 * len(seqs)
 
 
 @pytest.mark.parametrize("motif,k,slide,counts", [("CCCTAA", 5, 6, [1, 2, 3, 5, 6, 7, 9, 10, 11, 12]), ("AAACCCT", 5, 7, [13, 14])])

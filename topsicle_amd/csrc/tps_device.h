@@ -1693,9 +1693,15 @@ TPS_DEV void pp_expand(uint32_t ne, uint32_t no, uint32_t* b) {   // nibble word
     b[3] = (no >> 4) & 0x0F0F0F0Fu;               // patterns 3, 7, 11, 15
 }
 
-template <int S, int D>
-TPS_DEV void tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int delta, int w0, int tile, int nw_tile,
+// CD > 0 (with D = 0): CHAIN DETECTION on a table whose self-overlapping k-mers share the period CD.  The tile runs as if the
+// table had no self-overlap (no look-back, no skips, no repairs) and ANDs the fields CD positions apart on the way; if any
+// lane saw a pattern occur at p and again at p + CD inside the tile it returns true right after phase 1 (nothing but its own
+// exchange words written) and the caller runs tile_pp_s<S, CD> on the tile; otherwise every window's per-pattern count is
+// the plain prefix difference and the tile completes here (see tile_fused_s<.., CD> for the argument and the hand-over).
+template <int S, int D, int CD = 0>
+TPS_DEV bool tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int delta, int w0, int tile, int nw_tile,
                        int64_t out_base, uint64_t& s_total) {
+    static_assert(CD == 0 || (D == 0 && CD <= 6), "chain detection runs on the tile without self-overlap logic");
     // look-back over the previous lane's last LBK positions (tables with a self-overlap period only): enough for a chain that
     // starts inside it; a chain through the whole look-back takes the walk below
     constexpr int B = 8, POS = B * S, LBK = D > 0 ? 2 * D + 2 : 0;
@@ -1726,9 +1732,10 @@ TPS_DEV void tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
     };
 #ifdef TPS_EMU
     uint32_t keep[NT][2 * B + 3];
-    ++emu_counter(0);
+    if (CD == 0) ++emu_counter(0);
 #endif
     uint32_t ve[B], vo[B], chm = 0, chw = 0, unc = 0;
+    uint32_t chain_any = 0;                       // CD: (field at p) & (field at p + CD), OR over the lane's positions
     TPS_PHASE {
         const int span = tid;
         const int p0 = delta + span * POS;        // >= 16
@@ -1821,6 +1828,9 @@ TPS_DEV void tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
                 tv[p] = t;
                 const uint32_t pick = h ^ t;
                 pk[LBK + p] = pick;
+                if constexpr (CD > 0) {
+                    if (p >= CD) chain_any |= h & pk[p - CD];
+                }
                 acc += pick;
                 pb = (i + 1 == rp) ? acc : pb;
             }
@@ -1846,6 +1856,10 @@ TPS_DEV void tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
             chm |= ch3[B - 1] ? (1u << (B - 1)) : 0u;
             chw |= ch3[B - 1];
         }
+        if constexpr (CD > 0) {
+            TPS_UNROLL
+            for (int i = 0; i < CD; ++i) chain_any |= look(POS + i) & pk[POS + i - CD];   // pairs that reach into the next lane's positions
+        }
         tne[span] = pe;
         tno[span] = po;
         TPS_PIN_V(chm); TPS_PIN_V(chw); TPS_PIN_V(unc);
@@ -1858,6 +1872,18 @@ TPS_DEV void tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
 #endif
     }
     TPS_SYNC();
+    if constexpr (CD > 0) {
+#ifdef TPS_EMU
+        const bool chained = chain_any != 0;      // (the emulation's phase loop has OR-ed every lane into the one variable)
+#else
+        const bool chained = __builtin_amdgcn_ballot_w64(chain_any != 0) != 0;
+#endif
+        if (chained) return true;
+#ifdef TPS_EMU
+        ++emu_counter(0);
+        ++emu_counter(7);
+#endif
+    }
     // lanes whose look-back could not fix their state: every window that touches one of them is recounted
     uint64_t unc_mask = 0;
     if (D > 0) {
@@ -1979,6 +2005,14 @@ TPS_DEV void tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
             swv[j] = sw_keep[tid][j];
 #endif
             l.row[tid * (B + 1) + j] = swv[j];
+        }
+        if constexpr (CD > 0) {
+            // what a chained successor wants from this (chain-free) tile: no pick before its first position matters -- a pair
+            // across that position would lie inside this tile -- and nothing is uncertain
+            if (tid == clane) {
+                TPS_UNROLL
+                for (int i = 0; i < 7; ++i) carry[i] = 0u;
+            }
         }
     }
     if (staged) {
@@ -2156,6 +2190,7 @@ TPS_DEV void tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
         TPS_SYNC();
     }
     tile_candidates(tc, l, w0, tile, nw_tile, s_total);
+    return false;
 }
 
 // ------------------------------------------------------------------ step 2, self-overlap tables, sums only
@@ -3116,6 +3151,18 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
                     constexpr int SP = SV ? SV : 5;
                     if (pp && uniform(l.misc[M_INVALID]) == 0) {
                         if constexpr (SO) {
+                            // tiles without a chained occurrence complete as tiles of a table without self-overlap
+                            bool chained = true;
+                            if (a.so_fast) {
+                                switch (a.pp_d) {
+                                    case 2: chained = tile_pp_s<SP, 0, 2>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
+                                    case 3: chained = tile_pp_s<SP, 0, 3>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
+                                    case 4: chained = tile_pp_s<SP, 0, 4>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
+                                    case 5: chained = tile_pp_s<SP, 0, 5>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
+                                    default: chained = tile_pp_s<SP, 0, (SP < 6 ? SP : 6)>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
+                                }
+                            }
+                            if (!chained) continue;
                             switch (a.pp_d) {
                                 case 2: tile_pp_s<SP, 2>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
                                 case 3: tile_pp_s<SP, 3>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
