@@ -205,6 +205,30 @@ def test_config4_cli_cutoff_sweep_on_gpu(tmp_path):
     assert "with TRC >= 0.8" in open(out / "topsicle_run.log").read()
 
 
+@pytest.mark.gpu
+def test_cli_several_files_concurrently_equals_one_at_a_time(tmp_path):
+    """Six plain FASTQ files (the packed reader's thread team, the detached unmapping and two contexts per GPU are shared by
+    concurrent file threads), `--threads 4` against `--threads 1`: same rows per file, same filtered files."""
+    from topsicle_amd import main as cli
+    motif = "CCCTAA"
+    indir = tmp_path / "in"
+    indir.mkdir()
+    for f in range(6):
+        bases, offsets, _ = synth.make_reads(700 + 150 * f, 9000 + 1500 * f, motif, seed=100 + f, tract_min=200, tract_max=4000)
+        _write_fastq(indir / f"s{f}.fastq", bases, offsets)
+    outs = []
+    for threads in ("4", "1"):
+        out = tmp_path / f"out{threads}"
+        cli.main(["-i", str(indir), "-o", str(out), "--pattern", motif, "--threads", threads, "--minSeqLength", "5000"])
+        rows = sorted(tuple(r) for r in list(csv.reader(open(out / "telolengths_all.csv")))[1:])
+        filt = {n: open(out / n, "rb").read() for n in sorted(os.listdir(out)) if "_trc_over_" in n}
+        outs.append((rows, filt))
+    assert len(outs[0][0]) > 1500 and outs[0][0] == outs[1][0]
+    assert list(outs[0][1]) == list(outs[1][1]) and len(outs[0][1]) == 6
+    for n in outs[0][1]:
+        assert outs[0][1][n] == outs[1][1][n], n
+
+
 # --------------------------------------------------------------------------------------------- configs[0]
 def test_config1_demo_default_slide7_on_gpu(sc, tmp_path, gold_dir, demo_records, demo_windows):
     """BASELINE configs[0] as stated: --pattern AAACCCT, defaults (slide 7).  The k-mer set equals CCCTAAA's, so the
