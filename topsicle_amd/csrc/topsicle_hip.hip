@@ -186,7 +186,7 @@ struct tps_ctx {
     int zero_copy = 1;       // per-read results are written by the kernel straight into mapped pinned host memory
     int force_generic = 0;
     int64_t lds_target_dw = 32 * 256;
-    size_t lds_set_v[21] = {0};
+    size_t lds_set_v[32] = {0};
     uint32_t* h_flag = nullptr;      // mapped host word the pack kernel raises when a read has a non-ACGT letter
 };
 
@@ -408,9 +408,12 @@ int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm) {
                                  {(const void*)tps_scan_kernel_s7so, "tps_scan_kernel_s7so"}, {(const void*)tps_scan_kernel_s8so, "tps_scan_kernel_s8so"}};
         static const K sork[4] = {{(const void*)tps_scan_kernel_s5sor, "tps_scan_kernel_s5sor"}, {(const void*)tps_scan_kernel_s6sor, "tps_scan_kernel_s6sor"},
                                   {(const void*)tps_scan_kernel_s7sor, "tps_scan_kernel_s7sor"}, {(const void*)tps_scan_kernel_s8sor, "tps_scan_kernel_s8sor"}};
+        static const K solk[4] = {{(const void*)tps_scan_kernel_s5sol, "tps_scan_kernel_s5sol"}, {(const void*)tps_scan_kernel_s6sol, "tps_scan_kernel_s6sol"},
+                                  {(const void*)tps_scan_kernel_s7sol, "tps_scan_kernel_s7sol"}, {(const void*)tps_scan_kernel_s8sol, "tps_scan_kernel_s8sol"}};
         if (a.variant >= 5 && a.variant <= 8) {
-            const int fam = so ? (want_raw ? 4 : 3) : want_raw ? 2 : pair ? 1 : 0;
-            const K* tab[5] = {plain, pairk, rawk, sok, sork};
+            // sums only, self-overlap table: periods 2 .. 4 have their own kernels (96 registers, 5 waves per SIMD)
+            const int fam = so ? (want_raw ? 4 : (a.pp_d >= 2 && a.pp_d <= 4) ? 5 : 3) : want_raw ? 2 : pair ? 1 : 0;
+            const K* tab[6] = {plain, pairk, rawk, sok, sork, solk};
             const K& k = tab[fam][a.variant - 5];
             kfn = k.fn;
             sl.kernel_name = k.name;

@@ -2904,7 +2904,10 @@ TPS_DEV void binseg_from_lc(const ScanArgs& a, const Lds& l, uint64_t lc_g, cons
 // In the device build every lane of the wave executes this function; TPS_PHASE bodies run once
 // per lane and TPS_SYNC() is a wave-level fence.  In the emulation TPS_PHASE loops over the 64
 // lane ids, so phases run in program order.
-template <int SV, bool SO, bool PAIR = false, bool RAW = true, bool FULL = tile_full_default(SV)>
+// DCLASS (sums-only self-overlap kernels): which self-overlap periods this instantiation carries -- 0 all, 1 periods 2 .. 4,
+// 2 periods 5 and 6.  tile_so_s for a period <= 4 fits 96 registers (5 waves per SIMD); periods 5 and 6 need ~128, and one
+// kernel holding all of them is compiled for the worst (the host picks the kernel by ScanArgs::pp_d).
+template <int SV, bool SO, bool PAIR = false, bool RAW = true, bool FULL = tile_full_default(SV), int DCLASS = 0>
 TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_t* lut) {
     const Lds l = SV ? carve_fused<SV ? SV : 5, FULL>(lds_base, lut, a) : carve(lds_base, lut, a);
     const PatInfo& pat = a.pat;
@@ -3189,17 +3192,27 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
                         if (a.so_fast) {
 #define TPS_CD_RP(D_, N) case N: if constexpr (N < SP && D_ <= SP) chained = tile_fused_s<SP, false, false, (N < SP ? N : 0), false, false, (D_ <= SP ? D_ : 0)>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r); break;
 #define TPS_CD(D_) case D_: switch (tc.r) { TPS_CD_RP(D_, 0) TPS_CD_RP(D_, 1) TPS_CD_RP(D_, 2) TPS_CD_RP(D_, 3) TPS_CD_RP(D_, 4) TPS_CD_RP(D_, 5) TPS_CD_RP(D_, 6) TPS_CD_RP(D_, 7) default: break; } break;
-                            switch (a.pp_d) { TPS_CD(2) TPS_CD(3) TPS_CD(4) TPS_CD(5) TPS_CD(6) default: break; }
+                            if constexpr (DCLASS == 1) { switch (a.pp_d) { TPS_CD(2) TPS_CD(3) TPS_CD(4) default: break; } }
+                            else if constexpr (DCLASS == 2) { switch (a.pp_d) { TPS_CD(5) TPS_CD(6) default: break; } }
+                            else { switch (a.pp_d) { TPS_CD(2) TPS_CD(3) TPS_CD(4) TPS_CD(5) TPS_CD(6) default: break; } }
 #undef TPS_CD
 #undef TPS_CD_RP
                         }
                         if (!chained) continue;
-                        switch (a.pp_d) {
-                            case 2: tile_so_s<SP, 2>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
-                            case 3: tile_so_s<SP, 3>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
-                            case 4: tile_so_s<SP, 4>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
-                            case 5: tile_so_s<SP, 5>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
-                            default: tile_so_s<SP, (SP < 6 ? SP : 6)>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
+                        if constexpr (DCLASS != 2) {
+                            switch (a.pp_d) {
+                                case 2: tile_so_s<SP, 2>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
+                                case 3: tile_so_s<SP, 3>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
+                                case 4: tile_so_s<SP, 4>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
+                                default: break;
+                            }
+                        }
+                        if constexpr (DCLASS != 1) {
+                            switch (a.pp_d) {
+                                case 2: case 3: case 4: break;
+                                case 5: tile_so_s<SP, 5>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
+                                default: tile_so_s<SP, (SP < 6 ? SP : 6)>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
+                            }
                         }
                         continue;
                     }

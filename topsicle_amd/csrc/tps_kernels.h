@@ -11,7 +11,7 @@
 // One wave per read, tps::WPG waves per workgroup.  The lookup table is loaded once per workgroup
 // (the only workgroup barrier in the kernel); after that every wave runs its own read with
 // wave-level synchronisation only.
-#define TPS_SCAN_KERNEL_F(NAME, SV, SO, PAIR, RAW, MINW, FULL)                                                           \
+#define TPS_SCAN_KERNEL_F(NAME, SV, SO, PAIR, RAW, MINW, FULL, DCLASS)                                                           \
     extern "C" __global__ void __launch_bounds__(tps::NT * tps::WPG_MAX, MINW) NAME(tps::ScanArgs a) {     \
         extern __shared__ __attribute__((aligned(16))) uint32_t lds[];                                     \
         /* workgroup-shared tables: [pair table (PAIR kernels)][single table], both aligned to their size */ \
@@ -36,14 +36,15 @@
         const int64_t wave_dw = (tps::lds_dwords(a) + 3) & ~3ll;                                           \
         uint32_t* slice = lut + ((a.lut_n + 3) & ~3) + wave * wave_dw;                                     \
         const int64_t r = (int64_t)blockIdx.x * a.wpg + wave;                                              \
-        if (r < a.n_reads) tps::scan_read<SV, SO, PAIR, RAW, FULL>(a, r, slice, lut);                           \
+        if (r < a.n_reads) tps::scan_read<SV, SO, PAIR, RAW, FULL, DCLASS>(a, r, slice, lut);                           \
     }
 #ifndef TPS_SO_MINW
 #define TPS_SO_MINW 4     // waves per SIMD the sums-only self-overlap kernels are compiled for (tile_so_s wants ~128 VGPRs: 5 would spill ~120)
 #endif
-#define TPS_SCAN_KERNEL(NAME, SV, SO, PAIR, RAW, MINW) TPS_SCAN_KERNEL_F(NAME, SV, SO, PAIR, RAW, MINW, tps::tile_full_default(SV))
+#define TPS_SCAN_KERNEL(NAME, SV, SO, PAIR, RAW, MINW) TPS_SCAN_KERNEL_F(NAME, SV, SO, PAIR, RAW, MINW, tps::tile_full_default(SV), 0)
+#define TPS_SCAN_KERNEL_D(NAME, SV, SO, PAIR, RAW, MINW, DCLASS) TPS_SCAN_KERNEL_F(NAME, SV, SO, PAIR, RAW, MINW, tps::tile_full_default(SV), DCLASS)
 
-#define TPS_KGROUPS 9
+#define TPS_KGROUPS 11
 #ifdef TPS_KGROUP
 #define TPS_IN_GROUP(g) (TPS_KGROUP == (g))
 #else
@@ -68,6 +69,10 @@ TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s5so)
 TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s6so)
 TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s7so)
 TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s8so)
+TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s5sol)
+TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s6sol)
+TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s7sol)
+TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s8sol)
 TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s5sor)
 TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s6sor)
 TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s7sor)
@@ -93,12 +98,12 @@ TPS_SCAN_KERNEL(tps_scan_kernel_s7r, 7, false, false, true, 3)
 TPS_SCAN_KERNEL(tps_scan_kernel_s8r, 8, false, false, true, 3)
 #endif
 #if TPS_IN_GROUP(3)
-TPS_SCAN_KERNEL(tps_scan_kernel_s5so, 5, true, false, false, TPS_SO_MINW)      // ... self-overlapping k-mers in the table, sums only (tile_so_s)
-TPS_SCAN_KERNEL(tps_scan_kernel_s6so, 6, true, false, false, TPS_SO_MINW)
+TPS_SCAN_KERNEL_D(tps_scan_kernel_s5so, 5, true, false, false, TPS_SO_MINW, 2)      // ... self-overlapping k-mers in the table, sums only (tile_so_s)
+TPS_SCAN_KERNEL_D(tps_scan_kernel_s6so, 6, true, false, false, TPS_SO_MINW, 2)
 #endif
 #if TPS_IN_GROUP(4)
-TPS_SCAN_KERNEL(tps_scan_kernel_s7so, 7, true, false, false, TPS_SO_MINW)
-TPS_SCAN_KERNEL(tps_scan_kernel_s8so, 8, true, false, false, TPS_SO_MINW)
+TPS_SCAN_KERNEL_D(tps_scan_kernel_s7so, 7, true, false, false, TPS_SO_MINW, 2)
+TPS_SCAN_KERNEL_D(tps_scan_kernel_s8so, 8, true, false, false, TPS_SO_MINW, 2)
 #endif
 #if TPS_IN_GROUP(5)
 TPS_SCAN_KERNEL(tps_scan_kernel_s5sor, 5, true, false, true, 5)      // ... the same with the per-pattern raw counts (tile_pp_s)
@@ -111,4 +116,12 @@ TPS_SCAN_KERNEL(tps_scan_kernel_s7sor, 7, true, false, true, 5)
 #endif
 #if TPS_IN_GROUP(8)
 TPS_SCAN_KERNEL(tps_scan_kernel_s8sor, 8, true, false, true, 5)
+#endif
+#if TPS_IN_GROUP(9)
+TPS_SCAN_KERNEL_D(tps_scan_kernel_s5sol, 5, true, false, false, 5, 1)     // ... the same for self-overlap periods 2 .. 4: 96 registers, 5 waves per SIMD
+TPS_SCAN_KERNEL_D(tps_scan_kernel_s6sol, 6, true, false, false, 5, 1)
+#endif
+#if TPS_IN_GROUP(10)
+TPS_SCAN_KERNEL_D(tps_scan_kernel_s7sol, 7, true, false, false, 5, 1)
+TPS_SCAN_KERNEL_D(tps_scan_kernel_s8sol, 8, true, false, false, 5, 1)
 #endif
