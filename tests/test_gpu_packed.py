@@ -124,3 +124,45 @@ def test_packed_upload_without_inv_array_and_bad_descriptors(sc):
     bad["flags"][0] = hiplib.RD_HAS_INVALID               # flagged, but no inv array
     with pytest.raises(hiplib.TopsicleHipError):
         sc.upload_packed(5, seq2, None, bad)
+
+
+def test_clean_and_dirty_batches_alternate_in_one_slot(sc):
+    """A batch without non-ACGT letters is scanned without the invalid-mask staging area (one more workgroup per CU, the
+    staged bases inside row[]); the LDS layout is planned per uploaded batch.  Clean / dirty / clean batches through the
+    same slot and context, ASCII and host-packed uploads, every read against the oracle."""
+    motif, k, slide = "CCCTAA", 4, 6
+    pats = orc.kmer_table(motif, k)
+    sc.set_patterns(pats)
+    prm = hiplib.make_params(no_bp=1000, min_len=3000, min_count=1, window=100, slide=slide, trimfirst=100, maxlen=20000,
+                             flags=FULL)
+    rng = np.random.default_rng(23)
+    infos = []
+    for step, dirty in enumerate([False, True, False, True, False]):
+        b, o, _ = synth.make_reads(96, 9000, motif, seed=500 + step)
+        b = b.copy()
+        if dirty:
+            pos = rng.integers(0, b.size, b.size // 300)
+            b[pos] = np.frombuffer(b"Nn-RY", np.uint8)[rng.integers(0, 5, pos.size)]
+        if step % 2:
+            seq2, inv, desc = np_pack(b, o)
+            sc.upload_packed(0, seq2, inv if dirty else None, desc)
+        else:
+            sc.upload(0, b, o)
+        sc.scan(0, prm)
+        sc.sync()
+        infos.append(sc.kernel_info(0) if hasattr(sc, "kernel_info") else "")
+        res = sc.results(0)
+        sums, win_off = sc.window_sums(0)
+        raw = b.tobytes()
+        for i in range(0, 96, 5):
+            seq = raw[o[i]:o[i + 1]].decode("latin1")
+            cs, ce = orc.trc_counts(seq, pats)
+            assert res["best_start"][i] == max(cs) and res["best_end"][i] == max(ce), (step, i)
+            if res["pass"][i]:
+                tail = ["forward", "reverse"][int(res["tail"][i])]
+                _, counts = orc.window_count_matrix(seq, tail, pats, 100, slide, 100, 20000)
+                lo, hi = win_off[i], win_off[i + 1]
+                assert np.array_equal(sums[lo:hi], counts.sum(axis=1)), (step, i)
+                assert res["bkp"][i] == orc.binseg_l2_exact(counts.sum(axis=1)), (step, i)
+    if infos[0]:
+        assert infos[0] != infos[1] and infos[0] == infos[2], infos        # the plan follows the batch (LDS bytes per workgroup differ)
