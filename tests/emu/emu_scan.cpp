@@ -69,6 +69,16 @@ extern "C" int emu_scan(const char* pats, int P, int k, const uint8_t* bases, co
     a.c_end = (prm->flags & TPS_F_STEP1) ? c_end : nullptr;
     a.win_off = win_off.data();
     a.sums = sums;                                 // always present, like the library's device buffer
+    // fused kernels: 16-bit sums in the padded device layout (tps_plan.h: sums16_slots), widened below like the library's download
+    std::vector<int64_t> win_off16((size_t)n + 1);
+    {
+        int64_t acc16 = 0;
+        for (int64_t i = 0; i < n; ++i) { win_off16[(size_t)i] = acc16; acc16 += tps::sums16_slots(win_off[(size_t)i + 1] - win_off[(size_t)i]); }
+        win_off16[(size_t)n] = acc16;
+    }
+    std::vector<uint16_t> sums16((size_t)win_off16[(size_t)n] + 8, (uint16_t)0xBEEF);
+    a.sums16 = sums16.data();
+    a.win_off16 = win_off16.data();
     a.raw = (prm->flags & TPS_F_STORE_RAW) ? raw : nullptr;
     a.n_reads = n;
     a.prm = *prm;
@@ -107,6 +117,10 @@ extern "C" int emu_scan(const char* pats, int P, int k, const uint8_t* bases, co
         }
 #undef EMU_CASE
     }
+    if (a.variant && sums)
+        for (int64_t i = 0; i < n; ++i)
+            for (int64_t w = 0; w < win_off[(size_t)i + 1] - win_off[(size_t)i]; ++w)
+                sums[win_off[(size_t)i] + w] = (int32_t)sums16[(size_t)(win_off16[(size_t)i] + w)];
     return TPS_OK;
 }
 

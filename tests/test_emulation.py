@@ -498,13 +498,14 @@ def test_planner_picks_per_pattern_tiles():
 
 def test_planner_full_tiles_everywhere():
     """With the packed batch a tile is staged as whole 64-base quads whatever the slide, so every fused tile uses all 64
-    lanes: 512 - q - 1 windows (495 at slide 6, window 100), for the sums-only, raw-count and self-overlap kernels alike."""
+    lanes: 512 - q - 1 windows rounded down to an even number (494 at slide 6, window 100: tiles start at even windows because
+    the 16-bit window sums leave in whole dwords), for the sums-only, raw-count and self-overlap kernels alike."""
     def plan(motif, k, slide, nwin, flags=0):
         return emu.plan_table(orc.kmer_table(motif, k), hiplib.make_params(slide=slide, flags=hiplib.F_WINDOWS | flags), nwin)
     for nwin in (2467, 3301):
         p = plan("CCCTAA", 4, 6, nwin)
-        assert (p["tile_full"], p["tw"]) == (1, 495)
-    assert plan("CCCTAA", 4, 6, 2467, hiplib.F_STORE_RAW)["tw"] == 495 and plan("CCCTAA", 5, 6, 2467)["tw"] == 496
+        assert (p["tile_full"], p["tw"]) == (1, 494)
+    assert plan("CCCTAA", 4, 6, 2467, hiplib.F_STORE_RAW)["tw"] == 494 and plan("CCCTAA", 5, 6, 2467)["tw"] == 496
     assert plan("AAACCCT", 5, 7, 2829)["tile_full"] == 1 and plan("TTAGG", 4, 5, 3000)["tile_full"] == 1
 
 

@@ -133,12 +133,14 @@ struct DevBuf {
 };
 
 struct Slot {
-    DevBuf seq2, inv, desc, tails, results, c_start, c_end, win_off, sums, raw, stamps, lc;
+    DevBuf seq2, inv, desc, tails, results, c_start, c_end, win_off, win_off16, sums, raw, stamps, lc;
     int64_t n_words = 0;                 // words of seq2 / inv in use
     bool inv_valid = true;               // false: the batch came packed without an inv array (no read is flagged)
     bool any_invalid = true;             // some read of the batch is flagged TPS_RD_HAS_INVALID (the kernels then stage the invalid masks)
     std::vector<int64_t> h_offsets;      // host copy of offsets (n+1)
     std::vector<int64_t> h_win_off;      // window layout of the last plan
+    std::vector<int64_t> h_win_off16;    // ... of the fused kernels' 16-bit sums on the device (every read padded to a multiple of 8 windows)
+    std::vector<uint16_t> h_sums16;      // download scratch
     tps_read_result* h_results = nullptr;   // pinned
     size_t h_results_cap = 0;
     int64_t n = -1;
@@ -316,19 +318,27 @@ int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm) {
     if (!sl.planned || !same_params(prm, sl.plan_prm) || sl.plan_k != c->pat.k || sl.plan_p != P ||
         (sl.plan_dup != 0) != (c->pat.dup_mask != 0) || (sl.plan_so != 0) != (c->pat.so_mask != 0)) {
         sl.h_win_off.resize((size_t)n + 1);
-        int64_t acc = 0, mx = 0;
+        sl.h_win_off16.resize((size_t)n + 1);
+        int64_t acc = 0, acc16 = 0, mx = 0;
         for (int64_t i = 0; i < n; ++i) {
             sl.h_win_off[(size_t)i] = acc;
+            sl.h_win_off16[(size_t)i] = acc16;
             int64_t nw = window_count(sl.h_offsets[i + 1] - sl.h_offsets[i], prm.window, prm.slide, prm.trimfirst, prm.maxlen);
             mx = std::max(mx, nw);
             acc += nw;
+            acc16 += tps::sums16_slots(nw);
         }
         sl.h_win_off[(size_t)n] = acc;
+        sl.h_win_off16[(size_t)n] = acc16;
         sl.args = tps::ScanArgs{};
         sl.args.val_on = sl.any_invalid ? 1 : 0;
         if ((rc = plan_lds(c, sl, prm, mx))) return rc;
         if ((rc = sl.win_off.ensure((size_t)(n + 1) * 8))) return rc;
         HIP_TRY(hipMemcpyAsync(sl.win_off.p, sl.h_win_off.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+        if (sl.args.variant) {                          // fused kernels: the padded layout of their 16-bit sums
+            if ((rc = sl.win_off16.ensure((size_t)(n + 1) * 8))) return rc;
+            HIP_TRY(hipMemcpyAsync(sl.win_off16.p, sl.h_win_off16.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+        }
         HIP_TRY(hipStreamSynchronize(c->stream));       // h_win_off may be reused by the caller's next plan
         sl.plan_prm = prm;
         sl.plan_k = c->pat.k;
@@ -362,12 +372,21 @@ int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm) {
     }
     a.win_off = (const int64_t*)sl.win_off.p;
     a.sums = nullptr;
+    a.sums16 = nullptr;
+    a.win_off16 = nullptr;
     a.raw = nullptr;
     if (prm.flags & TPS_F_WINDOWS) {
-        // S_w always goes to HBM (4 B per window): it is the step's output and the only copy the
-        // exact change-point fallback can re-read; TPS_F_STORE_SUMS just makes it downloadable
-        if ((rc = sl.sums.ensure((size_t)std::max<int64_t>(total_win, 1) * 4))) return rc;
-        a.sums = (int32_t*)sl.sums.p;
+        // S_w always goes to HBM: it is the step's output and the only copy the exact change-point fallback can re-read;
+        // TPS_F_STORE_SUMS just makes it downloadable.  The fused kernels write 16-bit values (2 B per window, every read
+        // padded to 8 windows), the generic kernel int32; tps_batch_window_sums hands out int32 either way.
+        if (a.variant) {
+            if ((rc = sl.sums.ensure((size_t)std::max<int64_t>(sl.h_win_off16[(size_t)n], 8) * 2))) return rc;
+            a.sums16 = (uint16_t*)sl.sums.p;
+            a.win_off16 = (const int64_t*)sl.win_off16.p;
+        } else {
+            if ((rc = sl.sums.ensure((size_t)std::max<int64_t>(total_win, 1) * 4))) return rc;
+            a.sums = (int32_t*)sl.sums.p;
+        }
     }
     if (prm.flags & TPS_F_STORE_RAW) {
         if ((rc = sl.raw.ensure((size_t)std::max<int64_t>(total_win * P, 1)))) return rc;
@@ -513,7 +532,7 @@ int tps_ctx_destroy(tps_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (auto& sl : c->slots) {
-        sl.seq2.release(); sl.inv.release(); sl.desc.release(); sl.tails.release(); sl.results.release();
+        sl.seq2.release(); sl.inv.release(); sl.desc.release(); sl.tails.release(); sl.results.release(); sl.win_off16.release();
         sl.c_start.release(); sl.c_end.release(); sl.win_off.release(); sl.sums.release(); sl.raw.release(); sl.stamps.release(); sl.lc.release();
         if (sl.h_results) (void)hipHostFree(sl.h_results);
     }
@@ -759,7 +778,20 @@ int tps_batch_window_sums(tps_ctx* c, int32_t slot, int32_t* sums, int64_t nw) {
     if ((rc = need_scanned(c, slot, &sl))) return rc;
     if (!(sl->last_flags & TPS_F_STORE_SUMS)) return fail(TPS_E_STATE, "last scan did not store window sums");
     if (nw != sl->h_win_off[(size_t)sl->n] || (nw > 0 && !sums)) return fail(TPS_E_ARG, "sums must hold %lld windows", (long long)sl->h_win_off[(size_t)sl->n]);
-    if (nw) HIP_TRY(hipMemcpy(sums, sl->sums.p, (size_t)nw * 4, hipMemcpyDeviceToHost));
+    if (nw && sl->args.variant) {
+        // fused kernels: 16-bit sums in the padded device layout -> the caller's contiguous int32 array
+        const int64_t n16 = sl->h_win_off16[(size_t)sl->n];
+        sl->h_sums16.resize((size_t)n16);
+        HIP_TRY(hipMemcpy(sl->h_sums16.data(), sl->sums.p, (size_t)n16 * 2, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < sl->n; ++i) {
+            const uint16_t* src = sl->h_sums16.data() + sl->h_win_off16[(size_t)i];
+            int32_t* dst = sums + sl->h_win_off[(size_t)i];
+            const int64_t cnt = sl->h_win_off[(size_t)i + 1] - sl->h_win_off[(size_t)i];
+            for (int64_t w = 0; w < cnt; ++w) dst[w] = (int32_t)src[w];
+        }
+    } else if (nw) {
+        HIP_TRY(hipMemcpy(sums, sl->sums.p, (size_t)nw * 4, hipMemcpyDeviceToHost));
+    }
     return TPS_OK;
 }
 

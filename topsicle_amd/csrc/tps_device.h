@@ -244,7 +244,12 @@ struct ScanArgs {
     int32_t* c_start;            // n*P or nullptr
     int32_t* c_end;              // n*P or nullptr
     const int64_t* win_off;      // n+1 (window layout of sums/raw)
-    int32_t* sums;               // or nullptr
+    int32_t* sums;               // generic kernel: S_w as int32 at win_off[r]; or nullptr
+    // fused kernels (round 3): S_w leaves as 16-bit values (S_w <= 15 patterns x 225 occurrences there) -- the window sums are the
+    // kernel's largest output and HBM writes its scarcest resource (config 2: 98.7 MB of int32 per launch cost 10 of 68 us).  Every
+    // read's region starts at win_off16[r], a multiple of 8 windows (16-byte aligned); the library widens on download.
+    uint16_t* sums16;
+    const int64_t* win_off16;    // n+1
     uint8_t* raw;                // or nullptr
     uint64_t* stamps;            // diagnostics: 16 clock stamps per read, or nullptr
     int64_t n_reads;
@@ -1073,10 +1078,12 @@ struct TileConst {
     int32_t q, r;
     uint32_t jump, jump_magic, lc_cap, lc16;
     uint64_t lc_g;               // this read's off-chip candidate sums: Lc16, or absolute 32-bit sums (0 = they live in LDS)
+    uint16_t* sw16;              // this read's window sums (16-bit, ScanArgs::sums16)
 };
 TPS_DEV TileConst tile_const(const ScanArgs& a, int64_t r) {
     TileConst t;
     t.lc_g = a.lc_global ? (uint64_t)(uintptr_t)(a.lc_scratch + r * (int64_t)a.lc_stride) : 0ull;
+    t.sw16 = a.sums16 + (a.win_off16 ? a.win_off16[r] : 0);
     t.q = (int32_t)uniform((uint32_t)a.q); t.r = (int32_t)uniform((uint32_t)a.r);
     t.jump = uniform((uint32_t)a.prm.jump); t.jump_magic = uniform(a.jump_magic);
     t.lc_cap = uniform((uint32_t)a.lc_cap); t.lc16 = uniform((uint32_t)a.lc16);
@@ -1424,8 +1431,8 @@ TPS_DEV bool tile_fused_s(const ScanArgs& a, const TileConst& tc, const Lds& l, 
         uint32_t* ps = l.row + (lane + (lane >> LOG2B));                         // XS in, S_w out
         const uint32_t* pe = l.XPC + ((lane + (uint32_t)q) + ((lane + (uint32_t)q) >> LOG2B));
         const uint32_t* pf = (farl ? l.XT : l.XF) + (lane >> LOG2B);
-        int32_t* out = a.sums + (out_base + w0);
-        int32_t* outl = out + lane;
+        uint16_t* out = tc.sw16 + w0;
+        uint16_t* outl = out + lane;
         const uint32_t am = pat.all_mask << 16;
         const int nfull = nw_tile >> 6;                                          // uniform
         const uint32_t npart = (uint32_t)(nw_tile & 63);
@@ -1452,7 +1459,7 @@ TPS_DEV bool tile_fused_s(const ScanArgs& a, const TileConst& tc, const Lds& l, 
                         flags |= (m >> 31) << u;
                         present[u / 2] |= (u & 1) ? (m & 0xFFFF0000u) : (m >> 16);
                     }
-                    outl[u * NT] = (int32_t)sw;        // per-lane base + immediate offset
+                    outl[u * NT] = (uint16_t)sw;       // per-lane base + immediate offset
                 }
             }
             ps[u * RS] = sw;
@@ -1505,7 +1512,7 @@ TPS_DEV bool tile_fused_s(const ScanArgs& a, const TileConst& tc, const Lds& l, 
         }
         TPS_SYNC();
         const int n_redo = (int)uniform(l.misc[M_NTIE]);
-        int32_t* out = a.sums + (out_base + w0);
+        uint16_t* out = tc.sw16 + w0;
         if (n_redo > 0 && !(RAW && a.raw) && n_redo <= COOP_MAX && a.lw <= 128) {
             // few windows: the whole wave recounts one window at a time -- lanes look up the window's positions
             // and publish per-pattern occurrence bits, one lane per pattern walks its bits greedily
@@ -1548,7 +1555,7 @@ TPS_DEV bool tile_fused_s(const ScanArgs& a, const TileConst& tc, const Lds& l, 
                     if (tid == 0) {
                         const uint32_t sw = l.row[padded(wl, LOG2B)] - occ[60];
                         l.row[padded(wl, LOG2B)] = sw;
-                        out[wl] = (int32_t)sw;
+                        out[wl] = (uint16_t)sw;
                         occ[60] = 0;
                     }
                 }
@@ -1563,7 +1570,7 @@ TPS_DEV bool tile_fused_s(const ScanArgs& a, const TileConst& tc, const Lds& l, 
                     uint8_t* raw_row = (RAW && a.raw) ? a.raw + (out_base + w0 + wl) * (int64_t)pat.P : nullptr;
                     const uint32_t sw = window_exact(a, l, delta, wl, ent >> 16, l.row[padded(wl, LOG2B)], raw_row);
                     l.row[padded(wl, LOG2B)] = sw;
-                    out[wl] = (int32_t)sw;
+                    out[wl] = (uint16_t)sw;
                 }
             }
         }
@@ -1643,6 +1650,297 @@ TPS_DEV void tile_candidates(const TileConst& tc, const Lds& l, int w0, int tile
     }
     s_total += gsum;
     TPS_SYNC();
+}
+
+// ------------------------------------------------------------------ step 2, the default tile (round 3)
+// Tables without self-overlapping k-mers, sums only (kernels _s5 .. _s8, _s5p .. _s8p): the same published words as
+// tile_fused_s, but the windows are computed LANE-CONTIGUOUS -- lane L owns windows 8 L .. 8 L + 7, the ones that start at
+// its own blocks -- so everything about a window's start side stays in the lane's registers:
+//   phase 1  (lane-contiguous) as tile_fused_s; per block XPC[b] (prefix-OR | count r positions in) and per lane XF go to
+//            LDS, the suffix words XS[b] stay in registers
+//   phase 2  (lane-contiguous) window 8 L + j = XS[j] (registers) | whole lanes in between (2 - 3 neighbours' XF words,
+//            summed in registers) | XPC[8 L + j + q] (one LDS read per window, conflict-free: stride 9 words between
+//            lanes).  The lane's 8 S_w are added up in registers, a DPP scan over the 64 lane totals gives every window's
+//            exclusive prefix inside the tile; S_w leaves for HBM as 32 contiguous bytes per lane, the prefixes go to row[]
+//   phase 3  (candidate-strided) as before: Lc[c] = carry + prefix of window c * jump
+// Against tile_fused_s per tile and lane: 17 LDS stores instead of 35 (no XS, no rewritten XF / XT, no second copy of
+// S_w for the scan), 13 + the table gathers LDS loads instead of 37 + the gathers, three wave barriers instead of six,
+// two 16-byte stores to HBM instead of eight dword stores.
+#ifndef TPS_LC_TILE
+#define TPS_LC_TILE 1
+#endif
+// the lane's 8 window sums -> tile_out[8 lane .. 8 lane + 7] as 16-bit values, windows at or past nw_tile dropped
+#ifdef TPS_EMU
+TPS_DEV void g_store_sw8(uint16_t* tile_out, int lane, int nw_tile, const uint32_t* v) {
+    for (int i = 0; i < 8; ++i)
+        if (8 * lane + i < nw_tile) tile_out[8 * lane + i] = (uint16_t)v[i];
+}
+#else
+TPS_DEV void g_store_sw8(uint16_t* tile_out, int lane, int nw_tile, const uint32_t* v) {
+    // One buffer_store_dwordx4 (16 contiguous bytes per lane) through a raw buffer descriptor that ends behind the tile's last
+    // window: the hardware range-checks every dword of a multi-dword store on its own and drops the ones past the end (GCN3 /
+    // Vega ISA, "range checking": raw buffers, store_dword_x{2,3,4} per component) -- the lane that holds the tile's last windows
+    // needs no exec masking and no scalar fallback.  A dword is two windows: tiles start at even windows (plan_geometry keeps
+    // the windows per tile even, a read's region starts at a multiple of 8), and the odd last window of a read takes the padding
+    // slot behind it along.  The descriptor is wave-uniform (SGPRs only).
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)tile_out, 0, ((nw_tile + 1) & ~1) * 2, 0x00020000);
+    v4u t;
+    t.x = v[0] | (v[1] << 16); t.y = v[2] | (v[3] << 16); t.z = v[4] | (v[5] << 16); t.w = v[6] | (v[7] << 16);      // (v_lshl_or_b32; every S_w < 2^16)
+    __builtin_amdgcn_raw_buffer_store_b128(t, rs, lane * 16, 0, 0);
+}
+#endif
+// ROTZ: q (the window's whole blocks) is a multiple of 8 -- every window ends in the same block-in-lane it starts in, dl0
+// lanes on: no per-window choice between the near and the far end lane (the default geometry: W = 100, k = 4, slide 6).
+template <int S, bool INV, int RPT, bool PAIR, bool ROTZ>
+TPS_DEV void tile_lc_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int delta, int w0, int tile, int nw_tile,
+                       int64_t out_base, uint64_t& s_total, int64_t r) {
+    static_assert(!(PAIR && INV), "pair lookups need per-position independence");
+    constexpr bool RZ = RPT == 0;
+    typedef Geo<S> g_;
+    constexpr int WDW = g_::WDW, B = g_::B, LOG2B = g_::LOG2B, POS = g_::POS;
+    const PatInfo& pat = a.pat;
+    const int rp = RPT >= 0 ? RPT : tc.r, q = tc.q;
+    const uint32_t amask = pat.kmask << 2;
+    // what a lane keeps about its blocks (table entries are mask << 16 | count: the OR of entries is right in its high half,
+    // their sum in its low half -- the other halves are garbage that the window arithmetic never looks at)
+    uint32_t sfx[B], c0s[B], xf_own = 0;         // OR of this and the lane's later blocks; matches before the block; the lane's OR | matches
+#ifdef TPS_EMU
+    uint32_t sfx_keep[NT][B], c0_keep[NT][B], xf_keep[NT];
+#endif
+    TPS_PHASE {
+        const int span = tid;
+        const int p0 = delta + span * POS;        // >= 16: fused tiles are staged behind SEQ_LEAD words
+        const uint32_t sh2 = (uint32_t)((p0 - 1) & 15) * 2u;
+        const int d0 = (p0 - 1) >> 4;
+        uint32_t w[WDW];
+        {
+            uint32_t prev = l.seq2[d0];
+            TPS_UNROLL
+            for (int i = 0; i < WDW; ++i) {
+                uint32_t nx = l.seq2[d0 + i + 1];
+                w[i] = alignbit(nx, prev, sh2);
+                prev = nx;
+            }
+        }
+        auto v4_at = [&](int p) -> uint32_t {     // the base before position p at bit 0 (p constant after unrolling)
+            const int dw = p >> 4, bit = p & 15;
+            return bit ? alignbit(dw + 1 < WDW ? w[dw + 1] : 0u, w[dw], 2u * bit) : w[dw];
+        };
+        uint32_t cnt = 0, run_or = 0;
+        uint32_t gs[B];
+        uint32_t* xpc = l.XPC + span * (B + 1);
+        if constexpr (PAIR) {
+            constexpr int NP = S / 2, NH = NP + (S & 1);
+            const uint32_t amask2 = (pat.kmask << 4) | 0xCu;
+            const int rpe = rp & ~1;
+            uint32_t hc[NH], hn[NH];
+            auto fetch = [&](int blk, uint32_t* hh) {
+                TPS_UNROLL
+                for (int j = 0; j < NP; ++j) hh[j] = lut_at(l.lut2, v4_at(blk * S + 2 * j), amask2);
+                if (S & 1) hh[NP] = lut_at(l.lut, v4_at(blk * S + S - 1), amask);
+            };
+            fetch(0, hc);
+            TPS_UNROLL
+            for (int blk = 0; blk < B; ++blk) {
+                if (blk + 1 < B) fetch(blk + 1, hn);
+                uint32_t g = 0;
+                c0s[blk] = cnt;
+                if (RZ) xpc[blk] = pack_hi_lo(run_or, cnt);
+                TPS_UNROLL
+                for (int j = 0; j < NH; ++j) {
+                    if (!RZ) {
+                        if (2 * j == rpe) {
+                            uint32_t c1 = cnt, pp = run_or | g;
+                            if (rp & 1) {
+                                const uint32_t h1 = lut_at(l.lut, v4_at(blk * S + 2 * j), amask);
+                                c1 += h1;
+                                pp |= h1;
+                            }
+                            xpc[blk] = pack_hi_lo(pp, c1);
+                        }
+                    }
+                    g |= hc[j];
+                    cnt += hc[j];
+                }
+                gs[blk] = g;
+                run_or |= g;
+                TPS_UNROLL
+                for (int j = 0; j < NH; ++j) hc[j] = hn[j];
+            }
+        } else {
+            uint32_t hc[S], hn[S];
+            auto fetch = [&](int blk, uint32_t* hh) {
+                TPS_UNROLL
+                for (int i = 0; i < S; ++i) {
+                    const int p = blk * S + i;
+                    uint32_t h = lut_at(l.lut, v4_at(p), amask);
+                    if (INV) {
+                        if (h && invalid_at(l.val, p0 + p, pat.k)) h = 0;   // tiles with non-ACGT letters only
+                    }
+                    hh[i] = h;
+                }
+            };
+            fetch(0, hc);
+            TPS_UNROLL
+            for (int blk = 0; blk < B; ++blk) {
+                if (blk + 1 < B) fetch(blk + 1, hn);
+                uint32_t g = 0;
+                c0s[blk] = cnt;
+                uint32_t c1 = cnt, pp = run_or;
+                TPS_UNROLL
+                for (int i = 0; i < S; ++i) {
+                    const uint32_t h = hc[i];
+                    g |= h;
+                    cnt += h;
+                    if (!RZ) {
+                        if (i + 1 == rp) { c1 = cnt; pp = run_or | g; }
+                    }
+                }
+                xpc[blk] = pack_hi_lo(pp, c1);
+                gs[blk] = g;
+                run_or |= g;
+                TPS_UNROLL
+                for (int i = 0; i < S; ++i) hc[i] = hn[i];
+            }
+        }
+        uint32_t sf = 0;
+        TPS_UNROLL
+        for (int j = B - 1; j >= 0; --j) {
+            sf |= gs[j];
+            sfx[j] = sf;
+        }
+        xf_own = pack_hi_lo(sf, cnt);
+        l.XF[span] = xf_own;
+#ifdef TPS_EMU
+        for (int j = 0; j < B; ++j) { sfx_keep[tid][j] = sfx[j]; c0_keep[tid][j] = c0s[j]; }
+        xf_keep[tid] = xf_own;
+#endif
+    }
+    TPS_SYNC();
+    if (w0 == 0) TPS_STAMP(6);
+    const int rot = ROTZ ? 0 : (q & (B - 1)), dl0 = q >> LOG2B;
+    const int brk = B - rot;                      // windows j >= brk end one lane further on
+    uint32_t sw[B], ltot = 0;
+#ifdef TPS_EMU
+    uint32_t sw_keep[NT][B], tot_keep[NT];
+#endif
+    TPS_PHASE {
+#ifdef TPS_EMU
+        for (int j = 0; j < B; ++j) { sfx[j] = sfx_keep[tid][j]; c0s[j] = c0_keep[tid][j]; }
+        xf_own = xf_keep[tid];
+#endif
+        const int lane = tid;
+        // the far-end words first: one LDS round trip for the lane's 8 windows (rows past the tile's windows read in-bounds
+        // garbage: what they turn into is never stored and never counted)
+        const uint32_t* pe = l.XPC + (lane + dl0) * (B + 1) + rot;
+        uint32_t ev[B];
+        TPS_UNROLL
+        for (int j = 0; j < B; ++j) ev[j] = pe[j + ((!ROTZ && j >= brk) ? 1 : 0)];       // (the pad word between two lanes' blocks)
+        // whole lanes a window skips: OR of the lanes strictly in between, matches of every lane from its own up to the
+        // one before the last -- for both possible lane distances
+        uint32_t orw = 0, sumw = xf_own;
+        TPS_NOVEC
+        for (int t = 1; t < dl0; ++t) {
+            const uint32_t v = l.XF[lane + t];
+            orw |= v;
+            sumw += v;
+        }
+        uint32_t orb = orw, sumb = sumw;
+        if (!ROTZ) {
+            const uint32_t vb = l.XF[lane + dl0];
+            orb |= vb;
+            sumb += vb;
+        }
+        const uint32_t am = pat.all_mask << 16;
+        uint32_t run = 0;
+        TPS_UNROLL
+        for (int j = 0; j < B; ++j) {
+            const bool far_ = !ROTZ && j >= brk;
+            const uint32_t e = ev[j], fo = far_ ? orb : orw, fs = far_ ? sumb : sumw;
+            const uint32_t m = sfx[j] | e | fo;                 // presence: high halves
+            const uint32_t c = (e - c0s[j] + fs) & 0xFFFFu;     // matches: low halves
+            sw[j] = c + (uint32_t)popc(~m & am);
+            run += sw[j];
+        }
+        ltot = run;
+#ifdef TPS_EMU
+        for (int j = 0; j < B; ++j) sw_keep[tid][j] = sw[j];
+        tot_keep[tid] = ltot;
+#endif
+    }
+    // exclusive scan of the lane totals over the wave (lanes past the tile's last window add garbage behind every valid window)
+    uint32_t lexc = 0;
+#ifdef TPS_EMU
+    uint32_t exc_keep[NT];
+    { uint32_t acc = 0; for (int t = 0; t < NT; ++t) { exc_keep[t] = acc; acc += tot_keep[t]; } }
+#else
+    {
+        uint32_t inc = ltot;
+        inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xf, 0xf, false);   // row_shr:1
+        inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xf, 0xf, false);   // row_shr:2
+        inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xf, 0xf, false);   // row_shr:4
+        inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xf, 0xf, false);   // row_shr:8
+        inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+        inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+        lexc = inc - ltot;
+    }
+#endif
+    TPS_PHASE {
+#ifdef TPS_EMU
+        for (int j = 0; j < B; ++j) sw[j] = sw_keep[tid][j];
+        lexc = exc_keep[tid];
+#endif
+        const int lane = tid;
+#ifndef TPS_NO_SW_STORE                               /* (diagnostic builds only: what do the S_w stores cost?) */
+        g_store_sw8(tc.sw16 + w0, lane, nw_tile, sw);
+#endif
+        // what the candidate phase reads: every window's exclusive prefix inside its LANE (padded layout) and every lane's
+        // exclusive prefix inside the tile
+        uint32_t* pr = l.row + lane * (B + 1);
+        uint32_t run = 0;
+        TPS_UNROLL
+        for (int j = 0; j < B; ++j) { pr[j] = run; run += sw[j]; }
+        l.XT[lane] = lexc;
+    }
+    TPS_SYNC();
+    if (w0 == 0) TPS_STAMP(12);
+    // the tile's total = the prefix at its first window that is NOT part of it (nw_tile <= 512 - q - 1: a written entry)
+    const uint32_t gsum = uniform(l.row[nw_tile + (nw_tile >> LOG2B)] + l.XT[nw_tile >> LOG2B]);
+    {
+        // change-point candidates of this tile: c with w0 <= c * jump < w0 + nw_tile, 64 per pass
+        const uint32_t jump = tc.jump;
+        const uint32_t c_lo = div_jump((uint32_t)w0 + jump - 1u, tc.jump_magic);
+        uint32_t c_hi = div_jump((uint32_t)(w0 + nw_tile) + jump - 1u, tc.jump_magic);
+        if (c_hi > tc.lc_cap) c_hi = tc.lc_cap;
+        const int passes = c_hi > c_lo ? (int)((c_hi - c_lo + NT - 1) / NT) : 0;
+        TPS_PHASE {
+            const uint32_t carry = (uint32_t)s_total;
+            if (tid == 0) { l.misc[M_INVALID] = 0; l.misc[M_NTIE] = 0; }      // for the next tile's staging
+            if (tc.lc16 && tid == 0) l.Tc[tile] = carry;
+            uint32_t c = c_lo + (uint32_t)tid;
+            uint32_t w = c * jump - (uint32_t)w0;         // tile-local window index of candidate c
+            TPS_NOVEC
+            for (int t = 0; t < passes; ++t) {
+                if (c < c_hi) {
+                    const uint32_t pre = l.row[w + (w >> LOG2B)] + l.XT[w >> LOG2B];
+                    if (tc.lc16) {
+                        if (tc.lc_g) g16_store(tc.lc_g, c, pre);
+                        else l.Lc16[c] = (uint16_t)pre;
+                    } else if (tc.lc_g) {
+                        g32_store(tc.lc_g, c, carry + pre);
+                    } else {
+                        l.Lc[c] = carry + pre;
+                    }
+                }
+                c += NT;
+                w += NT * jump;
+            }
+        }
+    }
+    s_total += gsum;
+    TPS_SYNC();
+    (void)r;
 }
 
 // ------------------------------------------------------------------ step 2, per-pattern tiles
@@ -1942,7 +2240,6 @@ TPS_DEV bool tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
             ee[j] = eo[j] = 0;
             if (lane * B + j < nw_tile) { ee[j] = pee[eb + (eb >> 3)]; eo[j] = peo[eb + (eb >> 3)]; }
         }
-        int32_t* out = a.sums + (out_base + w0 + lane * B);
         if (D > 0) {
             // windows to repair after the fast pass: bits 0-7 recount (the lane's state before its first position is not
             // known), bits 8-15 chain parity
@@ -1984,7 +2281,6 @@ TPS_DEV bool tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
                     o[2] = perm(b_hi, a_hi, 0x05040100u);
                     o[3] = perm(b_hi, a_hi, 0x07060302u);
                 }
-                out[j] = (int32_t)sw;
             }
             swv[j] = sw;
             TPS_UNROLL
@@ -1996,6 +2292,7 @@ TPS_DEV bool tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
             for (int i = 0; i < 4; ++i) rows_keep[tid][j][i] = o[i];
 #endif
         }
+        g_store_sw8(tc.sw16 + w0, lane, nw_tile, swv);     // (0 for the windows past the tile: dropped by the range check)
     }
     TPS_SYNC();                                   // every END word has been read: S_w takes the place of the odd half
     TPS_PHASE {
@@ -2184,7 +2481,7 @@ TPS_DEV bool tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
                     }
                 }
                 l.row[lane * (B + 1) + j] = sw;
-                a.sums[out_base + w0 + wl] = (int32_t)sw;
+                tc.sw16[w0 + wl] = (uint16_t)sw;
             }
         }
         TPS_SYNC();
@@ -2402,7 +2699,7 @@ TPS_DEV void tile_so_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
         uint32_t* ps = l.row + (lane + (lane >> LOG2B));
         const uint32_t* pe = l.XPC + ((lane + (uint32_t)q) + ((lane + (uint32_t)q) >> LOG2B));
         const uint32_t* pf = (farl ? l.XT : l.XF) + (lane >> LOG2B);
-        int32_t* outl = a.sums + (out_base + w0) + lane;
+        uint16_t* outl = tc.sw16 + w0 + lane;
         const uint32_t am = pat.all_mask << 16;
         const int nfull = nw_tile >> 6;
         const uint32_t npart = (uint32_t)(nw_tile & 63);
@@ -2419,7 +2716,7 @@ TPS_DEV void tile_so_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
                 const uint32_t s_ = ((e - x + f) & 0xFFFFu) + (uint32_t)popc(~m & am);
                 if (valid) {
                     sw = s_;
-                    outl[u * NT] = (int32_t)sw;
+                    outl[u * NT] = (uint16_t)sw;
                 }
             }
             ps[u * RS] = sw;
@@ -2484,7 +2781,7 @@ TPS_DEV void tile_so_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
                 }
             }
             l.row[lane * (B + 1) + j] = sw;
-            a.sums[out_base + w0 + wl] = (int32_t)sw;
+            tc.sw16[w0 + wl] = (uint16_t)sw;
         }
     }
     TPS_SYNC();
@@ -2703,7 +3000,8 @@ TPS_DEV void binseg_wg(const ST* S, int n, int jump, int min_size, int n_pattern
 // Fused Binseg from the candidate left sums Lc[c] = sum_{w < c*jump} S_w (c = 1 .. (n-1)/jump) and
 // the total T: float64 scores, wave arg-max; if more than one candidate lies within float noise of
 // the best score the exact integer tournament re-reads S_w from HBM (rare).
-TPS_DEV void binseg_from_lc(const ScanArgs& a, const Lds& l, uint64_t lc_g, const int32_t* S_global, int n, uint64_t tot, int jump,
+template <typename ST>
+TPS_DEV void binseg_from_lc(const ScanArgs& a, const Lds& l, uint64_t lc_g, const ST* S_global, int n, uint64_t tot, int jump,
                             int min_size, int n_patterns, uint32_t* misc, uint32_t* xs, int& bkp, double& gain) {
     const int ncand = (n - 1) / jump;              // candidates b = c*jump, 1 <= c <= ncand  (b < n)
 #ifdef TPS_EMU
@@ -3222,14 +3520,18 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
                     }
                 }
                 constexpr int SF = SV ? SV : 1;
+                constexpr bool LC = TPS_LC_TILE != 0 && !SO && !RAW;     // the default kernels: lane-contiguous windows (tile_lc_s)
                 if (uniform(l.misc[M_INVALID]) != 0) {
-                    tile_fused_s<SF, SO, true, -1, false, RAW>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r);
+                    if constexpr (LC) tile_lc_s<SF, true, -1, false, false>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r);
+                    else tile_fused_s<SF, SO, true, -1, false, RAW>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r);
                 } else if constexpr (SO || RAW) {
                     // (these kernels reach the plain tile only as a fallback: one instantiation with r read at run time)
                     if (tc.r == 0) tile_fused_s<SF, SO, false, 0, PAIR, RAW>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r);
                     else tile_fused_s<SF, SO, false, -1, PAIR, RAW>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r);
                 } else {
-#define TPS_TILE_RP(N) case N: if constexpr (N < SF) tile_fused_s<SF, SO, false, (N < SF ? N : 0), PAIR, RAW>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r); break;
+#define TPS_TILE_RP(N) case N: if constexpr (N < SF) { if constexpr (LC) { if ((tc.q & 7) == 0) tile_lc_s<SF, false, (N < SF ? N : 0), PAIR, true>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r); \
+                                                                          else tile_lc_s<SF, false, (N < SF ? N : 0), PAIR, false>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r); } \
+                                                       else tile_fused_s<SF, SO, false, (N < SF ? N : 0), PAIR, RAW>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r); } break;
                     switch (tc.r) {
                         TPS_TILE_RP(0) TPS_TILE_RP(1) TPS_TILE_RP(2) TPS_TILE_RP(3) TPS_TILE_RP(4) TPS_TILE_RP(5) TPS_TILE_RP(6) TPS_TILE_RP(7)
                         default: break;
@@ -3252,8 +3554,12 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 #endif
         const uint64_t lc_g = a.lc_global ? (uint64_t)(uintptr_t)(a.lc_scratch + r * (int64_t)a.lc_stride) : 0ull;
-        binseg_from_lc(a, l, lc_g, a.sums + (a.win_off ? a.win_off[r] : 0), n_win, s_total, prm.jump, prm.min_size, pat.P,
-                       l.misc, l.blk, bkp, gain);
+        if constexpr (SV != 0)
+            binseg_from_lc(a, l, lc_g, (const uint16_t*)(a.sums16 + (a.win_off16 ? a.win_off16[r] : 0)), n_win, s_total, prm.jump, prm.min_size, pat.P,
+                           l.misc, l.blk, bkp, gain);
+        else
+            binseg_from_lc(a, l, lc_g, (const int32_t*)(a.sums + (a.win_off ? a.win_off[r] : 0)), n_win, s_total, prm.jump, prm.min_size, pat.P,
+                           l.misc, l.blk, bkp, gain);
         res.bkp = bkp;
         res.gain = gain;
     }

@@ -11,9 +11,19 @@
 // One wave per read, tps::WPG waves per workgroup.  The lookup table is loaded once per workgroup
 // (the only workgroup barrier in the kernel); after that every wave runs its own read with
 // wave-level synchronisation only.
+// diagnostics build: clock stamps at kernel entry (13: shader clock, 15: the 100 MHz device-wide real-time counter) and
+// behind the table barrier (14), per read like the stamps inside scan_read
+#ifdef TPS_STAMPS
+#define TPS_KSTAMP(i) do { const int64_t r_ = (int64_t)blockIdx.x * a.wpg + (int)(threadIdx.x >> 6);                          \
+        if (a.stamps && (threadIdx.x & 63u) == 0 && r_ < a.n_reads) { a.stamps[r_ * 16 + (i)] = __builtin_readcyclecounter(); \
+            if ((i) == 13) a.stamps[r_ * 16 + 15] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define TPS_KSTAMP(i) ((void)0)
+#endif
 #define TPS_SCAN_KERNEL_F(NAME, SV, SO, PAIR, RAW, MINW, FULL, DCLASS)                                                           \
     extern "C" __global__ void __launch_bounds__(tps::NT * tps::WPG_MAX, MINW) NAME(tps::ScanArgs a) {     \
         extern __shared__ __attribute__((aligned(16))) uint32_t lds[];                                     \
+        TPS_KSTAMP(13);                                                                                    \
         /* workgroup-shared tables: [pair table (PAIR kernels)][single table], both aligned to their size */ \
         uint32_t* lut = lds + ((PAIR) ? a.pair_n : 0);                                                     \
         const int nthr_ = tps::NT * a.wpg;            /* = blockDim.x */                                   \
@@ -27,6 +37,7 @@
                 *(uint4*)(lds + c) = *(const uint4*)(a.lut + a.lut_n + c);                                 \
         }                                                                                                  \
         __syncthreads();                                                                                   \
+        TPS_KSTAMP(14);                                                                                    \
         /* One read per wave; the hardware dispatcher balances the workgroups.  (Persistent waves were      \
            tried: a shared device counter sustains only ~50 M same-address atomics/s -- too slow for the  \
            claim rate -- and a static stride loses the dispatcher's dynamic balancing: 10 % slower on    \

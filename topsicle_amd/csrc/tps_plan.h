@@ -20,6 +20,10 @@ inline int64_t window_count(int64_t L, int W, int s, int t, int M) {
     return (ns - W) / s + 1;
 }
 
+// Device layout of the fused kernels' 16-bit window sums (ScanArgs::sums16): a read with nw windows owns this many slots, so
+// that every read's region starts 16-byte aligned and the dword that holds an odd last window ends in padding.
+inline int64_t sums16_slots(int64_t nw) { return (nw + 7) & ~7ll; }
+
 inline int gcd_i(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
 
 // Pattern list (P strings of k letters, reference order) -> 4^k lookup table of list masks and
@@ -185,7 +189,8 @@ inline std::string plan_geometry_core(ScanArgs& a, const tps_params& prm, int k,
     // 8-block chunk and its far end lies within the exchange halo (XLANES - NT lanes)
     int max_period = 0;                            // self-overlap periods of the table (0 = none)
     for (int i = 0; i < a.pat.n_periods; ++i) max_period = std::max(max_period, a.pat.period[i]);
-    const bool fused = !force_generic && spans_pref <= 0 && k <= TPS_DIRECT_K && has_specialised_slide(prm.slide) && P <= 15 && a.q >= 8 &&
+    const bool sw16_ok = (int64_t)P * ((a.lw + k - 1) / k + 1) < 65536;        // the fused kernels keep S_w in 16 bits
+    const bool fused = !force_generic && spans_pref <= 0 && k <= TPS_DIRECT_K && has_specialised_slide(prm.slide) && P <= 15 && a.q >= 8 && sw16_ok &&
                        a.q / 8 + 2 < (XLANES - NT) && max_period <= std::min(prm.slide, 6) &&
                        2 * a.head_dw <= fused_seq_dw(prm.slide);   // the two step-1 heads fit the tile buffer (TileGeo::SEQ)
     a.lc16 = 0; a.tile_cap = 0; a.tw = 0; a.tw_magic = 0; a.pair_n = 0; a.lc_global = 0; a.lc_stride = 0; a.pp_d = -1; a.so_fast = 0; a.seq_alias = 0; a.lut_fields = 0; a.tile_full = 0;
@@ -217,7 +222,9 @@ inline std::string plan_geometry_core(ScanArgs& a, const tps_params& prm, int k,
 #ifndef TPS_EMU
         if (a.pat.so_mask == 0 && !(prm.flags & TPS_F_STORE_RAW) && !getenv("TPS_NO_SEQ_ALIAS")) a.seq_alias = 1;
 #endif
-        a.tw = (int)NT * 8 - a.q - 1;
+        // windows per tile: every lane's 8 blocks hold window starts, a window spans q + 1 blocks; EVEN, because the fused
+        // kernels store S_w as 16-bit values in whole dwords (g_store_sw8): no tile but a read's last ends inside a dword
+        a.tw = ((int)NT * 8 - a.q - 1) & ~1;
         a.tw_magic = (uint32_t)(((1ull << 32) + (uint64_t)a.tw - 1) / (uint64_t)a.tw);
         a.tile_cap = (int)((max_nwin + a.tw - 1) / a.tw) + 1;
         // The candidates' left sums live off-chip (L2-resident scratch, written once and read once by the same wave) as
