@@ -151,6 +151,67 @@ def cpu_baseline(seqs, motif, k, prm, budget_s=15.0):
                 reads_per_s=done / dt)
 
 
+def reference_python_baseline(bases, offsets, motif, k, prm, reads_per_core=64):
+    """The reference's own CPU path beside the GPU number: oracle/ref_mirror.py -- `re.finditer` per window per
+    pattern, both tails, numpy-var Binseg, the file re-parsed per passing read, one Pool task per FILE like
+    Topsicle/main.py:232-235 -- on the first reads of the batch written out as one FASTQ file per usable core.  Must run
+    BEFORE this process touches a GPU (the Pool forks).  The rate is extrapolated from that sample to the batch."""
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_c
+    import ref_mirror
+    cores = oracle_c.usable_cores()
+    n = len(offsets) - 1
+    per = max(1, min(reads_per_core, n // cores))
+    tmp = tempfile.mkdtemp(prefix="tps_refpy_")
+    paths = []
+    try:
+        for c in range(cores):
+            pth = os.path.join(tmp, f"part{c}.fastq")
+            with open(pth, "w") as h:
+                for i in range(c * per, (c + 1) * per):
+                    sq = bases[offsets[i]:offsets[i + 1]].tobytes().decode()
+                    h.write(f"@r{i}\n{sq}\n+\n{'I' * len(sq)}\n")
+            paths.append(pth)
+        wall, n_pass, per_file = ref_mirror.timed_pool(paths, motif, k, prm.min_len, 0.7, prm.window, prm.slide, prm.trimfirst, prm.maxlen, cores)
+    finally:
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+    nb = int(offsets[cores * per])
+    return dict(value=nb / wall, unit="bases/s", cores=cores, kind="port", extrapolated=True, reads_per_s=cores * per / wall,
+                seconds_per_read_per_core=float(np.mean(per_file)) / per,
+                sample=f"{per} reads per core x {cores} cores ({n_pass} telomeric) of the same batch as {cores} FASTQ files through oracle/ref_mirror.py: "
+                       f"pure-Python mirror of Topsicle's process_file (re.finditer per window per pattern, both tails, numpy-var "
+                       f"Binseg, file re-parsed per passing read), one multiprocessing.Pool task per file like Topsicle/main.py:232-235; "
+                       f"{wall:.1f} s wall; the rate is per-read cost x reads, i.e. extrapolated to the batch")
+
+
+def gpu_topology():
+    """[(pci bdf, [cpus of its NUMA node])] of the node's GPUs in KFD order, read from sysfs without touching the GPU runtime."""
+    import glob
+    out = []
+    nodes = sorted(glob.glob("/sys/class/kfd/kfd/topology/nodes/*"), key=lambda d: int(os.path.basename(d)))
+    for d in nodes:
+        try:
+            props = dict(l.split()[:2] for l in open(os.path.join(d, "properties")) if len(l.split()) >= 2)
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) == 0:                   # a CPU node
+            continue
+        loc, dom = int(props.get("location_id", "0")), int(props.get("domain", "0"))
+        bdf = f"{dom:04x}:{(loc >> 8) & 255:02x}:{(loc >> 3) & 31:02x}.{loc & 7}"
+        cpus = []
+        try:
+            for part in open(f"/sys/bus/pci/devices/{bdf}/local_cpulist").read().strip().split(","):
+                if part:
+                    lo, _, hi = part.partition("-")
+                    cpus.extend(range(int(lo), int(hi or lo) + 1))
+        except (OSError, ValueError):
+            pass
+        out.append((bdf, cpus))
+    return out
+
+
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (this process has not
     touched a GPU and never will), one per GPU, rendezvous over 127.0.0.1; relay rank 0's output; non-zero exit if any
@@ -162,9 +223,20 @@ def spawn_ranks(n, argv):
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
     procs = []
+    topo = gpu_topology()
+    share = bool(os.environ.get("TPS_BENCH_SHARE_GPU"))
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TPS_BENCH_SPAWNED="1")
+        # every rank sees ONE GPU (set in the child's environment before it starts: a process that has touched a GPU is never
+        # re-executed) and runs on the CPUs of that GPU's NUMA node
+        if topo and (share or len(topo) >= n):
+            g = r % len(topo)
+            env["ROCR_VISIBLE_DEVICES"] = str(g)
+            env["TPS_BENCH_DEVICE"] = "0"
+            env["TPS_BENCH_PCI"] = topo[g][0]
+            if topo[g][1]:
+                env["TPS_BENCH_CPUS"] = ",".join(str(c) for c in topo[g][1])
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     out, _ = procs[0].communicate()
@@ -194,6 +266,11 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args.gpus, sys.argv[1:])
 
+    if os.environ.get("TPS_BENCH_CPUS"):         # spawned rank: the CPUs next to its GPU
+        try:
+            os.sched_setaffinity(0, {int(c) for c in os.environ["TPS_BENCH_CPUS"].split(",")})
+        except (OSError, ValueError):
+            pass
     lib = hiplib.load_library()                  # dlopen only (no GPU call): before torch.distributed brings its own HIP runtime in
     from topsicle_amd import dist
     grp = dist.Group()
@@ -224,6 +301,12 @@ def main():
         prm.flags |= hiplib.F_STORE_RAW
     if args.flags:
         prm.flags = args.flags
+    ref_py = None
+    if not args.no_cpu_baseline and world == 1 and not (args.flags or args.n_reads):
+        try:                                      # forks a Pool: before anything touches the GPU
+            ref_py = reference_python_baseline(bases, offsets, motif, k, prm)
+        except Exception as e:
+            ref_py = {"error": repr(e)}
     # kernel durations come from HIP events stamped by the dispatch itself; every 4th launch is timed (timing a
     # launch costs ~3.5 us of host/queue work, which would otherwise sit inside every timed step)
     os.environ.setdefault("TPS_EVENT_STRIDE", "4")
@@ -232,7 +315,11 @@ def main():
     n_dev = ctypes.c_int(0)
     lib.tps_device_count(ctypes.byref(n_dev))
     dev = local_rank
-    if os.environ.get("TPS_BENCH_SHARE_GPU"):
+    if "TPS_BENCH_DEVICE" in os.environ:         # spawned by this script: ROCR_VISIBLE_DEVICES leaves this rank one GPU
+        dev = int(os.environ["TPS_BENCH_DEVICE"])
+        if n_dev.value < 1:
+            raise SystemExit(f"rank {rank}: no GPU visible ({lib.tps_last_error().decode()})")
+    elif os.environ.get("TPS_BENCH_SHARE_GPU"):
         dev = local_rank % max(n_dev.value, 1)
     elif n_dev.value < world:
         raise SystemExit(f"--gpus {world} but only {n_dev.value} GPU(s) visible ({lib.tps_last_error().decode()})")
@@ -273,8 +360,10 @@ def main():
     dt_rank = time.perf_counter() - t0
     dt = grp.max(dt_rank)
     grp.barrier()
-    per_rank = grp.gather_objects(dict(rank=rank, device=dev, ms_per_step=dt_rank / args.steps * 1e3))
     n_launch, k_total_ms, k_mean_ms = sc.kernel_time_ms()
+    per_rank = grp.gather_objects(dict(rank=rank, device=dev, device_info=sc.device_info(), pci=os.environ.get("TPS_BENCH_PCI"),
+                                       cpus=len(os.sched_getaffinity(0)), ms_per_step=dt_rank / args.steps * 1e3,
+                                       kernel_ms_mean=k_mean_ms * len(tables), kernel_launches_timed=n_launch))
     lens = np.diff(offsets)
     last = (args.steps - 1) % copies
     alg_total = alg1 = alg2 = alg3 = 0
@@ -293,16 +382,25 @@ def main():
     kinfo = kinfos[0] if len(kinfos) == 1 else " | ".join(kinfos)
     k_mean_ms *= len(tables)                       # per step: the table passes' kernels together
     scanned = int((2 * np.minimum(lens, prm.no_bp)).sum() + np.maximum(np.minimum(lens, prm.maxlen) - prm.trimfirst, 0)[passed].sum())
+    # bases of the batch the path can touch at all (allsteps.py:176-177, 263-271): both 1000-base heads of every read, and the
+    # first / last min(L, maxlengthtelo) bases of a read that passes -- all of a read up to maxlengthtelo, 21 of 30 kb beyond
+    heads = np.minimum(lens, 2 * prm.no_bp)
+    tail_span = np.minimum(lens, prm.maxlen)
+    touched_per_read = np.where(passed, np.minimum(lens, tail_span + np.minimum(prm.no_bp, lens - tail_span)), heads)
+    touched = int(touched_per_read.sum())
 
     if rank == 0:
         total_bases = batch_bases * world * args.steps
-        value = total_bases / dt
+        # `value`: bases the path can touch per second (= input bases while reads are no longer than maxlengthtelo: configs 1-3;
+        # config 4's 30 kb reads have 9 kb nobody looks at); the plain input rate is reported beside it
+        value = touched * world * args.steps / dt
         achieved = alg_total / (k_mean_ms * 1e-3) / 1e9 if k_mean_ms > 0 else 0.0
         traffic, traffic_src = profiled_traffic(args.workload) if not (args.flags or args.n_reads) else (None, None)
         out = {
             "metric": "bases_scanned_per_sec",
             "value": value,
             "unit": "bases/s",
+            "input_bases_per_sec": total_bases / dt,
             "reads_per_sec": n_reads * world * args.steps / dt,
             "scanned_bases_per_sec": scanned * world * args.steps / dt,
             "n_gpus": world,
@@ -350,6 +448,8 @@ def main():
             seqs = synth.split_reads(bases[: offsets[min(n_reads, 4096)]], offsets[: min(n_reads, 4096) + 1])
             out["cpu_baseline"] = cpu_baseline(seqs, motif, k, prm)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+            if ref_py is not None:
+                out["cpu_baseline"]["reference_python"] = ref_py
         if not args.no_e2e and world == 1 and not (args.flags or args.n_reads):
             # PCIe- and parse-inclusive rates on a FASTQ file of the same reads: never `value` (topsicle_amd/e2e.py)
             from topsicle_amd import e2e

@@ -291,6 +291,14 @@ def test_bench_launches_its_own_ranks():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and sorted(x["rank"] for x in out["ranks"]) == [0, 1]
     assert out["value"] > 0 and out["roofline"]["kernel"].startswith("tps_scan_kernel")
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    topo = bench.gpu_topology()                                  # sysfs only: no GPU runtime call
+    for x in out["ranks"]:                                       # an N-rank line must be interpretable rank by rank
+        assert x["kernel_ms_mean"] > 0 and x["kernel_launches_timed"] > 0 and "gfx950" in x["device_info"] and "pci=" in x["device_info"]
+        if topo:                                                 # every spawned rank is handed ONE GPU (ROCR_VISIBLE_DEVICES) and sees it as device 0
+            assert x["pci"] in [t[0] for t in topo] and x["device"] == 0
     n_dev = hiplib.load_library()
     import ctypes
     cnt = ctypes.c_int(0)
@@ -298,3 +306,21 @@ def test_bench_launches_its_own_ranks():
     if cnt.value < 2:
         r = _run_bench(["--gpus", "2"], {})
         assert r.returncode != 0 and "GPU(s) visible" in (r.stdout + r.stderr)
+
+
+@pytest.mark.parametrize("workload,extra", [("config3_per_gpu", ["--n-reads", "1500"]), ("config4_sample", ["--n-reads", "1200"]), ("config5", ["--n-reads", "600"])])
+def test_bench_ranks_on_the_other_workloads(workload, extra):
+    """The self-launched multi-rank path with the other BASELINE shapes (HiFi slide 7, 30 kb reads, the three-k raw-count step):
+    two ranks sharing this box's GPU."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TPS_BENCH_PRIME="4", TPS_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-e2e",
+                        "--resident-copies", "2", "--workload", workload, "--gpus", "2"] + extra, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 2 and len(out["ranks"]) == 2 and out["value"] > 0
+    assert all(x["kernel_ms_mean"] > 0 for x in out["ranks"])

@@ -552,8 +552,8 @@ int tps_ctx_destroy(tps_ctx* c) {
 
 int tps_device_info(tps_ctx* c, char* buf, int32_t buf_len) {
     if (!c || !buf || buf_len < 1) return fail(TPS_E_ARG, "bad arguments");
-    snprintf(buf, (size_t)buf_len, "%s arch=%s CUs=%d LDS/block=%zu clock=%dkHz", c->prop.name, c->prop.gcnArchName,
-             c->prop.multiProcessorCount, c->prop.sharedMemPerBlock, c->prop.clockRate);
+    snprintf(buf, (size_t)buf_len, "%s arch=%s CUs=%d LDS/block=%zu clock=%dkHz pci=%04x:%02x:%02x", c->prop.name, c->prop.gcnArchName,
+             c->prop.multiProcessorCount, c->prop.sharedMemPerBlock, c->prop.clockRate, c->prop.pciDomainID, c->prop.pciBusID, c->prop.pciDeviceID);
     return TPS_OK;
 }
 
