@@ -259,6 +259,7 @@ def main():
     ap.add_argument("--n-reads", type=int, default=0, help="diagnostic: override the batch size (NOT the metric's workload)")
     ap.add_argument("--flags", type=int, default=0, help="diagnostic: override the scan flags (partial pipelines are NOT the metric)")
     ap.add_argument("--resident-copies", type=int, default=0, help="copies of the batch kept in HBM (0 = enough for >1 GB)")
+    ap.add_argument("--errors", default="", choices=["", "ont", "hifi", "none"], help="diagnostic: override the workload's per-base error profile (NOT the metric's workload)")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -282,6 +283,9 @@ def main():
     if args.n_reads:
         cfg["n_reads"] = args.n_reads
         cfg["desc"] += f" [diagnostic batch of {args.n_reads} reads]"
+    if args.errors:
+        cfg["errors"] = {"ont": synth.ONT, "hifi": synth.HIFI, "none": None}[args.errors]
+        cfg["desc"] += f" [diagnostic error profile: {args.errors}]"
     motif, k = cfg["motif"], cfg["k"]
     ks = cfg.get("ks", [k])
     tables = [kmer_table(motif, kk) for kk in ks]
@@ -302,7 +306,7 @@ def main():
     if args.flags:
         prm.flags = args.flags
     ref_py = None
-    if not args.no_cpu_baseline and world == 1 and not (args.flags or args.n_reads):
+    if not args.no_cpu_baseline and world == 1 and not (args.flags or args.n_reads or args.errors):
         try:                                      # forks a Pool: before anything touches the GPU
             ref_py = reference_python_baseline(bases, offsets, motif, k, prm)
         except Exception as e:

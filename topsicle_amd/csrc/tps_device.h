@@ -566,13 +566,20 @@ TPS_DEV bool invalid_at(const uint16_t* val, int q, int k) {
 // kernels), LUT_FIELDS = the one-hot 2-bit field 1 << 2 p of THE pattern p the k-mer belongs to (raw-count kernels on tables
 // without duplicate k-mers: what the per-pattern tiles and the packed step 1 add up, without the squaring).
 constexpr int LUT_FIELDS = 32;
-TPS_HD uint32_t mask_to_fields(uint32_t m) {          // pattern mask -> the same patterns as 2-bit fields (bit 2 p)
+// Which of the sixteen 2-bit fields belongs to list pattern p.  The per-pattern tiles widen fields to nibbles (even / odd
+// fields: two words) and nibbles to bytes (four words, pp_expand); with THIS assignment the four byte words come out in ROW
+// order -- word p / 4, byte p % 4 holds pattern p -- so a raw row is the words as they are (no byte transposition: 8 v_perm per
+// window before round 3), and a list of at most 12 patterns never touches the fourth word.
+TPS_HD int pp_field(int p) { return 4 * (p & 3) + 2 * ((p >> 2) & 1) + (p >> 3); }
+TPS_HD int pp_pattern(int f) { return (f >> 2) + 4 * (((f >> 1) & 1) + 2 * (f & 1)); }
+TPS_HD uint32_t mask_to_fields(uint32_t m) {          // pattern mask -> the same patterns as 2-bit fields (bit 2 pp_field(p))
     uint32_t f = 0;
-    for (int p = 0; p < 16; ++p) f |= ((m >> p) & 1u) << (2 * p);
+    for (int p = 0; p < 16; ++p) f |= ((m >> p) & 1u) << (2 * pp_field(p));
     return f;
 }
-TPS_DEV uint32_t field_to_mask(uint32_t f) { return f ? 1u << (ffs0(f) >> 1) : 0u; }                // one-hot field -> pattern mask
-TPS_DEV uint32_t field_to_entry(uint32_t f) { return f ? ((1u << (16 + (ffs0(f) >> 1))) | 1u) : 0u; } // ... -> mask << 16 | 1
+TPS_DEV uint32_t field_to_mask(uint32_t f) { return f ? 1u << pp_pattern(ffs0(f) >> 1) : 0u; }                // one-hot field -> pattern mask
+TPS_DEV uint32_t field_to_entry(uint32_t f) { return f ? ((1u << (16 + pp_pattern(ffs0(f) >> 1))) | 1u) : 0u; } // ... -> mask << 16 | 1
+template <int N> struct IntC { static constexpr int value = N; };
 // mask of list patterns whose k-mer is the low 2k bits of v (direct table or perfect hash)
 TPS_DEV uint32_t lut_mask(const uint32_t* lut, int lshift, const PatInfo& pat, uint32_t v) {
     const uint32_t code = v & pat.kmask;
@@ -763,7 +770,7 @@ TPS_DEV void trc_count_packed(const ScanArgs& a, const Lds& l, const Stage& st_s
         uint32_t cm = cf >> 16;
         if (FLD) {                                  // fields -> pattern mask (rare: only a lane that saw an overlapping pair)
             cm = 0;
-            while (cf) { cm |= 1u << (ffs0(cf) >> 1); cf &= cf - 1u; }
+            while (cf) { cm |= 1u << pp_pattern(ffs0(cf) >> 1); cf &= cf - 1u; }
         }
         lds_or(&l.misc[M_CMASK + side], cm);
     }
@@ -840,8 +847,10 @@ TPS_DEV int trc_walk_occ(const Lds& l, int side, int slot, int k) {
 TPS_DEV void trc_sum_packed(const ScanArgs& a, const Lds& l, const Stage& st_s, const Stage& st_e, int64_t r, int tid) {
     const int side = tid >> 5, p = tid & 31;
     if (p < a.pat.P) {
-        // byte of pattern p in a lane's 16 parked bytes: word [0, 2, 1, 3][p & 3], byte p >> 2
-        const uint8_t* src = (const uint8_t*)(l.blk + 4 * 32 * side) + 4 * (((p & 1) << 1) | ((p >> 1) & 1)) + (p >> 2);
+        // byte of pattern p in a lane's 16 parked bytes: fields in list order (mask tables, squared entries) put it in word
+        // [0, 2, 1, 3][p & 3], byte p >> 2; ready-made fields (LUT_FIELDS tables: pp_field) in row order, byte p
+        const int pbyte = l.lshift == LUT_FIELDS ? p : 4 * (((p & 1) << 1) | ((p >> 1) & 1)) + (p >> 2);
+        const uint8_t* src = (const uint8_t*)(l.blk + 4 * 32 * side) + pbyte;
         uint32_t sm = 0;
         TPS_UNROLL
         for (int t = 0; t < 32; ++t) sm += src[16 * t];
@@ -1669,6 +1678,12 @@ TPS_DEV void tile_candidates(const TileConst& tc, const Lds& l, int w0, int tile
 #ifndef TPS_LC_TILE
 #define TPS_LC_TILE 1
 #endif
+// Cache policy of the kernels' big output streams (S_w, raw rows: buffer stores): 2 = nt, non-temporal (gfx940+), 0 = default.
+// Nothing on the device reads these bytes again (the exact change-point tournament aside); streamed past the caches they cost
+// less HBM time: 10 000 x 25 kb reads with raw rows 192.7 -> 176.8 us per launch, config 2 57.4 -> 56.3 us (same box, A/B).
+#ifndef TPS_STORE_AUX
+#define TPS_STORE_AUX 2
+#endif
 // the lane's 8 window sums -> tile_out[8 lane .. 8 lane + 7] as 16-bit values, windows at or past nw_tile dropped
 #ifdef TPS_EMU
 TPS_DEV void g_store_sw8(uint16_t* tile_out, int lane, int nw_tile, const uint32_t* v) {
@@ -1687,7 +1702,26 @@ TPS_DEV void g_store_sw8(uint16_t* tile_out, int lane, int nw_tile, const uint32
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)tile_out, 0, ((nw_tile + 1) & ~1) * 2, 0x00020000);
     v4u t;
     t.x = v[0] | (v[1] << 16); t.y = v[2] | (v[3] << 16); t.z = v[4] | (v[5] << 16); t.w = v[6] | (v[7] << 16);      // (v_lshl_or_b32; every S_w < 2^16)
-    __builtin_amdgcn_raw_buffer_store_b128(t, rs, lane * 16, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(t, rs, lane * 16, 0, TPS_STORE_AUX);
+}
+#endif
+// 16 bytes -> base[cdw .. cdw + 3] (dwords), the dwords at or past n_dw dropped: one range-checked buffer_store_dwordx4 at a
+// dword-aligned address instead of four dword stores and a tail case
+#ifdef TPS_EMU
+TPS_DEV void g_store16_clamped(uint32_t* base, int n_dw, int cdw, const u32x4& t) {
+    const uint32_t v[4] = {t.x, t.y, t.z, t.w};
+    for (int i = 0; i < 4; ++i)
+        if (cdw + i < n_dw) base[cdw + i] = v[i];
+}
+#else
+TPS_DEV void g_store16_clamped(uint32_t* base, int n_dw, int cdw, const u32x4& t) {
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, n_dw * 4, 0x00020000);
+    v4u x;
+    x.x = t.x; x.y = t.y; x.z = t.z; x.w = t.w;
+#ifndef TPS_NO_RAW_STORE                              /* (diagnostic builds only: what do the raw-row stores cost?) */
+    __builtin_amdgcn_raw_buffer_store_b128(x, rs, cdw * 4, 0, TPS_STORE_AUX);
+#endif
 }
 #endif
 // ROTZ: q (the window's whole blocks) is a multiple of 8 -- every window ends in the same block-in-lane it starts in, dl0
@@ -1976,13 +2010,9 @@ struct GeoPP {
     // base before the look-back + look-back + positions + chain look-ahead (<= 6) + last k-mer (<= 7 bases)
     static constexpr int WDW = (1 + LBK + POS + 6 + 7 + 15) / 16;
 };
-#ifndef TPS_PP_FIELDS
-#define TPS_PP_FIELDS 1
-#endif
 // the raw-count kernels load their LDS table as one-hot 2-bit fields whenever the per-pattern tiles will run (plan_geometry
 // sets ScanArgs::lut_fields): a position then costs lookup + add, without the v_mul_hi_u32 that squares mask << 16 | 1 into
-// 1 << 2 p.  -DTPS_PP_FIELDS=0 keeps the squaring (A/B builds).
-constexpr bool PP_FIELDS = TPS_PP_FIELDS != 0;
+// 1 << 2 p (p: the pattern's field, pp_field).
 constexpr uint32_t PP_BIAS = 14;                  // V nibbles = PP_BIAS - prefix + start skips, all in 0..15
 TPS_DEV void pp_expand(uint32_t ne, uint32_t no, uint32_t* b) {   // nibble words (even / odd patterns) -> 4 byte words
     b[0] = ne & 0x0F0F0F0Fu;                      // patterns 0, 4, 8, 12
@@ -2022,11 +2052,11 @@ TPS_DEV bool tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
     TPS_UNROLL
     for (int i = 0; i < 7; ++i) cold[i] = (D > 0) ? uniform(carry[i]) : 0u;
     // was pattern pidx picked at LDS position pos, one of the D positions before the tile (delta - D <= pos < delta)?
-    auto picked_before_tile = [&](int pos, int pidx) -> bool {
+    auto picked_before_tile = [&](int pos, int fidx) -> bool {      // (fidx: the pattern's FIELD, pp_field)
         uint32_t cv = 0;
         TPS_UNROLL
         for (int i = 0; i < DH; ++i) cv = (pos - (delta - DH) == i) ? cold[i] : cv;
-        return w0 != 0 && ((cv >> (2 * pidx)) & 1u) != 0;
+        return w0 != 0 && ((cv >> (2 * fidx)) & 1u) != 0;
     };
 #ifdef TPS_EMU
     uint32_t keep[NT][2 * B + 3];
@@ -2054,7 +2084,7 @@ TPS_DEV bool tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
             const int idx = p + LBK, dw = idx >> 4, bit = idx & 15;
             const uint32_t v4 = bit ? alignbit(dw + 1 < WDW ? w[dw + 1] : 0u, w[dw], 2u * bit) : w[dw];
             const uint32_t h = lut_at(l.lut, v4, amask);
-            return PP_FIELDS ? h : mulhi32(h, h);       // (the table of these kernels holds the fields ready-made)
+            return h;                                   // (the table of these kernels holds the fields ready-made)
         };
         uint32_t pk[LBK + POS + AHEAD + 1];       // picks, index p + LBK (registers: only the last D are live)
         uint32_t tv[POS + 1];                     // skips
@@ -2081,12 +2111,12 @@ TPS_DEV bool tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
                 TPS_UNROLL
                 for (int i = LBK - DH; i < LBK; ++i) {
                     if (ca[i]) {
-                        const int pidx = ffs0(ca[i]) >> 1;
+                        const int fidx = ffs0(ca[i]) >> 1, pidx = pp_pattern(fidx);       // the pattern's field / its place in the list
                         int n = 0, pw = p0 - LBK + (i % DH) - DH;
                         while (pw >= delta && ((lut_mask(l.lut, l.lshift, pat, v_at(l.seq2, pw)) >> pidx) & 1u)) { ++n; pw -= DH; }
                         // the chain's earliest element in the tile is skipped iff the same pattern was picked D before it,
                         // which for an element within D of the tile's start is what the previous tile left
-                        const bool blocked = pw < delta && picked_before_tile(pw, pidx);
+                        const bool blocked = pw < delta && picked_before_tile(pw, fidx);
                         if (pw < delta && w0 != 0 && cold[6]) unc |= ca[i];
                         else if (((n & 1) != 0) != blocked) pk[i] ^= ca[i];
                     }
@@ -2212,33 +2242,18 @@ TPS_DEV bool tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
         chm = keep[tid][2 * B]; chw = keep[tid][2 * B + 2];
 #endif
         const int lane = tid;
-        // whole lanes a window covers after its own block: near end dl0 lanes (own lane included), far end one more
-        uint32_t fa[4] = {0, 0, 0, 0}, fb[4];
-        TPS_NOVEC
-        for (int t = 0; t < dl0; ++t) {
-            uint32_t x[4];
-            pp_expand(tne[lane + t], tno[lane + t], x);
-            fa[0] += x[0]; fa[1] += x[1]; fa[2] += x[2]; fa[3] += x[3];
-        }
-        {
-            uint32_t x[4];
-            pp_expand(tne[lane + dl0], tno[lane + dl0], x);
-            TPS_UNROLL
-            for (int i = 0; i < 4; ++i) {
-                fa[i] -= PP_BIAS * 0x01010101u;   // the bias of V; the running sums below are whole-word arithmetic
-                fb[i] = fa[i] + x[i];
-            }
-        }
         bool redo_all = false;
         if (D > 0) redo_all = ((unc_mask >> lane) & ((2ull << (dl0 + 1)) - 1ull)) != 0;
+        // the far-end words of the lane's 8 windows: one LDS round trip (windows past the tile read in-bounds garbage: their rows
+        // are never copied out, their sums are zeroed below)
         const uint32_t* pee = ende + lane * (B + 1);
         const uint32_t* peo = endo + lane * (B + 1);
         uint32_t ee[B], eo[B];
         TPS_UNROLL
         for (int j = 0; j < B; ++j) {
             const int eb = j + q;
-            ee[j] = eo[j] = 0;
-            if (lane * B + j < nw_tile) { ee[j] = pee[eb + (eb >> 3)]; eo[j] = peo[eb + (eb >> 3)]; }
+            ee[j] = pee[eb + (eb >> 3)];
+            eo[j] = peo[eb + (eb >> 3)];
         }
         if (D > 0) {
             // windows to repair after the fast pass: bits 0-7 recount (the lane's state before its first position is not
@@ -2248,50 +2263,66 @@ TPS_DEV bool tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
             todo_keep[tid] = todo;
 #endif
         }
-        // windows j >= B - rot end one lane further on (far end): the running totals switch from fa to fb there, once
-        // (a scalar branch around four copies instead of a select per word and window)
-        uint32_t fc[4] = {fa[0], fa[1], fa[2], fa[3]};
-        const int brk = B - rot;
-        TPS_UNROLL
-        for (int j = 0; j < B; ++j) {
-            const int wl = lane * B + j;
-            uint32_t sw = 0;
-            uint32_t o[4] = {0, 0, 0, 0};
-            if (j == brk) {                        // uniform
+        const int nv = nw_tile - lane * B;         // windows of this lane inside the tile (<= 0: none)
+        // NW byte words per row: the fields are laid out so that word i holds patterns 4 i .. 4 i + 3 (pp_field) -- a list of at
+        // most 12 patterns (every 6-mer motif) never touches the fourth word
+        auto windows = [&](auto nw_c) {
+            constexpr int NW = decltype(nw_c)::value;
+            // whole lanes a window covers after its own block: near end dl0 lanes (own lane included), far end one more
+            uint32_t fa[NW], fb[NW];
+            TPS_UNROLL
+            for (int i = 0; i < NW; ++i) fa[i] = 0;
+            TPS_NOVEC
+            for (int t = 0; t < dl0; ++t) {
+                uint32_t x[4];
+                pp_expand(tne[lane + t], tno[lane + t], x);
                 TPS_UNROLL
-                for (int i = 0; i < 4; ++i) { fc[i] = fb[i]; TPS_PIN_V(fc[i]); }
+                for (int i = 0; i < NW; ++i) fa[i] += x[i];
             }
-            if (wl < nw_tile) {
-                uint32_t v[4], e[4], c[4];
+            {
+                uint32_t x[4];
+                pp_expand(tne[lane + dl0], tno[lane + dl0], x);
+                TPS_UNROLL
+                for (int i = 0; i < NW; ++i) {
+                    fa[i] -= PP_BIAS * 0x01010101u;   // the bias of V; the running sums below are whole-word arithmetic
+                    fb[i] = fa[i] + x[i];
+                }
+            }
+            // windows j >= B - rot end one lane further on (far end): the running totals switch from fa to fb there, once
+            // (a scalar branch around the copies instead of a select per word and window)
+            uint32_t fc[NW];
+            TPS_UNROLL
+            for (int i = 0; i < NW; ++i) fc[i] = fa[i];
+            const int brk = B - rot;
+            TPS_UNROLL
+            for (int j = 0; j < B; ++j) {
+                if (j == brk) {                        // uniform
+                    TPS_UNROLL
+                    for (int i = 0; i < NW; ++i) { fc[i] = fb[i]; TPS_PIN_V(fc[i]); }
+                }
+                uint32_t v[4], e[4], c[4] = {0, 0, 0, 0};
                 pp_expand(ve[j], vo[j], v);
                 pp_expand(ee[j], eo[j], e);
-                sw = (uint32_t)pat.P - 16u;         // the 16 - P unused fields are floored to 1 like the others
+                uint32_t sw = (uint32_t)pat.P - 4u * NW;      // the fields no pattern owns are floored to 1 like the others
                 TPS_UNROLL
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < NW; ++i) {
                     c[i] = fc[i] + v[i] + e[i];
                     c[i] |= ((0x80808080u - c[i]) >> 7) & 0x01010101u;     // `matches or 1` per byte (counts <= 127): bit 0 set where the byte is 0
                     sw = add_bytes(c[i], sw);
                 }
-                if (a.raw) {
-                    // c[0] = patterns 0,4,8,12; c[2] = 1,5,9,13; c[1] = 2,6,10,14; c[3] = 3,7,11,15 -> pattern order
-                    const uint32_t a_lo = perm(c[2], c[0], 0x05010400u), a_hi = perm(c[2], c[0], 0x07030602u);
-                    const uint32_t b_lo = perm(c[3], c[1], 0x05010400u), b_hi = perm(c[3], c[1], 0x07030602u);
-                    o[0] = perm(b_lo, a_lo, 0x05040100u);
-                    o[1] = perm(b_lo, a_lo, 0x07060302u);
-                    o[2] = perm(b_hi, a_hi, 0x05040100u);
-                    o[3] = perm(b_hi, a_hi, 0x07060302u);
-                }
-            }
-            swv[j] = sw;
-            TPS_UNROLL
-            for (int i = 0; i < 3; ++i) rows[j][i] = o[i];
-            if (j & 1) rx[j >> 1] = pack_hi_lo(o[3] << 16, rx[j >> 1]);
-            else rx[j >> 1] = o[3] & 0xFFFFu;
+                swv[j] = j < nv ? sw : 0u;
+                TPS_UNROLL
+                for (int i = 0; i < 3; ++i) rows[j][i] = c[i];        // the row as it is: word i = patterns 4 i .. 4 i + 3
+                if (j & 1) rx[j >> 1] = pack_hi_lo(c[3] << 16, rx[j >> 1]);
+                else rx[j >> 1] = c[3] & 0xFFFFu;
 #ifdef TPS_EMU
-            sw_keep[tid][j] = sw;
-            for (int i = 0; i < 4; ++i) rows_keep[tid][j][i] = o[i];
+                sw_keep[tid][j] = swv[j];
+                for (int i = 0; i < 4; ++i) rows_keep[tid][j][i] = c[i];
 #endif
-        }
+            }
+        };
+        if (pat.P <= 12) windows(IntC<3>{});
+        else windows(IntC<4>{});
         g_store_sw8(tc.sw16 + w0, lane, nw_tile, swv);     // (0 for the windows past the tile: dropped by the range check)
     }
     TPS_SYNC();                                   // every END word has been read: S_w takes the place of the odd half
@@ -2350,15 +2381,11 @@ TPS_DEV bool tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
                 const int ncap = LPP * B * pd;
                 if (nvalid > ncap) nvalid = ncap;
                 uint32_t* g = gout + (int64_t)l0 * B * pd;
-                for (int cdw = 4 * tid; cdw < nvalid; cdw += 4 * NT) {
-                    const u32x4 t = *(const u32x4*)(buf + cdw);
-                    if (cdw + 4 <= nvalid) {
-                        g[cdw] = t.x; g[cdw + 1] = t.y; g[cdw + 2] = t.z; g[cdw + 3] = t.w;
-                    } else {
-                        g[cdw] = t.x;
-                        if (cdw + 1 < nvalid) g[cdw + 1] = t.y;
-                        if (cdw + 2 < nvalid) g[cdw + 2] = t.z;
-                    }
+                const int npass = (nvalid + 4 * NT - 1) / (4 * NT);      // uniform
+                TPS_NOVEC
+                for (int it = 0; it < npass; ++it) {
+                    const int cdw = 4 * tid + it * 4 * NT;
+                    g_store16_clamped(g, nvalid, cdw, *(const u32x4*)(buf + cdw));      // (reads past nvalid stay inside the wave's LDS slice; what they fetch is dropped)
                 }
             }
             TPS_SYNC();
@@ -2454,7 +2481,7 @@ TPS_DEV bool tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
                     uint32_t fw = chw;
                     bool lost = false;
                     while (fw) {
-                        const int pidx = ffs0(fw) >> 1;
+                        const int fidx = ffs0(fw) >> 1, pidx = pp_pattern(fidx);
                         fw &= fw - 1u;
                         int x = -1;
                         TPS_NOVEC
@@ -2463,7 +2490,7 @@ TPS_DEV bool tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
                         if (x >= 0) {
                             int n = 0, pb = x - D;
                             while (pb >= delta && ((lut_mask(l.lut, l.lshift, pat, v_at(l.seq2, pb)) >> pidx) & 1u)) { ++n; pb -= D; }
-                            const bool blocked = pb < delta && picked_before_tile(pb, pidx);
+                            const bool blocked = pb < delta && picked_before_tile(pb, fidx);
                             if (pb < delta && w0 != 0 && cold[6]) lost = true;      // the chain leaves the tile and the state there is unknown
                             int m = 1;
                             for (int pw = x + D; pw < a0 + a.lw && ((lut_mask(l.lut, l.lshift, pat, v_at(l.seq2, pw)) >> pidx) & 1u); pw += D) ++m;

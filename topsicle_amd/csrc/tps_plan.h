@@ -203,7 +203,7 @@ inline std::string plan_geometry_core(ScanArgs& a, const tps_params& prm, int k,
                                a.lw / k + 2 <= 127 && !getenv("TPS_NO_PP");
         if (pp_counts && a.pat.n_periods == 0) a.pp_d = 0;
         if (pp_counts && a.pat.n_periods == 1 && a.pat.period[0] >= 2 && 2 * a.pat.period[0] >= k) a.pp_d = a.pat.period[0];
-        a.lut_fields = (PP_FIELDS && a.pp_d >= 0 && (prm.flags & TPS_F_STORE_RAW)) ? 1 : 0;   // the per-pattern tiles will run: table of one-hot fields
+        a.lut_fields = (a.pp_d >= 0 && (prm.flags & TPS_F_STORE_RAW)) ? 1 : 0;   // the per-pattern tiles will run: table of one-hot fields
         a.so_fast = getenv("TPS_NO_SO_FAST") ? 0 : 1;   // sums only, pp_d > 0: chain-free tiles complete as plain tiles (tile_fused_s<.., CD>)
         a.variant = prm.slide;
         a.blk_log2 = 3;                            // 8 blocks per lane for every slide
