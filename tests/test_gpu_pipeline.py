@@ -1,0 +1,151 @@
+"""GPU parity on what real input looks like -- RAGGED batches at scale -- and the multi-context pipeline that no hardware run
+had exercised with more than two contexts:
+
+  * >= 5 000 reads of log-normal length (60 b .. 60 kb: some shorter than no_bp, some shorter than trimfirst + window, many
+    longer than maxlengthtelo), N and lower case sprinkled in, both strands, through the host packer and the packed upload:
+    every read against the float64 pipeline of the C oracle (pass, tail, best count, n_win, change-point), every 50th read's
+    window sums -- and raw rows, with and without self-overlapping k-mers -- window by window;
+  * batch.EnginePool with four contexts on this box's GPU ("2 GPUs x 2 contexts") over a ragged multi-batch file: results in
+    input order and equal to a one-context run; the pinned staging pool is allocated once and reused file after file.
+
+Everything goes through the C ABI on a real MI355X.  Integer work is compared bit-exact.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_c
+import topsicle_oracle as orc
+from topsicle_amd import allsteps, batch, hiplib, seqio, synth
+
+pytestmark = pytest.mark.gpu
+TAILS = ["forward", "reverse"]
+FULL = hiplib.F_STEP1 | hiplib.F_WINDOWS | hiplib.F_BINSEG | hiplib.F_STORE_SUMS
+
+
+@pytest.fixture(scope="module")
+def sc():
+    s = hiplib.HipScanner(0)
+    yield s
+    s.close()
+
+
+def _ragged(n, motif, seed, errors=synth.ONT):
+    """n reads of log-normal length plus a sprinkle of very short ones (below no_bp, below trimfirst + window)."""
+    b1, o1, t1 = synth.make_ragged_reads(n - 60, motif, seed, errors=errors, n_frac=0.0003, lower_frac=0.1)
+    b2, o2, t2 = synth.make_ragged_reads(60, motif, seed + 1, errors=errors, len_mu=5.6, len_sigma=0.7, min_len=60, max_len=2000,
+                                         tract_min=50, tract_max=1500, n_frac=0.001, lower_frac=0.2)
+    # the short ones go in between, not at the end: tiles of long and short reads next to each other in one launch
+    rng = np.random.default_rng(seed)
+    order = rng.permutation(n)
+    lens = np.concatenate([np.diff(o1), np.diff(o2)])
+    starts = np.concatenate([o1[:-1], o2[:-1] + o1[-1]])
+    allb = np.concatenate([b1, b2])
+    offsets = np.zeros(n + 1, np.int64)
+    np.cumsum(lens[order], out=offsets[1:])
+    bases = np.empty(int(offsets[-1]), np.uint8)
+    for j, i in enumerate(order):
+        bases[offsets[j]:offsets[j + 1]] = allb[starts[i]:starts[i] + lens[i]]
+    return bases, offsets
+
+
+def _params(motif, slide, flags=FULL, cutoff=0.5, min_len=1000):
+    return hiplib.make_params(no_bp=1000, min_len=min_len, min_count=allsteps.min_count_for_cutoff(cutoff, 1000 / len(motif), 1000),
+                              window=100, slide=slide, trimfirst=100, maxlen=20000, flags=flags)
+
+
+@pytest.mark.parametrize("motif,k,slide,raw", [("CCCTAA", 4, 6, False), ("CCCTAA", 4, 6, True), ("CCCTAA", 6, 6, True), ("AAACCCT", 5, 7, False)])
+def test_ragged_batch_at_scale_vs_oracle(sc, motif, k, slide, raw):
+    n = 5000
+    pats = orc.kmer_table(motif, k)
+    sc.set_patterns(pats)
+    bases, offsets = _ragged(n, motif, 20250919 + 11 * k + slide)
+    lens = np.diff(offsets)
+    assert lens.min() < 200 and (lens < 1000).sum() >= 20 and (lens > 20000).sum() >= 200 and lens.max() > 40000
+    seq2, inv, desc = seqio.pack_reads_host(bases, offsets)
+    assert (desc["flags"] & 1).any()                             # reads with N in the batch
+    sc.upload_packed(0, seq2, inv, desc)
+    cutoff, min_len = 0.5, 1000                                  # (minSeqLength 1000: the short reads take part in step 1, most long ones pass)
+    prm = _params(motif, slide, FULL | (hiplib.F_STORE_RAW if raw else 0), cutoff, min_len)
+    sc.scan(0, prm)
+    sc.sync()
+    res = sc.results(0).copy()
+    sums, win_off = sc.window_sums(0)
+    rows = sc.window_raw(0)[0] if raw else None
+    # every read against the float64 pipeline (what allsteps.py:310-311 computes), all reads
+    out, done, _ = oracle_c.batch(bases, offsets, pats, len(motif), 1000, min_len, cutoff, 100, slide, 100, 20000,
+                                  both_tails=False, threads=oracle_c.usable_cores())
+    assert done == n
+    assert np.array_equal(res["pass"], out[:, 0])
+    p = res["pass"].astype(bool)
+    assert 0.5 * n < p.sum() < n
+    assert np.array_equal(res["tail"][p], out[p, 1])
+    best = np.where(res["tail"] == 0, res["best_start"], res["best_end"])
+    assert np.array_equal(best[p], out[p, 3])
+    assert np.array_equal(res["n_win"][p], out[p, 4])
+    differ = np.nonzero(res["bkp"][p] != out[p, 5])[0]
+    assert len(differ) == 0, (differ[:10], res["bkp"][p][differ[:10]], out[p, 5][differ[:10]])
+    nw = np.array([hiplib.window_count(int(x), 100, slide, 100, 20000) for x in lens])
+    assert np.array_equal(np.diff(win_off), nw)                  # (the layout holds windows for every read, passing or not)
+    # window by window: every 50th read, plus the shortest and the longest passing ones
+    idx = set(range(0, n, 50)) | {int(np.nonzero(p)[0][np.argmin(lens[p])]), int(np.argmax(lens))}
+    checked = 0
+    for i in sorted(idx):
+        if not p[i]:
+            continue
+        seq = bytes(bases[offsets[i]:offsets[i + 1]]).decode()
+        s_c, raw_c = oracle_c.window_counts(seq, TAILS[int(res["tail"][i])], pats, 100, slide, 100, 20000)
+        assert np.array_equal(sums[win_off[i]:win_off[i + 1]], s_c), i
+        if raw:
+            assert np.array_equal(rows[win_off[i]:win_off[i + 1]], raw_c), i
+        checked += 1
+    assert checked >= 50
+
+
+def _write_fastq(path, bases, offsets):
+    with open(path, "wb") as h:
+        for i in range(len(offsets) - 1):
+            s = bases[offsets[i]:offsets[i + 1]].tobytes()
+            h.write(b"@r%d some text\n" % i + s + b"\n+\n" + b"I" * len(s) + b"\n")
+
+
+def test_engine_pool_four_contexts_ragged_file(tmp_path):
+    """Four contexts on device 0 pull batches of a ragged file from one queue: every batch comes back in file order with the
+    rows a single context computes; all contexts upload from the pinned pool the first one allocated (asynchronously: the
+    library's registry of pinned buffers is process-wide), and that pool is allocated once, not once per file."""
+    motif, k, slide = "CCCTAA", 4, 6
+    pats = orc.kmer_table(motif, k)
+    bases, offsets = _ragged(2500, motif, 77)
+    fq = str(tmp_path / "ragged.fastq")
+    _write_fastq(fq, bases, offsets)
+    prm = _params(motif, slide, hiplib.F_STEP1 | hiplib.F_WINDOWS | hiplib.F_BINSEG)
+    max_bases = 3 << 20                                          # ~ a dozen batches
+
+    def run(engines, times=1):
+        ids, rows = [], []
+        for _ in range(times):
+            ids, rows = [], []
+            pool = batch.EnginePool(engines, pats)               # (a new pool per file, as main.process_file_multi makes one)
+            for pb, res, _s, _r, _w in pool.scan_file(fq, prm, max_bases=max_bases):
+                ids += pb.ids
+                rows.append(res.copy())
+        return ids, np.concatenate(rows)
+
+    one = [hiplib.HipScanner(0)]
+    four = [hiplib.HipScanner(0) for _ in range(4)]
+    try:
+        ids1, r1 = run(one)
+        assert ids1 == [f"r{i}" for i in range(2500)]
+        ids4, r4 = run(four)
+        pinned_after_first = len(four[0]._pinned)
+        assert pinned_after_first > 0 and all(len(getattr(e, "_pinned", {})) == 0 for e in four[1:])
+        assert ids4 == ids1
+        for f in ("pass", "tail", "best_start", "best_end", "n_win", "bkp"):
+            assert np.array_equal(r4[f], r1[f]), f
+        ids4b, r4b = run(four, times=3)                          # three more files through the same contexts
+        assert ids4b == ids1 and np.array_equal(r4b["bkp"], r1["bkp"])
+        assert len(four[0]._pinned) == pinned_after_first        # the staging pool was reused, not re-allocated per file
+    finally:
+        for e in one + four:
+            e.close()

@@ -219,3 +219,20 @@ def test_cli_several_k_in_one_pass_equals_separate_runs(engine, demo_fastq, tmp_
     assert open(tmp_path / "k6" / last).read() == open(out / last).read()
     log = open(out / "topsicle_run.log").read()
     assert all(f"k-mer: {k}, with TRC >= 0.7" in log for k in (4, 5, 6))
+
+
+def test_cli_fasta_input_several_k_keeps_the_first_k_records(engine, tmp_path, demo_records):
+    """FASTA input, `--telophrase 4 6`: upstream's outer loop over k writes <name>.fasta for the first k and every later k
+    finds and REUSES it (main.py:64-66), so the filtered file holds the FIRST k's passing records (for FASTQ input the file is
+    rewritten per k and the last k's records stay: the test above)."""
+    fa = tmp_path / "reads.fasta"
+    with open(fa, "wt") as h:
+        for rid, seq in demo_records:
+            h.write(f">{rid}\n{seq}\n")
+    outs = {}
+    for tag, ks in (("k4", ["4"]), ("k6", ["6"]), ("both", ["4", "6"])):
+        out = tmp_path / tag
+        run_cli(engine, ["-i", str(fa), "-o", str(out), "--pattern", "CCCTAAA", "--slide", "6", "--cutoff", "0.3", "--telophrase"] + ks)
+        outs[tag] = open(out / "reads_trc_over_0.3.fasta").read()
+    assert outs["k4"] != outs["k6"]                     # (the two tables pass different reads at this cutoff)
+    assert outs["both"] == outs["k4"]

@@ -55,24 +55,33 @@ def upload_batch(engine, recs, slot: int = 0):
 
 def scan_jobs(engine, recs, jobs, slot: int = 0):
     """Upload once, then one fused scan per job.  Returns [(results, sums, raw, win_off), ...] in job order."""
-    upload_batch(engine, recs, slot)
     out = []
-    for n, job in enumerate(jobs):
-        if len(jobs) > 1 or getattr(engine, "patterns", None) != job.patterns:
-            engine.set_patterns(job.patterns)
-        p = hiplib.Params.from_buffer_copy(job.prm)
-        p.flags = job.prm.flags | (hiplib.F_STORE_SUMS if job.want_sums else 0) | (hiplib.F_STORE_RAW if job.want_raw else 0)
-        engine.scan(slot, p)
-        engine.sync()
-        if n == 0 and hasattr(recs, "release"):
-            recs.release()             # the upload has completed: the staging buffers go back to the reader
-        res = engine.results(slot)
-        sums = raw = win_off = None
-        if job.want_sums:
-            sums, win_off = engine.window_sums(slot)
-        if job.want_raw:
-            raw, win_off = engine.window_raw(slot)
-        out.append((res, sums, raw, win_off))
+    try:
+        upload_batch(engine, recs, slot)
+        for n, job in enumerate(jobs):
+            if len(jobs) > 1 or getattr(engine, "patterns", None) != job.patterns:
+                engine.set_patterns(job.patterns)
+            p = hiplib.Params.from_buffer_copy(job.prm)
+            p.flags = job.prm.flags | (hiplib.F_STORE_SUMS if job.want_sums else 0) | (hiplib.F_STORE_RAW if job.want_raw else 0)
+            engine.scan(slot, p)
+            engine.sync()
+            if n == 0 and hasattr(recs, "release"):
+                recs.release()             # the upload has completed: the staging buffers go back to the reader
+            res = engine.results(slot)
+            sums = raw = win_off = None
+            if job.want_sums:
+                sums, win_off = engine.window_sums(slot)
+            if job.want_raw:
+                raw, win_off = engine.window_raw(slot)
+            out.append((res, sums, raw, win_off))
+    except BaseException:
+        try:
+            engine.sync()                  # an asynchronous upload may still be reading the staging buffers
+        except Exception:
+            pass
+        if hasattr(recs, "release"):
+            recs.release()                 # a failed batch must not take its staging buffers with it
+        raise
     return out
 
 
@@ -103,13 +112,9 @@ class EnginePool:
         max_bases = max_bases or BATCH_BASES
         words_cap = max(max_bases // 16, 1024)                 # (a read's padding to whole 64-base quads counts too)
         reads_cap = min(BATCH_READS, max(64, max_bases // 256))
-        key = (words_cap, reads_cap)
-        if getattr(self, "_pool_key", None) != key:            # pinned staging buffers are allocated once and reused file after file
-            alloc = getattr(self.engines[0], "host_alloc", None)
-            self._pool = seqio.BufferPool(len(self.engines) + 2, words_cap, reads_cap, alloc)
-            self._pool_key = key
-        return self._single(self._run(seqio.read_batches_packed(filepath, self._pool, max_records=reads_cap),
-                                      [Job(self.patterns, prm, want_sums, want_raw)]))
+        pool = self._staging_pool(words_cap, reads_cap)
+        return self._single(self._run(seqio.read_batches_packed(filepath, pool, max_records=reads_cap),
+                                      [Job(self.patterns, prm, want_sums, want_raw)], pool))
 
     def scan_file_jobs(self, filepath, jobs, max_bases=None):
         """One pass over the file for several jobs (pattern tables): yields (PackedBatch, [(results, sums, raw, win_off) per job])."""
@@ -117,12 +122,23 @@ class EnginePool:
         max_bases = max_bases or BATCH_BASES
         words_cap = max(max_bases // 16, 1024)
         reads_cap = min(BATCH_READS, max(64, max_bases // 256))
-        key = (words_cap, reads_cap)
-        if getattr(self, "_pool_key", None) != key:
-            alloc = getattr(self.engines[0], "host_alloc", None)
-            self._pool = seqio.BufferPool(len(self.engines) + 2, words_cap, reads_cap, alloc)
-            self._pool_key = key
-        return self._run(seqio.read_batches_packed(filepath, self._pool, max_records=reads_cap), list(jobs))
+        pool = self._staging_pool(words_cap, reads_cap)
+        return self._run(seqio.read_batches_packed(filepath, pool, max_records=reads_cap), list(jobs), pool)
+
+    def _staging_pool(self, words_cap, reads_cap):
+        """The pinned staging buffers of this engine set: allocated ONCE per (engine set, geometry) and kept on the first engine,
+        so that a new EnginePool per input file (main.process_file_multi) reuses them -- they are only freed with the context
+        (a pool per file leaked ~28 MB of pinned memory per buffer set and file: ADVICE r2).  Every context uploads from them
+        asynchronously (the library keeps a process-wide registry of pinned buffers)."""
+        from . import seqio
+        owner = self.engines[0]
+        pools = getattr(owner, "_staging_pools", None)
+        if pools is None:
+            pools = owner._staging_pools = {}
+        key = (words_cap, reads_cap, len(self.engines) + 2)
+        if key not in pools:
+            pools[key] = seqio.BufferPool(len(self.engines) + 2, words_cap, reads_cap, getattr(owner, "host_alloc", None))
+        return pools[key]
 
     def scan_stream(self, records, prm, want_sums=False, want_raw=False, max_bases=None):
         return self._single(self._run(record_batches(records, max_bases=max_bases or BATCH_BASES), [Job(self.patterns, prm, want_sums, want_raw)]))
@@ -133,8 +149,10 @@ class EnginePool:
             yield (b,) + outs[0]
 
     # -- the pipeline
-    def _run(self, batches, jobs):
+    def _run(self, batches, jobs, pool=None):
         n = len(self.engines)
+        if pool is not None:
+            pool.abort.clear()
         q_in: queue.Queue = queue.Queue(maxsize=n + 1)
         q_out: queue.Queue = queue.Queue()
         stop = threading.Event()
@@ -150,6 +168,8 @@ class EnginePool:
                         except queue.Full:
                             continue
                     if stop.is_set():
+                        if hasattr(b, "release"):
+                            b.release()
                         break
                     count += 1
                 q_out.put(("eof", count, None))
@@ -189,9 +209,13 @@ class EnginePool:
                     nxt += 1
         finally:
             stop.set()
+            if pool is not None:
+                pool.abort.set()                       # a reader waiting for a staging buffer gives up
             try:
                 while True:
-                    q_in.get_nowait()
+                    item = q_in.get_nowait()
+                    if item is not None and hasattr(item[1], "release"):
+                        item[1].release()              # batches nobody will scan hand their staging buffers back
             except queue.Empty:
                 pass
             for _ in range(n):

@@ -10,6 +10,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <map>
+#include <mutex>
 #include <set>
 #include <string>
 #include <vector>
@@ -98,6 +100,20 @@ extern "C" __global__ void __launch_bounds__(256) tps_pack_kernel(const uint8_t*
 namespace {
 
 thread_local std::string g_err;
+
+// Pinned host buffers handed out by tps_host_alloc, process-wide: the pipeline allocates its staging pool through ONE context and
+// every context uploads from it (hipHostMallocPortable: pinned for all devices); tps_batch_upload_packed copies asynchronously
+// whenever its sources lie in registered buffers, whoever allocated them.
+std::mutex g_pinned_mu;
+std::map<uintptr_t, size_t> g_pinned;            // base -> bytes
+bool is_pinned(const void* p, size_t bytes) {
+    if (!p || !bytes) return true;
+    std::lock_guard<std::mutex> lk(g_pinned_mu);
+    auto it = g_pinned.upper_bound((uintptr_t)p);
+    if (it == g_pinned.begin()) return false;
+    --it;
+    return (uintptr_t)p + bytes <= it->first + it->second;
+}
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -296,7 +312,7 @@ int do_upload_packed(tps_ctx* c, Slot& sl, const uint32_t* seq2, const uint16_t*
     if (n_words) HIP_TRY(hipMemcpyAsync(sl.seq2.p, seq2, (size_t)n_words * 4, hipMemcpyHostToDevice, c->stream));
     if (n_words && inv) HIP_TRY(hipMemcpyAsync(sl.inv.p, inv, (size_t)n_words * 2, hipMemcpyHostToDevice, c->stream));
     if (n) HIP_TRY(hipMemcpyAsync(sl.desc.p, desc, (size_t)n * sizeof(tps_read_desc), hipMemcpyHostToDevice, c->stream));
-    const bool all_pinned = (!n_words || c->pinned.count((void*)seq2)) && (!inv || c->pinned.count((void*)inv)) && (!n || c->pinned.count((void*)desc));
+    const bool all_pinned = is_pinned(seq2, (size_t)n_words * 4) && is_pinned(inv, inv ? (size_t)n_words * 2 : 0) && is_pinned(desc, (size_t)n * sizeof(tps_read_desc));
     if (!all_pinned) HIP_TRY(hipStreamSynchronize(c->stream));     // ordinary memory: the copy is over when the call returns
     sl.inv_valid = inv != nullptr;
     sl.any_invalid = flagged;
@@ -541,7 +557,10 @@ int tps_ctx_destroy(tps_ctx* c) {
     c->ascii_off.release();
     c->follow_picks.release();
     c->follow_hist.release();
-    for (void* hp : c->pinned) (void)hipHostFree(hp);
+    for (void* hp : c->pinned) {
+        { std::lock_guard<std::mutex> lk(g_pinned_mu); g_pinned.erase((uintptr_t)hp); }
+        (void)hipHostFree(hp);
+    }
     if (c->h_flag) (void)hipHostFree(c->h_flag);
     c->pinned.clear();
     for (auto& ep : c->ev_pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
@@ -636,8 +655,9 @@ int tps_host_alloc(tps_ctx* c, int64_t bytes, void** out) {
     if (!out || bytes < 0) return fail(TPS_E_ARG, "bad arguments");
     *out = nullptr;
     void* p = nullptr;
-    HIP_TRY(hipHostMalloc(&p, (size_t)std::max<int64_t>(bytes, 16), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(&p, (size_t)std::max<int64_t>(bytes, 16), hipHostMallocPortable));
     c->pinned.insert(p);
+    { std::lock_guard<std::mutex> lk(g_pinned_mu); g_pinned[(uintptr_t)p] = (size_t)std::max<int64_t>(bytes, 16); }
     *out = p;
     return TPS_OK;
 }
@@ -647,6 +667,7 @@ int tps_host_free(tps_ctx* c, void* p) {
     if ((rc = bind(c))) return rc;
     if (!p) return TPS_OK;
     if (!c->pinned.erase(p)) return fail(TPS_E_ARG, "pointer was not allocated by tps_host_alloc of this context");
+    { std::lock_guard<std::mutex> lk(g_pinned_mu); g_pinned.erase((uintptr_t)p); }
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipHostFree(p));
     return TPS_OK;

@@ -459,10 +459,12 @@ struct Fast {
         } else {
             next = size;                                        // last line without a newline
         }
-        // (A quality line SHORTER than the sequence would put q1 inside the next record; that is only mistaken for a line end
-        // if that record's header happens to end exactly there, and then the next "record" starts with a base instead of '@'
-        // and the file is rejected one record later than Biopython would.  Scanning the quality bytes to rule that out
-        // cost a third of the decoding time.)
+        // A quality line SHORTER than the sequence puts q1 inside the next record; that is only mistaken for a line end if that
+        // record's header happens to end exactly there -- and then what follows is not a record start.  Scanning every quality
+        // line for a stray newline cost a third of the decoding time, so the bytes are only looked at in that case: the byte
+        // behind the record is not '@' (such a record was accepted and written out with an embedded newline).
+        if (sl && data[q1 - 1] == '\n') return 1;
+        if (next < size && data[next] != '@' && memchr(data + q0, '\n', sl)) return 1;
         if (sl > 0x7FFFFFFFull) return 1;
         if (sl && (data[s0] == ' ' || data[s0] == '\t' || data[s1 - 1] == ' ' || data[s1 - 1] == '\t')) return 1;
         r = Rec{s + 1, (uint64_t)(h1 - s - 1), s0, (uint64_t)sl, q0};

@@ -70,7 +70,10 @@ def measure(bases, offsets, motif: str, k: int, slide: int, device: int = 0, con
             prm = hiplib.make_params(no_bp=1000, min_len=9000, min_count=allsteps.min_count_for_cutoff(0.7, 1000 / len(motif), 1000),
                                      window=100, slide=slide, trimfirst=100, maxlen=20000)
             # -- PCIe-inclusive: packed batches already in pinned host memory -> upload -> scan -> per-read results
-            held = list(seqio.read_batches_packed(fq, pool)) if n_bases <= 3 * batch.BATCH_BASES else []
+            # (a pool of their own, one set more than the batches they can be: the reader asks for a set before it learns the file has ended)
+            held_pool = seqio.BufferPool(6, batch.BATCH_BASES // 16, min(batch.BATCH_READS, batch.BATCH_BASES // 64), engines[0].host_alloc) if n_bases <= 3 * batch.BATCH_BASES else None
+            held = list(seqio.read_batches_packed(fq, held_pool)) if held_pool is not None else []
+            assert len(held) < 6
             if held:
                 engines[0].set_patterns(pats)
                 best = None
@@ -87,7 +90,7 @@ def measure(bases, offsets, motif: str, k: int, slide: int, device: int = 0, con
                                       "note": "one context, no overlap between batches: H2D of 3 bits per base + scan + D2H of the result rows"}
                 for pb in held:
                     pb.release()
-            del held, pool
+            del held, pool, held_pool
             # -- file -> results
             ep = batch.EnginePool(engines, pats)
             prm = hiplib.make_params(no_bp=1000, min_len=9000, min_count=allsteps.min_count_for_cutoff(0.7, 1000 / len(motif), 1000),

@@ -88,7 +88,11 @@ def process_file_multi(args, seq_loc, phrases, engines):
         tprint(f"Temporary fasta file already exists: {fasta_temp}. Using existing file.")
     else:
         fasta_temp = os.path.join(args.outputDir, f"{file_name}_trc_over_{min_cutoff}.{fmt}")
-        out_handle = open(fasta_temp, "wb")        # holds the passing records of the LAST k, as after upstream's k loop
+        out_handle = open(fasta_temp, "wb")
+    # Which k's passing records the file holds after upstream's OUTER loop over k (main.py:206-235, 64-78): FASTA input -- the
+    # first k writes <name>.fasta, every later k finds it and reuses it, so the FIRST k's records stay; FASTQ input -- only
+    # `.fasta` is ever checked, the `.fastq` file is rewritten for every k, so the LAST k's records stay.
+    writer_k = 0 if fmt == "fasta" else len(phrases) - 1
 
     rows = [[] for _ in phrases]
     image_num = [1] * len(phrases)
@@ -100,7 +104,7 @@ def process_file_multi(args, seq_loc, phrases, engines):
         for pb, outs in pool.scan_file_jobs(seq_loc, jobs):
             for n, ((telo_phrase, pattern, sliding_val), (res, sums, raw, win_off)) in enumerate(zip(phrases, outs)):
                 idx = np.nonzero(res["pass"])[0]
-                if out_handle is not None and len(idx) and n == len(phrases) - 1:
+                if out_handle is not None and len(idx) and n == writer_k:
                     pb.write_records(out_handle, idx, fmt)                   # every passing record (main.py:83-86)
                 ids = [pb.read_id(int(i)) for i in idx]
                 if args.read_check:

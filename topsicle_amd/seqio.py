@@ -310,11 +310,22 @@ class BufferPool:
         self.words_cap, self.reads_cap = int(words_cap), int(reads_cap)
         self._free = queue.Queue()
         self._alloc = alloc
+        self.n_sets = int(n_sets)
+        import threading
+        self.abort = threading.Event()
         for _ in range(n_sets):
             self._free.put(BufferSet(words_cap, reads_cap, alloc))
 
     def get(self) -> BufferSet:
-        return self._free.get()
+        """A free set; while none is free the `abort` event is polled, so that a reader whose consumer has gone away (an error
+        downstream, an abandoned generator) ends instead of waiting for a buffer that will never come back."""
+        import queue
+        while True:
+            try:
+                return self._free.get(timeout=0.2)
+            except queue.Empty:
+                if self.abort.is_set():
+                    raise RuntimeError("the batch pipeline was stopped")
 
     def put(self, bs: BufferSet):
         self._free.put(bs)

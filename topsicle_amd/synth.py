@@ -79,3 +79,31 @@ def make_reads(n_reads: int, read_len: int, motif: str, seed: int, errors=ONT,
 def split_reads(bases: np.ndarray, offsets: np.ndarray) -> list[str]:
     raw = bases.tobytes()
     return [raw[offsets[i]:offsets[i + 1]].decode("ascii") for i in range(len(offsets) - 1)]
+
+
+def make_ragged_reads(n_reads: int, motif: str, seed: int, errors=ONT, len_mu: float = 9.3, len_sigma: float = 0.8,
+                      min_len: int = 60, max_len: int = 60000, n_frac: float = 0.0, lower_frac: float = 0.0,
+                      tract_min: int = 1000, tract_max: int = 8000, telomeric_fraction: float = 1.0):
+    """Reads of log-normal length (what a real ONT file looks like: the reference's demo data span 1.6 - 48 kb) from the same
+    generator: every read is cut out of a `max_len` read of make_reads -- its first L bases, or its last L when it was reverse-
+    complemented, so the telomere stays at the read's end.  `n_frac` of the bases become N, `lower_frac` of the READS are
+    written in lower case.  Returns (bases u8, offsets i64[n+1], truth) like make_reads."""
+    rng = np.random.default_rng(seed ^ 0x5EED)
+    lens = np.clip(np.exp(rng.normal(len_mu, len_sigma, n_reads)), min_len, max_len).astype(np.int64)
+    full, off, truth = make_reads(n_reads, max_len, motif, seed, errors, tract_min, tract_max, telomeric_fraction)
+    full = full.reshape(n_reads, max_len)
+    offsets = np.zeros(n_reads + 1, dtype=np.int64)
+    np.cumsum(lens, out=offsets[1:])
+    out = np.empty(int(offsets[-1]), dtype=np.uint8)
+    for i in range(n_reads):
+        L = int(lens[i])
+        out[offsets[i]:offsets[i + 1]] = full[i, max_len - L:] if truth["reverse"][i] else full[i, :L]
+    if n_frac > 0:
+        k = rng.binomial(out.size, n_frac)
+        out[rng.integers(0, out.size, k)] = ord("N")
+    if lower_frac > 0:
+        for i in np.nonzero(rng.random(n_reads) < lower_frac)[0]:
+            seg = out[offsets[i]:offsets[i + 1]]
+            seg |= 0x20                                   # ASCII lower case (N -> n as well)
+    truth = dict(truth, length=lens)
+    return out, offsets, truth
