@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define TPS_ABI_VERSION 2
+#define TPS_ABI_VERSION 3
 
 /* error codes */
 #define TPS_OK            0
@@ -91,7 +91,7 @@ typedef struct tps_params {
     uint32_t flags;       /* TPS_F_*                                                           */
 } tps_params;
 
-/* Per-read result of a scan (40 bytes). */
+/* Per-read result of a scan (48 bytes; ABI 3 added `flags`). */
 typedef struct tps_read_result {
     int32_t best_start;      /* max_p count in the first no_bp bases                (a3)      */
     int32_t best_start_idx;  /* first pattern index reaching it (allsteps.py:190)             */
@@ -102,7 +102,15 @@ typedef struct tps_read_result {
     int32_t n_win;           /* windows of the chosen tail (0 if not scanned)                 */
     int32_t bkp;             /* best split index, -1 if none admissible / not run   (a6)      */
     double  gain;            /* l2 gain of that split on y = S/P (float64, informational)     */
+    uint32_t flags;          /* TPS_RES_*                                                     */
+    uint32_t reserved;
 } tps_read_result;
+/* The change-point was decided by the exact integer tournament: two or more candidates lay within float64 rounding noise of
+ * the best gain (a constant signal; exact rational ties).  ruptures compares float64 gains there (allsteps.py:310-311), so
+ * its answer is a matter of rounding noise, not of the data: a caller that wants THAT answer downloads the read's S_w
+ * (tps_batch_read_sums) and repeats ruptures' float64 arithmetic on it -- a handful of reads at most; topsicle_amd does
+ * (hiplib.HipScanner.resolve_ties).  bkp itself holds the exact rule's answer: ties -> the larger index. */
+#define TPS_RES_TIE 1u
 
 /* ---- context ------------------------------------------------------------------------- */
 int  tps_abi_version(void);
@@ -157,6 +165,8 @@ int  tps_batch_window_offsets(tps_ctx* ctx, int32_t slot, int64_t* win_off, int6
 /* Download S_w (needs TPS_F_STORE_SUMS) / c'_p (needs TPS_F_STORE_RAW) of the last scan. */
 int  tps_batch_window_sums(tps_ctx* ctx, int32_t slot, int32_t* sums, int64_t n_windows);
 int  tps_batch_window_raw(tps_ctx* ctx, int32_t slot, uint8_t* raw, int64_t n_windows_times_p);
+/* S_w of ONE read of the last scan (any scan with TPS_F_WINDOWS; n_windows = the read's n_win). */
+int  tps_batch_read_sums(tps_ctx* ctx, int32_t slot, int64_t read, int32_t* sums, int64_t n_windows);
 /* Step-1 per-pattern counts of the last scan: c_start[n*P], c_end[n*P] (int32). */
 int  tps_batch_trc_counts(tps_ctx* ctx, int32_t slot, int32_t* c_start, int32_t* c_end, int64_t n_reads);
 
@@ -176,6 +186,9 @@ int  tps_window_counts(tps_ctx* ctx, const uint8_t* bases, const int64_t* offset
  * sums: bkp[n] (-1 = no admissible split), gain[n] (may be NULL). */
 int  tps_binseg_l2(tps_ctx* ctx, const int32_t* sums, const int64_t* win_off, int64_t n_reads,
                    int32_t n_patterns, int32_t jump, int32_t min_size, int32_t* bkp, double* gain);
+/* The same, also reporting per read whether the exact tournament decided (tie[n]: 1 = TPS_RES_TIE, see above; may be NULL). */
+int  tps_binseg_l2_ties(tps_ctx* ctx, const int32_t* sums, const int64_t* win_off, int64_t n_reads,
+                        int32_t n_patterns, int32_t jump, int32_t min_size, int32_t* bkp, double* gain, uint8_t* tie);
 
 /* Number of windows seq_cut_windows yields for a read of length L (allsteps.py:219, 263-271). */
 int64_t tps_window_count(int64_t read_len, int32_t window, int32_t slide, int32_t trimfirst, int32_t maxlen);

@@ -150,8 +150,8 @@ extern "C" int emu_followers(const char* pats, int P, int k, const uint8_t* base
 }
 
 extern "C" int emu_binseg(const int32_t* sums, const int64_t* win_off, int64_t n, int n_patterns, int jump,
-                          int min_size, int32_t* bkp, double* gain) {
-    tps::BinsegArgs a{sums, win_off, bkp, gain, n, n_patterns, jump, min_size};
+                          int min_size, int32_t* bkp, double* gain, uint8_t* tie) {
+    tps::BinsegArgs a{sums, win_off, bkp, gain, n, n_patterns, jump, min_size, tie};
     std::vector<uint32_t> miscbuf(tps::BINSEG_SMEM_DW + 8);
     struct { uint32_t* p; size_t n; uint32_t* data() { return p; } uint32_t* begin() { return p; } uint32_t* end() { return p + n; } } misc{(uint32_t*)(((uintptr_t)miscbuf.data() + 15) & ~(uintptr_t)15), (size_t)tps::BINSEG_SMEM_DW};
     for (int64_t r = 0; r < n; ++r) {

@@ -78,15 +78,16 @@ def followers(patterns, seqs, n_fwd, follow, lo=100, hi=2000, min_len=0):
     return picks, hist.astype(np.int64)
 
 
-def binseg(sums, win_off, n_patterns, jump=5, min_size=2):
+def binseg(sums, win_off, n_patterns, jump=5, min_size=2, want_tie=False):
     L = lib()
     sums = np.ascontiguousarray(sums, np.int32)
     win_off = np.ascontiguousarray(win_off, np.int64)
     n = len(win_off) - 1
     bkp = np.zeros(n, np.int32)
     gain = np.zeros(n, np.float64)
-    L.emu_binseg(_p(sums), _p(win_off), C.c_int64(n), n_patterns, jump, min_size, _p(bkp), _p(gain))
-    return bkp, gain
+    tie = np.zeros(n, np.uint8)
+    L.emu_binseg(_p(sums), _p(win_off), C.c_int64(n), n_patterns, jump, min_size, _p(bkp), _p(gain), _p(tie))
+    return (bkp, gain, tie) if want_tie else (bkp, gain)
 
 
 def plan(k, P, prm, max_nwin, spans_pref=0, lds_budget=160 * 1024, force_generic=0):

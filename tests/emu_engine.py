@@ -78,6 +78,11 @@ class EmuEngine:
         o = self.slots[slot]["out"]
         return o["sums"], o["win_off"]
 
+    def read_sums(self, slot, read, n_win):
+        o = self.slots[slot]["out"]
+        lo = int(o["win_off"][read])
+        return np.array(o["sums"][lo:lo + int(n_win)], np.int32)
+
     def window_raw(self, slot):
         o = self.slots[slot]["out"]
         return o["raw"], o["win_off"]
@@ -100,4 +105,8 @@ class EmuEngine:
         return o["sums"], o["win_off"], (o["raw"] if raw else None)
 
     def binseg_l2(self, sums, win_off, n_patterns, jump=5, min_size=2):
-        return emu.binseg(sums, win_off, n_patterns, jump, min_size)
+        bkp, gain, tie = emu.binseg(sums, win_off, n_patterns, jump, min_size, want_tie=True)
+        sums = np.asarray(sums)
+        for i in np.nonzero(tie)[0]:                   # like HipScanner.binseg_l2
+            bkp[i] = hiplib.binseg_l2_float64(sums[win_off[i]:win_off[i + 1]].astype(np.float64) / n_patterns, jump, min_size)
+        return bkp, gain

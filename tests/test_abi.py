@@ -25,12 +25,12 @@ def test_library_exports_every_declared_symbol():
     lib = C.CDLL(hiplib.LIB_PATH)
     for name in declared_symbols():
         assert hasattr(lib, name), name
-    assert hiplib.load_library().tps_abi_version() == 2
+    assert hiplib.load_library().tps_abi_version() == 3
 
 
 def test_struct_layouts_match_header():
     assert C.sizeof(hiplib.Params) == 40
-    assert hiplib.RESULT_DTYPE.itemsize == 40
+    assert hiplib.RESULT_DTYPE.itemsize == 48 and hiplib.RESULT_DTYPE.fields["flags"][1] == 40
     assert hiplib.RESULT_DTYPE.fields["gain"][1] == 32
     assert hiplib.DESC_DTYPE.itemsize == 16 and hiplib.DESC_DTYPE.fields["len"][1] == 8 and hiplib.DESC_DTYPE.fields["flags"][1] == 12
 

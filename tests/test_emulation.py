@@ -50,9 +50,11 @@ def check_case(c, arrs, ci, **emu_kw):
             assert r["bkp"] == -1, c["name"]
         else:
             exact = orc.binseg_l2_exact(want.sum(axis=1))
-            assert r["bkp"] == exact, c["name"]
-            if r["bkp"] * c["s"] + c["t"] != b:      # only legal where float64 cannot resolve a tie
-                assert c["name"] in ("polyC",), c["name"]
+            assert r["bkp"] == exact, c["name"]       # the kernel's own answer: the exact rule (ties -> the larger index)
+            if r["bkp"] * c["s"] + c["t"] != b:      # only legal where float64 cannot resolve a tie -- and then the read is flagged
+                assert c["name"] in ("polyC",) and (r["flags"] & hiplib.RES_TIE), c["name"]
+            if r["flags"] & hiplib.RES_TIE:          # ... and ruptures' float64 arithmetic on the read's S_w gives the reference's boundary
+                assert hiplib.binseg_l2_float64(out2["sums"] / len(pats)) * c["s"] + c["t"] == b, c["name"]
     return True
 
 

@@ -68,6 +68,8 @@ def scan_jobs(engine, recs, jobs, slot: int = 0):
             if n == 0 and hasattr(recs, "release"):
                 recs.release()             # the upload has completed: the staging buffers go back to the reader
             res = engine.results(slot)
+            if p.flags & hiplib.F_BINSEG:              # exact ties: ruptures' float64 answer (a handful of reads at most)
+                hiplib.resolve_ties(engine, slot, res, len(job.patterns), p.jump, p.min_size)
             sums = raw = win_off = None
             if job.want_sums:
                 sums, win_off = engine.window_sums(slot)

@@ -816,6 +816,25 @@ int tps_batch_window_sums(tps_ctx* c, int32_t slot, int32_t* sums, int64_t nw) {
     return TPS_OK;
 }
 
+int tps_batch_read_sums(tps_ctx* c, int32_t slot, int64_t read, int32_t* sums, int64_t nw) {
+    Slot* sl;
+    int rc;
+    if ((rc = need_scanned(c, slot, &sl))) return rc;
+    if (!(sl->last_flags & TPS_F_WINDOWS)) return fail(TPS_E_STATE, "last scan did not run the window step");
+    if (read < 0 || read >= sl->n) return fail(TPS_E_ARG, "read %lld out of range", (long long)read);
+    const int64_t lo = sl->h_win_off[(size_t)read], cnt = sl->h_win_off[(size_t)read + 1] - lo;
+    if (nw != cnt || (nw > 0 && !sums)) return fail(TPS_E_ARG, "sums must hold %lld windows", (long long)cnt);
+    if (!nw) return TPS_OK;
+    if (sl->args.variant) {
+        sl->h_sums16.resize((size_t)nw);
+        HIP_TRY(hipMemcpy(sl->h_sums16.data(), (const uint16_t*)sl->sums.p + sl->h_win_off16[(size_t)read], (size_t)nw * 2, hipMemcpyDeviceToHost));
+        for (int64_t w = 0; w < nw; ++w) sums[w] = (int32_t)sl->h_sums16[(size_t)w];
+    } else {
+        HIP_TRY(hipMemcpy(sums, (const int32_t*)sl->sums.p + lo, (size_t)nw * 4, hipMemcpyDeviceToHost));
+    }
+    return TPS_OK;
+}
+
 int tps_batch_window_raw(tps_ctx* c, int32_t slot, uint8_t* raw, int64_t nwp) {
     Slot* sl;
     int rc;
@@ -880,8 +899,15 @@ int tps_window_counts(tps_ctx* c, const uint8_t* bases, const int64_t* offsets, 
     return TPS_OK;
 }
 
+int tps_binseg_l2_ties(tps_ctx* c, const int32_t* sums, const int64_t* win_off, int64_t n, int32_t n_patterns,
+                       int32_t jump, int32_t min_size, int32_t* bkp, double* gain, uint8_t* tie);
 int tps_binseg_l2(tps_ctx* c, const int32_t* sums, const int64_t* win_off, int64_t n, int32_t n_patterns,
                   int32_t jump, int32_t min_size, int32_t* bkp, double* gain) {
+    return tps_binseg_l2_ties(c, sums, win_off, n, n_patterns, jump, min_size, bkp, gain, nullptr);
+}
+
+int tps_binseg_l2_ties(tps_ctx* c, const int32_t* sums, const int64_t* win_off, int64_t n, int32_t n_patterns,
+                       int32_t jump, int32_t min_size, int32_t* bkp, double* gain, uint8_t* tie) {
     int rc;
     if ((rc = bind(c))) return rc;
     if (n < 0 || !win_off || !bkp || jump < 1 || min_size < 1 || n_patterns < 1) return fail(TPS_E_ARG, "bad arguments");
@@ -905,7 +931,7 @@ int tps_binseg_l2(tps_ctx* c, const int32_t* sums, const int64_t* win_off, int64
     Slot& sl = c->slots[INTERNAL_SLOT];
     if ((rc = sl.sums.ensure((size_t)std::max<int64_t>(nw, 1) * 4))) return rc;
     if ((rc = sl.win_off.ensure((size_t)(n + 1) * 8))) return rc;
-    if ((rc = sl.results.ensure((size_t)n * 16))) return rc;          // bkp (4n) + gain (8n), gain first for alignment
+    if ((rc = sl.results.ensure((size_t)n * 17))) return rc;          // gain (8n), bkp (4n), tie (n): gain first for alignment
     sl.planned = false;                                                // the slot's plan buffers were overwritten
     sl.scanned = false;
     if (nw) HIP_TRY(hipMemcpyAsync(sl.sums.p, sums, (size_t)nw * 4, hipMemcpyHostToDevice, c->stream));
@@ -915,6 +941,7 @@ int tps_binseg_l2(tps_ctx* c, const int32_t* sums, const int64_t* win_off, int64
     a.win_off = (const int64_t*)sl.win_off.p;
     a.gain = (double*)sl.results.p;
     a.bkp = (int32_t*)((char*)sl.results.p + (size_t)n * 8);
+    a.tie = (uint8_t*)sl.results.p + (size_t)n * 12;
     a.n_reads = n;
     a.n_patterns = n_patterns;
     a.jump = jump;
@@ -923,6 +950,7 @@ int tps_binseg_l2(tps_ctx* c, const int32_t* sums, const int64_t* win_off, int64
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(bkp, a.bkp, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     if (gain) HIP_TRY(hipMemcpyAsync(gain, a.gain, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    if (tie) HIP_TRY(hipMemcpyAsync(tie, a.tie, (size_t)n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return TPS_OK;
 }

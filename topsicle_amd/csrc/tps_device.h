@@ -298,6 +298,7 @@ struct BinsegArgs {
     double* gain;
     int64_t n_reads;
     int32_t n_patterns, jump, min_size;
+    uint8_t* tie;                // per read: 1 = the exact tournament decided (TPS_RES_TIE), or nullptr
 };
 
 // ------------------------------------------------------------------ LDS carve
@@ -2943,7 +2944,7 @@ TPS_DEV Cand binseg_exact_wg(const ST* S, int n, int jump, int min_size, uint32_
 constexpr int CHUNK_REGS = 16;
 template <typename ST>
 TPS_DEV void binseg_wg(const ST* S, int n, int jump, int min_size, int n_patterns, uint32_t* bs, uint32_t* misc,
-                       uint32_t* xs, int& bkp, double& gain) {
+                       uint32_t* xs, int& bkp, double& gain, bool& tie) {
     const int per = (n + jump * NT - 1) / (jump * NT);
     const int cl = per * jump;
     const bool in_regs = cl <= CHUNK_REGS;
@@ -3011,7 +3012,8 @@ TPS_DEV void binseg_wg(const ST* S, int n, int jump, int min_size, int n_pattern
         if (best == m && best_b >= 0) lds_max_i32((int32_t*)&misc[M_BESTB], best_b);
     }
     TPS_SYNC();
-    if (misc[M_NTIE] > 1u) {                      // float noise cannot separate them: exact integers decide
+    tie = misc[M_NTIE] > 1u;
+    if (tie) {                                    // float noise cannot separate them: exact integers decide
         Cand ex = binseg_exact_wg(S, n, jump, min_size, xs);
         bkp = ex.b;
         gain = ex.b < 0 ? 0.0 : gain_from((int64_t)ex.d, ex.den, n, n_patterns);
@@ -3029,7 +3031,7 @@ TPS_DEV void binseg_wg(const ST* S, int n, int jump, int min_size, int n_pattern
 // the best score the exact integer tournament re-reads S_w from HBM (rare).
 template <typename ST>
 TPS_DEV void binseg_from_lc(const ScanArgs& a, const Lds& l, uint64_t lc_g, const ST* S_global, int n, uint64_t tot, int jump,
-                            int min_size, int n_patterns, uint32_t* misc, uint32_t* xs, int& bkp, double& gain) {
+                            int min_size, int n_patterns, uint32_t* misc, uint32_t* xs, int& bkp, double& gain, bool& tie) {
     const int ncand = (n - 1) / jump;              // candidates b = c*jump, 1 <= c <= ncand  (b < n)
 #ifdef TPS_EMU
     double* keep = (double*)xs;
@@ -3209,6 +3211,7 @@ TPS_DEV void binseg_from_lc(const ScanArgs& a, const Lds& l, uint64_t lc_g, cons
 #endif
     (void)misc;
     if (crowded) ntie = 2u;                        // the prefilter kept one candidate per lane: a second one that close needs the full comparison
+    tie = ntie > 1u;
     if (ntie > 1u) {                               // float noise cannot separate them: exact integers decide
 #ifdef TPS_EMU
         ++emu_counter(4);
@@ -3286,6 +3289,7 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
     res.best_start = res.best_end = 0;
     res.best_start_idx = res.best_end_idx = 0;
     res.n_win = 0; res.bkp = -1; res.gain = 0.0;
+    res.flags = 0; res.reserved = 0;
 
     TPS_STAMP(2);
     if (step1) {
@@ -3575,6 +3579,7 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
     if (n_win > 0 && (prm.flags & TPS_F_BINSEG) && binseg_admissible(n_win, prm.jump, prm.min_size)) {
         int bkp;
         double gain;
+        bool tie = false;
 #ifndef TPS_EMU
         // same wave, same CU: workgroup scope orders this wave's S_w / off-chip candidate-sum stores before its own
         // loads (an agent-scope fence writes the L2 back: measured 5x slower)
@@ -3583,12 +3588,13 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
         const uint64_t lc_g = a.lc_global ? (uint64_t)(uintptr_t)(a.lc_scratch + r * (int64_t)a.lc_stride) : 0ull;
         if constexpr (SV != 0)
             binseg_from_lc(a, l, lc_g, (const uint16_t*)(a.sums16 + (a.win_off16 ? a.win_off16[r] : 0)), n_win, s_total, prm.jump, prm.min_size, pat.P,
-                           l.misc, l.blk, bkp, gain);
+                           l.misc, l.blk, bkp, gain, tie);
         else
             binseg_from_lc(a, l, lc_g, (const int32_t*)(a.sums + (a.win_off ? a.win_off[r] : 0)), n_win, s_total, prm.jump, prm.min_size, pat.P,
-                           l.misc, l.blk, bkp, gain);
+                           l.misc, l.blk, bkp, gain, tie);
         res.bkp = bkp;
         res.gain = gain;
+        res.flags = tie ? TPS_RES_TIE : 0u;
     }
     TPS_PHASE { if (tid == 0) a.results[r] = res; }
     TPS_STAMP(10);
@@ -3605,13 +3611,15 @@ TPS_DEV void binseg_read(const BinsegArgs& a, int64_t r, uint32_t* smem) {
     uint32_t* bs = misc + MISC_DW;
     int bkp = -1;
     double gain = 0.0;
+    bool tie = false;
     if (binseg_admissible(n, a.jump, a.min_size)) {
-        binseg_wg(S, n, a.jump, a.min_size, a.n_patterns, bs, misc, xs, bkp, gain);
+        binseg_wg(S, n, a.jump, a.min_size, a.n_patterns, bs, misc, xs, bkp, gain, tie);
     }
     TPS_PHASE {
         if (tid == 0) {
             a.bkp[r] = bkp;
             if (a.gain) a.gain[r] = gain;
+            if (a.tie) a.tie[r] = tie ? 1 : 0;
         }
     }
 }

@@ -23,7 +23,7 @@ EXPORTS = [
     "tps_set_patterns", "tps_batch_upload", "tps_batch_upload_packed", "tps_host_alloc", "tps_host_free",
     "tps_batch_download_packed", "tps_batch_kmer_followers", "tps_batch_set_tails", "tps_batch_scan", "tps_sync",
     "tps_batch_results", "tps_batch_window_offsets", "tps_batch_window_sums", "tps_batch_window_raw",
-    "tps_batch_trc_counts", "tps_trc_counts", "tps_window_counts", "tps_binseg_l2", "tps_window_count",
+    "tps_batch_trc_counts", "tps_trc_counts", "tps_window_counts", "tps_binseg_l2", "tps_binseg_l2_ties", "tps_batch_read_sums", "tps_window_count",
     "tps_kernel_time_ms", "tps_kernel_time_reset", "tps_device_info", "tps_batch_kernel_info",
 ]
 
@@ -46,8 +46,9 @@ RD_HAS_INVALID = 1
 
 RESULT_DTYPE = np.dtype([("best_start", "<i4"), ("best_start_idx", "<i4"), ("best_end", "<i4"),
                          ("best_end_idx", "<i4"), ("tail", "<i4"), ("pass", "<i4"), ("n_win", "<i4"),
-                         ("bkp", "<i4"), ("gain", "<f8")], align=True)
-assert RESULT_DTYPE.itemsize == 40
+                         ("bkp", "<i4"), ("gain", "<f8"), ("flags", "<u4"), ("reserved", "<u4")], align=True)
+assert RESULT_DTYPE.itemsize == 48
+RES_TIE = 1            # TPS_RES_TIE: the exact tournament decided the change-point (candidates within float64 noise of each other)
 
 
 def make_params(no_bp=1000, min_len=0, min_count=-1, window=100, slide=6, trimfirst=100, maxlen=20000,
@@ -96,6 +97,8 @@ def load_library(path: str | None = None) -> C.CDLL:
         "tps_trc_counts": (C.c_int, [vp, vp, vp, i64, i32, vp, vp]),
         "tps_window_counts": (C.c_int, [vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, vp, vp]),
         "tps_binseg_l2": (C.c_int, [vp, vp, vp, i64, i32, i32, i32, vp, vp]),
+        "tps_binseg_l2_ties": (C.c_int, [vp, vp, vp, i64, i32, i32, i32, vp, vp, vp]),
+        "tps_batch_read_sums": (C.c_int, [vp, i32, i64, vp, i64]),
         "tps_window_count": (i64, [i64, i32, i32, i32, i32]),
         "tps_kernel_time_ms": (C.c_int, [vp, C.POINTER(i32), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "tps_kernel_time_reset": (C.c_int, [vp]),
@@ -133,6 +136,43 @@ def window_count(read_len: int, window: int, slide: int, trimfirst: int, maxlen:
     if window < 1 or slide < 1 or ns < window:
         return 0
     return (ns - window) // slide + 1
+
+
+def binseg_l2_float64(y, jump: int = 5, min_size: int = 2):
+    """`rpt.Binseg(model="l2").fit(y).predict(n_bkps=1)` in ruptures' own float64 arithmetic (allsteps.py:310-311; ruptures
+    1.1.9: CostL2.error = signal[a:b].var(axis=0).sum() * (b - a), candidates range(0, n, jump) with both sides >= min_size,
+    max() over (gain, bkp) tuples).  HOST arithmetic on purpose, and only ever run on reads the device flagged TPS_RES_TIE:
+    there two or more candidates are within float64 rounding noise of the best gain, upstream's answer is decided by that noise
+    (np.tile([12, 13], 200): 5, where the exact rule says 395), and the only way to give upstream's answer is to repeat
+    upstream's arithmetic.  Returns the split index or -1."""
+    sig = np.asarray(y, dtype=np.float64).reshape(-1, 1)
+    n = sig.shape[0]
+    if (n // jump) < 1 or (-(-min_size // jump)) * jump + min_size > n:
+        return -1
+
+    def cost(a, b):
+        return sig[a:b].var(axis=0).sum() * (b - a)
+
+    whole = cost(0, n)
+    best = None
+    for b in range(0, n, jump):
+        if b >= min_size and n - b >= min_size:
+            cand = (whole - cost(0, b) - cost(b, n), b)
+            if best is None or cand > best:
+                best = cand
+    return -1 if best is None else int(best[1])
+
+
+def resolve_ties(engine, slot: int, res: np.ndarray, n_patterns: int, jump: int = 5, min_size: int = 2) -> int:
+    """Reads of `res` whose change-point the device decided by its exact tournament (flags & RES_TIE) get ruptures' float64
+    answer instead: their S_w come down (engine.read_sums), y = S_w / P, binseg_l2_float64.  In place; returns how many."""
+    if "flags" not in res.dtype.names:
+        return 0
+    idx = np.nonzero((res["flags"] & RES_TIE) != 0)[0]
+    for i in idx:
+        s_w = engine.read_sums(slot, int(i), int(res["n_win"][i]))
+        res["bkp"][i] = binseg_l2_float64(np.asarray(s_w, dtype=np.float64) / n_patterns, jump, min_size)
+    return len(idx)
 
 
 class HipScanner:
@@ -282,6 +322,12 @@ class HipScanner:
         self._check(self.lib.tps_batch_window_sums(self._h, slot, _ptr(out), len(out)))
         return out, off
 
+    def read_sums(self, slot: int, read: int, n_win: int) -> np.ndarray:
+        """S_w of one read of the slot's last scan (any scan that ran the window step)."""
+        out = np.zeros(int(n_win), dtype=np.int32)
+        self._check(self.lib.tps_batch_read_sums(self._h, slot, int(read), _ptr(out), len(out)))
+        return out
+
     def window_raw(self, slot: int) -> tuple[np.ndarray, np.ndarray]:
         off = self.window_offsets(slot)
         p = len(self.patterns)
@@ -327,7 +373,10 @@ class HipScanner:
         n = len(win_off) - 1
         bkp = np.full(n, -1, dtype=np.int32)
         gain = np.zeros(n, dtype=np.float64)
-        self._check(self.lib.tps_binseg_l2(self._h, _ptr(sums), _ptr(win_off), n, n_patterns, jump, min_size, _ptr(bkp), _ptr(gain)))
+        tie = np.zeros(n, dtype=np.uint8)
+        self._check(self.lib.tps_binseg_l2_ties(self._h, _ptr(sums), _ptr(win_off), n, n_patterns, jump, min_size, _ptr(bkp), _ptr(gain), _ptr(tie)))
+        for i in np.nonzero(tie)[0]:                   # float64 cannot separate the best candidates: ruptures' own arithmetic decides
+            bkp[i] = binseg_l2_float64(sums[win_off[i]:win_off[i + 1]].astype(np.float64) / n_patterns, jump, min_size)
         return bkp, gain
 
     # -- measurement
