@@ -296,6 +296,24 @@ def test_packed_batch_writes_records_like_biopython(tmp_path, gold_dir):
         pb.write_records(got, [0], "fasta")
         pb.release()
     assert got.getvalue().decode() == want.getvalue()
+    # a real file handle takes the native writer (writev from the mapped input, neighbouring records merged); records whose
+    # text is not already in SeqIO.write's layout ('+' line that repeats the name, CRLF) are re-assembled piece by piece
+    odd = tmp_path / "odd.fastq"
+    odd.write_bytes(b"@a first\nACGT\n+\nIIII\n@b\nACGTAC\n+b\nIIIIII\n@c x\r\nAC\r\n+\r\nII\r\n@d\nA\n+\n#\n@e\nGG\n+\n!!\n")
+    for path, pick in ((str(plain), [0, 1, 2, 7, 8, 20, 43]), (str(plain), list(range(44))), (str(odd), [0, 1, 2, 3, 4]), (str(odd), [1, 3])):
+        recs = list(seqio.read_records(path))
+        want = io.StringIO()
+        for i in pick:
+            seqio.write_record(want, recs[i], "fastq")
+        outp = tmp_path / "out.fastq"
+        with open(outp, "wb") as h:
+            h.write(b"")
+            n = 0
+            for pb in seqio.read_batches_packed(path, seqio.BufferPool(2, 1 << 20, 4096)):
+                pb.release()
+                pb.write_records(h, [i - n for i in pick if n <= i < n + pb.n], "fastq")
+                n += pb.n
+        assert outp.read_bytes().decode() == want.getvalue(), (path, pick)
 
 
 def test_engine_pool_keeps_input_order_with_several_contexts(tmp_path):

@@ -224,19 +224,26 @@ def fit_quadratic_and_find_vertex(trc_list, telo_length_list, inputtrc, median_t
         vertex_x = inputtrc
     vertex_y = a * vertex_x ** 2 + b * vertex_x + c
     if save_path:
-        import matplotlib
-        matplotlib.use("Agg")
-        import matplotlib.pyplot as plt
-        xs = np.linspace(min(trc), max(trc), 100)
-        plt.figure(figsize=(7, 5))
-        plt.scatter(trc, telo, color="blue", label="Topsicle results")
-        plt.plot(xs, a * xs ** 2 + b * xs + c, color="red", label="Fit line")
-        plt.scatter([vertex_x], [vertex_y], color="green", label="Vertex")
-        plt.xlabel("TRC values")
-        plt.ylabel("Telomere length, each read (bp)")
-        plt.title("Quadratic fit plot")
-        plt.legend()
-        plt.tight_layout()
-        plt.savefig(save_path, dpi=300)
-        plt.close()
+        plot_quadratic_fit(trc, telo, coeffs, vertex_x, vertex_y, save_path)
     return vertex_x, vertex_y, coeffs
+
+
+def plot_quadratic_fit(trc, telo, coeffs, vertex_x, vertex_y, save_path):
+    """The PNG of allsteps.py:484-499.  Object-oriented matplotlib (no pyplot state): safe to run on a helper thread, which is
+    where the CLI runs it -- the fit's numbers are logged at once, the picture follows (main.summarize)."""
+    from matplotlib.backends.backend_agg import FigureCanvasAgg
+    from matplotlib.figure import Figure
+    a, b, c = coeffs
+    xs = np.linspace(min(trc), max(trc), 100)
+    fig = Figure(figsize=(7, 5))
+    FigureCanvasAgg(fig)
+    ax = fig.add_subplot(111)
+    ax.scatter(trc, telo, color="blue", label="Topsicle results")
+    ax.plot(xs, a * xs ** 2 + b * xs + c, color="red", label="Fit line")
+    ax.scatter([vertex_x], [vertex_y], color="green", label="Vertex")
+    ax.set_xlabel("TRC values")
+    ax.set_ylabel("Telomere length, each read (bp)")
+    ax.set_title("Quadratic fit plot")
+    ax.legend()
+    fig.tight_layout()
+    fig.savefig(save_path, dpi=300)

@@ -24,6 +24,7 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <sys/uio.h>
 #include <zlib.h>
 
 #include "tps_pack.h"
@@ -847,6 +848,56 @@ int64_t tps_pack_reads(const uint8_t* bases, const int64_t* offsets, int64_t n, 
         tps::pack_range(bases, offsets, a, b, desc, seq2, inv);
     });
     return nw;
+}
+
+// Writes the records idx[0 .. n) of a packed batch that was read from the mmap'ed plain FASTQ `text` to `fd`, in the layout
+// Biopython's SeqIO.write gives (main.py:83-86): "@" header "\n" sequence "\n+\n" quality "\n".  Nothing is copied in user
+// space: the iovecs point into the mapping (spans: 4 entries per record -- header offset, header length, sequence offset,
+// quality offset; lens: bases per record), a record whose text already has that layout is one iovec, and neighbouring
+// records that are neighbours in the file merge into one.  Replaces the per-record Python loop of the round-2 writer
+// (0.1 s per 300 MB, the largest part of the CLI's per-read time).  Returns the bytes written or -1.
+int64_t tps_write_fastq_spans(int fd, const char* text, int64_t text_len, const int64_t* spans, const int32_t* lens, const int64_t* idx, int64_t n) {
+    if (fd < 0 || !text || !spans || !lens || (n > 0 && !idx)) { g_err = "null argument"; return -1; }
+    static const char at = '@', nl = '\n', plus[3] = {'\n', '+', '\n'};
+    std::vector<struct iovec> iov;
+    iov.reserve(1024);
+    int64_t total = 0;
+    auto flush = [&]() -> bool {
+        size_t first = 0;
+        while (first < iov.size()) {
+            const int cnt = (int)std::min<size_t>(iov.size() - first, 1024);
+            ssize_t w = writev(fd, iov.data() + first, cnt);
+            if (w < 0) { if (errno == EINTR) continue; g_err = std::string("writev: ") + strerror(errno); return false; }
+            total += w;
+            size_t left = (size_t)w;                               // partial writes: advance inside the vector
+            while (first < iov.size() && left >= iov[first].iov_len) { left -= iov[first].iov_len; ++first; }
+            if (left) { iov[first].iov_base = (char*)iov[first].iov_base + left; iov[first].iov_len -= left; }
+        }
+        iov.clear();
+        return true;
+    };
+    auto push = [&](const char* p, size_t len) {
+        if (!len) return;
+        if (!iov.empty() && (const char*)iov.back().iov_base + iov.back().iov_len == p) { iov.back().iov_len += len; return; }
+        iov.push_back({(void*)p, len});
+    };
+    for (int64_t j = 0; j < n; ++j) {
+        const int64_t i = idx[j];
+        const int64_t h0 = spans[4 * i], hl = spans[4 * i + 1], s0 = spans[4 * i + 2], q0 = spans[4 * i + 3], sl = lens[i];
+        if (h0 < 1 || hl < 0 || s0 < 0 || q0 < 0 || sl < 0 || h0 + hl > text_len || s0 + sl > text_len || q0 + sl > text_len) { g_err = "record span outside the text"; return -1; }
+        // the text itself is "@head\nseq\n+\nqual\n": one piece
+        const bool verbatim = s0 == h0 + hl + 1 && q0 == s0 + sl + 3 && q0 + sl < text_len && text[h0 - 1] == '@' && text[h0 + hl] == '\n' &&
+                              memcmp(text + s0 + sl, plus, 3) == 0 && text[q0 + sl] == '\n';
+        if (verbatim) {
+            push(text + h0 - 1, (size_t)(q0 + sl + 1 - (h0 - 1)));
+        } else {
+            push(&at, 1); push(text + h0, (size_t)hl); push(&nl, 1); push(text + s0, (size_t)sl);
+            push(plus, 3); push(text + q0, (size_t)sl); push(&nl, 1);
+        }
+        if (iov.size() > 1000 && !flush()) return -1;
+    }
+    if (!flush()) return -1;
+    return total;
 }
 
 }  // extern "C"

@@ -202,6 +202,8 @@ def _load_io():
         lib.tps_pack_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
         lib.tps_packed_words_total.restype = C.c_int64
         lib.tps_packed_words_total.argtypes = [C.c_void_p, C.c_int64]
+        lib.tps_write_fastq_spans.restype = C.c_int64
+        lib.tps_write_fastq_spans.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
         _io_lib = lib
     return _io_lib or None
 
@@ -311,15 +313,25 @@ class BufferPool:
         self._free = queue.Queue()
         self._alloc = alloc
         self.n_sets = int(n_sets)
+        self._made = 0                                # sets are allocated on demand: a file of two batches pins two sets, not n_sets
         import threading
         self.abort = threading.Event()
-        for _ in range(n_sets):
-            self._free.put(BufferSet(words_cap, reads_cap, alloc))
+        self._lock = threading.Lock()
 
     def get(self) -> BufferSet:
         """A free set; while none is free the `abort` event is polled, so that a reader whose consumer has gone away (an error
         downstream, an abandoned generator) ends instead of waiting for a buffer that will never come back."""
         import queue
+        try:
+            return self._free.get_nowait()
+        except queue.Empty:
+            pass
+        with self._lock:
+            make = self._made < self.n_sets
+            if make:
+                self._made += 1
+        if make:
+            return BufferSet(self.words_cap, self.reads_cap, self._alloc)
         while True:
             try:
                 return self._free.get(timeout=0.2)
@@ -391,7 +403,26 @@ class PackedBatch:
         return Record(_first_token(d), d, self.seq_bytes(i).decode("ascii", "replace"), None if q is None else q.decode("ascii", "replace"))
 
     def write_records(self, handle, indices, fmt: str):
-        """Write the given records to a BINARY handle in the layout Biopython's SeqIO.write produces (main.py:84-86)."""
+        """Write the given records to a BINARY handle in the layout Biopython's SeqIO.write produces (main.py:84-86).  Records
+        of a batch that was packed straight from a mmap'ed plain FASTQ file leave through the native writer: writev from the
+        mapping, no copy in user space (tps_write_fastq_spans)."""
+        import numpy as np
+        if fmt == "fastq" and self.spans is not None and self.text is not None and len(indices):
+            lib = _load_io()
+            try:
+                fd = handle.fileno()                  # (an in-memory handle has none: the Python loop below serves it)
+            except (AttributeError, OSError, ValueError):
+                fd = None
+            if lib is not None and fd is not None:
+                handle.flush()
+                text = np.frombuffer(self.text, dtype=np.uint8)
+                idx = np.ascontiguousarray(indices, dtype=np.int64)
+                lens = np.ascontiguousarray(self.desc["len"], dtype=np.int32)
+                spans = np.ascontiguousarray(self.spans, dtype=np.int64)
+                got = lib.tps_write_fastq_spans(fd, text.ctypes.data, len(text), spans.ctypes.data, lens.ctypes.data, idx.ctypes.data, len(idx))
+                if got < 0:
+                    raise OSError(lib.tps_io_last_error().decode())
+                return
         out = []
         for i in indices:
             i = int(i)
