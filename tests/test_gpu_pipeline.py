@@ -139,13 +139,15 @@ def test_engine_pool_four_contexts_ragged_file(tmp_path):
         assert ids1 == [f"r{i}" for i in range(2500)]
         ids4, r4 = run(four)
         pinned_after_first = len(four[0]._pinned)
-        assert pinned_after_first > 0 and all(len(getattr(e, "_pinned", {})) == 0 for e in four[1:])
+        assert 0 < pinned_after_first <= 3 * (len(four) + 2) and all(len(getattr(e, "_pinned", {})) == 0 for e in four[1:])
         assert ids4 == ids1
         for f in ("pass", "tail", "best_start", "best_end", "n_win", "bkp"):
             assert np.array_equal(r4[f], r1[f]), f
         ids4b, r4b = run(four, times=3)                          # three more files through the same contexts
         assert ids4b == ids1 and np.array_equal(r4b["bkp"], r1["bkp"])
-        assert len(four[0]._pinned) == pinned_after_first        # the staging pool was reused, not re-allocated per file
+        # the staging pool is reused, not re-allocated per file: at most its len(engines) + 2 sets (3 pinned arrays each) exist,
+        # however many files went through (sets are pinned on demand, so a later file may add the ones the first never needed)
+        assert pinned_after_first <= len(four[0]._pinned) <= 3 * (len(four) + 2)
     finally:
         for e in one + four:
             e.close()
