@@ -1,0 +1,146 @@
+"""The parallel gzip inflater of libtopsicle_io.so (csrc/tps_gzpar.h: speculative block starts, 16-bit symbols with window
+markers, in-order stitching, CRC check) against zlib on the same files: FASTQ-like text at several levels, every deflate
+block type (stored, fixed, dynamic), strategies that produce odd Huffman trees, long-distance and overlapping matches,
+several members, many small rounds; corrupt and truncated files are errors, never wrong text."""
+import ctypes as C
+import gzip
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from topsicle_amd import seqio
+
+
+def _lib():
+    lib = seqio._load_io()
+    lib.tps_gz_inflate.restype = C.c_int64
+    lib.tps_gz_inflate.argtypes = [C.c_char_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p]
+    return lib
+
+
+def inflate(path, threads=8, want=0, cap=None):
+    lib = _lib()
+    cap = cap if cap is not None else 1 << 28
+    out = np.empty(cap, np.uint8)
+    stats = np.zeros(3, np.int64)
+    n = lib.tps_gz_inflate(str(path).encode(), out.ctypes.data, cap, threads, want, stats.ctypes.data)
+    return (None if n < 0 else out[:n].tobytes()), stats
+
+
+def gz_bytes(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, wbits=31, memlevel=8):
+    co = zlib.compressobj(level, zlib.DEFLATED, wbits, memlevel, strategy)
+    return co.compress(data) + co.flush()
+
+
+def fastq_text(n_reads, read_len, seed):
+    rng = np.random.default_rng(seed)
+    parts = []
+    for i in range(n_reads):
+        L = int(read_len * (0.5 + rng.random()))
+        s = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, L)]
+        if rng.random() < 0.5:                                   # telomere-like repeats: long matches
+            s[: L // 3] = np.frombuffer((b"CCCTAA" * (L // 18 + 1))[: L // 3], np.uint8)
+        q = (33 + rng.integers(0, 40, L)).astype(np.uint8)
+        parts.append(b"@read%d len=%d\n" % (i, L) + s.tobytes() + b"\n+\n" + q.tobytes() + b"\n")
+    return b"".join(parts)
+
+
+@pytest.fixture(scope="module")
+def text():
+    return fastq_text(2500, 12000, 7)                            # ~60 MB
+
+
+@pytest.mark.parametrize("level", [1, 6, 9])
+def test_fastq_text_levels(tmp_path, text, level):
+    p = tmp_path / f"l{level}.fastq.gz"
+    p.write_bytes(gz_bytes(text, level))
+    got, stats = inflate(p, threads=8, want=8 << 20)
+    assert got == text
+    assert stats[0] > 8 and stats[1] >= 0.6 * (stats[0] - stats[0] // 8)      # most speculative chunks were found and fitted
+    got1, _ = inflate(p, threads=1)
+    assert got1 == text
+
+
+def test_block_types_and_strategies(tmp_path, text):
+    rng = np.random.default_rng(1)
+    small = text[: 6 << 20]
+    cases = {
+        "stored": gz_bytes(rng.integers(0, 256, 5 << 20, dtype=np.uint8).tobytes(), 6),          # incompressible: stored blocks
+        "level0": gz_bytes(small, 0),
+        "fixed": gz_bytes(small, 6, zlib.Z_FIXED),
+        "huffman_only": gz_bytes(small, 6, zlib.Z_HUFFMAN_ONLY),
+        "rle": gz_bytes(small, 6, zlib.Z_RLE),
+        "filtered": gz_bytes(small, 9, zlib.Z_FILTERED),
+        "memlevel1": gz_bytes(small, 6, memlevel=1),                                             # many tiny blocks
+        "runs": gz_bytes(b"A" * (9 << 20) + b"CG" * (2 << 20) + small[: 1 << 20], 9),            # distance-1 / distance-2 overlapping matches
+        "mixed": gz_bytes(small[: 2 << 20] + rng.integers(0, 256, 2 << 20, dtype=np.uint8).tobytes() + small[2 << 20: 4 << 20], 6),
+    }
+    for name, blob in cases.items():
+        p = tmp_path / (name + ".gz")
+        p.write_bytes(blob)
+        want = gzip.decompress(blob)
+        for threads, w in ((8, 1 << 20), (3, 4 << 20), (1, 0)):
+            got, stats = inflate(p, threads=threads, want=w)
+            assert got == want, (name, threads, w, stats)
+
+
+def test_members_padding_and_small_files(tmp_path, text):
+    a, b, c = text[: 3 << 20], text[3 << 20: 3 << 20 | 5], text[5 << 20: 9 << 20]
+    blob = gz_bytes(a, 6) + gz_bytes(b, 9) + gz_bytes(b"", 6) + gz_bytes(c, 1)
+    p = tmp_path / "multi.gz"
+    p.write_bytes(blob)
+    assert inflate(p, threads=4, want=1 << 20)[0] == a + b + c
+    p.write_bytes(blob + b"\0" * 100)                            # zero padding behind the last member is ignored, like gzip does
+    assert inflate(p, threads=4)[0] == a + b + c
+    # header with name + extra field
+    import io
+    bio = io.BytesIO()
+    with gzip.GzipFile(filename="reads.fastq", fileobj=bio, mode="wb", compresslevel=6) as g:
+        g.write(a)
+    p.write_bytes(bio.getvalue())
+    assert inflate(p, threads=4, want=1 << 20)[0] == a
+    for data in (b"", b"x", b"@r\nACGT\n+\nIIII\n"):
+        p.write_bytes(gz_bytes(data))
+        assert inflate(p)[0] == data
+
+
+def test_corrupt_and_truncated_files_are_errors(tmp_path, text):
+    blob = bytearray(gz_bytes(text[: 8 << 20], 6))
+    p = tmp_path / "bad.gz"
+    for cut in (len(blob) - 3, len(blob) // 2, 40):
+        p.write_bytes(bytes(blob[:cut]))
+        assert inflate(p, threads=4, want=1 << 20)[0] is None
+    rng = np.random.default_rng(5)
+    bad = 0
+    for _ in range(6):
+        b2 = bytearray(blob)
+        pos = int(rng.integers(100, len(b2) - 100))
+        b2[pos] ^= 1 << int(rng.integers(8))
+        p.write_bytes(bytes(b2))
+        got, _ = inflate(p, threads=4, want=1 << 20)
+        assert got is None                                       # a flipped bit never yields text (CRC)
+        bad += 1
+    assert bad == 6
+
+
+def test_reader_takes_the_parallel_path_for_fastq_gz(tmp_path, text):
+    """seqio on an ordinary .fastq.gz: same records as on the plain file (the reader inflates with the thread team)."""
+    plain = tmp_path / "r.fastq"
+    plain.write_bytes(text)
+    gz = tmp_path / "r.fastq.gz"
+    gz.write_bytes(gz_bytes(text, 6))
+    a = [(r.id, r.seq, r.qual) for rb in seqio.read_batches(str(plain), max_bases=8 << 20) for r in rb.records()] if hasattr(seqio.RecordBatch, "records") else None
+    ids_plain = [i for pb in seqio.read_batches_packed(str(plain), seqio.BufferPool(2, 1 << 22, 1 << 16)) for i in pb.ids]
+    ids_gz, nb = [], 0
+    for pb in seqio.read_batches_packed(str(gz), seqio.BufferPool(2, 1 << 22, 1 << 16)):
+        ids_gz += pb.ids
+        nb += pb.n_bases
+    assert ids_gz == ids_plain and len(ids_gz) == 2500
+    os.environ["TPS_IO_NO_PARGZ"] = "1"
+    try:
+        ids_z = [i for pb in seqio.read_batches_packed(str(gz), seqio.BufferPool(2, 1 << 22, 1 << 16)) for i in pb.ids]
+    finally:
+        del os.environ["TPS_IO_NO_PARGZ"]
+    assert ids_z == ids_plain

@@ -22,7 +22,8 @@ def _build_io_asan():
     src = os.path.join(ROOT, "topsicle_amd", "csrc", "tps_io.cpp")
     out = os.path.join(BUILD, "libtopsicle_io_asan.so")
     os.makedirs(BUILD, exist_ok=True)
-    deps = [src, os.path.join(ROOT, "topsicle_amd", "csrc", "tps_pack.h"), os.path.join(ROOT, "include", "topsicle_hip.h")]
+    deps = [src, os.path.join(ROOT, "topsicle_amd", "csrc", "tps_pack.h"), os.path.join(ROOT, "topsicle_amd", "csrc", "tps_gzpar.h"),
+            os.path.join(ROOT, "include", "topsicle_hip.h")]
     if not (os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps)):
         subprocess.check_call(["g++", "-O1", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-std=c++17", "-shared", "-fPIC",
                                "-Wall", "-o", out, src, "-lz", "-lpthread"])
@@ -49,6 +50,14 @@ def test_reader_and_packer_under_asan_ubsan():
     lib = _build_io_asan()
     out = _run_under_sanitizers(["tests/test_seqio_native.py"], {"TOPSICLE_IO_LIB": lib})
     assert " passed" in out and "skipped" not in out.split("passed")[-1]
+
+
+def test_parallel_gzip_inflater_under_asan_ubsan():
+    """csrc/tps_gzpar.h (speculative block starts, symbol buffers written through raw pointers, window markers) on every block
+    type, on corrupt and truncated files: no out-of-bounds access whatever the input holds."""
+    lib = _build_io_asan()
+    out = _run_under_sanitizers(["tests/test_gzpar.py", "-k", "block_types or members or corrupt"], {"TOPSICLE_IO_LIB": lib})
+    assert " passed" in out
 
 
 def test_kernel_emulation_under_asan_ubsan():

@@ -28,6 +28,7 @@
 #include <zlib.h>
 
 #include "tps_pack.h"
+#include "tps_gzpar.h"
 
 #include <algorithm>
 #include <cstdint>
@@ -234,16 +235,23 @@ void team(int nthreads, F f) {                 // f(thread index, thread count);
     pool().run(nthreads, std::function<void(int, int)>(f));
 }
 
-// BGZF (bgzip): a gzip file made of independent <= 64 KiB members whose size is in the header's "BC" extra field
-// -- the one gzip flavour that can be inflated in parallel.  The compressed file is mmap'ed; read_group() inflates
-// the next run of blocks with the thread team and appends the text to `out`.
-struct Bgzf {
+// A compressed input whose text arrives group by group: read_group() appends the next stretch of text to `out` (about `want`
+// bytes), inflated with the thread team.
+struct TextSource {
+    bool failed = false;
+    virtual ~TextSource() {}
+    virtual bool read_group(gzpar::TextBuf& out, size_t want) = 0;
+    virtual bool eof() const = 0;
+};
+
+// BGZF (bgzip): a gzip file made of independent <= 64 KiB members whose size is in the header's "BC" extra field:
+// blocks inflate independently.  The compressed file is mmap'ed.
+struct Bgzf : TextSource {
     int fd = -1;
     const uint8_t* data = nullptr;
     size_t size = 0, cpos = 0;
     int threads = 1;
-    bool failed = false;
-    ~Bgzf() {
+    ~Bgzf() override {
         if (data) munmap((void*)data, size);
         if (fd >= 0) close(fd);
     }
@@ -263,8 +271,8 @@ struct Bgzf {
         }
         return false;
     }
-    bool eof() const { return cpos >= size; }
-    bool read_group(std::vector<char>& out, size_t want) {
+    bool eof() const override { return cpos >= size; }
+    bool read_group(gzpar::TextBuf& out, size_t want) override {
         struct Blk { size_t in, in_len, isize, ooff; uint32_t crc; };
         std::vector<Blk> blks;
         size_t total = 0;
@@ -307,10 +315,28 @@ struct Bgzf {
     }
 };
 
+// Ordinary gzip (one deflate stream per member): speculative parallel inflate, tps_gzpar.h.  The compressed file is mmap'ed.
+struct GzSource : TextSource {
+    int fd = -1;
+    const uint8_t* data = nullptr;
+    size_t size = 0;
+    gzpar::ParGz z;
+    ~GzSource() override {
+        if (data) munmap((void*)data, size);
+        if (fd >= 0) close(fd);
+    }
+    bool eof() const override { return z.eof(); }
+    bool read_group(gzpar::TextBuf& out, size_t want) override {
+        // (a round keeps 2 bytes per byte of text in flight: smaller groups than BGZF's)
+        if (!z.read(out, std::min<size_t>(want, (size_t)96 << 20))) { g_err = "gzip: " + z.err; failed = true; return false; }
+        return true;
+    }
+};
+
 struct Fast {
     int fd = -1;
-    Bgzf* src = nullptr;                       // BGZF input: `data` is `mem`, refilled group by group
-    std::vector<char> mem;
+    TextSource* src = nullptr;                 // compressed input (BGZF, gzip): `data` is `mem`, refilled group by group
+    gzpar::TextBuf mem;                        // (resize() does not zero: the thread team writes the text)
     uint64_t base_off = 0;                     // uncompressed offset of data[0] (BGZF)
     const char* data = nullptr;
     size_t size = 0;
@@ -724,6 +750,36 @@ int tps_reader_open(const char* path, void** out) {
         }
         delete z;
     }
+    if (!plain && !h->fast && h->format == 2 && !getenv("TPS_IO_NO_MMAP") && !getenv("TPS_IO_NO_PARGZ")) {
+        // ordinary gzip'ed FASTQ: the deflate stream is inflated by the thread team (speculative block starts, tps_gzpar.h),
+        // then the same thread-team record decoder runs over the text.  Small files stay with zlib's stream.
+        GzSource* z = new GzSource();
+        z->fd = open(path, O_RDONLY);
+        struct stat st;
+        if (z->fd >= 0 && fstat(z->fd, &st) == 0 && st.st_size >= ((off_t)1 << 20)) {
+            void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, z->fd, 0);
+            if (m != MAP_FAILED) {
+                z->data = (const uint8_t*)m;
+                z->size = (size_t)st.st_size;
+                madvise(m, z->size, MADV_SEQUENTIAL);
+                z->z.data = z->data;
+                z->z.size = z->size;
+                z->z.threads = io_threads();
+                z->z.team = [](int n, const std::function<void(int, int)>& f) { team(n, f); };
+                Fast* f = new Fast();
+                f->src = z;
+                f->threads = z->z.threads;
+                f->pos = 0;
+                f->index_window();
+                while (f->pos < f->size && (f->data[f->pos] == '\n' || f->data[f->pos] == '\r' || f->data[f->pos] == ' ')) ++f->pos;
+                if (f->pos) f->index_window();
+                h->fast = f;
+                if (z->failed) { delete h; return -1; }            // (g_err says why; `f` owns `z`)
+                z = nullptr;
+            }
+        }
+        delete z;
+    }
     if (plain && h->format == 2 && !getenv("TPS_IO_NO_MMAP")) {
         Fast* f = new Fast();
         f->fd = open(path, O_RDONLY);
@@ -848,6 +904,39 @@ int64_t tps_pack_reads(const uint8_t* bases, const int64_t* offsets, int64_t n, 
         tps::pack_range(bases, offsets, a, b, desc, seq2, inv);
     });
     return nw;
+}
+
+// Test / diagnostics hook: the whole text of a gzip file through the parallel inflater (tps_gzpar.h).  Returns the number of
+// bytes (written to out up to cap), -1 on a corrupt file; stats[0..2] = chunks tried, speculative chunks accepted, chunks redone
+// from the known position.  want = bytes of text per round (0 = default), threads = 0 = the team's size.
+int64_t tps_gz_inflate(const char* path, uint8_t* out, int64_t cap, int32_t threads, int64_t want, int64_t* stats) {
+    int fd = open(path, O_RDONLY);
+    struct stat st;
+    if (fd < 0 || fstat(fd, &st) != 0) { g_err = "cannot open file"; if (fd >= 0) close(fd); return -1; }
+    if (st.st_size == 0) { close(fd); return 0; }
+    void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (m == MAP_FAILED) { close(fd); g_err = "mmap failed"; return -1; }
+    gzpar::ParGz z;
+    z.data = (const uint8_t*)m;
+    z.size = (size_t)st.st_size;
+    z.threads = threads > 0 ? threads : io_threads();
+    z.team = [](int n, const std::function<void(int, int)>& f) { team(n, f); };
+    gzpar::TextBuf buf;
+    int64_t total = 0;
+    bool ok = true;
+    while (ok && !z.eof()) {
+        buf.clear();
+        ok = z.read(buf, want > 0 ? (size_t)want : (size_t)64 << 20);
+        if (!ok) break;
+        const int64_t n = (int64_t)buf.size();
+        if (out && n > 0 && total < cap) memcpy(out + total, buf.data(), (size_t)std::min<int64_t>(n, cap - total));
+        total += n;
+    }
+    if (stats) { stats[0] = (int64_t)z.n_chunks; stats[1] = (int64_t)z.n_spec_ok; stats[2] = (int64_t)z.n_serial; }
+    munmap(m, (size_t)st.st_size);
+    close(fd);
+    if (!ok) { g_err = "gzip: " + z.err; return -1; }
+    return total;
 }
 
 // Writes the records idx[0 .. n) of a packed batch that was read from the mmap'ed plain FASTQ `text` to `fd`, in the layout

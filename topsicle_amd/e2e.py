@@ -108,6 +108,42 @@ def measure(bases, offsets, motif: str, k: int, slide: int, device: int = 0, con
             out["file_to_results"] = {"value": n_bases / min(times), "unit": "bases/s", "seconds_best": round(min(times), 4),
                                       "seconds_mean": round(float(np.mean(times)), 4), "reads_passing": npass,
                                       "batch_bases": batch.BATCH_BASES}
+            # -- the same through ordinary gzip (one deflate stream: what `gzip` / `pigz` write, the reference's demo input): the
+            # native reader inflates it with the thread team (csrc/tps_gzpar.h) instead of one zlib stream
+            import zlib
+            gz = fq + ".gz"
+            t0 = time.perf_counter()
+            co = zlib.compressobj(1, zlib.DEFLATED, 31)
+            with open(fq, "rb") as src, open(gz, "wb") as dst:
+                while True:
+                    blk = src.read(16 << 20)
+                    if not blk:
+                        break
+                    dst.write(co.compress(blk))
+                dst.write(co.flush())
+            t_gz = time.perf_counter() - t0
+            legs = {}
+            for name, env in (("parallel", None), ("zlib_stream", "1")):
+                if env:
+                    os.environ["TPS_IO_NO_PARGZ"] = env
+                try:
+                    times = []
+                    for _ in range(2 if env is None else 1):
+                        t0 = time.perf_counter()
+                        nr = 0
+                        for pb, res, _s, _r, _w in ep.scan_file(gz, prm):
+                            nr += pb.n
+                        times.append(time.perf_counter() - t0)
+                        assert nr == n_reads
+                    legs[name] = min(times)
+                finally:
+                    os.environ.pop("TPS_IO_NO_PARGZ", None)
+            out["gz_file_to_results"] = {"value": n_bases / legs["parallel"], "unit": "bases/s", "seconds_best": round(legs["parallel"], 4),
+                                         "zlib_stream_value": n_bases / legs["zlib_stream"], "zlib_stream_seconds": round(legs["zlib_stream"], 4),
+                                         "gz_bytes": os.path.getsize(gz), "gz_write_s": round(t_gz, 2),
+                                         "note": "ordinary single-stream gzip (level 1) of the same FASTQ file -> results; "
+                                                 "zlib_stream_* = the same with the reader's one-stream zlib path (TPS_IO_NO_PARGZ=1)"}
+            os.unlink(gz)
         finally:
             for e in engines:
                 e.close()
