@@ -1183,7 +1183,7 @@ TPS_DEV Lds carve_fused(uint32_t* base, uint32_t* lut, const ScanArgs& a) {
 // XS aliases row[]: the only reader of XS[w] is the lane that then writes row[w].
 // Windows beyond nw_tile (they need blocks of the next tile) are not produced.
 #ifdef TPS_EMU
-inline int& emu_counter(int i) { static int c[8] = {0, 0, 0, 0, 0, 0, 0, 0}; return c[i]; }   // tests: 0 = per-pattern tiles, 1 = windows recounted there, 4 = exact change-point tournaments, 5 = tile_so_s tiles, 6 = chain-free tiles of a self-overlap table completed as plain tiles
+inline int& emu_counter(int i) { static int c[8] = {0, 0, 0, 0, 0, 0, 0, 0}; return c[i]; }   // tests: 0 = per-pattern tiles, 1 = windows recounted there, 4 = exact change-point tournaments, 5 = sums tiles of a self-overlap table with chains corrected, 6 = ... without a chain
 #endif
 TPS_DEV uint32_t pack_hi_lo(uint32_t hi_src, uint32_t lo_src) { return perm(hi_src, lo_src, 0x07060100u); }
 
@@ -1193,17 +1193,9 @@ TPS_DEV uint32_t pack_hi_lo(uint32_t hi_src, uint32_t lo_src) { return perm(hi_s
 // A window ends r positions into a block, so every block publishes its prefix words at that position; with r known at
 // compile time the capture is a plain copy at one unrolled position instead of two selects at every position (measured on
 // the slide-7 kernel, r = 4: 112 of ~565 instructions per tile).  scan_read switches on r once per tile.
-// CD > 0: CHAIN DETECTION for a table whose self-overlapping k-mers share the one period CD (sums only).  Occurrences of
-// such a k-mer D apart are counted once by the reference's non-overlapping search; a tile in which NO pattern occurs at
-// p and again at p + CD (both inside the tile) needs none of that: every window's count is the plain prefix difference.
-// Phase 1 ANDs the table entries CD positions apart (one v_and_or per position); if any lane saw a chain the tile returns
-// true right after phase 1, nothing but its own exchange words written, and the caller runs tile_so_s on it.  Otherwise
-// it completes as a plain tile and leaves tile_so_s's carry (the picks of the CD positions before the next tile's first
-// = plain occurrences there) for a following chained tile.
-template <int S, bool SO, bool INV, int RPT, bool PAIR, bool RAW, int CD = 0>
-TPS_DEV bool tile_fused_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int delta, int w0, int tile, int nw_tile,
+template <int S, bool SO, bool INV, int RPT, bool PAIR, bool RAW>
+TPS_DEV void tile_fused_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int delta, int w0, int tile, int nw_tile,
                           int64_t out_base, uint64_t& s_total, int64_t r) {
-    static_assert(CD == 0 || (!SO && !INV && !PAIR && CD <= S), "chain detection: single lookups on clean tiles, period <= slide");
     // RZ: the window has no partial block (W - k divisible by the slide), so nothing is captured mid-block
     constexpr bool RZ = RPT == 0;
     typedef Geo<S> g_;
@@ -1212,7 +1204,6 @@ TPS_DEV bool tile_fused_s(const ScanArgs& a, const TileConst& tc, const Lds& l, 
     const PatInfo& pat = a.pat;
     const int rp = RPT >= 0 ? RPT : tc.r, q = tc.q;   // rp: positions of the partial block (a.r)
     const uint32_t amask = pat.kmask << 2;        // k-mer code as a byte offset into the 4-byte table
-    uint32_t chain_any = 0;                       // CD: mask half of (entry at p) & (entry at p + CD), OR over the lane's positions
     TPS_PHASE {
         const int span = tid;
         // The lane's bases start at an arbitrary bit offset; one per-lane funnel shift aligns the base
@@ -1284,7 +1275,6 @@ TPS_DEV bool tile_fused_s(const ScanArgs& a, const TileConst& tc, const Lds& l, 
         } else {
             // table lookups run one block ahead of their use (software pipeline, 2 S values in flight)
             uint32_t hc[S], hn[S];
-            uint32_t cf = 0;
             auto fetch = [&](int blk, uint32_t* hh, int cnt_) {
                 TPS_UNROLL
                 for (int i = 0; i < S; ++i) {
@@ -1326,11 +1316,6 @@ TPS_DEV bool tile_fused_s(const ScanArgs& a, const TileConst& tc, const Lds& l, 
             for (int blk = 0; blk < B; ++blk) {
                 if (blk + 1 < B) fetch(blk + 1, hn, S);
                 else if (SO) fetch(B, hn, MAXD);          // look-ahead past the lane's last block (w[] holds 13 extra bases)
-                else if (CD > 0) fetch(B, hn, CD);
-                if constexpr (CD > 0) {
-                    TPS_UNROLL
-                    for (int i = 0; i < S; ++i) cf |= hc[i] & (i + CD < S ? hc[i + CD] : hn[i + CD - S]);
-                }
                 uint32_t g = 0;
                 c0s[blk] = cnt;
                 uint32_t c1 = cnt, pp = run_or;
@@ -1360,7 +1345,6 @@ TPS_DEV bool tile_fused_s(const ScanArgs& a, const TileConst& tc, const Lds& l, 
                 TPS_UNROLL
                 for (int i = 0; i < S; ++i) hc[i] = hn[i];
             }
-            if constexpr (CD > 0) chain_any |= cf & 0xFFFF0000u;
         }
         uint32_t sfx = 0;
         TPS_UNROLL
@@ -1371,17 +1355,6 @@ TPS_DEV bool tile_fused_s(const ScanArgs& a, const TileConst& tc, const Lds& l, 
         l.XF[span] = pack_hi_lo(sfx, cnt);        // the lane's OR | the lane's matches
     }
     TPS_SYNC();
-    if constexpr (CD > 0) {
-#ifdef TPS_EMU
-        const bool chained = chain_any != 0;      // (the emulation's phase loop has OR-ed every lane into the one variable)
-#else
-        const bool chained = __builtin_amdgcn_ballot_w64(chain_any != 0) != 0;
-#endif
-        if (chained) return true;
-#ifdef TPS_EMU
-        ++emu_counter(6);
-#endif
-    }
     if (w0 == 0) TPS_STAMP(6);
     if (w0 == 0) TPS_STAMP(7);
     const int rot = q & (B - 1), dl0 = q >> LOG2B;
@@ -1415,17 +1388,6 @@ TPS_DEV bool tile_fused_s(const ScanArgs& a, const TileConst& tc, const Lds& l, 
 #endif
         l.XF[tid] = fo_a;
         l.XT[tid] = fo_b;
-        if constexpr (CD > 0) {
-            // what tile_so_s wants to know about the positions before the NEXT tile's first one: no chain here, so the
-            // picks there are the plain occurrences, and nothing is uncertain
-            if (tid == (a.tw >> LOG2B)) {
-                uint32_t* carry = l.misc + M_SCAN;
-                const int pn = delta + a.tw * S - CD;
-                TPS_UNROLL
-                for (int i = 0; i < CD; ++i) carry[i] = lut_mask(l.lut, l.lshift, pat, v_at(l.seq2, pn + i)) << 16;
-                carry[6] = 0;
-            }
-        }
     }
     TPS_SYNC();
 #ifdef TPS_EMU
@@ -1622,7 +1584,6 @@ TPS_DEV bool tile_fused_s(const ScanArgs& a, const TileConst& tc, const Lds& l, 
     }
     s_total += gsum;
     TPS_SYNC();
-    return false;
 }
 
 // After the window phase of a fused tile (row[] = S_w of the tile's windows, padded layout, 0 beyond nw_tile):
@@ -1727,10 +1688,22 @@ TPS_DEV void g_store16_clamped(uint32_t* base, int n_dw, int cdw, const u32x4& t
 #endif
 // ROTZ: q (the window's whole blocks) is a multiple of 8 -- every window ends in the same block-in-lane it starts in, dl0
 // lanes on: no per-window choice between the near and the far end lane (the default geometry: W = 100, k = 4, slide 6).
-template <int S, bool INV, int RPT, bool PAIR, bool ROTZ>
+// CD > 0: the table's self-overlapping k-mers share the ONE period CD (2 CD >= k), sums only.  re.finditer counts leftmost
+// non-overlapping occurrences (allsteps.py:281): along a CHAIN of occurrences CD apart it takes every other one, restarting
+// at the window's first.  The tile counts every occurrence as a plain tile does and takes the difference back afterwards: a
+// window that holds n consecutive elements of a chain counted n, finditer counts ceil(n / 2) -- the correction floor(n / 2)
+// is piecewise constant in the window index, so the lane that finds a chain's HEAD (an occurrence at p and at p + CD, none
+// at p - CD: one AND per position on table entries that are in registers anyway) adds its steps to a difference array in
+// LDS (row[]: free until the prefixes are written) -- for a pair, the usual case (one deleted base makes one), +1 at the
+// first window that holds both and -1 behind the last.  Tiles with a chain (most telomeric tiles at k = 6, few elsewhere)
+// then prefix-sum the array and subtract.  This replaces the canonical-pick tile of round 2 (tile_so_s: one dependent pick
+// per position in every lane of every chained tile, 2.3 x a plain tile) and its chain-parity repairs.
+template <int S, bool INV, int RPT, bool PAIR, bool ROTZ, int CD_ = 0>
 TPS_DEV void tile_lc_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int delta, int w0, int tile, int nw_tile,
                        int64_t out_base, uint64_t& s_total, int64_t r) {
     static_assert(!(PAIR && INV), "pair lookups need per-position independence");
+    constexpr int CD = CD_;
+    static_assert(CD == 0 || (!PAIR && !INV && CD <= S), "chain corrections: single lookups on clean tiles, period <= slide");
     constexpr bool RZ = RPT == 0;
     typedef Geo<S> g_;
     constexpr int WDW = g_::WDW, B = g_::B, LOG2B = g_::LOG2B, POS = g_::POS;
@@ -1743,6 +1716,41 @@ TPS_DEV void tile_lc_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
 #ifdef TPS_EMU
     uint32_t sfx_keep[NT][B], c0_keep[NT][B], xf_keep[NT];
 #endif
+    uint32_t lane_chain = 0;                      // CD: this lane found the head of a chain
+    if constexpr (CD > 0) {
+        TPS_PHASE {
+            TPS_UNROLL
+            for (int i = 0; i < B + 1; ++i) l.row[tid + i * NT] = 0;          // the difference array, indexed by padded window
+        }
+        TPS_SYNC();
+    }
+    // (CD) the steps of floor(n / 2) for the chain of pattern mask `pm` whose head is at tile position tp
+    auto chain_steps = [&](int tp, uint32_t pm) {
+        constexpr int CD = CD_ > 0 ? CD_ : 1;     // (never called for CD_ = 0; keeps the divisions below well-formed)
+        const int lw = a.lw;
+        auto occ = [&](int pos) -> bool { return (lut_mask(l.lut, l.lshift, pat, v_at(l.seq2, delta + pos)) & pm) != 0; };
+        auto w_in = [&](int e) -> int { const int x = e - lw + 1; return x <= 0 ? 0 : (x + S - 1) / S; };     // first window that holds position e
+        auto step = [&](int w, uint32_t d) { if (w < NT * B) lds_add(&l.row[w + (w >> LOG2B)], d); };
+        const int tend = NT * POS;                                           // positions of the tile
+        int c = 2;
+        while (tp + c * CD < tend && occ(tp + c * CD)) ++c;
+        if (c == 2) {
+            const int lo = w_in(tp + CD), hi = tp / S;                       // windows that hold both
+            if (lo <= hi) { step(lo, 1u); step(hi + 1, (uint32_t)-1); }
+            return;
+        }
+        int prev = 0;
+        const int wb = (tp + (c - 1) * CD) / S + 1;
+        for (int w = w_in(tp); w <= wb && w <= NT * B; ++w) {
+            // chain elements j with w S <= tp + j CD < w S + lw
+            const int a0 = w * S - tp, a1 = w * S + lw - 1 - tp;
+            int jlo = a0 <= 0 ? 0 : (a0 + CD - 1) / CD, jhi = a1 < 0 ? -1 : a1 / CD;
+            if (jhi > c - 1) jhi = c - 1;
+            const int cur = jhi >= jlo ? (jhi - jlo + 1) >> 1 : 0;
+            if (cur != prev) step(w, (uint32_t)(cur - prev));
+            prev = cur;
+        }
+    };
     TPS_PHASE {
         const int span = tid;
         const int p0 = delta + span * POS;        // >= 16: fused tiles are staged behind SEQ_LEAD words
@@ -1764,6 +1772,7 @@ TPS_DEV void tile_lc_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
         };
         uint32_t cnt = 0, run_or = 0;
         uint32_t gs[B];
+        uint32_t pair_lo = 0, pair_hi = 0;        // CD: bit p = some pattern occurs at the lane's position p and again CD further on
         uint32_t* xpc = l.XPC + span * (B + 1);
         if constexpr (PAIR) {
             constexpr int NP = S / 2, NH = NP + (S & 1);
@@ -1805,21 +1814,41 @@ TPS_DEV void tile_lc_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
             }
         } else {
             uint32_t hc[S], hn[S];
-            auto fetch = [&](int blk, uint32_t* hh) {
+            auto fetch = [&](int blk, uint32_t* hh, int cnt_) {
                 TPS_UNROLL
                 for (int i = 0; i < S; ++i) {
-                    const int p = blk * S + i;
-                    uint32_t h = lut_at(l.lut, v4_at(p), amask);
-                    if (INV) {
-                        if (h && invalid_at(l.val, p0 + p, pat.k)) h = 0;   // tiles with non-ACGT letters only
+                    if (i < cnt_) {
+                        const int p = blk * S + i;
+                        uint32_t h = lut_at(l.lut, v4_at(p), amask);
+                        if (INV) {
+                            if (h && invalid_at(l.val, p0 + p, pat.k)) h = 0;   // tiles with non-ACGT letters only
+                        }
+                        hh[i] = h;
+                    } else {
+                        hh[i] = 0;
                     }
-                    hh[i] = h;
                 }
             };
-            fetch(0, hc);
+            fetch(0, hc, S);
             TPS_UNROLL
             for (int blk = 0; blk < B; ++blk) {
-                if (blk + 1 < B) fetch(blk + 1, hn);
+                if (blk + 1 < B) fetch(blk + 1, hn, S);
+                else if (CD > 0) fetch(B, hn, CD);        // look-ahead past the lane's last block (w[] holds 13 extra bases)
+                if constexpr (CD > 0) {
+                    uint32_t cfb = 0;                     // some pattern occurs at p and again at p + CD, p in this block
+                    TPS_UNROLL
+                    for (int i = 0; i < S; ++i) cfb |= hc[i] & (i + CD < S ? hc[i + CD] : hn[i + CD - S]);
+                    if (cfb & 0xFFFF0000u) {              // rare: a deleted or inserted base inside a telomeric stretch
+                        // remember WHERE (one bit per position of the lane); the chains are walked behind the block loop, by one
+                        // copy of that code instead of one per unrolled position
+                        TPS_UNROLL
+                        for (int i = 0; i < S; ++i) {
+                            const uint32_t pr = ((hc[i] & (i + CD < S ? hc[i + CD] : hn[i + CD - S])) >> 16) ? 1u : 0u;
+                            if (blk * S + i < 32) pair_lo |= pr << ((blk * S + i) & 31);
+                            else pair_hi |= pr << ((blk * S + i) & 31);
+                        }
+                    }
+                }
                 uint32_t g = 0;
                 c0s[blk] = cnt;
                 uint32_t c1 = cnt, pp = run_or;
@@ -1847,6 +1876,20 @@ TPS_DEV void tile_lc_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
         }
         xf_own = pack_hi_lo(sf, cnt);
         l.XF[span] = xf_own;
+        if constexpr (CD > 0) {
+            // the lane's occurrence pairs: the ones that HEAD a chain (no occurrence of the pattern CD before them; what lies
+            // before the tile's first position is in none of its windows) put the chain's steps into the difference array
+            TPS_PIN_V(pair_lo); TPS_PIN_V(pair_hi);
+            while (pair_lo | pair_hi) {
+                int p;
+                if (pair_lo) { p = ffs0(pair_lo); pair_lo &= pair_lo - 1u; }
+                else { p = 32 + ffs0(pair_hi); pair_hi &= pair_hi - 1u; }
+                const int tp = span * POS + p;    // position in the tile
+                const uint32_t pm = lut_mask(l.lut, l.lshift, pat, v_at(l.seq2, delta + tp));
+                const bool head = tp < CD || (lut_mask(l.lut, l.lshift, pat, v_at(l.seq2, delta + tp - CD)) & pm) == 0;
+                if (head) { chain_steps(tp, pm); lane_chain = 1u; }
+            }
+        }
 #ifdef TPS_EMU
         for (int j = 0; j < B; ++j) { sfx_keep[tid][j] = sfx[j]; c0_keep[tid][j] = c0s[j]; }
         xf_keep[tid] = xf_own;
@@ -1902,6 +1945,46 @@ TPS_DEV void tile_lc_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
 #ifdef TPS_EMU
         for (int j = 0; j < B; ++j) sw_keep[tid][j] = sw[j];
         tot_keep[tid] = ltot;
+#endif
+    }
+    if constexpr (CD > 0) {
+        // a chain somewhere in the tile: the windows give back what the chains' skipped occurrences added -- the prefix sum of
+        // the difference array, lane-contiguous like the windows themselves
+#ifdef TPS_EMU
+        const bool tile_chain = lane_chain != 0;  // (the emulation's phase loop has OR-ed every lane into the one variable)
+        if (tile_chain) {
+            ++emu_counter(5);
+            uint32_t acc = 0;
+            for (int t = 0; t < NT; ++t) {
+                uint32_t tot = 0;
+                for (int j = 0; j < B; ++j) { acc += l.row[t * (B + 1) + j]; sw_keep[t][j] -= acc; tot += sw_keep[t][j]; }
+                tot_keep[t] = tot;
+            }
+        } else {
+            ++emu_counter(6);
+        }
+#else
+        const bool tile_chain = __builtin_amdgcn_ballot_w64(lane_chain != 0) != 0;
+        if (tile_chain) {
+            uint32_t pd[B], dt = 0;
+            TPS_PHASE {
+                const uint32_t* pr = l.row + tid * (B + 1);
+                TPS_UNROLL
+                for (int j = 0; j < B; ++j) { dt += pr[j]; pd[j] = dt; }
+            }
+            uint32_t inc = dt;
+            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xf, 0xf, false);   // row_shr:1
+            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xf, 0xf, false);   // row_shr:2
+            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xf, 0xf, false);   // row_shr:4
+            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xf, 0xf, false);   // row_shr:8
+            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+            const uint32_t dbase = inc - dt;
+            uint32_t run = 0;
+            TPS_UNROLL
+            for (int j = 0; j < B; ++j) { sw[j] -= dbase + pd[j]; run += sw[j]; }
+            ltot = run;
+        }
 #endif
     }
     // exclusive scan of the lane totals over the wave (lanes past the tile's last window add garbage behind every valid window)
@@ -2518,304 +2601,6 @@ TPS_DEV bool tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
     return false;
 }
 
-// ------------------------------------------------------------------ step 2, self-overlap tables, sums only
-// S_w alone (no raw rows) for a table whose k-mers have ONE self-overlap period D (2 D >= k), without the per-pattern
-// fields of tile_pp_s: the CANONICAL PICKS of tile_pp_s (pick(p) = occ(p) & ~pick(p - D), greedy from the head of every
-// chain of overlapping occurrences) computed on the table's one-bit-per-pattern masks, inside the published words of
-// tile_fused_s.  Per position: one lookup, t = h & pick[p - D] (the canonically skipped occurrence), pick = h ^ t,
-// count += popcount(pick), presence |= h.  A window's count is then the prefix-count difference of tile_fused_s, plus its
-// START SKIPS (occurrences in its first D positions that are skipped only because of a pick before the window: their
-// number is folded into the count a block publishes for windows that start there), and only a window whose start skip
-// heads a chain that goes on (>= 3 chained occurrences) is repaired afterwards by walking that chain (as in tile_pp_s).
-//   phase 1  (lane-contiguous) look-back over the previous lane's last 16 positions, picks of the lane's 8 blocks; per
-//            block XS = suffix-OR | count before the block - start skips, XPC = prefix-OR | count r positions in
-//   phase 1b / 2  exactly tile_fused_s: lane-strided windows from three LDS reads, S_w to HBM and row[]
-//   repairs  (lane-contiguous: lane L owns windows 8 L .. 8 L + 7) chain-parity walks, exact recount where a lane's
-//            incoming state is unknown
-//   phase 3  tile_candidates
-template <int S, int D>
-TPS_DEV void tile_so_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int delta, int w0, int tile, int nw_tile,
-                       int64_t out_base, uint64_t& s_total) {
-    // look-back over the previous lane's last LBK positions: enough for a chain that starts inside it (two links); a chain
-    // through the whole look-back takes the walk below
-    constexpr int B = 8, LOG2B = 3, POS = B * S, LBK = 2 * D + 2;
-    constexpr int WDW = (1 + LBK + POS + 6 + 7 + 15) / 16;
-    constexpr int RS = NT + NT / B;
-    constexpr int AHEAD = (2 * D > S) ? 2 * D - S : 0;
-    constexpr uint32_t MH = 0xFFFF0000u;              // the mask half of a table entry (mask << 16 | 1)
-    static_assert(D >= 2 && D <= 6, "one self-overlap period, 2 .. 6 (2 D >= k >= 4)");
-    const PatInfo& pat = a.pat;
-    int rp = tc.r, q = tc.q;
-    TPS_PIN_S(rp); TPS_PIN_S(q);
-    const uint32_t amask = pat.kmask << 2;
-    uint32_t* carry = l.misc + M_SCAN;            // [0, 6): picks (mask half) of the D positions before the next tile's first; [6]: uncertain
-    const int cblk = a.tw & (B - 1), clane = a.tw >> 3;
-    uint32_t cold[7];
-    TPS_UNROLL
-    for (int i = 0; i < 7; ++i) cold[i] = uniform(carry[i]);
-    auto picked_before_tile = [&](int pos, int pidx) -> bool {
-        uint32_t cv = 0;
-        TPS_UNROLL
-        for (int i = 0; i < D; ++i) cv = (pos - (delta - D) == i) ? cold[i] : cv;
-        return w0 != 0 && ((cv >> (16 + pidx)) & 1u) != 0;
-    };
-#ifdef TPS_EMU
-    uint32_t keep[NT][3];
-#endif
-    uint32_t chm = 0, chw = 0, unc = 0;
-    TPS_PHASE {
-        const int span = tid;
-        const int p0 = delta + span * POS;
-        const uint32_t sh2 = (uint32_t)((p0 - 1 - LBK) & 15) * 2u;
-        // the lane's registers start LBK positions before its first one (p0 >= 64: fused tiles are staged behind SEQ_LEAD words)
-        const int d0 = (p0 - 1 - LBK) >> 4;
-        uint32_t w[WDW];
-        {
-            uint32_t prev = l.seq2[d0];
-            TPS_UNROLL
-            for (int i = 0; i < WDW; ++i) {
-                uint32_t nx = l.seq2[d0 + i + 1];
-                w[i] = alignbit(nx, prev, sh2);
-                prev = nx;
-            }
-        }
-        auto look = [&](int p) -> uint32_t {          // table entry of the k-mer at position p (relative to the lane's first, -LBK <= p)
-            const int idx = p + LBK, dw = idx >> 4, bit = idx & 15;
-            const uint32_t v4 = bit ? alignbit(dw + 1 < WDW ? w[dw + 1] : 0u, w[dw], 2u * bit) : w[dw];
-            return lut_at(l.lut, v4, amask);
-        };
-        uint32_t pk[LBK + POS + AHEAD + 1];           // picks (mask half only), index p + LBK
-        uint32_t tv[POS + 1];                         // canonically skipped occurrences
-        {
-            uint32_t ca[LBK];
-            TPS_UNROLL
-            for (int i = 0; i < LBK; ++i) {
-                const uint32_t h = look(i - LBK);
-                if (i >= D) {
-                    pk[i] = (h ^ (h & pk[i - D])) & MH;
-                    ca[i] = h & ca[i - D];
-                } else {
-                    pk[i] = h & MH;
-                    ca[i] = h & MH;
-                }
-            }
-            TPS_UNROLL
-            for (int i = LBK - D; i < LBK; ++i) unc |= ca[i];
-            if (unc && span > 0) {
-                // one pattern chains through the whole look-back: walk the chain further back (rare)
-                unc = 0;
-                TPS_UNROLL
-                for (int i = LBK - D; i < LBK; ++i) {
-                    if (ca[i]) {
-                        const int pidx = ffs0(ca[i]) - 16;
-                        int n = 0, pw = p0 - LBK + (i % D) - D;
-                        while (pw >= delta && ((lut_mask(l.lut, l.lshift, pat, v_at(l.seq2, pw)) >> pidx) & 1u)) { ++n; pw -= D; }
-                        const bool blocked = pw < delta && picked_before_tile(pw, pidx);
-                        if (pw < delta && w0 != 0 && cold[6]) unc |= ca[i];
-                        else if (((n & 1) != 0) != blocked) pk[i] ^= ca[i];
-                    }
-                }
-            }
-            if (span == 0) {
-                TPS_UNROLL
-                for (int i = 0; i < D; ++i) pk[LBK - D + i] = cold[i];
-                unc = cold[6];
-            }
-        }
-        uint32_t cnt = 0, run_or = 0;
-        uint32_t gs[B], c0s[B], ch3[B];
-        uint32_t* xs = l.row + span * (B + 1);
-        uint32_t* xpc = l.XPC + span * (B + 1);
-        TPS_UNROLL
-        for (int blk = 0; blk < B; ++blk) ch3[blk] = 0;
-        TPS_UNROLL
-        for (int blk = 0; blk < B; ++blk) {
-            if (blk == cblk && span == clane) {       // this block is the next tile's first
-                TPS_UNROLL
-                for (int i = 0; i < D; ++i) carry[i] = pk[LBK + blk * S - D + i];
-                carry[6] = unc;
-            }
-            uint32_t g = 0, sfw = 0;
-            uint32_t c1 = cnt, pp_ = run_or;
-            const uint32_t c0 = cnt;
-            TPS_UNROLL
-            for (int i = 0; i < S; ++i) {
-                const int p = blk * S + i;
-                const uint32_t h = look(p);
-                const uint32_t t = h & pk[LBK + p - D];           // (pk holds mask bits only, so does t)
-                if (i < D) sfw |= t;
-                const int pm = p - D;
-                if (pm >= 0 && pm % S < D) ch3[pm / S] |= h & tv[pm];
-                tv[p] = t;
-                const uint32_t pick = (h ^ t) & MH;
-                pk[LBK + p] = pick;
-                cnt += (uint32_t)popc(pick);
-                g |= h;
-                if (i + 1 == rp) { c1 = cnt; pp_ = run_or | g; }
-            }
-            xpc[blk] = pack_hi_lo(pp_, c1);
-            gs[blk] = g;
-            run_or |= g;
-            c0s[blk] = c0 - (uint32_t)popc(sfw);      // windows that start here also pick their start skips
-            if (blk > 0) {
-                chm |= ch3[blk - 1] ? (1u << (blk - 1)) : 0u;
-                chw |= ch3[blk - 1];
-                TPS_PIN_V(chm); TPS_PIN_V(chw);
-            }
-        }
-        TPS_UNROLL
-        for (int i = 0; i < AHEAD; ++i) {
-            const int p = POS + i, pm = p - D;
-            if (pm % S < D) ch3[pm / S] |= look(p) & tv[pm];
-        }
-        chm |= ch3[B - 1] ? (1u << (B - 1)) : 0u;
-        chw |= ch3[B - 1];
-        uint32_t sfx = 0;
-        TPS_UNROLL
-        for (int j = B - 1; j >= 0; --j) {
-            sfx |= gs[j];
-            xs[j] = pack_hi_lo(sfx, c0s[j]);
-        }
-        l.XF[span] = pack_hi_lo(sfx, cnt);
-        TPS_PIN_V(chm); TPS_PIN_V(chw); TPS_PIN_V(unc);
-#ifdef TPS_EMU
-        keep[tid][0] = chm; keep[tid][1] = chw; keep[tid][2] = unc;
-        chm = 0; chw = 0; unc = 0;
-        ++emu_counter(5);
-#endif
-    }
-    TPS_SYNC();
-    uint64_t unc_mask = 0;
-#ifdef TPS_EMU
-    for (int t = 0; t < NT; ++t) unc_mask |= (uint64_t)(keep[t][2] != 0) << t;
-    emu_counter(2) += __builtin_popcountll(unc_mask);
-#else
-    unc_mask = __builtin_amdgcn_ballot_w64(unc != 0);
-#endif
-    const int rot = q & (B - 1), dl0 = q >> LOG2B;
-    uint32_t fo_a = 0, fo_b = 0;
-#ifdef TPS_EMU
-    uint32_t fo_keep[NT][2];
-#endif
-    TPS_PHASE {
-        uint32_t orw = 0, sumw = l.XF[tid];
-        TPS_NOVEC
-        for (int t = 1; t < dl0; ++t) {
-            const uint32_t v = l.XF[tid + t];
-            orw |= v;
-            sumw += v;
-        }
-        const uint32_t vb = l.XF[tid + dl0];
-        fo_a = pack_hi_lo(orw, sumw);
-        fo_b = pack_hi_lo(orw | vb, sumw + vb);
-#ifdef TPS_EMU
-        fo_keep[tid][0] = fo_a; fo_keep[tid][1] = fo_b;
-#endif
-    }
-    TPS_SYNC();
-    TPS_PHASE {
-#ifdef TPS_EMU
-        fo_a = fo_keep[tid][0]; fo_b = fo_keep[tid][1];
-#endif
-        l.XF[tid] = fo_a;
-        l.XT[tid] = fo_b;
-    }
-    TPS_SYNC();
-    TPS_PHASE {
-        const uint32_t lane = (uint32_t)tid;
-        const bool farl = (((lane & (B - 1)) + (uint32_t)rot) >> LOG2B) != 0;
-        uint32_t* ps = l.row + (lane + (lane >> LOG2B));
-        const uint32_t* pe = l.XPC + ((lane + (uint32_t)q) + ((lane + (uint32_t)q) >> LOG2B));
-        const uint32_t* pf = (farl ? l.XT : l.XF) + (lane >> LOG2B);
-        uint16_t* outl = tc.sw16 + w0 + lane;
-        const uint32_t am = pat.all_mask << 16;
-        const int nfull = nw_tile >> 6;
-        const uint32_t npart = (uint32_t)(nw_tile & 63);
-        uint32_t xv[B], ev[B], fv[B];
-        TPS_UNROLL
-        for (int u = 0; u < B; ++u) { xv[u] = ps[u * RS]; ev[u] = pe[u * RS]; fv[u] = pf[u * (NT / B)]; }
-        TPS_UNROLL
-        for (int u = 0; u < B; ++u) {
-            uint32_t sw = 0;
-            if (u <= nfull) {
-                const bool valid = (u < nfull) || (lane < npart);
-                const uint32_t x = xv[u], e = ev[u], f = fv[u];
-                const uint32_t m = x | e | f;
-                const uint32_t s_ = ((e - x + f) & 0xFFFFu) + (uint32_t)popc(~m & am);
-                if (valid) {
-                    sw = s_;
-                    outl[u * NT] = (uint16_t)sw;
-                }
-            }
-            ps[u * RS] = sw;
-        }
-    }
-    TPS_SYNC();
-    // Repairs (rare, lane-divergent): S_w is in row[] and in HBM by now.  Lane L owns windows 8 L .. 8 L + 7, the ones that
-    // start at its own blocks.
-#ifndef TPS_EMU
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-#endif
-    TPS_PHASE {
-#ifdef TPS_EMU
-        chm = keep[tid][0]; chw = keep[tid][1];
-#endif
-        const int lane = tid;
-        const bool redo_all = ((unc_mask >> lane) & ((2ull << (dl0 + 1)) - 1ull)) != 0;
-        uint32_t todo = redo_all ? 0xFFu : (chm << 8);
-        while (todo) {
-            const int bit = ffs0(todo);
-            todo &= todo - 1u;
-            const int j = bit & 7, wl = lane * B + j;
-            if (wl >= nw_tile) continue;
-            uint32_t sw = l.row[lane * (B + 1) + j];
-            if (bit < 8) {
-#ifdef TPS_EMU
-                ++emu_counter(1);
-#endif
-                sw = window_exact(a, l, delta, wl, pat.all_mask, 0u, nullptr, true);
-            } else {
-#ifdef TPS_EMU
-                ++emu_counter(3);
-#endif
-                // the window starts on a canonically skipped occurrence x whose chain goes on: it picks x, x + 2 D, ... = one
-                // more than canonical iff the chain has an odd number of elements from x; the start skip was added -- take
-                // it back for an even count
-                const int a0 = delta + wl * S;
-                uint32_t fw = chw;
-                bool lost = false;
-                while (fw) {
-                    const int pidx = ffs0(fw) - 16;
-                    fw &= fw - 1u;
-                    int x = -1;
-                    TPS_NOVEC
-                    for (int i = 0; i < D; ++i)
-                        if ((lut_mask(l.lut, l.lshift, pat, v_at(l.seq2, a0 + i)) >> pidx) & 1u) x = a0 + i;
-                    if (x >= 0) {
-                        int n = 0, pb = x - D;
-                        while (pb >= delta && ((lut_mask(l.lut, l.lshift, pat, v_at(l.seq2, pb)) >> pidx) & 1u)) { ++n; pb -= D; }
-                        const bool blocked = pb < delta && picked_before_tile(pb, pidx);
-                        if (pb < delta && w0 != 0 && cold[6]) lost = true;
-                        int m = 1;
-                        for (int pw = x + D; pw < a0 + a.lw && ((lut_mask(l.lut, l.lshift, pat, v_at(l.seq2, pw)) >> pidx) & 1u); pw += D) ++m;
-                        if ((((n & 1) != 0) != blocked) && (m & 1) == 0) sw -= 1u;
-                    }
-                }
-                if (lost) {
-#ifdef TPS_EMU
-                    ++emu_counter(1);
-#endif
-                    sw = window_exact(a, l, delta, wl, pat.all_mask, 0u, nullptr, true);
-                }
-            }
-            l.row[lane * (B + 1) + j] = sw;
-            tc.sw16[w0 + wl] = (uint16_t)sw;
-        }
-    }
-    TPS_SYNC();
-    tile_candidates(tc, l, w0, tile, nw_tile, s_total);
-}
-
 // ------------------------------------------------------------------ step 3: single-split Binseg (l2)
 // gain(b) = cost(0,n) - cost(0,b) - cost(b,n) = (n L_b - T b)^2 / (n b (n-b))   [y = S / P]
 // so the arg-max over b in {0, jump, 2 jump, ...}, b >= min_size, n-b >= min_size is that of
@@ -3233,8 +3018,7 @@ TPS_DEV void binseg_from_lc(const ScanArgs& a, const Lds& l, uint64_t lc_g, cons
 // per lane and TPS_SYNC() is a wave-level fence.  In the emulation TPS_PHASE loops over the 64
 // lane ids, so phases run in program order.
 // DCLASS (sums-only self-overlap kernels): which self-overlap periods this instantiation carries -- 0 all, 1 periods 2 .. 4,
-// 2 periods 5 and 6.  tile_so_s for a period <= 4 fits 96 registers (5 waves per SIMD); periods 5 and 6 need ~128, and one
-// kernel holding all of them is compiled for the worst (the host picks the kernel by ScanArgs::pp_d).
+// 2 periods 5 and 6 (one tile_lc_s<.., CD> per period and partial-block position: the host picks the kernel by ScanArgs::pp_d).
 template <int SV, bool SO, bool PAIR = false, bool RAW = true, bool FULL = tile_full_default(SV), int DCLASS = 0>
 TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_t* lut) {
     const Lds l = SV ? carve_fused<SV ? SV : 5, FULL>(lds_base, lut, a) : carve(lds_base, lut, a);
@@ -3513,41 +3297,22 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
                     }
                 }
                 if constexpr (SO && !RAW) {
-                    // sums only, a table with one self-overlap period: canonical picks on the mask words (tile_so_s)
+                    // sums only, a table with one self-overlap period
                     constexpr int SP = SV ? SV : 5;
                     if (a.pp_d > 0 && uniform(l.misc[M_INVALID]) == 0) {
-                        // tiles without a chained occurrence (most tiles outside the telomere) complete as plain tiles
-                        bool chained = true;
+                        // every occurrence counted as in a plain tile, the chains' skipped ones taken back (tile_lc_s<.., CD>)
+                        bool done = false;
+#define TPS_LC_CD_RP(D_, N) case N: if constexpr (N < SP && D_ <= SP) { tile_lc_s<SP, false, (N < SP ? N : 0), false, false, (D_ <= SP ? D_ : 0)>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r); done = true; } break;
+#define TPS_LC_CD(D_) case D_: switch (tc.r) { TPS_LC_CD_RP(D_, 0) TPS_LC_CD_RP(D_, 1) TPS_LC_CD_RP(D_, 2) TPS_LC_CD_RP(D_, 3) TPS_LC_CD_RP(D_, 4) TPS_LC_CD_RP(D_, 5) TPS_LC_CD_RP(D_, 6) TPS_LC_CD_RP(D_, 7) default: break; } break;
                         if (a.so_fast) {
-#define TPS_CD_RP(D_, N) case N: if constexpr (N < SP && D_ <= SP) chained = tile_fused_s<SP, false, false, (N < SP ? N : 0), false, false, (D_ <= SP ? D_ : 0)>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r); break;
-#define TPS_CD(D_) case D_: switch (tc.r) { TPS_CD_RP(D_, 0) TPS_CD_RP(D_, 1) TPS_CD_RP(D_, 2) TPS_CD_RP(D_, 3) TPS_CD_RP(D_, 4) TPS_CD_RP(D_, 5) TPS_CD_RP(D_, 6) TPS_CD_RP(D_, 7) default: break; } break;
-                            if constexpr (DCLASS == 1) { switch (a.pp_d) { TPS_CD(2) TPS_CD(3) TPS_CD(4) default: break; } }
-                            else if constexpr (DCLASS == 2) { switch (a.pp_d) { TPS_CD(5) TPS_CD(6) default: break; } }
-                            else { switch (a.pp_d) { TPS_CD(2) TPS_CD(3) TPS_CD(4) TPS_CD(5) TPS_CD(6) default: break; } }
-#undef TPS_CD
-#undef TPS_CD_RP
+                            if constexpr (DCLASS == 1) { switch (a.pp_d) { TPS_LC_CD(2) TPS_LC_CD(3) TPS_LC_CD(4) default: break; } }
+                            else if constexpr (DCLASS == 2) { switch (a.pp_d) { TPS_LC_CD(5) TPS_LC_CD(6) default: break; } }
+                            else { switch (a.pp_d) { TPS_LC_CD(2) TPS_LC_CD(3) TPS_LC_CD(4) TPS_LC_CD(5) TPS_LC_CD(6) default: break; } }
                         }
-                        if (!chained) continue;
-                        if constexpr (DCLASS != 2) {
-                            switch (a.pp_d) {
-                                case 2: tile_so_s<SP, 2>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
-                                case 3: tile_so_s<SP, 3>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
-                                case 4: tile_so_s<SP, 4>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
-                                default: break;
-                            }
-                        }
-                        if constexpr (DCLASS != 1) {
-                            switch (a.pp_d) {
-                                case 2: case 3: case 4: break;
-                                case 5: tile_so_s<SP, 5>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
-                                default: tile_so_s<SP, (SP < 6 ? SP : 6)>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
-                            }
-                        }
-                        continue;
-                    }
-                    if (a.pp_d > 0) {                      // a tile with non-ACGT letters takes the recount path: the next tile starts blind
-                        TPS_PHASE { if (tid == 0) l.misc[M_SCAN + 6] = 1u; }
-                        TPS_SYNC();
+#undef TPS_LC_CD
+#undef TPS_LC_CD_RP
+                        if (done) continue;
+                        // (TPS_NO_SO_FAST: the flag-and-recount tile below; so does a tile with non-ACGT letters)
                     }
                 }
                 constexpr int SF = SV ? SV : 1;

@@ -50,7 +50,7 @@
         if (r < a.n_reads) tps::scan_read<SV, SO, PAIR, RAW, FULL, DCLASS>(a, r, slice, lut);                           \
     }
 #ifndef TPS_SO_MINW
-#define TPS_SO_MINW 4     // waves per SIMD the sums-only self-overlap kernels are compiled for (tile_so_s wants ~128 VGPRs: 5 would spill ~120)
+#define TPS_SO_MINW 5     // waves per SIMD the sums-only self-overlap kernels are compiled for
 #endif
 #define TPS_SCAN_KERNEL(NAME, SV, SO, PAIR, RAW, MINW) TPS_SCAN_KERNEL_F(NAME, SV, SO, PAIR, RAW, MINW, tps::tile_full_default(SV), 0)
 #define TPS_SCAN_KERNEL_D(NAME, SV, SO, PAIR, RAW, MINW, DCLASS) TPS_SCAN_KERNEL_F(NAME, SV, SO, PAIR, RAW, MINW, tps::tile_full_default(SV), DCLASS)
@@ -109,7 +109,7 @@ TPS_SCAN_KERNEL(tps_scan_kernel_s7r, 7, false, false, true, 3)
 TPS_SCAN_KERNEL(tps_scan_kernel_s8r, 8, false, false, true, 3)
 #endif
 #if TPS_IN_GROUP(3)
-TPS_SCAN_KERNEL_D(tps_scan_kernel_s5so, 5, true, false, false, TPS_SO_MINW, 2)      // ... self-overlapping k-mers in the table, sums only (tile_so_s)
+TPS_SCAN_KERNEL_D(tps_scan_kernel_s5so, 5, true, false, false, TPS_SO_MINW, 2)      // ... self-overlapping k-mers in the table, sums only (tile_lc_s<.., CD>: plain counts, chains corrected), periods 5 and 6
 TPS_SCAN_KERNEL_D(tps_scan_kernel_s6so, 6, true, false, false, TPS_SO_MINW, 2)
 #endif
 #if TPS_IN_GROUP(4)
@@ -129,7 +129,7 @@ TPS_SCAN_KERNEL(tps_scan_kernel_s7sor, 7, true, false, true, 5)
 TPS_SCAN_KERNEL(tps_scan_kernel_s8sor, 8, true, false, true, 5)
 #endif
 #if TPS_IN_GROUP(9)
-TPS_SCAN_KERNEL_D(tps_scan_kernel_s5sol, 5, true, false, false, 5, 1)     // ... the same for self-overlap periods 2 .. 4: 96 registers, 5 waves per SIMD
+TPS_SCAN_KERNEL_D(tps_scan_kernel_s5sol, 5, true, false, false, 5, 1)     // ... the same for self-overlap periods 2 .. 4
 TPS_SCAN_KERNEL_D(tps_scan_kernel_s6sol, 6, true, false, false, 5, 1)
 #endif
 #if TPS_IN_GROUP(10)
