@@ -62,7 +62,7 @@ extern "C" {
 #define TPS_F_STEP1      1u   /* run the TRC step (a3) and choose tail / pass per read       */
 #define TPS_F_WINDOWS    2u   /* run the sliding-window count step (a5) on passing reads     */
 #define TPS_F_BINSEG     4u   /* run the single-split change-point step (a6) in the same launch */
-#define TPS_F_STORE_SUMS 8u   /* keep S_w (int32 per window) in device memory for download   */
+#define TPS_F_STORE_SUMS 8u   /* make S_w downloadable (tps_batch_window_sums hands out int32)  */
 #define TPS_F_STORE_RAW 16u   /* keep c'_p per window and pattern (u8) -- rawCountPattern (a7) */
 #define TPS_F_TAILS_IN  32u   /* without STEP1: tails[] and pass come from the caller         */
 
@@ -152,7 +152,7 @@ int  tps_batch_set_tails(tps_ctx* ctx, int32_t slot, const uint8_t* tails);
 
 /* One pass of the hot path over a resident batch: patternTRC_count (allsteps.py:152-204) +
  * bound_detect's window loop (allsteps.py:257-297) + process_mean/Binseg
- * (allsteps.py:300-333), one workgroup per read, one launch.  Asynchronous on the
+ * (allsteps.py:300-333), one 64-lane wave per read, one launch.  Asynchronous on the
  * context's stream; results land in context-owned pinned memory. */
 int  tps_batch_scan(tps_ctx* ctx, int32_t slot, const tps_params* prm);
 /* Wait for everything enqueued on the context's stream. */

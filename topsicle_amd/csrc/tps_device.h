@@ -1,24 +1,26 @@
 // tps_device.h -- per-read scan logic of the telomere k-mer scanner (MI355X / gfx950).
 //
-// One WAVE (64 lanes) owns one read and runs, in one launch (4 independent waves per workgroup):
+// One WAVE (64 lanes) owns one read and runs, in one launch (4 or 8 independent waves per workgroup):
 //   step 1  TRC counts of the first / reversed-last no_bp bases      (allsteps.py:152-204)
 //   step 2  sliding-window k-mer counts S_w of the chosen tail        (allsteps.py:257-297)
 //   step 3  single-split l2 change-point on S_w                      (allsteps.py:300-333)
 //
 // Data flow inside the wave (everything between HBM and the result lives in registers and LDS):
-//   HBM ASCII bases --16 B/lane coalesced loads--> 2-bit packed tile in LDS (seq2)
+//   HBM packed bases (tps_pack.h: 2 bits per base) --one aligned 16-byte quad (64 bases) per lane--> tile in LDS (seq2)
 //   seq2 --k-mer code per position--> LDS lookup table (4^k entries over the pattern list; a pair table
 //          for k <= 4; a perfect hash of the pattern codes for k > 7)
 //   per block of `slide` positions: OR of the masks + running match count
-//   per window: S_w = matches + #patterns absent  (OR over the window's blocks, count differences) -> HBM
+//   per window: S_w = matches + #patterns absent  (OR over the window's blocks, count differences) -> HBM (16-bit)
 //   prefix sums of S_w at the change-point candidates --> arg-max of the split gain (f64 fractions compared by
 //   cross-multiplication, exact 128-bit integer tournament when float64 cannot separate the best).
 //
-// Two block/window code paths share everything else:
-//   * fused (template <S>): slide S in {5..8} known at compile time, <= 15 patterns, k <= 7.  A lane keeps its
-//     8 blocks of the packed read in registers (immediate shifts), publishes two words per block
-//     (suffix-OR | count, prefix-OR | count; conflict-free padded layout) and windows are computed
-//     lane-strided from three LDS reads each (tile_fused_s).
+// Block/window code paths that share everything else:
+//   * default (tile_lc_s, template <S>): slide S in {5..8} known at compile time, <= 15 patterns, k <= 7, sums only.  A lane
+//     keeps its 8 blocks of the packed read in registers (immediate shifts), publishes one word per block (prefix-OR | count)
+//     and computes its OWN 8 windows from registers + one LDS read each; prefix scan in registers; tables with
+//     self-overlapping k-mers count plainly and take the chains' skipped occurrences back (CD).
+//   * per-pattern tiles (tile_pp_s): the exact count of every pattern in every window (raw rows).
+//   * tile_fused_s: the round-1/2 lane-strided tile, kept for tiles with non-ACGT letters and as recount fallback.
 //   * generic: any slide, up to 31 patterns, k up to 15; per-block masks in LDS, q+1 reads per window.
 //
 // The file is written against a tiny portability layer so that the SAME source also builds
