@@ -332,9 +332,25 @@ def main():
     copies = args.resident_copies or max(2, min(hiplib.MAX_SLOTS, -(-(1 << 30) // max(batch_bases, 1))))
     for s in range(copies):
         sc.upload(s, bases, offsets)
+    # several tables per batch (config 5: k = 4, 5, 6): one context per table, all scanning the SAME resident batch at the same
+    # time (the helpers borrow it: tps_batch_share), as batch.scan_jobs runs `--telophrase 4 5 6`;
+    # TOPSICLE_SEQUENTIAL_TABLES=1: back to back on the one context (the A/B switch)
+    concurrent = len(tables) > 1 and os.environ.get("TOPSICLE_SEQUENTIAL_TABLES", "0") != "1"
+    engines = [sc]
+    if concurrent:
+        engines += [sc.helper(j) for j in range(len(tables) - 1)]
+        for eng, t in zip(engines, tables):
+            eng.set_patterns(t)
+            if eng is not sc:
+                for s in range(copies):
+                    eng.share(s, sc, s)
+
+    def sync_all():
+        for eng in engines:
+            eng.sync()
 
     def barrier():
-        sc.sync()
+        sync_all()
         grp.barrier()
 
     # prime every resident copy once (first scan of a slot plans its LDS geometry and allocates result
@@ -345,6 +361,9 @@ def main():
     def step(slot):
         if len(tables) == 1:
             sc.scan(slot, prm)
+        elif concurrent:
+            for eng in engines:                    # one launch per table, each on its own stream: they overlap on the GPU
+                eng.scan(slot, prm)
         else:
             for t in tables:                       # resident tables: switching is a pointer swap in the library
                 sc.set_patterns(t)
@@ -352,19 +371,24 @@ def main():
 
     for s in range(max(int(os.environ.get("TPS_BENCH_PRIME", "256")) // len(tables), 4 * copies)):
         step(s % copies)
-    sc.sync()
+    sync_all()
     for i in range(args.warmup):
         step(i % copies)
     barrier()
-    sc.kernel_time_reset()
+    for eng in engines:
+        eng.kernel_time_reset()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i % copies)
-    sc.sync()                      # device idle: every step's kernel and result copy has finished
+    sync_all()                     # device idle: every step's kernel and result copy has finished
     dt_rank = time.perf_counter() - t0
     dt = grp.max(dt_rank)
     grp.barrier()
-    n_launch, k_total_ms, k_mean_ms = sc.kernel_time_ms()
+    if concurrent:                 # per step: the sum of the overlapping launches' own durations (each stretched by its neighbours)
+        kt = [eng.kernel_time_ms() for eng in engines]
+        n_launch, k_mean_ms = sum(x[0] for x in kt), sum(x[2] for x in kt) / len(tables)
+    else:
+        n_launch, k_total_ms, k_mean_ms = sc.kernel_time_ms()
     per_rank = grp.gather_objects(dict(rank=rank, device=dev, device_info=sc.device_info(), pci=os.environ.get("TPS_BENCH_PCI"),
                                        cpus=len(os.sched_getaffinity(0)), ms_per_step=dt_rank / args.steps * 1e3,
                                        kernel_ms_mean=k_mean_ms * len(tables), kernel_launches_timed=n_launch))
@@ -372,17 +396,18 @@ def main():
     last = (args.steps - 1) % copies
     alg_total = alg1 = alg2 = alg3 = 0
     kinfos = []
-    for t in tables:                               # algorithmic bytes of every table pass of a step (one pass: the usual case)
-        if len(tables) > 1:
+    for j, t in enumerate(tables):                 # algorithmic bytes of every table pass of a step (one pass: the usual case)
+        eng = engines[j] if concurrent else sc
+        if len(tables) > 1 and not concurrent:
             sc.set_patterns(t)
             sc.scan(last, prm)
             sc.sync()
-        res = sc.results(last)
+        res = eng.results(last)
         passed = res["pass"].astype(bool)
         n_win = res["n_win"].astype(np.int64)
         a_t, a_1, a_2, a_3 = algorithmic_bytes(lens, passed, n_win, len(t), prm)
         alg_total += a_t; alg1 += a_1; alg2 += a_2; alg3 += a_3
-        kinfos.append(sc.kernel_info(last))
+        kinfos.append(eng.kernel_info(last))
     kinfo = kinfos[0] if len(kinfos) == 1 else " | ".join(kinfos)
     k_mean_ms *= len(tables)                       # per step: the table passes' kernels together
     scanned = int((2 * np.minimum(lens, prm.no_bp)).sum() + np.maximum(np.minimum(lens, prm.maxlen) - prm.trimfirst, 0)[passed].sum())
@@ -398,7 +423,10 @@ def main():
         # `value`: bases the path can touch per second (= input bases while reads are no longer than maxlengthtelo: configs 1-3;
         # config 4's 30 kb reads have 9 kb nobody looks at); the plain input rate is reported beside it
         value = touched * world * args.steps / dt
-        achieved = alg_total / (k_mean_ms * 1e-3) / 1e9 if k_mean_ms > 0 else 0.0
+        # overlapping launches: the step's wall time bounds them together (their own event durations overlap and would count
+        # the GPU's time more than once); a single launch: its own duration
+        roof_ms = dt / args.steps * 1e3 if concurrent else k_mean_ms
+        achieved = alg_total / (roof_ms * 1e-3) / 1e9 if roof_ms > 0 else 0.0
         traffic, traffic_src = profiled_traffic(args.workload) if not (args.flags or args.n_reads) else (None, None)
         out = {
             "metric": "bases_scanned_per_sec",
@@ -441,11 +469,14 @@ def main():
                 "traffic_source": traffic_src,
                 # physical HBM rate of the same launch (PMC bytes / event time): the fused kernel moves fewer bytes than the
                 # contract's algorithmic count (S_w is consumed from LDS, never re-read), so this is the lower figure
-                "traffic_frac": (traffic / (k_mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and k_mean_ms > 0) else None,
+                "traffic_frac": (traffic / (roof_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and roof_ms > 0) else None,
                 "algorithmic_bytes_per_launch": alg_total,
                 "algorithmic_bytes_split": {"step1": alg1, "windows": alg2, "binseg": alg3},
                 "kernel_ms_mean": k_mean_ms,
                 "kernel_launches_timed": n_launch,
+                "duration_ms": roof_ms,
+                "duration_source": ("wall time of one step: %d launches (one per table) overlapping on %d streams" % (len(tables), len(tables)))
+                                   if concurrent else "HIP events around the launch",
             },
         }
         if not args.no_cpu_baseline and world == 1:        # the CPU baseline leg runs at N = 1 only

@@ -140,6 +140,12 @@ int  tps_batch_upload(tps_ctx* ctx, int32_t slot, const uint8_t* bases, const in
  * slot) has returned; ordinary memory is copied before the call returns. */
 int  tps_batch_upload_packed(tps_ctx* ctx, int32_t slot, const uint32_t* seq2, const uint16_t* inv,
                              const tps_read_desc* desc, int64_t n_reads, int64_t n_words);
+/* Make `slot` of `ctx` refer to the resident packed batch of `src_slot` of ANOTHER context on the same device (no copy; the
+ * batch stays owned by `src`, which must neither upload into that slot nor be destroyed while the borrower may still scan it;
+ * `ctx`'s stream waits for `src`'s pending upload).  Several pattern tables over one batch -- `--telophrase 4 5 6`, the
+ * reference's outer loop over k (Topsicle/main.py:206-235) -- are then scanned by one context per table at the same time:
+ * every context keeps its own table, outputs and stream, the launches overlap on the GPU. */
+int  tps_batch_share(tps_ctx* ctx, int32_t slot, tps_ctx* src, int32_t src_slot);
 /* Pinned host memory for upload staging buffers (double buffering: fill one while the other is in flight). */
 int  tps_host_alloc(tps_ctx* ctx, int64_t bytes, void** out);
 int  tps_host_free(tps_ctx* ctx, void* p);

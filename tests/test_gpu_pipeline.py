@@ -151,3 +151,44 @@ def test_engine_pool_four_contexts_ragged_file(tmp_path):
     finally:
         for e in one + four:
             e.close()
+
+
+def test_tables_scanned_concurrently_equal_back_to_back(sc, monkeypatch):
+    """`--telophrase 4 5 6`: batch.scan_jobs gives every table beyond the first to a helper context that borrows the resident
+    batch (tps_batch_share) and launches all of them at once.  Row for row, window for window and raw count for raw count the
+    answers are those of the same tables scanned back to back on the one context -- batch after batch (the helpers re-borrow
+    a slot the owner has re-uploaded, also after it grew), and against the C oracle for the k = 6 table."""
+    motif, slide = "CCCTAA", 6
+    jobs = [batch.Job(orc.kmer_table(motif, k), _params(motif, slide, hiplib.F_STEP1 | hiplib.F_WINDOWS | hiplib.F_BINSEG),
+                      want_sums=True, want_raw=(k != 5)) for k in (4, 5, 6)]
+    for n, seed in ((600, 5), (1500, 6), (300, 7)):              # the slot grows, then shrinks
+        bases, offsets = _ragged(n, motif, seed)
+        recs = type("B", (), {"bases": bases, "offsets": offsets})()     # (goes up as ASCII: batch.upload_batch)
+        monkeypatch.setenv("TOPSICLE_SEQUENTIAL_TABLES", "1")
+        seq = batch.scan_jobs(sc, recs, jobs)
+        monkeypatch.setenv("TOPSICLE_SEQUENTIAL_TABLES", "0")
+        con = batch.scan_jobs(sc, recs, jobs)
+        assert len(sc._helpers) == 2
+        for j, ((r1, s1, w1, o1), (r2, s2, w2, o2)) in enumerate(zip(seq, con)):
+            for f in r1.dtype.names:
+                assert np.array_equal(r1[f], r2[f]), (n, j, f)
+            assert np.array_equal(o1, o2) and (w1 is None) == (w2 is None), (n, j)
+            keep = np.repeat(r1["pass"].astype(bool), np.diff(o1))       # (windows of reads that fail the filter are never written)
+            assert keep.sum() > 0.5 * len(keep) and np.array_equal(s1[keep], s2[keep]), (n, j)
+            assert w1 is None or np.array_equal(w1[keep], w2[keep]), (n, j)
+        res = con[2][0]
+        out, done, _ = oracle_c.batch(bases, offsets, jobs[2].patterns, len(motif), 1000, 1000, 0.5, 100, slide, 100, 20000,
+                                      both_tails=False, threads=oracle_c.usable_cores())
+        p = res["pass"].astype(bool)
+        assert np.array_equal(res["pass"], out[:, 0]) and np.array_equal(res["bkp"][p], out[p, 5])
+
+
+def test_share_refuses_what_cannot_work(sc):
+    other = hiplib.HipScanner(0)
+    try:
+        with pytest.raises(hiplib.TopsicleHipError, match="another context"):
+            sc.share(0, sc, 1)
+        with pytest.raises(hiplib.TopsicleHipError, match="no batch"):
+            other.share(0, sc, hiplib.MAX_SLOTS - 1)
+    finally:
+        other.close()

@@ -9,6 +9,7 @@ context, two contexts per GPU -- pull batches from ONE shared queue (dynamic bal
 """
 from __future__ import annotations
 
+import os
 import queue
 import threading
 
@@ -54,33 +55,52 @@ def upload_batch(engine, recs, slot: int = 0):
 
 
 def scan_jobs(engine, recs, jobs, slot: int = 0):
-    """Upload once, then one fused scan per job.  Returns [(results, sums, raw, win_off), ...] in job order."""
+    """Upload once, then one fused scan per job.  Returns [(results, sums, raw, win_off), ...] in job order.
+
+    Several jobs (pattern tables) on a HipScanner run AT THE SAME TIME: job j > 0 goes to the engine's j-th helper context,
+    which borrows the resident batch (tps_batch_share) and keeps its own table -- no table switch per batch, and the launches
+    of the k passes overlap on the GPU (measured: 603 vs 785 us per 10 000 x 25 kb batch for k = 4, 5, 6).
+    TOPSICLE_SEQUENTIAL_TABLES=1 scans them back to back on the one context instead (the A/B switch)."""
     out = []
+    concurrent = len(jobs) > 1 and hasattr(engine, "helper") and os.environ.get("TOPSICLE_SEQUENTIAL_TABLES", "0") != "1"
+    engines = [engine] + ([engine.helper(j) for j in range(len(jobs) - 1)] if concurrent else [engine] * (len(jobs) - 1))
     try:
         upload_batch(engine, recs, slot)
-        for n, job in enumerate(jobs):
-            if len(jobs) > 1 or getattr(engine, "patterns", None) != job.patterns:
-                engine.set_patterns(job.patterns)
+        prms = []
+        for job in jobs:
             p = hiplib.Params.from_buffer_copy(job.prm)
             p.flags = job.prm.flags | (hiplib.F_STORE_SUMS if job.want_sums else 0) | (hiplib.F_STORE_RAW if job.want_raw else 0)
-            engine.scan(slot, p)
-            engine.sync()
+            prms.append(p)
+        if concurrent:
+            for eng, job, p in zip(engines, jobs, prms):
+                if eng is not engine:
+                    eng.share(slot, engine, slot)
+                if getattr(eng, "patterns", None) != job.patterns:
+                    eng.set_patterns(job.patterns)
+                eng.scan(slot, p)
+        for n, (eng, job, p) in enumerate(zip(engines, jobs, prms)):
+            if not concurrent:
+                if len(jobs) > 1 or getattr(eng, "patterns", None) != job.patterns:
+                    eng.set_patterns(job.patterns)
+                eng.scan(slot, p)
+            eng.sync()
             if n == 0 and hasattr(recs, "release"):
                 recs.release()             # the upload has completed: the staging buffers go back to the reader
-            res = engine.results(slot)
+            res = eng.results(slot)
             if p.flags & hiplib.F_BINSEG:              # exact ties: ruptures' float64 answer (a handful of reads at most)
-                hiplib.resolve_ties(engine, slot, res, len(job.patterns), p.jump, p.min_size)
+                hiplib.resolve_ties(eng, slot, res, len(job.patterns), p.jump, p.min_size)
             sums = raw = win_off = None
             if job.want_sums:
-                sums, win_off = engine.window_sums(slot)
+                sums, win_off = eng.window_sums(slot)
             if job.want_raw:
-                raw, win_off = engine.window_raw(slot)
+                raw, win_off = eng.window_raw(slot)
             out.append((res, sums, raw, win_off))
     except BaseException:
-        try:
-            engine.sync()                  # an asynchronous upload may still be reading the staging buffers
-        except Exception:
-            pass
+        for eng in dict.fromkeys(engines):
+            try:
+                eng.sync()                 # an asynchronous upload / a borrowed batch may still be in use
+            except Exception:
+                pass
         if hasattr(recs, "release"):
             recs.release()                 # a failed batch must not take its staging buffers with it
         raise

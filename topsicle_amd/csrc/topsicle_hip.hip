@@ -137,7 +137,9 @@ constexpr int INTERNAL_SLOT = TPS_MAX_SLOTS;
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    bool borrowed = false;               // p belongs to another context's slot (tps_batch_share): never freed, never grown here
     int ensure(size_t bytes) {
+        if (borrowed) { p = nullptr; cap = 0; borrowed = false; }
         if (bytes <= cap) return TPS_OK;
         if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
         size_t want = bytes + bytes / 8 + 256;
@@ -145,7 +147,8 @@ struct DevBuf {
         cap = want;
         return TPS_OK;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release() { if (p && !borrowed) (void)hipFree(p); p = nullptr; cap = 0; borrowed = false; }
+    void borrow(const DevBuf& o) { release(); p = o.p; cap = o.cap; borrowed = true; }
 };
 
 struct Slot {
@@ -206,6 +209,7 @@ struct tps_ctx {
     int64_t lds_target_dw = 32 * 256;
     size_t lds_set_v[32] = {0};
     uint32_t* h_flag = nullptr;      // mapped host word the pack kernel raises when a read has a non-ACGT letter
+    hipEvent_t share_ev = nullptr;   // tps_batch_share: orders this context's stream behind the lender's upload
 };
 
 namespace {
@@ -562,6 +566,7 @@ int tps_ctx_destroy(tps_ctx* c) {
         (void)hipHostFree(hp);
     }
     if (c->h_flag) (void)hipHostFree(c->h_flag);
+    if (c->share_ev) (void)hipEventDestroy(c->share_ev);
     c->pinned.clear();
     for (auto& ep : c->ev_pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     (void)hipStreamDestroy(c->stream);
@@ -647,6 +652,31 @@ int tps_batch_upload_packed(tps_ctx* c, int32_t slot, const uint32_t* seq2, cons
     Slot* sl = get_slot(c, slot);
     if (!sl) return TPS_E_ARG;
     return do_upload_packed(c, *sl, seq2, inv, desc, n, n_words);
+}
+
+int tps_batch_share(tps_ctx* c, int32_t slot, tps_ctx* src, int32_t src_slot) {
+    int rc;
+    if ((rc = bind(c))) return rc;
+    if (!src || src == c) return fail(TPS_E_ARG, "the batch must come from another context");
+    if (src->device != c->device) return fail(TPS_E_ARG, "both contexts must be on the same device (%d vs %d)", c->device, src->device);
+    Slot* sl = get_slot(c, slot);
+    Slot* from = get_slot(src, src_slot);
+    if (!sl || !from) return TPS_E_ARG;
+    if (from->n < 0) return fail(TPS_E_STATE, "no batch uploaded in the source slot");
+    // whatever this context still has in flight on the slot's old buffers must be over before they are let go
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    sl->seq2.borrow(from->seq2);
+    sl->inv.borrow(from->inv);
+    sl->desc.borrow(from->desc);
+    sl->h_offsets = from->h_offsets;
+    sl->inv_valid = from->inv_valid;
+    sl->any_invalid = from->any_invalid;
+    reset_slot(*sl, from->n, from->n_words);
+    // the source's upload may still be running on ITS stream: this context's stream waits for it
+    if (!c->share_ev) HIP_TRY(hipEventCreateWithFlags(&c->share_ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(c->share_ev, src->stream));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->share_ev, 0));
+    return TPS_OK;
 }
 
 int tps_host_alloc(tps_ctx* c, int64_t bytes, void** out) {

@@ -20,7 +20,7 @@ MAX_K, MAX_PATTERNS, MAX_SLOTS = 15, 31, 16
 
 EXPORTS = [
     "tps_abi_version", "tps_device_count", "tps_ctx_create", "tps_ctx_destroy", "tps_last_error",
-    "tps_set_patterns", "tps_batch_upload", "tps_batch_upload_packed", "tps_host_alloc", "tps_host_free",
+    "tps_set_patterns", "tps_batch_upload", "tps_batch_upload_packed", "tps_batch_share", "tps_host_alloc", "tps_host_free",
     "tps_batch_download_packed", "tps_batch_kmer_followers", "tps_batch_set_tails", "tps_batch_scan", "tps_sync",
     "tps_batch_results", "tps_batch_window_offsets", "tps_batch_window_sums", "tps_batch_window_raw",
     "tps_batch_trc_counts", "tps_trc_counts", "tps_window_counts", "tps_binseg_l2", "tps_binseg_l2_ties", "tps_batch_read_sums", "tps_window_count",
@@ -82,6 +82,7 @@ def load_library(path: str | None = None) -> C.CDLL:
         "tps_set_patterns": (C.c_int, [vp, C.c_char_p, i32, i32]),
         "tps_batch_upload": (C.c_int, [vp, i32, vp, vp, i64]),
         "tps_batch_upload_packed": (C.c_int, [vp, i32, vp, vp, vp, i64, i64]),
+        "tps_batch_share": (C.c_int, [vp, i32, vp, i32]),
         "tps_host_alloc": (C.c_int, [vp, i64, C.POINTER(vp)]),
         "tps_host_free": (C.c_int, [vp, vp]),
         "tps_batch_download_packed": (C.c_int, [vp, i32, vp, vp, vp, i64, i64, C.POINTER(i64)]),
@@ -190,6 +191,16 @@ class HipScanner:
         self.device = int(device)
         self.patterns: list[str] = []
         self._n = {}
+        self._lib_path = lib_path
+        self._helpers: list["HipScanner"] = []
+
+    def helper(self, j: int) -> "HipScanner":
+        """The j-th helper context on this context's device (made on first use, closed with this one): with several pattern
+        tables per batch (`--telophrase 4 5 6`) every table beyond the first is scanned by a helper that BORROWS this context's
+        resident batch (share) and keeps its own table, outputs and stream -- the k passes overlap on the GPU."""
+        while len(self._helpers) <= j:
+            self._helpers.append(HipScanner(self.device, self._lib_path))
+        return self._helpers[j]
 
     # -- plumbing
     def _err(self) -> str:
@@ -201,6 +212,9 @@ class HipScanner:
             raise TopsicleHipError(f"libtopsicle_hip error {rc}: {self._err()}")
 
     def close(self):
+        for h in getattr(self, "_helpers", []):      # (they borrow this context's batches: they go first)
+            h.close()
+        self._helpers = []
         if getattr(self, "_h", None):
             self.lib.tps_ctx_destroy(self._h)
             self._h = None
@@ -255,6 +269,12 @@ class HipScanner:
         assert inv is None or len(inv) == nw
         self._check(self.lib.tps_batch_upload_packed(self._h, slot, _ptr(seq2), _ptr(inv), _ptr(desc), n, nw))
         self._n[slot] = n
+
+    def share(self, slot: int, src: "HipScanner", src_slot: int):
+        """This context's `slot` = the resident batch of `src`'s `src_slot` (same device, no copy): one context per pattern
+        table scans one batch at the same time (tps_batch_share)."""
+        self._check(self.lib.tps_batch_share(self._h, slot, src._h, src_slot))
+        self._n[slot] = src._n[src_slot]
 
     def host_alloc(self, nbytes: int) -> np.ndarray:
         """Pinned host memory as a uint8 array (freed with the context or by `host_free`)."""
