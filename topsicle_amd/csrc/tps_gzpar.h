@@ -15,6 +15,9 @@
 // cannot run without its window.  No dependency besides zlib.
 #pragma once
 #include <zlib.h>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 #include <algorithm>
 #include <cstdint>
@@ -88,10 +91,21 @@ struct Bits {
     void align_byte() { drop(cnt & 7); }
 };
 
+static const uint16_t LEN_BASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+static const uint8_t LEN_EXTRA[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+static const uint16_t DIST_BASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+static const uint8_t DIST_EXTRA[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+
+// Entries of the FAST tables the symbol loop decodes from (Huff::fast, same indexing as Huff::tab): everything a symbol
+// needs in one word -- bits 0-4 codeword length, bits 8-11 number of extra bits, bits 16-31 the literal / the length base /
+// the distance base; bit 15 literal; bit 14 anything else (bit 13 pointer to a secondary table: bits 8-11 its index bits,
+// bits 16-31 its offset; bit 12 end of block; neither: not a code)
+enum : uint32_t { FE_LIT = 0x8000u, FE_EXC = 0x4000u, FE_SUB = 0x2000u, FE_EOB = 0x1000u };
+
 // Canonical Huffman decoding table: primary table of 2^PB entries, secondary tables for longer codes.
 // entry: bits 0-15 symbol (or secondary table offset), bits 16-19 code length (or secondary index bits), bit 31 = secondary
 struct Huff {
-    std::vector<uint32_t> tab;
+    std::vector<uint32_t> tab, fast;
     int pb = 0;
     bool complete = false, empty = true;
     static uint32_t rev(uint32_t c, int n) {
@@ -156,6 +170,28 @@ struct Huff {
         }
         return true;
     }
+    void make_fast(bool is_dist) {
+        fast.resize(tab.size());
+        for (size_t i = 0; i < tab.size(); ++i) {
+            const uint32_t e = tab[i];
+            uint32_t f = FE_EXC;                                   // not a code
+            if (e & 0x80000000u) {
+                f = FE_EXC | FE_SUB | (((e >> 16) & 15u) << 8) | ((e & 0xFFFFu) << 16);
+            } else if (const uint32_t l = (e >> 16) & 15u) {
+                const uint32_t sym = e & 0xFFFFu;
+                if (is_dist) {
+                    if (sym < 30) f = l | ((uint32_t)DIST_EXTRA[sym] << 8) | ((uint32_t)DIST_BASE[sym] << 16);
+                } else if (sym < 256) {
+                    f = FE_LIT | l | (sym << 16);
+                } else if (sym == 256) {
+                    f = FE_EXC | FE_EOB | l;
+                } else if (sym - 257 < 29) {
+                    f = l | ((uint32_t)LEN_EXTRA[sym - 257] << 8) | ((uint32_t)LEN_BASE[sym - 257] << 16);
+                }
+            }
+            fast[i] = f;
+        }
+    }
     // decoded symbol, or -1 (invalid code)
     inline int decode(Bits& b) const {
         if (b.cnt < 15) b.refill();
@@ -175,10 +211,6 @@ struct Huff {
     }
 };
 
-static const uint16_t LEN_BASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-static const uint8_t LEN_EXTRA[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-static const uint16_t DIST_BASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-static const uint8_t DIST_EXTRA[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 static const uint8_t CL_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 // Header of a dynamic block (the 3 header bits already consumed).  `strict`: what a block-start SEARCH accepts -- complete
@@ -285,7 +317,93 @@ int inflate_blocks(const uint8_t* data, size_t nbytes, uint64_t start, uint64_t 
         } else {
             if (type == 1) fixed_codes(lit, dist);
             else if (!read_dynamic(b, lit, dist, false)) return -1;
-            for (;;) {
+            lit.make_fast(false);
+            dist.make_fast(true);
+            // FAST loop, while 16 input bytes and 1 KB of output space are at hand: one 8-byte refill covers up to three
+            // literals or a whole length / distance pair, every symbol is one table word, matches are copied in 8-byte words
+            bool eob = false;
+            {
+                const uint32_t* LT = lit.fast.data();
+                const uint32_t* DT = dist.fast.data();
+                const int lpb = lit.pb, dpb = dist.pb;
+                const uint64_t lmask = (1ull << lpb) - 1ull, dmask = (1ull << dpb) - 1ull;
+                uint64_t buf = b.buf;
+                int cnt = b.cnt;
+                const uint8_t* ip = b.p;
+                const uint8_t* const ifast = (b.end - b.base) >= 16 ? b.end - 16 : b.base - 0;     // (inputs below 16 bytes: slow loop only)
+                const bool fast_ok = (b.end - b.base) >= 16;
+                constexpr int64_t EW = 8 / (int64_t)sizeof(T);        // elements per 8-byte word
+                int bad = 0;
+#define GZ_REFILL() do { uint64_t w_; memcpy(&w_, ip, 8); buf |= w_ << cnt; ip += (63 - cnt) >> 3; cnt |= 56; } while (0)
+#define GZ_TAKE(nb) do { buf >>= (nb); cnt -= (int)(nb); } while (0)
+                while (fast_ok && ip <= ifast && !b.over) {
+                    if (n + 1024 > cap) need(1024);
+                    GZ_REFILL();
+                    uint32_t e = LT[buf & lmask];
+                    if (e & FE_LIT) {
+                        GZ_TAKE(e & 31u); o[n++] = (T)(e >> 16);
+                        e = LT[buf & lmask];
+                        if (e & FE_LIT) {
+                            GZ_TAKE(e & 31u); o[n++] = (T)(e >> 16);
+                            e = LT[buf & lmask];
+                            if (e & FE_LIT) { GZ_TAKE(e & 31u); o[n++] = (T)(e >> 16); continue; }
+                        }
+                        GZ_REFILL();                               // (the entry in hand stays valid: the low bits did not change)
+                    }
+                    if (e & FE_EXC) {
+                        if (e & FE_SUB) {
+                            e = LT[(e >> 16) + (uint32_t)((buf >> lpb) & ((1ull << ((e >> 8) & 15u)) - 1ull))];
+                            if (e & FE_LIT) { GZ_TAKE(e & 31u); o[n++] = (T)(e >> 16); continue; }
+                        }
+                        if (e & FE_EXC) {
+                            if (e & FE_EOB) { GZ_TAKE(e & 31u); eob = true; break; }
+                            bad = 1;
+                            break;
+                        }
+                    }
+                    const uint32_t lx = (e >> 8) & 15u, ll = e & 31u;
+                    const int ml = (int)((e >> 16) + (uint32_t)((buf >> ll) & ((1ull << lx) - 1ull)));
+                    GZ_TAKE(ll + lx);                              // <= 20 bits: >= 36 are left, a distance takes <= 28
+                    uint32_t f = DT[buf & dmask];
+                    if (f & FE_EXC) {
+                        if (!(f & FE_SUB)) { bad = 1; break; }
+                        f = DT[(f >> 16) + (uint32_t)((buf >> dpb) & ((1ull << ((f >> 8) & 15u)) - 1ull))];
+                        if (f & FE_EXC) { bad = 1; break; }
+                    }
+                    const uint32_t dx = (f >> 8) & 15u, dl = f & 31u;
+                    const int64_t d = (int64_t)((f >> 16) + (uint32_t)((buf >> dl) & ((1ull << dx) - 1ull)));
+                    GZ_TAKE(dl + dx);
+                    const int64_t at = (int64_t)n;
+                    if (d <= at) {
+                        T* dst = o + at;
+                        const T* src = dst - d;
+                        if (d >= EW) {                             // whole words; up to 7 bytes past the match, overwritten by what follows
+                            T* const dend = dst + ml;
+                            do { memcpy(dst, src, 8); dst += EW; src += EW; } while (dst < dend);
+                        } else {
+                            for (int i = 0; i < ml; ++i) dst[i] = src[i];       // short period: element by element, as deflate defines it
+                        }
+                    } else {
+                        if (SPEC ? (d - at > WSIZE) : (d - at > (int64_t)win_len)) { bad = 1; break; }
+                        for (int i = 0; i < ml; ++i) {
+                            const int64_t src = at + i - d;
+                            if (src >= 0) o[at + i] = o[src];
+                            else if (SPEC) o[at + i] = (T)(MARK + (uint16_t)(WSIZE + src));
+                            else o[at + i] = (T)win[(int64_t)win_len + src];
+                        }
+                    }
+                    n += (size_t)ml;
+                }
+#undef GZ_REFILL
+#undef GZ_TAKE
+                if (bad) return -1;
+                // hand the position back: whole bytes only above `cnt` bits may stay in the buffer
+                if (cnt < 0) return -1;
+                b.buf = cnt < 64 ? buf & ((1ull << cnt) - 1ull) : buf;
+                b.cnt = cnt;
+                b.p = ip;
+            }
+            for (; !eob;) {
                 need(300);
                 if (b.cnt < 48) b.refill();                       // one refill per symbol: 15 + 5 + 15 + 13 bits at most
                 int s = lit.decode_nofill(b);
@@ -579,8 +697,26 @@ struct ParGz {
                     const std::vector<uint8_t>& w = mid[j];
                     const int64_t shift = (int64_t)WSIZE - (int64_t)w.size();
                     const size_t ns = c.sym.size();
-                    for (size_t i = 0; i < ns; ++i) {
-                        const uint16_t s = c.sym[i];
+                    const uint16_t* sy = c.sym.data();
+                    size_t i = 0;
+#if defined(__SSE2__)
+                    // markers only occur while a chunk still reaches into the 32 KiB before it: almost every group of 16 symbols
+                    // is 16 plain bytes -- one pack instruction
+                    for (; i + 16 <= ns; i += 16) {
+                        const __m128i a = _mm_loadu_si128((const __m128i*)(sy + i)), b2 = _mm_loadu_si128((const __m128i*)(sy + i + 8));
+                        if (_mm_movemask_epi8(_mm_or_si128(a, b2)) & 0xAAAA) {
+                            for (size_t j = i; j < i + 16; ++j) {
+                                const uint16_t s = sy[j];
+                                const int64_t k = (int64_t)(s - MARK) - shift;
+                                d2[j] = s < MARK ? (uint8_t)s : (k >= 0 ? w[(size_t)k] : 0);
+                            }
+                        } else {
+                            _mm_storeu_si128((__m128i*)(d2 + i), _mm_packus_epi16(a, b2));
+                        }
+                    }
+#endif
+                    for (; i < ns; ++i) {
+                        const uint16_t s = sy[i];
                         if (s < MARK) d2[i] = (uint8_t)s;
                         else {
                             const int64_t k = (int64_t)(s - MARK) - shift;
