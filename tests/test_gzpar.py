@@ -144,3 +144,25 @@ def test_reader_takes_the_parallel_path_for_fastq_gz(tmp_path, text):
     finally:
         del os.environ["TPS_IO_NO_PARGZ"]
     assert ids_z == ids_plain
+
+
+def test_clmul_crc32_equals_zlib():
+    """The carry-less-multiplication CRC-32 the inflater checks members with (tps_gzpar.h: crc32_fast) against zlib.crc32:
+    every length around the 16- and 64-byte folding steps, unaligned starts, chained calls, a long buffer."""
+    lib = seqio._load_io()
+    lib.tps_crc32.restype = C.c_uint32
+    lib.tps_crc32.argtypes = [C.c_uint32, C.c_void_p, C.c_int64]
+    rng = np.random.default_rng(7)
+    buf = rng.integers(0, 256, (3 << 20) + 77, dtype=np.uint8)
+    raw = buf.tobytes()
+    for n in list(range(0, 700)) + [1023, 1024, 1025, 4096 + 15, 65536 + 48, len(raw)]:
+        for off in (0, 1, 3, 13):
+            if off + n > len(raw):
+                continue
+            assert lib.tps_crc32(0, buf.ctypes.data + off, n) == zlib.crc32(raw[off:off + n]), (n, off)
+    c1, c2, pos = 0, 0, 0
+    for n in (5, 300, 64, 1000, 16, 257, 100000, 3):     # chained: the running value goes in and out
+        c1 = lib.tps_crc32(c1, buf.ctypes.data + pos, n)
+        c2 = zlib.crc32(raw[pos:pos + n], c2)
+        pos += n
+        assert c1 == c2

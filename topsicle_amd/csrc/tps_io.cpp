@@ -353,6 +353,10 @@ struct Fast {
         give_spare();
         if (src) {
             delete src;
+            if (mem.capacity()) {                // the text buffer of a compressed file is parked for the next one, like the chunks
+                std::lock_guard<std::mutex> lk(spare_mu());
+                if (spare_mem().capacity() < mem.capacity()) { mem.clear(); spare_mem().swap(mem); }
+            }
         } else if (data) {
             // Unmapping a few hundred MB that 16 threads have touched takes milliseconds (page-table teardown, TLB shootdowns,
             // and the GPU driver's MMU notifier when the process holds a device context: 7 ms for 300 MB on the GPU box, more
@@ -367,8 +371,13 @@ struct Fast {
         }
         if (fd >= 0) close(fd);
     }
+    static gzpar::TextBuf& spare_mem() { static gzpar::TextBuf b; return b; }
     void index_window() {
         if (src) {
+            if (!mem.capacity()) {
+                std::lock_guard<std::mutex> lk(spare_mu());
+                mem.swap(spare_mem());
+            }
             // keep the unconsumed tail (a partial record), inflate the next group of blocks behind it
             const size_t keep = size - pos;
             if (pos) memmove(mem.data(), mem.data() + pos, keep);
@@ -938,6 +947,9 @@ int64_t tps_gz_inflate(const char* path, uint8_t* out, int64_t cap, int32_t thre
     if (!ok) { g_err = "gzip: " + z.err; return -1; }
     return total;
 }
+
+// Test hook: the carry-less-multiplication CRC-32 of tps_gzpar.h (tests compare it with zlib's).
+uint32_t tps_crc32(uint32_t crc, const uint8_t* p, int64_t n) { return (uint32_t)gzpar::crc32_fast((uLong)crc, p, (size_t)(n > 0 ? n : 0)); }
 
 // Writes the records idx[0 .. n) of a packed batch that was read from the mmap'ed plain FASTQ `text` to `fd`, in the layout
 // Biopython's SeqIO.write gives (main.py:83-86): "@" header "\n" sequence "\n+\n" quality "\n".  Nothing is copied in user
