@@ -166,3 +166,22 @@ def test_clmul_crc32_equals_zlib():
         c2 = zlib.crc32(raw[pos:pos + n], c2)
         pos += n
         assert c1 == c2
+
+
+@pytest.mark.parametrize("level", [1, 6, 9])
+def test_short_period_runs(tmp_path, level):
+    """Matches whose distance is below one 8-byte word (periods 1 .. 7 bytes, 1 .. 3 symbols in a speculative chunk): the fast
+    symbol loop copies them as words at a multiple of the period."""
+    rng = np.random.default_rng(level)
+    parts = []
+    for rep in range(400):
+        period = int(rng.integers(1, 12))
+        unit = bytes(rng.integers(65, 70, period, dtype=np.uint8))
+        parts.append(unit * int(rng.integers(1, 3000 // period + 2)))
+        parts.append(bytes(rng.integers(33, 74, int(rng.integers(0, 40)), dtype=np.uint8)))
+    data = b"".join(parts) * 6
+    p = tmp_path / "runs.gz"
+    p.write_bytes(gz_bytes(data, level))
+    for threads, want in ((1, 0), (4, 1 << 16), (8, 1 << 18)):
+        text, _ = inflate(p, threads=threads, want=want)
+        assert text == data

@@ -461,7 +461,12 @@ int inflate_blocks(const uint8_t* data, size_t nbytes, uint64_t start, uint64_t 
                             T* const dend = dst + ml;
                             do { memcpy(dst, src, 8); dst += EW; src += EW; } while (dst < dend);
                         } else {
-                            for (int i = 0; i < ml; ++i) dst[i] = src[i];       // short period: element by element, as deflate defines it
+                            // short period (runs: a quality line of one letter is a chain of 258-byte matches at distance 1):
+                            // element by element up to a multiple of the period that is at least a word, whole words from there
+                            const int64_t dd = d * ((EW + d - 1) / d);
+                            int i = 0;
+                            for (; i < ml && i < dd; ++i) dst[i] = src[i];
+                            for (; i < ml; i += (int)EW) memcpy(dst + i, dst + i - dd, 8);
                         }
                     } else {
                         if (SPEC ? (d - at > WSIZE) : (d - at > (int64_t)win_len)) { bad = 1; break; }
