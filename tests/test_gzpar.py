@@ -174,14 +174,17 @@ def test_short_period_runs(tmp_path, level):
     symbol loop copies them as words at a multiple of the period."""
     rng = np.random.default_rng(level)
     parts = []
-    for rep in range(400):
+    for rep in range(3000):
         period = int(rng.integers(1, 12))
         unit = bytes(rng.integers(65, 70, period, dtype=np.uint8))
         parts.append(unit * int(rng.integers(1, 3000 // period + 2)))
-        parts.append(bytes(rng.integers(33, 74, int(rng.integers(0, 40)), dtype=np.uint8)))
-    data = b"".join(parts) * 6
+        parts.append(bytes(rng.integers(33, 127, int(rng.integers(0, 1200)), dtype=np.uint8)))   # (noise: the compressed file is large enough to be cut)
+    data = b"".join(parts)
     p = tmp_path / "runs.gz"
     p.write_bytes(gz_bytes(data, level))
+    spec = 0
     for threads, want in ((1, 0), (4, 1 << 16), (8, 1 << 18)):
-        text, _ = inflate(p, threads=threads, want=want)
+        text, stats = inflate(p, threads=threads, want=want)
         assert text == data
+        spec += int(stats[1])
+    assert spec > 0                                      # speculative chunks (16-bit symbols) took part
