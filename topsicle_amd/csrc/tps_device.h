@@ -164,12 +164,24 @@ TPS_DEV uint32_t bitrev32(uint32_t x) { return __builtin_bitreverse32(x); }     
 // mask + base fold into one v_and_or_b32.
 #ifdef TPS_EMU
 TPS_DEV uint32_t lut_at(const uint32_t* lut, uint32_t v4, uint32_t amask) { return *(const uint32_t*)((const char*)lut + (v4 & amask)); }
+#define lut_at_tile lut_at
 #else
 TPS_DEV uint32_t lut_at(const uint32_t* lut, uint32_t v4, uint32_t amask) {
     typedef const __attribute__((address_space(3))) uint32_t* lptr_t;
     const uint32_t base = (uint32_t)(uintptr_t)(lptr_t)lut;
     return *(lptr_t)(uintptr_t)((v4 & amask) | base);
 }
+#ifdef TPS_DIAG_NOCONF
+/* diagnostic builds only (WRONG window sums, same control flow): the default tile's table gathers with every lane on its own
+   bank -- what do the gathers' bank conflicts cost? */
+TPS_DEV uint32_t lut_at_tile(const uint32_t* lut, uint32_t v4, uint32_t amask) {
+    typedef const __attribute__((address_space(3))) uint32_t* lptr_t;
+    const uint32_t base = (uint32_t)(uintptr_t)(lptr_t)lut;
+    return *(lptr_t)(uintptr_t)((((v4 & amask) >> 30) | ((threadIdx.x & 63u) << 2)) | base);
+}
+#else
+#define lut_at_tile lut_at
+#endif
 #endif
 
 // 16-bit candidate sums kept off-chip: explicit global address space (a generic pointer would become FLAT
@@ -1783,8 +1795,8 @@ TPS_DEV void tile_lc_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
             uint32_t hc[NH], hn[NH];
             auto fetch = [&](int blk, uint32_t* hh) {
                 TPS_UNROLL
-                for (int j = 0; j < NP; ++j) hh[j] = lut_at(l.lut2, v4_at(blk * S + 2 * j), amask2);
-                if (S & 1) hh[NP] = lut_at(l.lut, v4_at(blk * S + S - 1), amask);
+                for (int j = 0; j < NP; ++j) hh[j] = lut_at_tile(l.lut2, v4_at(blk * S + 2 * j), amask2);
+                if (S & 1) hh[NP] = lut_at_tile(l.lut, v4_at(blk * S + S - 1), amask);
             };
             fetch(0, hc);
             TPS_UNROLL
