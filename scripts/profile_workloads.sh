@@ -1,15 +1,17 @@
 #!/bin/bash
 # rocprofv3 evidence for the non-default kernels: per workload (and scan flags) one --kernel-trace --stats run and one
 # FETCH_SIZE / WRITE_SIZE PMC pass each (separate runs, as MI355X_MICROARCH.md prescribes).
-# usage: scripts/profile_workloads.sh <tag> "<workload>[:flags] ..."      -> gpurun_out/profw_<tag>/<workload>_f<flags>/
+# usage: scripts/profile_workloads.sh <tag> "<workload>[@seq][:flags] ..."      -> gpurun_out/profw_<tag>/<workload>[_seq]_f<flags>/
+# (@seq: TOPSICLE_SEQUENTIAL_TABLES=1 -- config 5's three table passes back to back on one stream instead of overlapping)
 set -u
 TAG=${1:-r02}
-LIST=${2:-"config3_per_gpu config4_sample config5_k4:31 config5_k5 config5_k5:31 config5_k6 config5_k6:31 config5"}
+LIST=${2:-"config3_per_gpu config4_sample config5_k4:31 config5_k5 config5_k5:31 config5_k6 config5_k6:31 config5 config5@seq"}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 for item in $LIST; do
   W=${item%%:*}; F=0; [[ "$item" == *:* ]] && F=${item##*:}
-  OUT=$ROOT/gpurun_out/profw_$TAG/${W}_f$F
+  SEQ=""; if [[ "$W" == *@seq ]]; then W=${W%@seq}; SEQ="_seq"; export TOPSICLE_SEQUENTIAL_TABLES=1; else unset TOPSICLE_SEQUENTIAL_TABLES; fi
+  OUT=$ROOT/gpurun_out/profw_$TAG/${W}${SEQ}_f$F
   rm -rf $OUT; mkdir -p $OUT
   FL=""; [ "$F" != "0" ] && FL="--flags $F"
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 400 --warmup 3 --no-cpu-baseline --no-e2e --workload $W $FL > $OUT/bench.json 2> $OUT/trace.err
