@@ -1,10 +1,7 @@
 """The native FASTA/FASTQ(.gz) batch decoder (csrc/tps_io.cpp) yields exactly the records of the
 pure-Python parser, in batches that respect the size limits."""
 import gzip
-import io
 import os
-import subprocess
-import sys
 
 import numpy as np
 import pytest
@@ -317,42 +314,6 @@ def test_packed_batch_writes_records_like_biopython(tmp_path, gold_dir):
                 pb.write_records(h, [i - n for i in pick if n <= i < n + pb.n], "fastq")
                 n += pb.n
         assert outp.read_bytes().decode() == want.getvalue(), (path, pick)
-
-
-def test_native_writer_large_batch_is_written_in_parallel(tmp_path):
-    """A batch of passing records above 16 MB leaves through several pwritev threads at their own file offsets (the byte
-    ranges cut iovecs in two): byte for byte what the one-thread writer gives, the handle left at the end of what was written,
-    text written before and after in place -- verbatim records, records whose '+' line repeats the name, and a subset."""
-    rng = np.random.default_rng(11)
-    fq = tmp_path / "big.fastq"
-    n, L = 1800, 6000
-    with open(fq, "wb") as h:
-        for i in range(n):
-            s = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), L))
-            q = bytes(rng.integers(35, 74, L, dtype=np.uint8))
-            plus = b"+r%d" % i if i % 7 == 3 else b"+"               # (not SeqIO.write's layout: re-assembled piece by piece)
-            h.write(b"@r%d text\n" % i + s + b"\n" + plus + b"\n" + q + b"\n")
-    pick = [i for i in range(n) if i % 11 != 5]
-    outs = {}
-    for threads in ("1", "4", "7"):
-        code = ("import os, sys; sys.path.insert(0, %r); os.environ['TPS_IO_WRITE_THREADS'] = %r\n"
-                "from topsicle_amd import seqio\n"
-                "pick = set(%r)\n"
-                "with open(%r, 'wb') as h:\n"
-                "    h.write(b'HEAD\\n'); n = 0\n"
-                "    for pb in seqio.read_batches_packed(%r, seqio.BufferPool(2, 4 << 20, 8192)):\n"
-                "        pb.release(); pb.write_records(h, [i - n for i in range(n, n + pb.n) if i in pick], 'fastq'); n += pb.n\n"
-                "        h.write(b'MARK%%d\\n' %% n)\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), threads, pick,
-                                                       str(tmp_path / ("out%s.fastq" % threads)), str(fq))
-        subprocess.run([sys.executable, "-c", code], check=True)
-        outs[threads] = (tmp_path / ("out%s.fastq" % threads)).read_bytes()
-    assert len(outs["1"]) > (16 << 20) and outs["1"].startswith(b"HEAD\n@r0 text\n") and outs["1"].endswith(b"MARK%d\n" % n)
-    assert outs["4"] == outs["1"] and outs["7"] == outs["1"]
-    recs = list(seqio.read_records(str(fq)))
-    want = io.StringIO()
-    for i in pick[:40]:
-        seqio.write_record(want, recs[i], "fastq")
-    assert outs["1"][5:5 + len(want.getvalue())].decode() == want.getvalue()
 
 
 def test_engine_pool_keeps_input_order_with_several_contexts(tmp_path):

@@ -962,19 +962,19 @@ int64_t tps_write_fastq_spans(int fd, const char* text, int64_t text_len, const 
     static const char at = '@', nl = '\n', plus[3] = {'\n', '+', '\n'};
     std::vector<struct iovec> iov;
     iov.reserve(1024);
-    // writes iov[a .. b) at file offset `off` (off < 0: at the descriptor's position); false + g_err on failure
-    auto write_range = [&](size_t a, size_t b, int64_t off) -> bool {
-        std::vector<struct iovec> v(iov.begin() + (ptrdiff_t)a, iov.begin() + (ptrdiff_t)b);
+    int64_t total = 0;
+    auto flush = [&]() -> bool {
         size_t first = 0;
-        while (first < v.size()) {
-            const int cnt = (int)std::min<size_t>(v.size() - first, 1024);
-            const ssize_t w = off < 0 ? writev(fd, v.data() + first, cnt) : pwritev(fd, v.data() + first, cnt, (off_t)off);
+        while (first < iov.size()) {
+            const int cnt = (int)std::min<size_t>(iov.size() - first, 1024);
+            ssize_t w = writev(fd, iov.data() + first, cnt);
             if (w < 0) { if (errno == EINTR) continue; g_err = std::string("writev: ") + strerror(errno); return false; }
-            if (off >= 0) off += w;
+            total += w;
             size_t left = (size_t)w;                               // partial writes: advance inside the vector
-            while (first < v.size() && left >= v[first].iov_len) { left -= v[first].iov_len; ++first; }
-            if (left) { v[first].iov_base = (char*)v[first].iov_base + left; v[first].iov_len -= left; }
+            while (first < iov.size() && left >= iov[first].iov_len) { left -= iov[first].iov_len; ++first; }
+            if (left) { iov[first].iov_base = (char*)iov[first].iov_base + left; iov[first].iov_len -= left; }
         }
+        iov.clear();
         return true;
     };
     auto push = [&](const char* p, size_t len) {
@@ -982,7 +982,6 @@ int64_t tps_write_fastq_spans(int fd, const char* text, int64_t text_len, const 
         if (!iov.empty() && (const char*)iov.back().iov_base + iov.back().iov_len == p) { iov.back().iov_len += len; return; }
         iov.push_back({(void*)p, len});
     };
-    int64_t total = 0;
     for (int64_t j = 0; j < n; ++j) {
         const int64_t i = idx[j];
         const int64_t h0 = spans[4 * i], hl = spans[4 * i + 1], s0 = spans[4 * i + 2], q0 = spans[4 * i + 3], sl = lens[i];
@@ -992,54 +991,13 @@ int64_t tps_write_fastq_spans(int fd, const char* text, int64_t text_len, const 
                               memcmp(text + s0 + sl, plus, 3) == 0 && text[q0 + sl] == '\n';
         if (verbatim) {
             push(text + h0 - 1, (size_t)(q0 + sl + 1 - (h0 - 1)));
-            total += q0 + sl + 1 - (h0 - 1);
         } else {
             push(&at, 1); push(text + h0, (size_t)hl); push(&nl, 1); push(text + s0, (size_t)sl);
             push(plus, 3); push(text + q0, (size_t)sl); push(&nl, 1);
-            total += 2 * sl + hl + 6;
         }
+        if (iov.size() > 1000 && !flush()) return -1;
     }
-    // A large write (a batch of passing records is tens to hundreds of MB) is a copy into the page cache at one core's memcpy rate:
-    // on a seekable file it is cut into byte ranges that a few threads write with pwritev at their own offsets
-    // (TPS_IO_WRITE_THREADS, default 4; 1 = the plain writev)
-    static const int wthreads = [] { const char* e = getenv("TPS_IO_WRITE_THREADS"); const int t = e ? atoi(e) : 4; return std::max(1, std::min(t, 16)); }();
-    off_t base = -1;
-    if (wthreads > 1 && total >= ((int64_t)16 << 20)) {
-        const int fl = fcntl(fd, F_GETFL);
-        if (fl >= 0 && !(fl & O_APPEND)) base = lseek(fd, 0, SEEK_CUR);
-    }
-    if (base < 0) return write_range(0, iov.size(), -1) ? total : -1;
-    // split the vector at byte boundaries total * t / T (an iovec that straddles one is cut in two)
-    const int T = wthreads;
-    std::vector<size_t> cut((size_t)T + 1, 0);
-    {
-        std::vector<struct iovec> v2;
-        v2.reserve(iov.size() + (size_t)T);
-        int64_t acc = 0;
-        int t = 1;
-        for (const struct iovec& e : iov) {
-            const char* p = (const char*)e.iov_base;
-            size_t len = e.iov_len;
-            while (t < T && acc + (int64_t)len > total * t / T) {
-                const size_t head = (size_t)(total * t / T - acc);
-                if (head) { v2.push_back({(void*)p, head}); p += head; len -= head; acc += (int64_t)head; }
-                cut[(size_t)t++] = v2.size();
-            }
-            if (len) { v2.push_back({(void*)p, len}); acc += (int64_t)len; }
-        }
-        while (t <= T) cut[(size_t)t++] = v2.size();
-        iov.swap(v2);
-    }
-    std::vector<std::string> errs((size_t)T);
-    std::vector<char> ok((size_t)T, 1);
-    std::vector<std::thread> th;
-    for (int t = 1; t < T; ++t)
-        th.emplace_back([&, t] { if (!write_range(cut[(size_t)t], cut[(size_t)t + 1], (int64_t)base + total * t / T)) { ok[(size_t)t] = 0; errs[(size_t)t] = g_err; } });
-    if (!write_range(cut[0], cut[1], (int64_t)base)) { ok[0] = 0; errs[0] = g_err; }
-    for (auto& x : th) x.join();
-    for (int t = 0; t < T; ++t)
-        if (!ok[(size_t)t]) { g_err = errs[(size_t)t]; return -1; }
-    if (lseek(fd, base + (off_t)total, SEEK_SET) < 0) { g_err = std::string("lseek: ") + strerror(errno); return -1; }
+    if (!flush()) return -1;
     return total;
 }
 
