@@ -20,6 +20,21 @@ class EmuEngine:
     def close(self):
         pass
 
+    # -- several pattern tables over one batch (HipScanner.helper / share): one emulated context per table
+    def helper(self, j):
+        hs = self.__dict__.setdefault("_helpers", [])
+        while len(hs) <= j:
+            hs.append(EmuEngine())
+        return hs[j]
+
+    def share(self, slot, src, src_slot):
+        if src is self:
+            raise hiplib.TopsicleHipError("the batch must come from another context")
+        if src_slot not in src.slots:
+            raise hiplib.TopsicleHipError("no batch uploaded in the source slot")
+        s = src.slots[src_slot]
+        self.slots[slot] = dict(bases=s["bases"], offsets=s["offsets"], tails=None, out=None)     # (borrowed: the same arrays)
+
     def set_patterns(self, patterns):
         k = len(patterns[0])
         if k > hiplib.MAX_K or len(patterns) > hiplib.MAX_PATTERNS or any(set(p.upper()) - set("ACGT") for p in patterns):

@@ -236,3 +236,31 @@ def test_cli_fasta_input_several_k_keeps_the_first_k_records(engine, tmp_path, d
         outs[tag] = open(out / "reads_trc_over_0.3.fasta").read()
     assert outs["k4"] != outs["k6"]                     # (the two tables pass different reads at this cutoff)
     assert outs["both"] == outs["k4"]
+
+
+def test_scan_jobs_tables_on_helper_contexts_equal_back_to_back(monkeypatch):
+    """batch.scan_jobs with several pattern tables: job j > 0 runs on the engine's j-th helper context, which borrows the batch
+    (share) and keeps its own table -- the host logic of `--telophrase 4 5 6`, here on emulated contexts: the same rows, sums
+    and raw counts as the tables back to back on the one context (TOPSICLE_SEQUENTIAL_TABLES=1), batch after batch."""
+    from emu_engine import EmuEngine
+    import topsicle_oracle as orc
+    from topsicle_amd import batch, hiplib, synth
+    eng = EmuEngine()
+    prm = hiplib.make_params(no_bp=300, min_len=500, min_count=3, window=100, slide=6, trimfirst=100, maxlen=20000,
+                             flags=hiplib.F_STEP1 | hiplib.F_WINDOWS | hiplib.F_BINSEG)
+    jobs = [batch.Job(orc.kmer_table("CCCTAA", k), prm, want_sums=True, want_raw=(k == 5)) for k in (4, 5, 6)]
+    for seed, n in ((1, 7), (2, 12)):
+        bases, offsets, _ = synth.make_reads(n, 2500, "CCCTAA", seed=seed, errors=synth.ONT, tract_min=300, tract_max=1800)
+        recs = type("B", (), {"bases": bases, "offsets": offsets})()
+        monkeypatch.setenv("TOPSICLE_SEQUENTIAL_TABLES", "1")
+        seq = batch.scan_jobs(eng, recs, jobs)
+        monkeypatch.delenv("TOPSICLE_SEQUENTIAL_TABLES")
+        con = batch.scan_jobs(eng, recs, jobs)
+        assert len(eng._helpers) == 2 and [h.patterns for h in eng._helpers] == [jobs[1].patterns, jobs[2].patterns]
+        assert eng.patterns == jobs[0].patterns                          # (the owner keeps the first table: no switch per batch)
+        for (r1, s1, w1, o1), (r2, s2, w2, o2) in zip(seq, con):
+            for f in ("pass", "tail", "best_start", "best_end", "n_win", "bkp"):
+                assert np.array_equal(r1[f], r2[f]), f
+            assert np.array_equal(o1, o2) and np.array_equal(s1, s2)
+            assert (w1 is None) == (w2 is None) and (w1 is None or np.array_equal(w1, w2))
+        assert con[0][0]["pass"].sum() > 0
