@@ -324,3 +324,35 @@ def test_bench_ranks_on_the_other_workloads(workload, extra):
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert out["n_gpus"] == 2 and len(out["ranks"]) == 2 and out["value"] > 0
     assert all(x["kernel_ms_mean"] > 0 for x in out["ranks"])
+
+
+def test_bench_eight_ranks_through_the_drivers_launcher():
+    """The driver's own N = 8 command -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1
+    ... bench.py --gpus 8` -- on this box's ONE GPU (TPS_BENCH_SHARE_GPU=1: the ranks wrap around the visible devices): the
+    eight-rank gloo rendezvous, the barrier-bracketed timing, the max over ranks and the one JSON line with all eight ranks'
+    own numbers.  (What eight GPUs give is the driver's to measure; that the command runs is checked here.)"""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, TPS_BENCH_PRIME="8", TPS_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "2",
+                        "--resident-copies", "2"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                       # rank 0 prints, once
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["steps"] == 20 and out["warmup"] == 2 and out["scaling"] == "weak"
+    assert sorted(x["rank"] for x in out["ranks"]) == list(range(8))
+    assert all(x["kernel_ms_mean"] > 0 and x["ms_per_step"] > 0 for x in out["ranks"])
+    assert abs(out["ms_per_step"] - max(x["ms_per_step"] for x in out["ranks"])) < 1e-9      # the MAX over ranks
+    assert "cpu_baseline" not in out and "e2e" not in out        # N = 1 legs only
+    # whole-job value: eight ranks' batches over the slowest rank's time
+    per_step = out["config"]["reads_per_step_per_gpu"] * out["config"]["read_len"]
+    assert out["input_bases_per_sec"] == pytest.approx(8 * per_step / (out["ms_per_step"] * 1e-3), rel=0.02)
