@@ -686,9 +686,12 @@ struct ParGz {
         }
         const uint64_t file_bits = (uint64_t)size * 8u;
         const size_t max_out = cs * 1100 + (1u << 20);            // deflate cannot expand more than 1032 x
+        std::vector<double> t_chunk(timing ? nc : 0, 0.0), t_find(timing ? nc : 0, 0.0);
         auto work = [&](int t, int nt) {
             for (size_t j = (size_t)t; j < nc; j += (size_t)nt) {
                 Chunk& c = ch[j];
+                const double tc0 = timing ? now() : 0.0;
+                struct Fin { std::vector<double>& v; size_t j; double t0; bool on; ~Fin() { if (on) v[j] = now() - t0; } } fin{t_chunk, j, tc0, timing};
                 const uint64_t stop = j + 1 < nc ? ch[j + 1].cut : std::min<uint64_t>(file_bits, c.cut + (uint64_t)cs * 8u);
                 if (j == 0) {
                     c.start = bit;
@@ -696,6 +699,7 @@ struct ParGz {
                     c.rc = inflate_blocks<false>(data, size, bit, stop, win.data(), win.size(), c.bytes, c.end, max_out);
                 } else {
                     c.start = find_block(data, size, c.cut, stop);
+                    if (timing) t_find[j] = now() - tc0;
                     if (c.start == ~0ull) { c.rc = -1; continue; }
                     c.sym.reserve((size_t)((double)cs * ratio * 1.3) + 4096);
                     c.rc = inflate_blocks<true>(data, size, c.start, stop, nullptr, 0, c.sym, c.end, max_out);
@@ -831,6 +835,11 @@ struct ParGz {
         const double t2 = timing ? now() : 0.0;
         if (team && used > 1) team((int)std::min<size_t>(used, (size_t)T), resolve);
         else resolve(0, 1);
+        if (timing && nc > 1) {
+            double mn = 1e9, mx = 0, sum = 0, fsum = 0;
+            for (size_t j = 0; j < nc; ++j) { mn = std::min(mn, t_chunk[j]); mx = std::max(mx, t_chunk[j]); sum += t_chunk[j]; fsum += t_find[j]; }
+            fprintf(stderr, "[gzpar] chunks: decode min %.1f / mean %.1f / max %.1f ms, block search mean %.2f ms\n", 1e3 * mn, 1e3 * sum / (double)nc, 1e3 * mx, 1e3 * fsum / (double)nc);
+        }
         if (timing) fprintf(stderr, "[gzpar] round: %zu chunks of %zu KB, inflate %.1f ms, stitch %.1f ms, resolve+crc %.1f ms, %zu MB text, %llu gaps so far\n", nc, cs >> 10,
                             1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (now() - t2), total >> 20, (unsigned long long)n_gap);
         // a marker below the start of the known history would be a reference before the member's first byte
