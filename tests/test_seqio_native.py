@@ -1,7 +1,6 @@
 """The native FASTA/FASTQ(.gz) batch decoder (csrc/tps_io.cpp) yields exactly the records of the
 pure-Python parser, in batches that respect the size limits."""
 import gzip
-import io
 import os
 
 import numpy as np
@@ -315,43 +314,6 @@ def test_packed_batch_writes_records_like_biopython(tmp_path, gold_dir):
                 pb.write_records(h, [i - n for i in pick if n <= i < n + pb.n], "fastq")
                 n += pb.n
         assert outp.read_bytes().decode() == want.getvalue(), (path, pick)
-
-
-def test_native_writer_long_runs_leave_through_copy_file_range(tmp_path, monkeypatch):
-    """Long runs of records that are written as they stand in the input go from the input file to the output file inside the
-    kernel (copy_file_range), the pieces in between through writev: byte for byte what the writev-only writer gives and what
-    the record-by-record Python writer gives -- runs of verbatim records, records whose '+' line repeats the name (re-assembled),
-    skipped records, text written before and after through the same handle."""
-    rng = np.random.default_rng(11)
-    fq = tmp_path / "big.fastq"
-    n, L = 1500, 5000
-    with open(fq, "wb") as h:
-        for i in range(n):
-            s = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), L))
-            q = bytes(rng.integers(35, 74, L, dtype=np.uint8))
-            plus = b"+r%d" % i if i % 211 == 3 else b"+"               # (not SeqIO.write's layout: re-assembled piece by piece)
-            h.write(b"@r%d text\n" % i + s + b"\n" + plus + b"\n" + q + b"\n")
-    pick = set(i for i in range(n) if i % 97 != 5 and not 700 <= i < 720)
-    outs = {}
-    for mode in ("cfr", "writev"):
-        monkeypatch.setenv("TPS_IO_NO_COPY_FILE_RANGE", "1" if mode == "writev" else "0")
-        outp = tmp_path / ("out_%s.fastq" % mode)
-        with open(outp, "wb") as h:
-            h.write(b"HEAD\n")
-            k = 0
-            for pb in seqio.read_batches_packed(str(fq), seqio.BufferPool(2, 4 << 20, 8192)):
-                pb.release()
-                pb.write_records(h, [i - k for i in range(k, k + pb.n) if i in pick], "fastq")
-                k += pb.n
-                h.write(b"MARK%d\n" % k)
-        outs[mode] = outp.read_bytes()
-    assert len(outs["cfr"]) > (12 << 20) and outs["cfr"] == outs["writev"]
-    assert outs["cfr"].startswith(b"HEAD\n@r0 text\n") and outs["cfr"].endswith(b"MARK%d\n" % n)
-    recs = list(seqio.read_records(str(fq)))
-    want = io.StringIO()
-    for i in sorted(pick):
-        seqio.write_record(want, recs[i], "fastq")
-    assert outs["cfr"][5:-len(b"MARK%d\n" % n)].decode() == want.getvalue()
 
 
 def test_engine_pool_keeps_input_order_with_several_contexts(tmp_path):

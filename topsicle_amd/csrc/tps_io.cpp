@@ -957,13 +957,12 @@ uint32_t tps_crc32(uint32_t crc, const uint8_t* p, int64_t n) { return (uint32_t
 // quality offset; lens: bases per record), a record whose text already has that layout is one iovec, and neighbouring
 // records that are neighbours in the file merge into one.  Replaces the per-record Python loop of the round-2 writer
 // (0.1 s per 300 MB, the largest part of the CLI's per-read time).  Returns the bytes written or -1.
-int64_t tps_write_fastq_spans(int fd, int src_fd, const char* text, int64_t text_len, const int64_t* spans, const int32_t* lens, const int64_t* idx, int64_t n) {
+int64_t tps_write_fastq_spans(int fd, const char* text, int64_t text_len, const int64_t* spans, const int32_t* lens, const int64_t* idx, int64_t n) {
     if (fd < 0 || !text || !spans || !lens || (n > 0 && !idx)) { g_err = "null argument"; return -1; }
     static const char at = '@', nl = '\n', plus[3] = {'\n', '+', '\n'};
     std::vector<struct iovec> iov;
     iov.reserve(1024);
     int64_t total = 0;
-    bool cfr_ok = src_fd >= 0;                       // copy_file_range works between these two files (until it says otherwise)
     auto flush = [&]() -> bool {
         size_t first = 0;
         while (first < iov.size()) {
@@ -978,38 +977,9 @@ int64_t tps_write_fastq_spans(int fd, int src_fd, const char* text, int64_t text
         iov.clear();
         return true;
     };
-    // A long run of records that leave as they stand in the input (src_fd = the mmap'ed input file, text[0] = its byte 0) is
-    // copied INSIDE the kernel, page cache to page cache (copy_file_range: 9.4 GB/s on the GPU box against 4.3 GB/s for a
-    // write() from the mapping, which also walks the mapping's page tables); everything else goes through writev as before
-    auto flush_all = [&]() -> bool {
-        if (cfr_ok && !iov.empty() && iov.back().iov_len >= ((size_t)1 << 20) && (const char*)iov.back().iov_base >= text &&
-            (const char*)iov.back().iov_base + iov.back().iov_len <= text + text_len) {
-            const struct iovec big = iov.back();
-            iov.pop_back();
-            if (!flush()) return false;
-            off_t off_in = (off_t)((const char*)big.iov_base - text);
-            size_t left = big.iov_len;
-            while (left) {
-                const ssize_t w = copy_file_range(src_fd, &off_in, fd, nullptr, left, 0);
-                if (w <= 0) {
-                    if (w < 0 && errno == EINTR) continue;
-                    cfr_ok = false;                  // other file system, old kernel, ...: the rest the ordinary way
-                    iov.push_back({(void*)(text + off_in), left});
-                    return flush();
-                }
-                total += w;
-                left -= (size_t)w;
-            }
-            return true;
-        }
-        return flush();
-    };
-    bool failed = false;
     auto push = [&](const char* p, size_t len) {
-        if (!len || failed) return;
+        if (!len) return;
         if (!iov.empty() && (const char*)iov.back().iov_base + iov.back().iov_len == p) { iov.back().iov_len += len; return; }
-        // (the piece in front is complete now: a long run of input text leaves through copy_file_range at once)
-        if (cfr_ok && !iov.empty() && iov.back().iov_len >= ((size_t)1 << 20) && !flush_all()) { failed = true; return; }
         iov.push_back({(void*)p, len});
     };
     for (int64_t j = 0; j < n; ++j) {
@@ -1025,10 +995,9 @@ int64_t tps_write_fastq_spans(int fd, int src_fd, const char* text, int64_t text
             push(&at, 1); push(text + h0, (size_t)hl); push(&nl, 1); push(text + s0, (size_t)sl);
             push(plus, 3); push(text + q0, (size_t)sl); push(&nl, 1);
         }
-        if (failed) return -1;
         if (iov.size() > 1000 && !flush()) return -1;
     }
-    if (!flush_all()) return -1;
+    if (!flush()) return -1;
     return total;
 }
 

@@ -9,7 +9,6 @@ from __future__ import annotations
 import gzip
 import io
 import logging
-import os
 from dataclasses import dataclass
 
 
@@ -204,7 +203,7 @@ def _load_io():
         lib.tps_packed_words_total.restype = C.c_int64
         lib.tps_packed_words_total.argtypes = [C.c_void_p, C.c_int64]
         lib.tps_write_fastq_spans.restype = C.c_int64
-        lib.tps_write_fastq_spans.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+        lib.tps_write_fastq_spans.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
         _io_lib = lib
     return _io_lib or None
 
@@ -348,8 +347,7 @@ class PackedBatch:
     """A batch of reads in the packed upload format, plus what is needed to write single records back out: either the
     records' spans in the mmap'ed input file (plain FASTQ, nothing was copied) or the ASCII RecordBatch it was packed from."""
 
-    def __init__(self, seq2, inv, desc, heads, head_off, fmt, spans=None, text=None, ascii_batch=None, bufset=None, pool=None, text_fh=None):
-        self.text_fh = text_fh                          # the open input file `text` maps (kept open as long as a batch refers to it)
+    def __init__(self, seq2, inv, desc, heads, head_off, fmt, spans=None, text=None, ascii_batch=None, bufset=None, pool=None):
         self.seq2, self.inv, self.desc, self.heads, self.head_off, self.fmt = seq2, inv, desc, heads, head_off, fmt
         self.spans, self.text, self.ascii_batch = spans, text, ascii_batch
         self.n = len(desc)
@@ -421,13 +419,7 @@ class PackedBatch:
                 idx = np.ascontiguousarray(indices, dtype=np.int64)
                 lens = np.ascontiguousarray(self.desc["len"], dtype=np.int32)
                 spans = np.ascontiguousarray(self.spans, dtype=np.int64)
-                src_fd = -1
-                if self.text_fh is not None and os.environ.get("TPS_IO_NO_COPY_FILE_RANGE", "0") != "1":
-                    try:
-                        src_fd = self.text_fh.fileno()
-                    except (OSError, ValueError):
-                        src_fd = -1
-                got = lib.tps_write_fastq_spans(fd, src_fd, text.ctypes.data, len(text), spans.ctypes.data, lens.ctypes.data, idx.ctypes.data, len(idx))
+                got = lib.tps_write_fastq_spans(fd, text.ctypes.data, len(text), spans.ctypes.data, lens.ctypes.data, idx.ctypes.data, len(idx))
                 if got < 0:
                     raise OSError(lib.tps_io_last_error().decode())
                 return
@@ -481,7 +473,7 @@ def read_batches_packed(filepath: str, pool: BufferPool, max_records: int = 1 <<
                     fh = open(filepath, "rb")
                     mm = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
                 yield PackedBatch(bs.seq2[:nw.value], bs.inv[:nw.value], bs.desc[:n], heads[:int(head_off[n])].copy(), head_off[:n + 1].copy(),
-                                  fmt, spans=spans[:n].copy(), text=mm, bufset=bs, pool=pool, text_fh=fh)
+                                  fmt, spans=spans[:n].copy(), text=mm, bufset=bs, pool=pool)
                 continue
             pool.put(bs)
             if n == 0:
