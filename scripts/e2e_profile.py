@@ -28,12 +28,14 @@ for e in engines: e.close()
 od = os.path.join(tmp, "out")
 argv = ["--inputDir", fq, "--outputDir", od, "--pattern", "CCCTAA", "--telophrase", "4", "--slide", "6"]
 e2e._quiet(cli.main, argv)
+cli.wait_for_plots()
 shutil.rmtree(od)
 pr = cProfile.Profile()
 t0 = time.perf_counter()
 pr.enable()
 e2e._quiet(cli.main, argv)
 pr.disable()
-print("cli total ms", round((time.perf_counter() - t0) * 1e3, 1))
+print("cli total ms", round((time.perf_counter() - t0) * 1e3, 1), cli.LAST_TIMINGS)
+cli.wait_for_plots()
 s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(30); print(s.getvalue()[:6000])
 shutil.rmtree(tmp)
