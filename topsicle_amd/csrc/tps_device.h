@@ -721,7 +721,7 @@ TPS_DEV bool trc_packed_ok(const ScanArgs& a, int npos) {
 }
 // FLD: the table holds one-hot 2-bit fields (LUT_FIELDS): no squaring, and the overlap test runs on fields
 template <bool SO_, bool FLD = false>
-TPS_DEV void trc_count_packed(const ScanArgs& a, const Lds& l, const Stage& st_s, const Stage& st_e, int tid) {
+TPS_DEV void trc_count_packed(const ScanArgs& a, const Lds& l, const Stage& st_s, const Stage& st_e, int tid, uint32_t* keep = nullptr) {
     const PatInfo& pat = a.pat;
     const int side = tid >> 5, t = tid & 31;
     const int delta = side ? st_e.delta : st_s.delta;
@@ -789,7 +789,7 @@ TPS_DEV void trc_count_packed(const ScanArgs& a, const Lds& l, const Stage& st_s
         }
         lds_or(&l.misc[M_CMASK + side], cm);
     }
-    uint32_t* dst = l.blk + 4 * tid;
+    uint32_t* dst = keep ? keep : l.blk + 4 * tid;  // (keep: the caller sums the lanes' words itself -- trc_decide_packed)
     dst[0] = ne & 0x0F0F0F0Fu;
     dst[1] = (ne >> 4) & 0x0F0F0F0Fu;
     dst[2] = no & 0x0F0F0F0Fu;
@@ -885,6 +885,56 @@ TPS_DEV void trc_sum_packed(const ScanArgs& a, const Lds& l, const Stage& st_s, 
         lds_max_i32((int32_t*)&l.misc[M_BEST + side], (int32_t)((sm << 5) | (uint32_t)(31 - p)));
     }
 }
+
+#ifndef TPS_EMU
+// Plain tables (no self-overlap, no duplicates, clean heads) in the default kernels: count, sum and decide without leaving the
+// registers.  The 32 lanes of a side add their four words of per-pattern bytes by DPP (a side's count of a pattern is at most
+// 255: trc_packed_ok), lanes 31 and 63 hold the sides' totals, and the arg-max over the patterns runs on the scalar unit --
+// instead of parking 16 bytes per lane in LDS, a barrier, 32 byte reads by each of P lanes, an LDS atomic max, another barrier
+// and two uniform reads (a fifth of step 1's latency, which every read pays before its first tile can be requested).
+// Returns the keys count << 5 | (31 - p) of the first pattern with the largest count, per side.
+TPS_DEV void trc_decide_packed(const ScanArgs& a, const Lds& l, const Stage& st_s, const Stage& st_e, int64_t r, uint32_t& ks, uint32_t& ke) {
+    uint32_t x[4];
+    TPS_PHASE { trc_count_packed<false, false>(a, l, st_s, st_e, tid, x); }
+    uint32_t s0[4], s1[4];
+    TPS_UNROLL
+    for (int w = 0; w < 4; ++w) {
+        uint32_t v = x[w];
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+        s0[w] = (uint32_t)__builtin_amdgcn_readlane((int)v, 31);
+        s1[w] = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+    }
+    // pattern p's byte: word [0, 2, 1, 3][p & 3], byte p >> 2 (the layout trc_sum_packed reads from LDS)
+    const int P = a.pat.P;
+    uint32_t bs = 0, be = 0;
+    TPS_UNROLL
+    for (int p = 0; p < 15; ++p) {
+        if (p < P) {                                  // uniform
+            const int wi = ((p & 1) << 1) | ((p >> 1) & 1), sh = 8 * (p >> 2);
+            const uint32_t c0 = (s0[wi] >> sh) & 255u, c1 = (s1[wi] >> sh) & 255u;
+            const uint32_t k0 = (c0 << 5) | (uint32_t)(31 - p), k1 = (c1 << 5) | (uint32_t)(31 - p);
+            bs = k0 > bs ? k0 : bs;
+            be = k1 > be ? k1 : be;
+        }
+    }
+    ks = bs;
+    ke = be;
+    if (a.c_start) {                                  // the per-pattern counts of both heads, if the caller asked for them
+        const int lane = (int)(threadIdx.x & 63u), side = lane >> 5, p = lane & 31;
+        if (p < P) {
+            const int wi = ((p & 1) << 1) | ((p >> 1) & 1);
+            const uint32_t w0 = wi == 0 ? s0[0] : wi == 1 ? s0[1] : wi == 2 ? s0[2] : s0[3];
+            const uint32_t w1 = wi == 0 ? s1[0] : wi == 1 ? s1[1] : wi == 2 ? s1[2] : s1[3];
+            const uint32_t c = ((side ? w1 : w0) >> (8 * (p >> 2))) & 255u;
+            (side ? a.c_end : a.c_start)[r * P + p] = (int32_t)c;
+        }
+    }
+}
+#endif
 
 // Thread (side, p): sum the private histograms; if pattern p has overlapping occurrences, recount
 // it leftmost-non-overlapping (sequential, rare); publish the count and bid for the side's
@@ -3095,7 +3145,19 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
         const bool plain = clean && pat.so_mask == 0;
         bool packed1 = false;
         if constexpr (SV != 0) packed1 = clean && trc_packed_ok(a, st_s.n - pat.k + 1);
-        if (packed1) {
+        uint32_t ks = 0, ke = 0;
+        bool decided = false;
+#if !defined(TPS_EMU) && !defined(TPS_NO_DECIDE_FAST)           /* (TPS_NO_DECIDE_FAST: A/B builds) */
+        if constexpr (SV != 0 && !SO && !RAW) {
+            if (packed1) {
+                trc_decide_packed(a, l, st_s, st_e, r, ks, ke);
+                decided = true;
+                TPS_STAMP(3);
+            }
+        }
+#endif
+        if (decided) {
+        } else if (packed1) {
             bool fld = false;
             if constexpr (RAW) fld = a.lut_fields != 0;
             if (fld) {
@@ -3124,8 +3186,11 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
             TPS_STAMP(3);
             TPS_PHASE { trc_sum_thread(a, l, st_s, st_e, r, tid); }
         }
-        TPS_SYNC();
-        const uint32_t ks = uniform(l.misc[M_BEST]), ke = uniform(l.misc[M_BEST + 1]);
+        if (!decided) {
+            TPS_SYNC();
+            ks = uniform(l.misc[M_BEST]);
+            ke = uniform(l.misc[M_BEST + 1]);
+        }
         res.best_start = (int32_t)(ks >> 5); res.best_start_idx = 31 - (int32_t)(ks & 31u);
         res.best_end = (int32_t)(ke >> 5); res.best_end_idx = 31 - (int32_t)(ke & 31u);
         // forward only if strictly larger (allsteps.py:193); strict cutoff and length tests
