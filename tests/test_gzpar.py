@@ -188,3 +188,12 @@ def test_short_period_runs(tmp_path, level):
         assert text == data
         spec += int(stats[1])
     assert spec > 0                                      # speculative chunks (16-bit symbols) took part
+
+
+def test_differential_fuzz_against_zlib():
+    """tests/gz_fuzz.py: random texts, random deflate parameters and flushes, random damage (bit flips, truncation, trailing
+    bytes) -- the text zlib gives or an error, never anything else.  Seed 1's case 11 is the damaged stream whose speculative
+    chunk decoded garbage without ever reaching a block end and asked for 78 GB (growth is bounded where the buffer grows now)."""
+    import gz_fuzz
+    ok, err = gz_fuzz.run(40, seed=1)
+    assert ok >= 3 and err >= 8 and ok + err >= 20

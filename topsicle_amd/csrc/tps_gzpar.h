@@ -358,15 +358,19 @@ int inflate_blocks(const uint8_t* data, size_t nbytes, uint64_t start, uint64_t 
     // `out` is used as a buffer larger than what is in use (n elements): the symbol loop writes through a raw pointer with one
     // capacity test per symbol; every exit trims it to n
     size_t n = out.size();
-    out.resize(std::max<size_t>(out.capacity(), n + (1u << 20)));
+    out.resize(std::max<size_t>(std::min<size_t>(out.capacity(), max_out + ((size_t)4 << 20)), n + (1u << 20)));
     T* o = out.data();
     size_t cap = out.size();
-    auto need = [&](size_t extra) {
+    // false: the chunk would outgrow max_out -- a speculative start that decodes garbage (or a deflate bomb) must not be able to
+    // ask for memory without end: growth is checked HERE, not only where a block ends
+    auto need = [&](size_t extra) -> bool {
         if (n + extra > cap) {
-            out.resize(std::max(cap * 2, n + extra + (1u << 20)));
+            if (n + extra > max_out + ((size_t)2 << 20)) return false;
+            out.resize(std::min(std::max(cap * 2, n + extra + (1u << 20)), max_out + ((size_t)4 << 20)));
             o = out.data();
             cap = out.size();
         }
+        return true;
     };
     struct Trim { V& v; size_t& n; ~Trim() { v.resize(n); } } trim{out, n};
     for (;;) {
@@ -382,7 +386,7 @@ int inflate_blocks(const uint8_t* data, size_t nbytes, uint64_t start, uint64_t 
             if (b.cnt < 32) return -1;
             const uint32_t ln = b.get(16), nln = b.get(16);
             if ((ln ^ 0xFFFFu) != nln) return -1;
-            need((size_t)ln + 8);
+            if (!need((size_t)ln + 8)) return -1;
             // the rest of the bit buffer is whole bytes; then straight from the input
             size_t left = ln;
             while (left && b.cnt >= 8) { o[n++] = (T)b.get(8); --left; }
@@ -417,7 +421,7 @@ int inflate_blocks(const uint8_t* data, size_t nbytes, uint64_t start, uint64_t 
 #define GZ_REFILL() do { uint64_t w_; memcpy(&w_, ip, 8); buf |= w_ << cnt; ip += (63 - cnt) >> 3; cnt |= 56; } while (0)
 #define GZ_TAKE(nb) do { buf >>= (nb); cnt -= (int)(nb); } while (0)
                 while (fast_ok && ip <= ifast && !b.over) {
-                    if (n + 1024 > cap) need(1024);
+                    if (n + 1024 > cap && !need(1024)) { bad = 1; break; }
                     GZ_REFILL();
                     uint32_t e = LT[buf & lmask];
                     if (e & FE_LIT) {
@@ -489,7 +493,7 @@ int inflate_blocks(const uint8_t* data, size_t nbytes, uint64_t start, uint64_t 
                 b.p = ip;
             }
             for (; !eob;) {
-                need(300);
+                if (!need(300)) return -1;
                 if (b.cnt < 48) b.refill();                       // one refill per symbol: 15 + 5 + 15 + 13 bits at most
                 int s = lit.decode_nofill(b);
                 if (s < 256) {
@@ -686,6 +690,9 @@ struct ParGz {
         }
         const uint64_t file_bits = (uint64_t)size * 8u;
         const size_t max_out = cs * 1100 + (1u << 20);            // deflate cannot expand more than 1032 x
+        // ... but a SPECULATIVE chunk (16-bit symbols, possibly a false start decoding garbage) is not allowed that much memory:
+        // beyond a few times what the round expects of it, it counts as not found and is inflated again from the known position
+        const size_t spec_max = std::min(max_out, std::max<size_t>((size_t)32 << 20, 8 * (want / (size_t)T + 1)));
         std::vector<double> t_chunk(timing ? nc : 0, 0.0), t_find(timing ? nc : 0, 0.0);
         auto work = [&](int t, int nt) {
             for (size_t j = (size_t)t; j < nc; j += (size_t)nt) {
@@ -702,7 +709,7 @@ struct ParGz {
                     if (timing) t_find[j] = now() - tc0;
                     if (c.start == ~0ull) { c.rc = -1; continue; }
                     c.sym.reserve((size_t)((double)cs * ratio * 1.3) + 4096);
-                    c.rc = inflate_blocks<true>(data, size, c.start, stop, nullptr, 0, c.sym, c.end, max_out);
+                    c.rc = inflate_blocks<true>(data, size, c.start, stop, nullptr, 0, c.sym, c.end, spec_max);
                 }
             }
         };
