@@ -342,3 +342,12 @@ def test_engine_pool_keeps_input_order_with_several_contexts(tmp_path):
         tail = "forward" if max(cs) > max(ce) else "reverse"
         _, counts = orc.window_count_matrix(seq, tail, pats, 100, 6, 100, 20000)
         assert bkps[i] == orc.binseg_l2_exact(counts.sum(axis=1))
+
+
+def test_differential_fuzz_against_the_python_parser():
+    """tests/reader_fuzz.py: random FASTQ / FASTA files (CRLF, blank lines, wrapped sequences, lower case, N, '@' and '+' in
+    quality lines, plain / gzip / two members), intact and damaged, through the packed mmap reader and the streaming ASCII
+    reader: an intact file reads exactly as the pure-Python parser reads it, a damaged one as a prefix of the same records."""
+    import reader_fuzz
+    same, prefix = reader_fuzz.run(60, seed=4)
+    assert same >= 60 and same + prefix == 120
