@@ -19,8 +19,8 @@ from topsicle_amd import seqio  # noqa: E402
 
 def make_file(rng, path):
     fastq = rng.random() < 0.75
-    crlf = rng.random() < 0.15
-    nl = b"\r\n" if crlf else b"\n"
+    u = rng.random()
+    nl = b"\r\n" if u < 0.15 else b"\r" if u < 0.22 else b"\n"          # (CR alone: classic Mac OS text, a line end in Python's text mode)
     n = int(rng.integers(0, 60))
     out = []
     for i in range(n):
@@ -43,13 +43,13 @@ def make_file(rng, path):
     if damage == 1 and len(data) > 10:
         data = data[:int(rng.integers(1, len(data)))]
     elif damage == 2 and len(data) > 10:
-        lines = data.split(b"\n")
+        lines = data.split(nl)
         del lines[int(rng.integers(len(lines)))]
-        data = b"\n".join(lines)
+        data = nl.join(lines)
     elif damage == 3 and len(data) > 10:
         b = bytearray(data)
         for _ in range(int(rng.integers(1, 4))):
-            b[int(rng.integers(len(b)))] = int(rng.choice(np.frombuffer(b"\n@+>A ", np.uint8)))     # (no lone CR: text mode makes it a line end, the native reader data)
+            b[int(rng.integers(len(b)))] = int(rng.choice(np.frombuffer(b"@+>A " + (b"\r" if nl == b"\r" else b"\n"), np.uint8)))   # (no lone CR in LF text, no LF in CR text: in a mixed file a lone CR is a line end for text mode and data for the native reader)
         data = bytes(b)
     ext = ".fastq" if fastq else ".fasta"
     mode = int(rng.integers(3))

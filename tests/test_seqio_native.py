@@ -344,6 +344,33 @@ def test_engine_pool_keeps_input_order_with_several_contexts(tmp_path):
         assert bkps[i] == orc.binseg_l2_exact(counts.sum(axis=1))
 
 
+def test_classic_mac_line_ends_read_like_text_mode(tmp_path):
+    """A file whose lines end in a lone CR: the reference reads its input in Python's text mode, where that is a line end.  The
+    native reader takes such a file (its first line ends in a lone CR) through the streaming decoder with the same three line
+    ends; plain and gzip'ed, FASTQ and FASTA, a CR exactly at the decoder's buffer boundary included."""
+    rng = np.random.default_rng(3)
+    recs = []
+    for i in range(3000):
+        L = int(rng.integers(1, 3000))
+        s = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), L))
+        recs.append(b"@r%d text\r" % i + s + b"\r+\r" + bytes(rng.integers(33, 74, L, dtype=np.uint8)) + b"\r")
+    data = b"".join(recs)
+    (tmp_path / "cr.fastq").write_bytes(data)
+    with gzip.open(tmp_path / "cr.fastq.gz", "wb", compresslevel=1) as h:
+        h.write(data)
+    (tmp_path / "cr.fasta").write_bytes(b">a one\rACGT\rAC\r>b\rGG\r")
+    for name in ("cr.fastq", "cr.fastq.gz", "cr.fasta"):
+        path = str(tmp_path / name)
+        py = [(r.id, r.description, r.seq) for r in seqio.read_records(path)]
+        assert len(py) == (2 if name.endswith("fasta") else 3000)
+        assert [(r.id, r.description, r.seq) for r in all_records(path)] == py
+        got = []
+        for pb in seqio.read_batches_packed(path, seqio.BufferPool(2, 1 << 20, 4096)):
+            got += [(pb.read_id(i), pb.head(i), bytes(pb.seq_bytes(i)).decode()) for i in range(pb.n)]
+            pb.release()
+        assert got == py
+
+
 def test_differential_fuzz_against_the_python_parser():
     """tests/reader_fuzz.py: random FASTQ / FASTA files (CRLF, blank lines, wrapped sequences, lower case, N, '@' and '+' in
     quality lines, plain / gzip / two members), intact and damaged, through the packed mmap reader and the streaming ASCII

@@ -71,11 +71,29 @@ struct Reader {
         len += (size_t)got;
         return true;
     }
-    // next line without the trailing \r\n; false at end of input
+    // next line without its line end; false at end of input.  Line ends as Python's text mode -- what the reference reads its
+    // input through (allsteps.py:127-149) -- sees them: "\n", "\r\n", and a lone "\r" (cr_lines: the file's first line ended in
+    // one -- classic Mac OS text; without that a stray CR inside a line stays what it was before round 3: data)
+    bool cr_lines = false;
     bool getline(std::string& out) {
         out.clear();
         for (;;) {
             char* nl = (char*)memchr(buf.data() + pos, '\n', len - pos);
+            if (cr_lines) {
+                char* cr = (char*)memchr(buf.data() + pos, '\r', (nl ? (size_t)(nl - buf.data()) : len) - pos);
+                if (cr) {
+                    if (cr + 1 == buf.data() + len && !eof) {         // is a "\n" behind it?  it may be in the next buffer
+                        out.append(buf.data() + pos, (size_t)(cr - (buf.data() + pos)));
+                        pos = (size_t)(cr - buf.data());
+                        if (fill() && len - pos > 1) continue;        // (the CR is at buf[pos] again, with what follows it)
+                        pos = len;                                    // end of input behind the CR
+                        break;
+                    }
+                    out.append(buf.data() + pos, (size_t)(cr - (buf.data() + pos)));
+                    pos = (size_t)(cr - buf.data()) + ((cr + 1 < buf.data() + len && cr[1] == '\n') ? 2 : 1);
+                    break;
+                }
+            }
             if (nl) {
                 out.append(buf.data() + pos, (size_t)(nl - (buf.data() + pos)));
                 pos = (size_t)(nl - buf.data()) + 1;
@@ -730,7 +748,17 @@ int tps_reader_open(const char* path, void** out) {
         delete h;
         return -1;
     }
-    if (!plain && h->format == 2 && !getenv("TPS_IO_NO_MMAP") && !getenv("TPS_IO_NO_BGZF")) {
+    // Text whose first line ends in a lone CR (classic Mac OS line ends): only the streaming decoder reads that as the reference
+    // does; the thread-team decoders below split at "\n" and are left out
+    {
+        const char* p0 = r->buf.data();
+        for (size_t j = i; j < r->len; ++j) {
+            if (p0[j] == '\n') break;
+            if (p0[j] == '\r') { r->cr_lines = j + 1 < r->len && p0[j + 1] != '\n'; break; }
+        }
+    }
+    const bool cr_lines = r->cr_lines;
+    if (!plain && !cr_lines && h->format == 2 && !getenv("TPS_IO_NO_MMAP") && !getenv("TPS_IO_NO_BGZF")) {
         // bgzip'ed FASTQ: blocks inflate in parallel, then the same thread-team record decoder runs over the text
         Bgzf* z = new Bgzf();
         z->fd = open(path, O_RDONLY);
@@ -759,7 +787,7 @@ int tps_reader_open(const char* path, void** out) {
         }
         delete z;
     }
-    if (!plain && !h->fast && h->format == 2 && !getenv("TPS_IO_NO_MMAP") && !getenv("TPS_IO_NO_PARGZ")) {
+    if (!plain && !cr_lines && !h->fast && h->format == 2 && !getenv("TPS_IO_NO_MMAP") && !getenv("TPS_IO_NO_PARGZ")) {
         // ordinary gzip'ed FASTQ: the deflate stream is inflated by the thread team (speculative block starts, tps_gzpar.h),
         // then the same thread-team record decoder runs over the text.  Small files stay with zlib's stream.
         GzSource* z = new GzSource();
@@ -789,7 +817,7 @@ int tps_reader_open(const char* path, void** out) {
         }
         delete z;
     }
-    if (plain && h->format == 2 && !getenv("TPS_IO_NO_MMAP")) {
+    if (plain && !cr_lines && h->format == 2 && !getenv("TPS_IO_NO_MMAP")) {
         Fast* f = new Fast();
         f->fd = open(path, O_RDONLY);
         struct stat st;
