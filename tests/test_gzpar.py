@@ -195,5 +195,5 @@ def test_differential_fuzz_against_zlib():
     bytes) -- the text zlib gives or an error, never anything else.  Seed 1's case 11 is the damaged stream whose speculative
     chunk decoded garbage without ever reaching a block end and asked for 78 GB (growth is bounded where the buffer grows now)."""
     import gz_fuzz
-    ok, err = gz_fuzz.run(40, seed=1)
-    assert ok >= 3 and err >= 8 and ok + err >= 20
+    ok, err = gz_fuzz.run(16, seed=1)
+    assert ok >= 1 and err >= 3 and ok + err >= 8
