@@ -151,7 +151,7 @@ def cpu_baseline(seqs, motif, k, prm, budget_s=15.0):
                 reads_per_s=done / dt)
 
 
-def reference_python_baseline(bases, offsets, motif, k, prm, reads_per_core=64):
+def reference_python_baseline(bases, offsets, motif, k, prm, reads_per_core=192):
     """The reference's own CPU path beside the GPU number: oracle/ref_mirror.py -- `re.finditer` per window per
     pattern, both tails, numpy-var Binseg, the file re-parsed per passing read, one Pool task per FILE like
     Topsicle/main.py:232-235 -- on the first reads of the batch written out as one FASTQ file per usable core.  Must run
@@ -480,7 +480,8 @@ def main():
             },
         }
         if not args.no_cpu_baseline and world == 1:        # the CPU baseline leg runs at N = 1 only
-            seqs = synth.split_reads(bases[: offsets[min(n_reads, 4096)]], offsets[: min(n_reads, 4096) + 1])
+            n_cpu = min(n_reads, 16384)               # (config 2: the whole batch, ~5 s on 16 cores; the budget inside stops a slow host)
+            seqs = synth.split_reads(bases[: offsets[n_cpu]], offsets[: n_cpu + 1])
             out["cpu_baseline"] = cpu_baseline(seqs, motif, k, prm)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
             if ref_py is not None:
