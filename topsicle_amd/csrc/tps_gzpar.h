@@ -554,6 +554,23 @@ inline uint64_t find_block(const uint8_t* data, size_t nbytes, uint64_t from, ui
         w >>= (pos & 7);
         if ((w & 7u) != 4u) continue;
         if (((w >> 3) & 31u) > 29u || ((w >> 8) & 31u) > 29u) continue;      // HLIT, HDIST
+        // the code-length code must be a complete prefix code (what read_dynamic(strict) asks first): its Kraft sum straight from
+        // the header's 3-bit lengths -- 99 % of the candidates end here, without a table being built
+        {
+            const uint32_t hclen = ((w >> 13) & 15u) + 4u;
+            uint64_t q = 0;
+            const uint64_t at = pos + 17;                                   // first 3-bit length
+            if ((at >> 3) + 9 <= nbytes) {
+                memcpy(&q, data + (at >> 3), 8);
+                q >>= (at & 7);                                              // >= 57 bits: 19 lengths
+                uint32_t kraft = 0;
+                for (uint32_t j = 0; j < hclen; ++j) {
+                    const uint32_t l = (uint32_t)(q >> (3 * j)) & 7u;
+                    if (l) kraft += 128u >> l;
+                }
+                if (kraft != 128u) continue;
+            }
+        }
         Bits b(data, nbytes, pos + 3);
         if (read_dynamic(b, lit, dist, true)) return pos;
     }
