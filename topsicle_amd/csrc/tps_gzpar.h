@@ -414,30 +414,33 @@ int inflate_blocks(const uint8_t* data, size_t nbytes, uint64_t start, uint64_t 
                 uint64_t buf = b.buf;
                 int cnt = b.cnt;
                 const uint8_t* ip = b.p;
-                const uint8_t* const ifast = (b.end - b.base) >= 16 ? b.end - 16 : b.base - 0;     // (inputs below 16 bytes: slow loop only)
-                const bool fast_ok = (b.end - b.base) >= 16;
+                // (up to three 8-byte refills behind one test of the input position; inputs below 32 bytes: slow loop only)
+                const uint8_t* const ifast = (b.end - b.base) >= 32 ? b.end - 32 : b.base - 0;
+                const bool fast_ok = (b.end - b.base) >= 32;
                 constexpr int64_t EW = 8 / (int64_t)sizeof(T);        // elements per 8-byte word
                 int bad = 0;
 #define GZ_REFILL() do { uint64_t w_; memcpy(&w_, ip, 8); buf |= w_ << cnt; ip += (63 - cnt) >> 3; cnt |= 56; } while (0)
 #define GZ_TAKE(nb) do { buf >>= (nb); cnt -= (int)(nb); } while (0)
+                // the entry of the NEXT symbol is looked up as soon as the bits are there -- before the match in hand is copied --
+                // so the table load's latency runs beside the copy instead of in front of every symbol
+                uint32_t e = 0;
+                if (fast_ok && ip <= ifast) { GZ_REFILL(); e = LT[buf & lmask]; }
                 while (fast_ok && ip <= ifast && !b.over) {
                     if (n + 1024 > cap && !need(1024)) { bad = 1; break; }
-                    GZ_REFILL();
-                    uint32_t e = LT[buf & lmask];
                     if (e & FE_LIT) {
                         GZ_TAKE(e & 31u); o[n++] = (T)(e >> 16);
                         e = LT[buf & lmask];
                         if (e & FE_LIT) {
                             GZ_TAKE(e & 31u); o[n++] = (T)(e >> 16);
                             e = LT[buf & lmask];
-                            if (e & FE_LIT) { GZ_TAKE(e & 31u); o[n++] = (T)(e >> 16); continue; }
+                            if (e & FE_LIT) { GZ_TAKE(e & 31u); o[n++] = (T)(e >> 16); GZ_REFILL(); e = LT[buf & lmask]; continue; }
                         }
                         GZ_REFILL();                               // (the entry in hand stays valid: the low bits did not change)
                     }
                     if (e & FE_EXC) {
                         if (e & FE_SUB) {
                             e = LT[(e >> 16) + (uint32_t)((buf >> lpb) & ((1ull << ((e >> 8) & 15u)) - 1ull))];
-                            if (e & FE_LIT) { GZ_TAKE(e & 31u); o[n++] = (T)(e >> 16); continue; }
+                            if (e & FE_LIT) { GZ_TAKE(e & 31u); o[n++] = (T)(e >> 16); GZ_REFILL(); e = LT[buf & lmask]; continue; }
                         }
                         if (e & FE_EXC) {
                             if (e & FE_EOB) { GZ_TAKE(e & 31u); eob = true; break; }
@@ -457,6 +460,8 @@ int inflate_blocks(const uint8_t* data, size_t nbytes, uint64_t start, uint64_t 
                     const uint32_t dx = (f >> 8) & 15u, dl = f & 31u;
                     const int64_t d = (int64_t)((f >> 16) + (uint32_t)((buf >> dl) & ((1ull << dx) - 1ull)));
                     GZ_TAKE(dl + dx);
+                    GZ_REFILL();
+                    e = LT[buf & lmask];                           // (the next symbol's entry: in flight during the copy)
                     const int64_t at = (int64_t)n;
                     if (d <= at) {
                         T* dst = o + at;
