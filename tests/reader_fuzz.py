@@ -61,11 +61,27 @@ def make_file(rng, path):
         p = path + ext + ".gz"
         with gzip.open(p, "wb", compresslevel=int(rng.integers(1, 10))) as h:
             h.write(data)
-    else:
+    elif mode == 2 and rng.random() < 0.5:
         p = path + ext + ".gz"
         with open(p, "wb") as h:                                  # several members
             cut = int(rng.integers(0, len(data) + 1))
             h.write(gzip.compress(data[:cut]) + gzip.compress(data[cut:]))
+    else:
+        p = path + ext + ".gz"                                    # BGZF: independent blocks with the 'BC' extra field
+        import struct
+        import zlib
+
+        def member(chunk):
+            co = zlib.compressobj(int(rng.integers(1, 10)), zlib.DEFLATED, -15)
+            body = co.compress(chunk) + co.flush()
+            bsize = 12 + 6 + len(body) + 8
+            return (b"\x1f\x8b\x08\x04" + b"\x00" * 4 + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1) +
+                    body + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+        block = int(rng.choice([300, 5000, 60000]))
+        with open(p, "wb") as h:
+            for lo in range(0, len(data), block):
+                h.write(member(data[lo:lo + block]))
+            h.write(member(b""))
     return p, damage
 
 
@@ -76,6 +92,13 @@ def run(cases=300, seed=0):
     for case in range(cases):
         rng = np.random.default_rng(seed * 1000003 + case)
         p, damage = make_file(rng, os.path.join(tmp, "f%d" % case))
+        # compressed inputs: the thread team's inflaters also on small files, windows of inflated text from tiny to default
+        os.environ["TPS_IO_PARGZ_MIN"] = str(int(rng.choice([0, 1 << 40])))
+        g = int(rng.choice([0, 700, 20000, 1 << 20]))
+        if g:
+            os.environ["TPS_IO_BGZF_GROUP"] = str(g)
+        else:
+            os.environ.pop("TPS_IO_BGZF_GROUP", None)
         if os.environ.get("RD_FUZZ_VERBOSE"):
             print("case", case, p, flush=True)
         want = [(r.id, r.description, r.seq.upper() if False else r.seq) for r in seqio.read_records(p)]
@@ -108,6 +131,8 @@ def run(cases=300, seed=0):
                 prefix += 1
         os.unlink(p)
     os.rmdir(tmp)
+    os.environ.pop("TPS_IO_PARGZ_MIN", None)
+    os.environ.pop("TPS_IO_BGZF_GROUP", None)
     return same, prefix
 
 

@@ -41,6 +41,7 @@
 #include <pthread.h>
 #include <ctime>
 #include <string>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -304,10 +305,12 @@ struct Bgzf : TextSource {
             total += isize;
             cpos += bsize;
         }
+        const double t_bg0 = io_timing() ? now_s() : 0.0;
         const size_t base = out.size();
         out.resize(base + total);
         std::vector<int> bad((size_t)std::max(1, threads), 0);
         const int T = total < (4u << 20) ? 1 : threads;
+        struct Rep { double t0; size_t n, bytes; int T; ~Rep() { if (io_timing()) fprintf(stderr, "[tps_io] bgzf group: %zu blocks, %zu MB of text, %d threads, %.2f ms\n", n, bytes >> 20, T, 1e3 * (now_s() - t0)); } } rep{t_bg0, blks.size(), total, T};
         // every block is a raw deflate stream of its own: the in-tree inflater (tps_gzpar.h: one-word table entries, 8-byte refills,
         // word copies -- 1.7 x zlib's rate per thread) into a per-thread scratch block, checked against the block's ISIZE and its
         // CRC-32 (carry-less multiplication), then copied to its place.  TPS_IO_BGZF_ZLIB=1: zlib's inflate as before (A/B)
@@ -373,10 +376,38 @@ struct GzSource : TextSource {
     }
 };
 
+// The inflated text of a compressed input, one buffer per group of blocks.  Reference-counted: the reader holds the window it is
+// decoding, and every packed batch handed to the caller holds the window its records' spans point into (header, sequence and
+// quality text of the passing records are written out from there, long after the reader has moved on) -- tps_reader_text_hold /
+// tps_text_release.  Released buffers are parked (a few hundred MB are not mapped, faulted in and unmapped per group).
+struct TextHold {
+    gzpar::TextBuf buf;                        // (resize() does not zero: the thread team writes the text)
+    std::atomic<int> refs{1};
+    static std::mutex& mu() { static std::mutex m; return m; }
+    static std::vector<TextHold*>& parked() { static std::vector<TextHold*> v; return v; }
+    static TextHold* get() {
+        {
+            std::lock_guard<std::mutex> lk(mu());
+            if (!parked().empty()) { TextHold* h = parked().back(); parked().pop_back(); h->refs = 1; h->buf.clear(); return h; }
+        }
+        return new TextHold();
+    }
+    void ref() { refs.fetch_add(1); }
+    void unref() {
+        if (refs.fetch_sub(1) != 1) return;
+        {
+            std::lock_guard<std::mutex> lk(mu());
+            if (parked().size() < 3) { parked().push_back(this); return; }
+        }
+        delete this;
+    }
+};
+
 struct Fast {
     int fd = -1;
-    TextSource* src = nullptr;                 // compressed input (BGZF, gzip): `data` is `mem`, refilled group by group
-    gzpar::TextBuf mem;                        // (resize() does not zero: the thread team writes the text)
+    TextSource* src = nullptr;                 // compressed input (BGZF, gzip): `data` is the text of `hold`, a new one per group
+    TextHold* hold = nullptr;
+    size_t fill_target = 0;                    // text a refilled window should hold (set by the packed reader from its caller's buffers)
     uint64_t base_off = 0;                     // uncompressed offset of data[0] (BGZF)
     const char* data = nullptr;
     size_t size = 0;
@@ -393,10 +424,7 @@ struct Fast {
         give_spare();
         if (src) {
             delete src;
-            if (mem.capacity()) {                // the text buffer of a compressed file is parked for the next one, like the chunks
-                std::lock_guard<std::mutex> lk(spare_mu());
-                if (spare_mem().capacity() < mem.capacity()) { mem.clear(); spare_mem().swap(mem); }
-            }
+            if (hold) hold->unref();             // (parked for the next file once the last batch that points into it is gone)
         } else if (data) {
             // Unmapping a few hundred MB that 16 threads have touched takes milliseconds (page-table teardown, TLB shootdowns,
             // and the GPU driver's MMU notifier when the process holds a device context: 7 ms for 300 MB on the GPU box, more
@@ -411,24 +439,37 @@ struct Fast {
         }
         if (fd >= 0) close(fd);
     }
-    static gzpar::TextBuf& spare_mem() { static gzpar::TextBuf b; return b; }
+    // more text into the CURRENT window while nobody but the reader points into it (appending may move the buffer)
+    void top_up(size_t target) {
+        if (!src || !hold || hold->refs.load() != 1) return;
+        size_t group = (size_t)128 << 20;
+        if (const char* e = getenv("TPS_IO_BGZF_GROUP")) { const long long g = atoll(e); if (g > 0) group = (size_t)g; }
+        while (!src->eof() && !src->failed && size - pos < target) {
+            src->read_group(hold->buf, group);
+            data = hold->buf.data();
+            size = hold->buf.size();
+        }
+    }
     void index_window() {
         if (src) {
-            if (!mem.capacity()) {
-                std::lock_guard<std::mutex> lk(spare_mu());
-                mem.swap(spare_mem());
-            }
-            // keep the unconsumed tail (a partial record), inflate the next group of blocks behind it
+            // a NEW buffer for the next group of blocks (batches already handed out keep pointing into the old one): the
+            // unconsumed tail (a partial record) is copied to its front, the group is inflated behind it
             const size_t keep = size - pos;
-            if (pos) memmove(mem.data(), mem.data() + pos, keep);
-            mem.resize(keep);
+            TextHold* nh = TextHold::get();
+            nh->buf.resize(keep);
+            if (keep) memcpy(nh->buf.data(), data + pos, keep);
+            if (hold) hold->unref();
+            hold = nh;
             base_off += pos;
             pos = 0;
-            size_t group = (size_t)256 << 20;          // text per refill (tests shrink it to exercise the carry-over)
+            size_t group = (size_t)128 << 20;          // text per refill (tests shrink it to exercise the carry-over)
             if (const char* e = getenv("TPS_IO_BGZF_GROUP")) { const long long g = atoll(e); if (g > 0) group = (size_t)g; }
-            if (!src->eof()) src->read_group(mem, group);
-            data = mem.data();
-            size = mem.size();
+            if (!src->eof()) src->read_group(hold->buf, group);
+            // (packed batches: a window should hold a whole batch's worth of text -- nobody else points into this new buffer
+            // yet, so further groups are simply appended to it)
+            while (!src->eof() && !src->failed && hold->buf.size() < fill_target) src->read_group(hold->buf, group);
+            data = hold->buf.data();
+            size = hold->buf.size();
         }
         const double t_ix = io_timing() ? now_s() : 0.0;
         const size_t lo = pos, span = src ? size - lo : std::min<size_t>(size - lo, (size_t)512 << 20);
@@ -815,7 +856,8 @@ int tps_reader_open(const char* path, void** out) {
         GzSource* z = new GzSource();
         z->fd = open(path, O_RDONLY);
         struct stat st;
-        if (z->fd >= 0 && fstat(z->fd, &st) == 0 && st.st_size >= ((off_t)1 << 20)) {
+        const char* pm = getenv("TPS_IO_PARGZ_MIN");               // (tests: the team's inflater on small files too)
+        if (z->fd >= 0 && fstat(z->fd, &st) == 0 && st.st_size >= (pm ? (off_t)atoll(pm) : ((off_t)1 << 20)) && st.st_size >= 64) {
             void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, z->fd, 0);
             if (m != MAP_FAILED) {
                 z->data = (const uint8_t*)m;
@@ -934,12 +976,42 @@ int64_t tps_reader_next_packed(void* hv, uint32_t* seq2, uint16_t* inv, int64_t 
     *n_words = 0;
     head_off[0] = 0;
     if (!h->format) return 0;
-    if (!h->fast || h->fast->src) return -4;
-    const int64_t n = h->fast->next_packed(seq2, inv, words_cap, desc, max_records, heads, heads_cap, head_off, spans);
+    if (!h->fast) return -4;
+    Fast* f = h->fast;
+    if (f->src) {
+        f->top_up((size_t)std::max<int64_t>(words_cap, 1024) * 32);      // (a batch's worth of text in the window, if it can still grow)
+        if (f->src->failed) return -1;
+    }
+    int64_t n = f->next_packed(seq2, inv, words_cap, desc, max_records, heads, heads_cap, head_off, spans);
+    // compressed input: the window ends in an incomplete record (or is used up) while the source has more -- the next group
+    // of blocks is inflated into a new window behind the unconsumed tail.  (An unconsumed stretch longer than any record that
+    // yields nothing is not an incomplete record: the streaming decoder judges it.)
+    while (f->src && (n == 0 || n == -3) && !f->src->eof() && !f->src->failed && f->size - f->pos < ((size_t)64 << 20)) {
+        f->fill_target = (size_t)std::max<int64_t>(words_cap, 1024) * 32 + (f->size - f->pos);
+        f->index_window();
+        if (f->src->failed) return -1;
+        n = f->next_packed(seq2, inv, words_cap, desc, max_records, heads, heads_cap, head_off, spans);
+    }
     if (n == -3) return -4;                 // (the position is unchanged: tps_reader_next re-reads this record its own way)
     if (n > 0) *n_words = desc[n - 1].word_off + tps::packed_words(desc[n - 1].len);
     return n;
 }
+
+// The text the spans of the LAST packed batch point into, for a compressed input (for a plain file the caller maps the file
+// itself and *hold stays NULL): *text / *len = the window, *hold = a reference the caller gives back with tps_text_release when
+// it is done with the batch's records.
+int tps_reader_text_hold(void* hv, const char** text, int64_t* len, void** hold) {
+    Handle* h = (Handle*)hv;
+    if (!h || !text || !len || !hold) { g_err = "null argument"; return -1; }
+    *text = nullptr; *len = 0; *hold = nullptr;
+    if (!h->fast || !h->fast->src || !h->fast->hold) return 0;
+    h->fast->hold->ref();
+    *text = h->fast->data;
+    *len = (int64_t)h->fast->size;
+    *hold = h->fast->hold;
+    return 0;
+}
+void tps_text_release(void* hold) { if (hold) ((TextHold*)hold)->unref(); }
 
 // Packs an ASCII batch (concatenated bases + n+1 offsets) into the layout of tps_pack.h with the reader's thread team.
 // seq2 / inv must hold tps_packed_words_total(offsets, n) entries; inv may be NULL.  Returns the words written.

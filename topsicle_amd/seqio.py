@@ -202,6 +202,10 @@ def _load_io():
         lib.tps_pack_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
         lib.tps_packed_words_total.restype = C.c_int64
         lib.tps_packed_words_total.argtypes = [C.c_void_p, C.c_int64]
+        lib.tps_reader_text_hold.restype = C.c_int
+        lib.tps_reader_text_hold.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_void_p)]
+        lib.tps_text_release.restype = None
+        lib.tps_text_release.argtypes = [C.c_void_p]
         lib.tps_write_fastq_spans.restype = C.c_int64
         lib.tps_write_fastq_spans.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
         _io_lib = lib
@@ -415,7 +419,7 @@ class PackedBatch:
                 fd = None
             if lib is not None and fd is not None:
                 handle.flush()
-                text = np.frombuffer(self.text, dtype=np.uint8)
+                text = np.frombuffer(self.text.buffer() if hasattr(self.text, "buffer") else self.text, dtype=np.uint8)
                 idx = np.ascontiguousarray(indices, dtype=np.int64)
                 lens = np.ascontiguousarray(self.desc["len"], dtype=np.int32)
                 spans = np.ascontiguousarray(self.spans, dtype=np.int64)
@@ -441,6 +445,39 @@ class PackedBatch:
                 out = []
         if out:
             handle.write(b"".join(out))
+
+
+class _HeldText:
+    """A window of inflated text that belongs to the native reader (compressed input), kept alive by a reference
+    (tps_reader_text_hold) until this object goes: a read-only buffer like the mmap of a plain file."""
+
+    def __init__(self, lib, ptr, length, hold):
+        import ctypes as C
+        self._lib, self._hold = lib, hold
+        self._arr = (C.c_char * length).from_address(ptr) if length else (C.c_char * 0)()
+        self._mv = memoryview(self._arr).cast("B")
+
+    def __len__(self):
+        return len(self._mv)
+
+    def __getitem__(self, key):
+        v = self._mv[key]
+        return bytes(v) if isinstance(key, slice) else v
+
+    def __buffer__(self, flags):              # (Python >= 3.12)
+        return self._mv
+
+    def buffer(self):
+        return self._mv
+
+    def __del__(self):
+        try:
+            hold, self._hold = self._hold, None
+            if hold:
+                self._mv.release()
+                self._lib.tps_text_release(hold)
+        except Exception:
+            pass
 
 
 def read_batches_packed(filepath: str, pool: BufferPool, max_records: int = 1 << 20):
@@ -469,11 +506,19 @@ def read_batches_packed(filepath: str, pool: BufferPool, max_records: int = 1 <<
             n = lib.tps_reader_next_packed(h, bs.seq2.ctypes.data, bs.inv.ctypes.data, bs.words_cap, bs.desc.ctypes.data, nrec_cap,
                                            heads.ctypes.data, bs.heads_cap, head_off.ctypes.data, spans.ctypes.data, C.byref(nw))
             if n > 0:
-                if mm is None:
-                    fh = open(filepath, "rb")
-                    mm = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
+                # the text the spans point into: the mapped file itself, or -- compressed input -- the reader's window of inflated
+                # text, which this batch keeps alive (tps_reader_text_hold) until it is gone
+                tp, tl, th = C.c_void_p(), C.c_int64(0), C.c_void_p()
+                lib.tps_reader_text_hold(h, C.byref(tp), C.byref(tl), C.byref(th))
+                if th.value:
+                    text = _HeldText(lib, tp.value, tl.value, th.value)
+                else:
+                    if mm is None:
+                        fh = open(filepath, "rb")
+                        mm = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
+                    text = mm
                 yield PackedBatch(bs.seq2[:nw.value], bs.inv[:nw.value], bs.desc[:n], heads[:int(head_off[n])].copy(), head_off[:n + 1].copy(),
-                                  fmt, spans=spans[:n].copy(), text=mm, bufset=bs, pool=pool)
+                                  fmt, spans=spans[:n].copy(), text=text, bufset=bs, pool=pool)
                 continue
             pool.put(bs)
             if n == 0:
