@@ -264,3 +264,35 @@ def test_scan_jobs_tables_on_helper_contexts_equal_back_to_back(monkeypatch):
             assert np.array_equal(o1, o2) and np.array_equal(s1, s2)
             assert (w1 is None) == (w2 is None) and (w1 is None or np.array_equal(w1, w2))
         assert con[0][0]["pass"].sum() > 0
+
+
+def test_cli_same_outputs_from_plain_gzip_and_bgzf_input(engine, tmp_path, demo_records, monkeypatch):
+    """The same reads as plain FASTQ, ordinary gzip (inflated by the thread team: TPS_IO_PARGZ_MIN=0 takes that path for a small
+    file too) and BGZF, with windows of inflated text far smaller than the file (many refills; the passing records of a batch are
+    written from the window the batch keeps alive): telolengths_all.csv and the filtered FASTQ are byte for byte the same."""
+    import struct
+    import zlib
+    from topsicle_amd import e2e
+    rng = np.random.default_rng(2)
+    fq = tmp_path / "reads.fastq"
+    with open(fq, "wb") as h:
+        for rid, seq in demo_records[:30]:
+            q = bytes(rng.integers(35, 74, len(seq), dtype=np.uint8))
+            h.write(b"@" + rid.encode() + b" extra words\n" + seq.encode() + b"\n+\n" + q + b"\n")
+    d_gz, d_bg = tmp_path / "gz", tmp_path / "bg"
+    d_gz.mkdir(); d_bg.mkdir()
+    with open(fq, "rb") as src, gzip.open(d_gz / "reads.fastq.gz", "wb", compresslevel=1) as dst:
+        dst.write(src.read())
+    e2e.write_bgzf(str(d_bg / "reads.fastq.gz"), str(fq), block=20000)
+    monkeypatch.setenv("TPS_IO_PARGZ_MIN", "0")
+    monkeypatch.setenv("TPS_IO_BGZF_GROUP", "150000")
+    outs = {}
+    for tag, path in (("plain", fq), ("gz", d_gz / "reads.fastq.gz"), ("bgzf", d_bg / "reads.fastq.gz")):
+        out = tmp_path / ("o_" + tag)
+        run_cli(engine, ["-i", str(path), "-o", str(out), "--pattern", "CCCTAAA", "--slide", "6", "--cutoff", "0.4"])
+        rows = [r[1:] for r in csv.reader(open(out / "telolengths_all.csv"))]          # (column 0 is the file's name: reads / reads.fastq)
+        filtered = [f for f in os.listdir(out) if "_trc_over_0.4" in f]
+        assert len(filtered) == 1 and filtered[0].endswith(".fastq")
+        outs[tag] = (rows, open(out / filtered[0], "rb").read())
+    assert len(outs["plain"][0]) > 5 and len(outs["plain"][1]) > 100000
+    assert outs["gz"] == outs["plain"] and outs["bgzf"] == outs["plain"]
