@@ -211,7 +211,7 @@ def measure(bases, offsets, motif: str, k: int, slide: int, device: int = 0, con
             od = os.path.join(tmp, "out")
             argv = ["--inputDir", fq, "--outputDir", od, "--pattern", motif, "--telophrase", str(k), "--slide", str(slide), "--device", str(device)]
             times, parts = [], {}
-            for r in range(2):
+            for r in range(3):
                 shutil.rmtree(od, ignore_errors=True)
                 t0 = time.perf_counter()
                 _quiet(cli.main, argv)
