@@ -192,3 +192,43 @@ def test_share_refuses_what_cannot_work(sc):
             other.share(0, sc, hiplib.MAX_SLOTS - 1)
     finally:
         other.close()
+
+
+def test_compressed_inputs_scan_like_the_plain_file(tmp_path, monkeypatch):
+    """The same ragged reads as plain FASTQ, as ordinary gzip (inflated by the thread team) and as BGZF, through
+    batch.EnginePool.scan_file with two contexts: compressed text is packed from reference-counted windows of inflated text
+    (several per file here), batches arrive in file order, and ids and result rows are those of the plain file."""
+    from topsicle_amd import e2e
+    motif, k, slide = "CCCTAA", 4, 6
+    pats = orc.kmer_table(motif, k)
+    bases, offsets = _ragged(3000, motif, 123)
+    fq = str(tmp_path / "r.fastq")
+    _write_fastq(fq, bases, offsets)
+    import gzip
+    import shutil
+    gz = str(tmp_path / "g" / "r.fastq.gz")
+    bg = str(tmp_path / "b" / "r.fastq.gz")
+    os.makedirs(os.path.dirname(gz)); os.makedirs(os.path.dirname(bg))
+    with open(fq, "rb") as src, gzip.open(gz, "wb", compresslevel=1) as dst:
+        shutil.copyfileobj(src, dst)
+    e2e.write_bgzf(bg, fq)
+    assert os.path.getsize(gz) > (1 << 20)                      # (large enough for the parallel inflater)
+    monkeypatch.setenv("TPS_IO_BGZF_GROUP", str(6 << 20))       # windows of ~6 MB of text: several refills per file
+    prm = _params(motif, slide, hiplib.F_STEP1 | hiplib.F_WINDOWS | hiplib.F_BINSEG)
+    engines = [hiplib.HipScanner(0), hiplib.HipScanner(0)]
+    try:
+        got = {}
+        for tag, path in (("plain", fq), ("gz", gz), ("bgzf", bg)):
+            ids, rows = [], []
+            for pb, res, _s, _r, _w in batch.EnginePool(engines, pats).scan_file(path, prm, max_bases=4 << 20):
+                ids += pb.ids
+                rows.append(res.copy())
+            got[tag] = (ids, np.concatenate(rows))
+        assert got["plain"][0] == [f"r{i}" for i in range(3000)]
+        for tag in ("gz", "bgzf"):
+            assert got[tag][0] == got["plain"][0], tag
+            for f in ("pass", "tail", "best_start", "best_end", "n_win", "bkp"):
+                assert np.array_equal(got[tag][1][f], got["plain"][1][f]), (tag, f)
+    finally:
+        for e in engines:
+            e.close()
