@@ -499,6 +499,7 @@ struct Fast {
     // >= 0: records decoded; -3: not plain 4-line FASTQ here -> caller switches to the streaming decoder at `pos`
     int64_t next(uint8_t* bases, int64_t bases_cap, int64_t* offsets, int64_t max_records, char* heads, int64_t heads_cap,
                  int64_t* head_off, uint8_t* quals) {
+        if (fasta) return -3;                          // (ASCII batches of FASTA: the streaming decoder, from this byte on)
         recs.clear();
         int64_t nb = 0, nh = 0;
         offsets[0] = 0;
@@ -550,7 +551,41 @@ struct Fast {
     // One 4-line FASTQ record at text offset s: 0 = well formed (r filled, next = start of the following record), 1 = not a
     // plain 4-line record here (or the text ends inside it).  The quality line is located by the sequence length and only
     // the byte behind it is looked at -- its own bytes are never read.
+    bool fasta = false;                        // two-line FASTA records ('>' header, the whole sequence on one line) instead of FASTQ
+    bool final_window() const { return !src || src->eof(); }      // the text in hand reaches the end of the input
+    // One FASTA record whose sequence is ONE line (what read sets converted from FASTQ look like): 0 = well formed, 1 = anything
+    // else (wrapped sequence, blank line, text that ends inside the record): the streaming decoder takes those.
+    int parse_fasta_at(size_t s, Rec& r, size_t& next) const {
+        if (s >= size || data[s] != '>') return 1;
+        const char* e0p = (const char*)memchr(data + s, '\n', size - s);
+        if (!e0p) return 1;
+        const size_t e0 = (size_t)(e0p - data);
+        const size_t h1 = (e0 > s && data[e0 - 1] == '\r') ? e0 - 1 : e0;
+        if (h1 <= s) return 1;
+        const size_t s0 = e0 + 1;
+        if (s0 >= size) return 1;
+        const char* e1p = (const char*)memchr(data + s0, '\n', size - s0);
+        size_t e1, s1;
+        if (e1p) {
+            e1 = (size_t)(e1p - data);
+            s1 = (e1 > s0 && data[e1 - 1] == '\r') ? e1 - 1 : e1;
+            next = e1 + 1;
+        } else {
+            if (!final_window()) return 1;                      // (the line may go on in the next group of blocks)
+            e1 = s1 = size;
+            if (s1 > s0 && data[s1 - 1] == '\r') --s1;
+            next = size;
+        }
+        // the next line has to open the next record: a wrapped sequence or a blank line is not this decoder's business
+        if (next < size ? data[next] != '>' : !final_window()) return 1;
+        const size_t sl = s1 - s0;
+        if (sl > 0x7FFFFFFFull) return 1;
+        if (sl && (data[s0] == ' ' || data[s0] == '\t' || data[s1 - 1] == ' ' || data[s1 - 1] == '\t' || data[s0] == '>')) return 1;
+        r = Rec{s + 1, (uint64_t)(h1 - s - 1), s0, (uint64_t)sl, 0};
+        return 0;
+    }
     int parse_at(size_t s, Rec& r, size_t& next) const {
+        if (fasta) return parse_fasta_at(s, r, next);
         if (s >= size || data[s] != '@') return 1;
         const char* e0p = (const char*)memchr(data + s, '\n', size - s);
         if (!e0p) return 1;
@@ -648,7 +683,7 @@ struct Fast {
                 while (q) {
                     const size_t cand = (size_t)(q - data) + 1;
                     if (cand >= b) break;
-                    if (data[cand] == '@' && parse_at(cand, r, nx) == 0) { s = cand; break; }
+                    if (data[cand] == (fasta ? '>' : '@') && parse_at(cand, r, nx) == 0) { s = cand; break; }
                     q = (const char*)memchr(data + cand, '\n', b - cand);
                 }
             }
@@ -821,7 +856,7 @@ int tps_reader_open(const char* path, void** out) {
         }
     }
     const bool cr_lines = r->cr_lines;
-    if (!plain && !cr_lines && h->format == 2 && !getenv("TPS_IO_NO_MMAP") && !getenv("TPS_IO_NO_BGZF")) {
+    if (!plain && !cr_lines && !getenv("TPS_IO_NO_MMAP") && !getenv("TPS_IO_NO_BGZF")) {
         // bgzip'ed FASTQ: blocks inflate in parallel, then the same thread-team record decoder runs over the text
         Bgzf* z = new Bgzf();
         z->fd = open(path, O_RDONLY);
@@ -836,6 +871,7 @@ int tps_reader_open(const char* path, void** out) {
                     madvise(m, z->size, MADV_SEQUENTIAL);
                     z->threads = io_threads();
                     Fast* f = new Fast();
+                    f->fasta = h->format == 1;
                     f->src = z;
                     f->threads = z->threads;
                     f->pos = 0;
@@ -850,7 +886,7 @@ int tps_reader_open(const char* path, void** out) {
         }
         delete z;
     }
-    if (!plain && !cr_lines && !h->fast && h->format == 2 && !getenv("TPS_IO_NO_MMAP") && !getenv("TPS_IO_NO_PARGZ")) {
+    if (!plain && !cr_lines && !h->fast && !getenv("TPS_IO_NO_MMAP") && !getenv("TPS_IO_NO_PARGZ")) {
         // ordinary gzip'ed FASTQ: the deflate stream is inflated by the thread team (speculative block starts, tps_gzpar.h),
         // then the same thread-team record decoder runs over the text.  Small files stay with zlib's stream.
         GzSource* z = new GzSource();
@@ -868,6 +904,7 @@ int tps_reader_open(const char* path, void** out) {
                 z->z.threads = io_threads();
                 z->z.team = [](int n, const std::function<void(int, int)>& f) { team(n, f); };
                 Fast* f = new Fast();
+                    f->fasta = h->format == 1;
                 f->src = z;
                 f->threads = z->z.threads;
                 f->pos = 0;
@@ -881,8 +918,9 @@ int tps_reader_open(const char* path, void** out) {
         }
         delete z;
     }
-    if (plain && !cr_lines && h->format == 2 && !getenv("TPS_IO_NO_MMAP")) {
+    if (plain && !cr_lines && !getenv("TPS_IO_NO_MMAP")) {
         Fast* f = new Fast();
+                    f->fasta = h->format == 1;
         f->fd = open(path, O_RDONLY);
         struct stat st;
         if (f->fd >= 0 && fstat(f->fd, &st) == 0 && st.st_size > 0) {

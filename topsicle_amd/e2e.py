@@ -138,6 +138,26 @@ def measure(bases, offsets, motif: str, k: int, slide: int, device: int = 0, con
             out["file_to_results"] = {"value": n_bases / min(times), "unit": "bases/s", "seconds_best": round(min(times), 4),
                                       "seconds_mean": round(float(np.mean(times)), 4), "reads_passing": npass,
                                       "batch_bases": batch.BATCH_BASES}
+            # -- the same reads as two-line FASTA (what a read set converted from FASTQ looks like): packed from the mapped file by
+            # the same thread team (multi-line FASTA goes through the streaming decoder)
+            fa = os.path.join(tmp, "reads.fasta")
+            raw = bases.tobytes()
+            with open(fa, "wb", buffering=1 << 22) as h:
+                for i in range(n_reads):
+                    h.write(b">read%d\n" % i)
+                    h.write(raw[int(offsets[i]):int(offsets[i + 1])])
+                    h.write(b"\n")
+            times = []
+            for _ in range(repeats):
+                t0 = time.perf_counter()
+                nr = 0
+                for pb, res, _s, _r, _w in ep.scan_file(fa, prm):
+                    nr += pb.n
+                times.append(time.perf_counter() - t0)
+                assert nr == n_reads
+            out["fasta_file_to_results"] = {"value": n_bases / min(times), "unit": "bases/s", "seconds_best": round(min(times), 4),
+                                            "fasta_bytes": os.path.getsize(fa)}
+            os.unlink(fa)
             # -- the same through ordinary gzip (one deflate stream: what `gzip` / `pigz` write, the reference's demo input): the
             # native reader inflates it with the thread team (csrc/tps_gzpar.h) instead of one zlib stream.  Twice: the file as
             # it is (constant quality lines: long matches, the inflater's easy case) and with ONT-like noisy quality lines
