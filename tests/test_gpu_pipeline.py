@@ -212,20 +212,24 @@ def test_compressed_inputs_scan_like_the_plain_file(tmp_path, monkeypatch):
     with open(fq, "rb") as src, gzip.open(gz, "wb", compresslevel=1) as dst:
         shutil.copyfileobj(src, dst)
     e2e.write_bgzf(bg, fq)
+    fa = str(tmp_path / "r.fasta")                              # the same reads as two-line FASTA: the same packed decoder
+    with open(fa, "wb") as h:
+        for i in range(len(offsets) - 1):
+            h.write(b">r%d some text\n" % i + bases[offsets[i]:offsets[i + 1]].tobytes() + b"\n")
     assert os.path.getsize(gz) > (1 << 20)                      # (large enough for the parallel inflater)
     monkeypatch.setenv("TPS_IO_BGZF_GROUP", str(6 << 20))       # windows of ~6 MB of text: several refills per file
     prm = _params(motif, slide, hiplib.F_STEP1 | hiplib.F_WINDOWS | hiplib.F_BINSEG)
     engines = [hiplib.HipScanner(0), hiplib.HipScanner(0)]
     try:
         got = {}
-        for tag, path in (("plain", fq), ("gz", gz), ("bgzf", bg)):
+        for tag, path in (("plain", fq), ("gz", gz), ("bgzf", bg), ("fasta", fa)):
             ids, rows = [], []
             for pb, res, _s, _r, _w in batch.EnginePool(engines, pats).scan_file(path, prm, max_bases=4 << 20):
                 ids += pb.ids
                 rows.append(res.copy())
             got[tag] = (ids, np.concatenate(rows))
         assert got["plain"][0] == [f"r{i}" for i in range(3000)]
-        for tag in ("gz", "bgzf"):
+        for tag in ("gz", "bgzf", "fasta"):
             assert got[tag][0] == got["plain"][0], tag
             for f in ("pass", "tail", "best_start", "best_end", "n_win", "bkp"):
                 assert np.array_equal(got[tag][1][f], got["plain"][1][f]), (tag, f)
