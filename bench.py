@@ -48,6 +48,9 @@ CONFIGS = {
     "config4_1pct": dict(n_reads=10000, read_len=30000, motif="CCCTAA", k=4, window=100, slide=6,
                          errors=synth.ONT, seed=20250919 + 3, telomeric_fraction=0.01,
                          desc="BASELINE configs[3] sample, 1 % of the reads telomeric (the step-1-dominated regime of real WGS data)"),
+    "config4_01pct": dict(n_reads=10000, read_len=30000, motif="CCCTAA", k=4, window=100, slide=6,
+                          errors=synth.ONT, seed=20250919 + 3, telomeric_fraction=0.001,
+                          desc="BASELINE configs[3] sample, 0.1 % of the reads telomeric"),
     # BASELINE configs[4] runs one pass per k (--telophrase 4 5 6) with --rawcountpattern: a sample of one GPU's shard per k
     # (add --flags 31 for the raw counts; k = 5 and 6 use tables with self-overlapping k-mers)
     "config5_k4": dict(n_reads=10000, read_len=25000, motif="CCCTAA", k=4, window=100, slide=6, errors=synth.ONT, seed=20250919 + 4,

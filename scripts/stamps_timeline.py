@@ -12,10 +12,10 @@ pats = allsteps.patterns_to_search(motif, k)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 rl = int(sys.argv[2]) if len(sys.argv) > 2 else 15000
 wpg = int(sys.argv[3]) if len(sys.argv) > 3 else 4
-b, o, _ = synth.make_reads(n, rl, motif, 20250920, errors=synth.ONT)
+b, o, _ = synth.make_reads(n, rl, motif, 20250920, errors=synth.ONT, telomeric_fraction=float(os.environ.get("TPS_TELO_FRAC", "1")))
 sc = hiplib.HipScanner(0); sc.set_patterns(pats)
 sc.upload(0, b, o)
-prm = hiplib.make_params(min_len=9000, min_count=100, slide=slide, flags=1 | 2 | 4 | 8)
+prm = hiplib.make_params(min_len=9000, min_count=allsteps.min_count_for_cutoff(0.7, 1000 / len(motif), 1000), slide=slide, flags=1 | 2 | 4 | 8)
 for _ in range(300):
     sc.scan(0, prm)
 sc.sync()
@@ -59,8 +59,10 @@ for label, sel in (("reads started early (first 30 %)", early), ("reads started 
     print(label, int(sel.sum()))
     prev = 13
     for i in order[1:]:
-        if (s[:, i] == 0).all():
+        ok = (s[:, i] != 0) & (s[:, prev] != 0)      # (reads that fail the TRC filter never stamp the tile phases)
+        if not ok.any():
             continue
-        d = s[:, i] - s[:, prev]
-        print("  %-16s +%8.0f clocks (median %8.0f)" % (names[i], d.mean(), np.median(d)))
-        prev = i
+        d = (s[:, i] - s[:, prev])[ok]
+        print("  %-16s +%8.0f clocks (median %8.0f)  [%d reads]" % (names[i], d.mean(), np.median(d), int(ok.sum())))
+        if ok.sum() * 2 > len(s):
+            prev = i

@@ -1,22 +1,78 @@
-"""The heat map half of Topsicle/descriptive_plot.py (exploratory plots; reference file:line cited per function).
+"""Topsicle/descriptive_plot.py's two exploratory plots (reference file:line cited per function).
 
 The heat map's counting -- every k-mer of the doubled motif followed by the next len(motif) - k bases, bases 100..2000 of
 both strands (descriptive_plot.py:259-291) -- runs on the GPU (tps_batch_kmer_followers): the kernel
 returns one bit per match position, from which the reference's DataFrame rows are built, and the crosstab itself.  Drawing
-uses matplotlib only.  The scatter of whole-motif hits (descriptive_plot.py:89-165) is out of scope (SURVEY section 2 row 13:
-visualisation only, no part of the hot path) and is not mirrored here.
+uses matplotlib only.  The scatter of whole-motif hits (descriptive_plot.py:89-165: visualisation of at most 41 reads, no part
+of the hot path) is a host-side literal search over the few reads that passed the TRC filter on the GPU.
 """
 from __future__ import annotations
+
+import re
 
 from . import seqio
 from .allsteps import pattern_scramble_telo
 
 _COMPLEMENT = str.maketrans("ACGT", "TGCA")
 LO, HI = 100, 2000               # the stretch of either end the heat map looks at (descriptive_plot.py:264-266)
+MAX_READS_DRAWN = 41             # the scatter stops after this many reads (descriptive_plot.py:146-150)
 
 
 def _file_label(filepath: str) -> str:
     return filepath.split("/")[-1].split(".")[0]
+
+
+# ---------------------------------------------------------------------------- scatter of whole-motif hits
+def match_positions(seq: str, pattern: str, minSeqLength: int):
+    """Start positions of the (non-overlapping) occurrences of the motif and of its complement in the
+    first `minSeqLength` bases of the read and of the reversed read (descriptive_plot.py:103-136).
+    Returns {pattern: (positions in seq, positions in reversed seq)} for the two patterns."""
+    pats = [pattern.upper(), pattern.translate(_COMPLEMENT).upper()]
+    s1 = seq[:minSeqLength].upper()
+    s2 = seq[::-1][:minSeqLength].upper()
+    return {p: ([m.start() for m in re.finditer(re.escape(p), s1)], [m.start() for m in re.finditer(re.escape(p), s2)])
+            for p in pats}
+
+
+def descriptive_plot_records(records, label, pattern, minSeqLength):
+    """The scatter for records already in memory; returns the ids drawn."""
+    import matplotlib
+    matplotlib.use("Agg")
+    import matplotlib.pyplot as plt
+    _fig, ax = plt.subplots(figsize=(10, 15))
+    colors = ["#0173b2", "#de8f05"]
+    labels = [f"5'-{pattern.upper()}-3'", f"3'-{pattern.translate(_COMPLEMENT).upper()}-5'"]
+    drawn = []
+    for rec in records:
+        if len(rec.seq) <= minSeqLength:
+            continue
+        y = 2 * len(drawn)
+        for i, (m1, m2) in enumerate(match_positions(rec.seq, pattern, minSeqLength).values()):
+            ax.scatter(m1 + m2, [y] * (len(m1) + len(m2)), color=colors[i], marker="|", label=None if drawn else labels[i], zorder=2)
+        drawn.append(rec.id)
+        if len(drawn) >= MAX_READS_DRAWN:
+            print("file has more than 40 reads, but it is not recommended to have plot with that many reads")
+            print("so the output plot will have 40 reads only")
+            break
+    ax.set_title(f"Location of telomere patterns in {label}")
+    ax.set_xlabel("Position")
+    if drawn:
+        ax.legend(title="Pattern")
+    ax.set_yticks([2 * i for i in range(len(drawn))])
+    ax.set_yticklabels(drawn)
+    ax.grid(True, color="grey", linestyle="--")
+    plt.tight_layout()
+    return drawn
+
+
+def descriptive_plot(filepath, pattern, minSeqLength):
+    """Location of the telomere motif (and its complement) along the first `minSeqLength` bases of
+    both ends of every read longer than `minSeqLength`, at most 41 reads (descriptive_plot.py:89-165)."""
+    if seqio.check_file_type(filepath) is None:
+        print("problem in filepath, can not have descriptive plot")
+        return None
+    descriptive_plot_records(seqio.read_records(filepath), _file_label(filepath), pattern, minSeqLength)
+    return "plotted"
 
 
 # ---------------------------------------------------------------------------- k-mer followers (the heat map)

@@ -1,12 +1,12 @@
-"""`python -m topsicle_amd.overview_plot`: the k-mer heat map of a run's telomeric reads -- which bases follow each k-mer of
-the motif -- as a thin driver over the GPU entry points.
+"""`python -m topsicle_amd.overview_plot`: the exploratory overview of a run's telomeric reads -- where the motif sits in each
+read, and which bases follow each of its k-mers -- as a thin driver over the GPU entry points.
 
 Stages (the upstream script of the same name filters at a fixed TRC cutoff of 0.7 and then plots, overview_plot.py:63):
   1. one batched pass of the TRC step (kernel step 1) over every input file picks the reads to look at;
   2. their k-mer / follower counts come from tps_batch_kmer_followers (descriptive_plot.pattern_matches);
-  3. with --recfindingpattern matplotlib draws heatmap_<i>.png; --rawcount keeps the heat map's rows as CSV.
-Nothing is written to a temporary FASTA: the selected records stay in memory.  Upstream's scatter of whole-motif hits
-(descriptive_plot_<i>.png) is visualisation outside the hot path and is not reproduced.
+  3. matplotlib always draws descriptive_plot_<i>.png (the scatter of whole-motif hits, upstream overview_plot.py:92; host side,
+     at most 41 reads) and, with --recfindingpattern, heatmap_<i>.png; --rawcount keeps the heat map's rows as CSV.
+Nothing is written to a temporary FASTA: the selected records stay in memory.
 """
 from __future__ import annotations
 
@@ -52,6 +52,9 @@ def run(args, engines=None):
                 continue
             shown += 1
             print(f"{path}: {len(recs)} reads with TRC > {TRC_CUTOFF}")
+            dp.descriptive_plot_records(recs, os.path.basename(path).split(".")[0], args.pattern, args.minSeqLength)
+            plt.savefig(os.path.join(args.outputDir, f"descriptive_plot_{shown}.png"), format="png", dpi=300)
+            plt.close()
             if not args.recfindingpattern:
                 continue
             for k in phrases:
