@@ -33,7 +33,7 @@ extern "C" int emu_scan(const char* pats, int P, int k, const uint8_t* bases, co
                         int64_t* win_off_out, int32_t* sums, uint8_t* raw) {
     std::vector<uint32_t> lut;
     tps::ScanArgs a{};
-    a.val_on = 1;                                  // (the emulation always keeps the invalid-mask staging area)
+    a.val_on = getenv("TPS_EMU_VAL_OFF") ? 0 : 1;  // (the emulation keeps the invalid-mask staging area; TPS_EMU_VAL_OFF: the layout of a clean batch, bases without invalid letters only)
     std::string err = tps::build_patterns(pats, P, k, lut, a.pat);
     if (!err.empty()) { g_err = err; return TPS_E_PATTERN; }
     std::vector<int64_t> win_off((size_t)n + 1);
@@ -87,6 +87,9 @@ extern "C" int emu_scan(const char* pats, int P, int k, const uint8_t* bases, co
     // the workgroup-shared tables (read-only for the waves): [pair table][single table]
     std::vector<uint32_t> lutbuf((size_t)a.pair_n + lut.size());
     uint32_t* lut1 = lutbuf.data() + a.pair_n;
+    if (a.lut16) {                                 // sums-only kernels of self-overlap tables: 16-bit pattern masks
+        for (size_t i = 0; i < lut.size(); ++i) ((uint16_t*)lut1)[i] = (uint16_t)lut[i];
+    } else
     for (size_t i = 0; i < lut.size(); ++i)
         lut1[i] = !a.variant ? lut[i] : a.lut_fields ? tps::mask_to_fields(lut[i])                 // raw-count kernels on the per-pattern tiles: one-hot fields
                                                      : ((lut[i] << 16) | (uint32_t)__builtin_popcount(lut[i]));   // fused kernels: mask << 16 | count

@@ -537,3 +537,38 @@ def test_planner_refuses_sums_beyond_32_bits():
         emu.plan(4, 12, prm, 500000)
     prm = hiplib.make_params(window=255 * 4 + 4, slide=6, flags=hiplib.F_WINDOWS | hiplib.F_STORE_RAW)
     emu.plan(4, 12, prm, 3000)                       # 255 occurrences at most: still fine
+
+
+@pytest.mark.parametrize("motif,k,slide,units", [
+    ("CCCTAA", 5, 6, ["CTAA", "GATT"]),
+    ("CCCTAA", 6, 6, ["CCTAA", "GGATT", "CTAAC"]),
+    ("CCCTAA", 6, 7, ["CCTAA"]),
+    ("TTTAGGG", 7, 8, ["TTTAGG"]),
+])
+def test_emulation_self_overlap_sums_clean_batch_layout(motif, k, slide, units, monkeypatch):
+    """The sums-only kernels of self-overlap tables on a batch WITHOUT non-ACGT letters (round 4): 16-bit pattern masks in the
+    LDS table (ScanArgs::lut16) and XT aliased onto the head of the staged bases (xt_alias without xt_own) -- the layout the
+    planner picks for a clean batch on the device.  Whole pipeline (step 1 on the 16-bit table, chain-corrected tiles, change
+    point) against the oracle, both tails decided by step 1."""
+    monkeypatch.setenv("TPS_EMU_VAL_OFF", "1")
+    rng = np.random.default_rng(99 + 10 * k + slide)
+    pats, seqs = _pp_reads(rng, motif, k, 6, 7000, units)
+    seqs = [s if i % 2 == 0 else s[::-1] for i, s in enumerate(seqs)]
+    plan = emu.plan_table(pats, hiplib.make_params(window=100, slide=slide), 3301)
+    assert plan["variant"] == slide and plan["pp_d"] > 0
+    L = emu.lib()
+    flags = hiplib.F_STEP1 | hiplib.F_WINDOWS | hiplib.F_BINSEG | hiplib.F_STORE_SUMS
+    prm = hiplib.make_params(no_bp=1000, min_len=1000, min_count=0, window=100, slide=slide, trimfirst=100, maxlen=20000, flags=flags)
+    t0 = L.emu_counter(5) + L.emu_counter(6)
+    out = emu.scan(pats, seqs, prm, base_shift=int(rng.integers(16)))
+    assert L.emu_counter(5) + L.emu_counter(6) - t0 >= 6
+    for i, seq in enumerate(seqs):
+        cs, ce = orc.trc_counts(seq, pats)
+        assert np.array_equal(out["c_start"][i], cs) and np.array_equal(out["c_end"][i], ce), i
+        call = orc.trc_call(cs, ce, pats, len(motif), -1.0)
+        tail = call[1]
+        assert out["results"][i]["tail"] == (0 if tail == "forward" else 1)
+        _, counts = orc.window_count_matrix(seq, tail, pats, 100, slide, 100, 20000)
+        lo, hi = out["win_off"][i], out["win_off"][i + 1]
+        assert np.array_equal(out["sums"][lo:hi], counts.sum(axis=1)), i
+        assert out["results"][i]["bkp"] == orc.binseg_l2_exact(counts.sum(axis=1))

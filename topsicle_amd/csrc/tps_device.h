@@ -184,6 +184,17 @@ TPS_DEV uint32_t lut_at_tile(const uint32_t* lut, uint32_t v4, uint32_t amask) {
 #endif
 #endif
 
+// 16-bit table entry (LUT_M16 tables: one pattern mask per k-mer code) at byte offset `off2` (already masked to the table size)
+#ifdef TPS_EMU
+TPS_DEV uint32_t lut16_at(const uint32_t* lut, uint32_t v2, uint32_t amask1) { return *(const uint16_t*)((const char*)lut + (v2 & amask1)); }
+#else
+TPS_DEV uint32_t lut16_at(const uint32_t* lut, uint32_t v2, uint32_t amask1) {
+    typedef const __attribute__((address_space(3))) uint16_t* lptr16_t;
+    const uint32_t base = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t*)lut;
+    return *(lptr16_t)(uintptr_t)((v2 & amask1) | base);      // ds_read_u16: zero-extended
+}
+#endif
+
 // 16-bit candidate sums kept off-chip: explicit global address space (a generic pointer would become FLAT
 // instructions, which also count on the LDS counter)
 #ifdef TPS_EMU
@@ -216,6 +227,11 @@ TPS_DEV uint32_t g32_load(uint64_t base, uint32_t i) {
 
 // high half of a 32 x 32-bit product (v_mul_hi_u32, full rate) and the sum of the four bytes of a word (v_sad_u8)
 TPS_DEV uint32_t mulhi32(uint32_t x, uint32_t y) { return (uint32_t)(((uint64_t)x * (uint64_t)y) >> 32); }
+#ifdef TPS_EMU
+TPS_DEV uint32_t mul24(uint32_t x, uint32_t y) { return (x & 0xFFFFFFu) * (y & 0xFFFFFFu); }
+#else
+TPS_DEV uint32_t mul24(uint32_t x, uint32_t y) { return (x & 0xFFFFFFu) * (y & 0xFFFFFFu); }      // (the masks let the compiler pick v_mul_u32_u24)
+#endif
 #ifdef TPS_EMU
 TPS_DEV uint32_t add_bytes(uint32_t v, uint32_t acc) { return acc + (v & 255u) + ((v >> 8) & 255u) + ((v >> 16) & 255u) + (v >> 24); }
 #else
@@ -253,7 +269,8 @@ struct ScanArgs {
     const uint16_t* inv;         // bit j of inv[w] = base j of word w is not acgtACGT; only read for reads flagged in desc
     const tps_read_desc* desc;   // n: word offset, length, flags of every read
     const uint8_t* tails_in;     // n, or nullptr
-    const uint32_t* lut;         // 4^k masks over the pattern list
+    const uint32_t* lut;         // 4^k masks over the pattern list (+ the pair table behind them)
+    const uint32_t* lut_img;     // fused kernels: the table as it sits in LDS (mask << 16 | count, one-hot fields or 16-bit masks: lut_dw(a) dwords)
     tps_read_result* results;    // n
     int32_t* c_start;            // n*P or nullptr
     int32_t* c_end;              // n*P or nullptr
@@ -303,6 +320,10 @@ struct ScanArgs {
     int32_t seq_alias;           // fused sums-only kernels without self-overlap: the staged bases share LDS with the tail of row[]
     int32_t lut_fields;          // raw-count kernels on a table the per-pattern tiles take: the LDS table holds ready-made one-hot
                                  // 2-bit fields (1 << 2 p for pattern p) instead of mask << 16 | count
+    int32_t lut16;               // sums-only kernels of self-overlap tables: the LDS table holds 16-bit pattern masks (LUT_M16), half the
+                                 // bytes of mask << 16 | count -- at k = 6 that is 8 KB instead of 16 KB per workgroup; counts come from v_bcnt
+    int32_t xt_alias;            // ... and their XT words (written behind a tile's window phase) share LDS with the head of the staged bases
+    int32_t xt_own;              // xt_alias kernels whose fallback tile may run (non-ACGT letters in the batch, TPS_NO_SO_FAST): XT gets its own words
 };
 
 struct BinsegArgs {
@@ -348,10 +369,11 @@ struct Lds {
     uint32_t* misc;
 };
 constexpr int XLANES = NT + 16;                  // most lanes an exchange row can hold: NT + halo lanes read past the tile end
-TPS_HD int64_t xchg_dw(const ScanArgs& a) {      // fused path: XPC (9 words per lane), XF, XT
-    (void)a;
-    return 9ll * NT + 2ll * XLANES;
+TPS_HD int64_t xchg_dw(const ScanArgs& a) {      // fused path: XPC (9 words per lane), XF, XT (xt_alias: XT lives elsewhere)
+    return 9ll * NT + (a.xt_alias ? 1ll : 2ll) * XLANES;
 }
+// dwords of the workgroup's LDS table: 4^k entries of 4 bytes, or of 2 (lut16)
+TPS_HD int64_t lut_dw(const ScanArgs& a) { return a.lut16 ? ((((int64_t)a.lut_n + 1) / 2 + 3) & ~3ll) : (((int64_t)a.lut_n + 3) & ~3ll); }
 TPS_HD int64_t blk_region_dw(const ScanArgs& a) {
     // generic kernel: G, Gp (u32) and C0, C1 (u16) per block; fused kernels: the exchange arrays
     int64_t need = a.variant ? xchg_dw(a) : 2ll * a.nblk_cap + 2ll * ((a.nblk_cap + 1) / 2);
@@ -394,10 +416,11 @@ TPS_DEV Lds carve(uint32_t* base, uint32_t* lut, const ScanArgs& a) {
     return l;
 }
 TPS_HD int64_t lds_dwords(const ScanArgs& a) {
-    return (int64_t)a.blk_dw + (a.seq_alias ? 0 : a.seq_dw) + val_dw(a) + a.tot_dw + lc_dw(a) + row_dw(a) + MISC_DW;   // per wave; + lut_n per workgroup
+    return (int64_t)a.blk_dw + (a.seq_alias ? 0 : a.seq_dw) + val_dw(a) + a.tot_dw + lc_dw(a) + row_dw(a) + MISC_DW +
+           ((a.xt_alias && a.xt_own) ? XLANES : 0);   // per wave; + the table per workgroup
 }
 // LDS dwords of a whole workgroup: the shared table + WPG wave slices (each rounded to 16 bytes)
-TPS_HD int64_t wg_lds_dwords(const ScanArgs& a) { return a.pair_n + ((a.lut_n + 3) & ~3) + (int64_t)(a.wpg > 0 ? a.wpg : WPG) * ((lds_dwords(a) + 3) & ~3ll); }
+TPS_HD int64_t wg_lds_dwords(const ScanArgs& a) { return a.pair_n + lut_dw(a) + (int64_t)(a.wpg > 0 ? a.wpg : WPG) * ((lds_dwords(a) + 3) & ~3ll); }
 // misc layout (dwords)
 constexpr int M_BEST = 0;        // 2: step-1 arg-max keys (count << 5 | 31 - pattern) of the two sides
 constexpr int M_CMASK = 2;       // 2: conflict masks of step 1 (start, end)
@@ -581,6 +604,7 @@ TPS_DEV bool invalid_at(const uint16_t* val, int q, int k) {
 // kernels), LUT_FIELDS = the one-hot 2-bit field 1 << 2 p of THE pattern p the k-mer belongs to (raw-count kernels on tables
 // without duplicate k-mers: what the per-pattern tiles and the packed step 1 add up, without the squaring).
 constexpr int LUT_FIELDS = 32;
+constexpr int LUT_M16 = 48;                       // 16-bit entries: the pattern mask alone (ScanArgs::lut16)
 // Which of the sixteen 2-bit fields belongs to list pattern p.  The per-pattern tiles widen fields to nibbles (even / odd
 // fields: two words) and nibbles to bytes (four words, pp_expand); with THIS assignment the four byte words come out in ROW
 // order -- word p / 4, byte p % 4 holds pattern p -- so a raw row is the words as they are (no byte transposition: 8 v_perm per
@@ -603,6 +627,7 @@ TPS_DEV uint32_t lut_mask(const uint32_t* lut, int lshift, const PatInfo& pat, u
         return lut[2 * slot] == code ? lut[2 * slot + 1] : 0u;
     }
     if (lshift == LUT_FIELDS) return field_to_mask(lut[code]);
+    if (lshift == LUT_M16) return ((const uint16_t*)lut)[code];
     return lut[code] >> lshift;
 }
 // mask of list patterns whose k-mer starts at position q
@@ -719,14 +744,17 @@ TPS_DEV bool trc_packed_ok(const ScanArgs& a, int npos) {
     for (int i = 0; i < a.pat.n_periods; ++i) maxd = a.pat.period[i] > maxd ? a.pat.period[i] : maxd;
     return a.pat.P <= 15 && maxd <= 6 && mp >= 3 && npos <= 255 * mp && iters * ((16 + mp - 1) / mp) <= 15;
 }
-// FLD: the table holds one-hot 2-bit fields (LUT_FIELDS): no squaring, and the overlap test runs on fields
-template <bool SO_, bool FLD = false>
+// FMT 1: the table holds one-hot 2-bit fields (LUT_FIELDS): no squaring, and the overlap test runs on fields; FMT 2: 16-bit
+// pattern masks (LUT_M16): the one-hot mask 1 << p squares to the field 1 << 2 p by a plain 24-bit multiply
+template <bool SO_, int FMT = 0>
 TPS_DEV void trc_count_packed(const ScanArgs& a, const Lds& l, const Stage& st_s, const Stage& st_e, int tid, uint32_t* keep = nullptr) {
     const PatInfo& pat = a.pat;
     const int side = tid >> 5, t = tid & 31;
     const int delta = side ? st_e.delta : st_s.delta;
     const uint32_t* seq2 = l.seq2 + side * a.head_dw;
-    const uint32_t amask = pat.kmask << 2;
+    constexpr bool FLD = FMT == 1, M16 = FMT == 2;
+    constexpr int LS = M16 ? 1 : 2;                 // log2(bytes per table entry)
+    const uint32_t amask = pat.kmask << LS;
     const int npos = st_s.n - pat.k + 1;
     const int nchunks = (npos + 15) >> 4;
     constexpr int LA = SO_ ? 6 : 0;                 // look-ahead entries for the overlap test
@@ -738,26 +766,28 @@ TPS_DEV void trc_count_packed(const ScanArgs& a, const Lds& l, const Stage& st_s
         for (int i = 0; i < pat.n_periods; ++i) {
             TPS_UNROLL
             for (int d = 1; d < 7; ++d)
-                if (pat.period[i] == d) ppd[d] |= FLD ? mask_to_fields(pat.period_pat[i]) : pat.period_pat[i] << 16;
+                if (pat.period[i] == d) ppd[d] |= FLD ? mask_to_fields(pat.period_pat[i]) : M16 ? pat.period_pat[i] : pat.period_pat[i] << 16;
         }
     }
     uint32_t ne = 0, no = 0;                        // per-pattern counts of this lane, nibbles: even / odd patterns
     uint32_t cf = 0;
     for (int c0 = 0; c0 < nchunks; c0 += 32) {      // uniform trip count
         const int c = c0 + t;
-        // the base BEFORE the chunk's first one goes to bit 0: alignbit(.., 2 j) & (kmask << 2) is then
-        // the table's byte offset of position j (the two bits below it are masked away)
-        const int qm = delta + 16 * c - 1;
-        const int idx = qm >> 4;                     // -1 for the very first chunk of an aligned head: harmless
-        const uint32_t sh = (uint32_t)(qm & 15) * 2u;
+        // the base BEFORE the chunk's first one goes to bit 0 (4-byte entries; 2-byte entries: its high bit): alignbit(.., 2 j) &
+        // (kmask << LS) is then the table's byte offset of position j (the bits below it are masked away)
+        const int bo = 2 * (delta + 16 * c) - LS;
+        const int idx = bo >> 5;                     // -1 for the very first chunk of an aligned head: harmless
+        const uint32_t sh = (uint32_t)(bo & 31);
         const uint32_t d0 = seq2[idx], d1 = seq2[idx + 1], d2 = seq2[idx + 2];
         const uint32_t w0 = alignbit(d1, d0, sh), w1 = alignbit(d2, d1, sh);
         uint32_t w2 = 0;
         if (SO_) w2 = alignbit(seq2[idx + 3], d2, sh);
         uint32_t h[16 + LA];
         TPS_UNROLL
-        for (int j = 0; j < 16 + LA; ++j)
-            h[j] = lut_at(l.lut, j == 0 ? w0 : j < 16 ? alignbit(w1, w0, 2u * j) : j == 16 ? w1 : alignbit(w2, w1, 2u * (j - 16)), amask);
+        for (int j = 0; j < 16 + LA; ++j) {
+            const uint32_t v_ = j == 0 ? w0 : j < 16 ? alignbit(w1, w0, 2u * j) : j == 16 ? w1 : alignbit(w2, w1, 2u * (j - 16));
+            h[j] = M16 ? lut16_at(l.lut, v_, amask) : lut_at(l.lut, v_, amask);
+        }
         if (16 * (c0 + 32) + LA > npos) {            // uniform: the pass that holds the end of the head
             TPS_UNROLL
             for (int j = 0; j < 16 + LA; ++j)
@@ -776,13 +806,13 @@ TPS_DEV void trc_count_packed(const ScanArgs& a, const Lds& l, const Stage& st_s
         for (int half = 0; half < 2; ++half) {
             uint32_t x2 = 0;                         // 2-bit fields: <= 3 occurrences of a pattern in 8 positions
             TPS_UNROLL
-            for (int j = 8 * half; j < 8 * half + 8; ++j) x2 += FLD ? h[j] : mulhi32(h[j], h[j]);
+            for (int j = 8 * half; j < 8 * half + 8; ++j) x2 += FLD ? h[j] : M16 ? mul24(h[j], h[j]) : mulhi32(h[j], h[j]);
             ne += x2 & 0x33333333u;
             no += (x2 >> 2) & 0x33333333u;
         }
     }
     if (SO_ && cf) {
-        uint32_t cm = cf >> 16;
+        uint32_t cm = M16 ? cf : cf >> 16;
         if (FLD) {                                  // fields -> pattern mask (rare: only a lane that saw an overlapping pair)
             cm = 0;
             while (cf) { cm |= 1u << pp_pattern(ffs0(cf) >> 1); cf &= cf - 1u; }
@@ -826,8 +856,8 @@ TPS_DEV void trc_publish_occ(const ScanArgs& a, const Lds& l, const Stage& st_s,
             const uint32_t w0 = alignbit(d1, d0, sh), w1 = alignbit(d2, d1, sh);
             TPS_UNROLL
             for (int j = 0; j < 16; ++j) {
-                uint32_t h = lut_at(l.lut, j ? alignbit(w1, w0, 2u * j) : w0, amask);
-                h = l.lshift == LUT_FIELDS ? field_to_mask(h) : h >> 16;
+                // (w0 holds the base before the chunk at bit 0: two bits above it the k-mer code starts -- any table format)
+                uint32_t h = lut_mask(l.lut, l.lshift, pat, (j ? alignbit(w1, w0, 2u * j) : w0) >> 2);
                 if (16 * c + j >= npos) h = 0;
                 h &= cmask;
                 while (h) {
@@ -1194,9 +1224,14 @@ constexpr bool tile_full_default(int s) { return s >= 1; }
 // LDS slice of a wave in the fused kernels: everything whose size is known at compile time comes first, at
 // compile-time offsets from the slice base (one SGPR for all of it, offsets folded into the DS instructions);
 // only the candidate / tile sums, whose size depends on the longest read, follow.  Sizes = plan_geometry's.
-template <int S, bool FULL>
+// XTA (the sums-only kernels of self-overlap tables, ScanArgs::xt_alias): XT -- written behind a tile's window phase, read by its
+// candidate phase -- shares its words with the head of the staged bases, which nothing reads after the tile's first phase
+// (tile_lc_s<.., CD>: the lanes' registers and the chain walks).  80 dwords per wave less: with the 16-bit table that is the fifth
+// 4-wave workgroup per CU at k = 6 (8 192 + 4 x 5 856 B = 31 616 <= 32 000).  The fallback tile (tile_fused_s: recounts read the
+// bases AFTER it has rewritten XT) gets XT words of its own behind everything else whenever it can run (ScanArgs::xt_own).
+template <int S, bool FULL, bool XTA = false>
 TPS_DEV Lds carve_fused(uint32_t* base, uint32_t* lut, const ScanArgs& a) {
-    constexpr int BLK = 9 * NT + 2 * XLANES, ROW = NT * Geo<S>::B + NT, SEQ = TileGeo<S, FULL>::SEQ;
+    constexpr int BLK = 9 * NT + (XTA ? 1 : 2) * XLANES, ROW = NT * Geo<S>::B + NT, SEQ = TileGeo<S, FULL>::SEQ;
     const int VAL = a.val_on ? ((SEQ + 4 + 3) / 4) * 2 : 0;
     static_assert(BLK % 4 == 0 && ROW % 4 == 0 && MISC_DW % 4 == 0 && SEQ % 4 == 0, "seq2 must be 16-byte aligned");
     // seq_alias: the staged bases live in the LAST SEQ dwords of row[].  A tile's lanes read them into registers at the very
@@ -1208,11 +1243,11 @@ TPS_DEV Lds carve_fused(uint32_t* base, uint32_t* lut, const ScanArgs& a) {
     Lds l;
     l.lut2 = lut - a.pair_n;
     l.lut = lut;
-    l.lshift = a.lut_fields ? LUT_FIELDS : 16;
+    l.lshift = XTA ? LUT_M16 : a.lut_fields ? LUT_FIELDS : 16;     // (the XTA kernels are the LUT_M16 kernels)
     l.blk = base;
     l.XPC = base;
     l.XF = base + 9 * NT;
-    l.XT = l.XF + XLANES;
+    l.XT = l.XF + XLANES;                      // (XTA: set below)
     l.G = l.Gp = base; l.C0 = l.C1 = (uint16_t*)base;      // generic-path views: unused here
     l.row = base + BLK;
     l.misc = l.row + ROW;
@@ -1229,6 +1264,7 @@ TPS_DEV Lds carve_fused(uint32_t* base, uint32_t* lut, const ScanArgs& a) {
     l.Lc = p;
     l.Lc16 = (uint16_t*)p;
     l.Tc = p + ((a.lc16 && a.lc_global) ? 0 : ((a.lc_cap + 3) / 4) * 2);
+    if (XTA) l.XT = a.xt_own ? p + lc_dw(a) : l.seq2;
     return l;
 }
 
@@ -1346,7 +1382,13 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const TileConst& tc, const Lds& l, 
                         const int p = blk * S + i;        // constant after unrolling
                         const int dw = p >> 4, bit = p & 15;
                         uint32_t v4 = bit ? alignbit(dw + 1 < WDW ? w[dw + 1] : 0u, w[dw], 2u * bit) : w[dw];
-                        uint32_t h = lut_at(l.lut, v4, amask);
+                        uint32_t h;
+                        if constexpr (SO && !RAW) {       // these kernels' table holds 16-bit masks (LUT_M16): rebuild mask << 16 | count
+                            const uint32_t m16 = lut16_at(l.lut, v4 >> 1, amask >> 1);
+                            h = (m16 << 16) | (uint32_t)popc(m16);
+                        } else {
+                            h = lut_at(l.lut, v4, amask);
+                        }
                         if constexpr (INV && RAW) {
                             if (a.lut_fields) h = field_to_entry(h);    // (a tile with non-ACGT letters of a batch on the per-pattern tiles)
                         }
@@ -1769,11 +1811,16 @@ TPS_DEV void tile_lc_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
     constexpr int CD = CD_;
     static_assert(CD == 0 || (!PAIR && !INV && CD <= S), "chain corrections: single lookups on clean tiles, period <= slide");
     constexpr bool RZ = RPT == 0;
+    // M16: the kernels that run the chain-corrected tiles keep their LDS table as 16-bit pattern masks (ScanArgs::lut16): a block's
+    // OR is the masks' OR, its match count their popcounts added up (v_bcnt_u32_b32: one instruction, like the add it replaces);
+    // the published words keep the layout mask << 16 | count
+    constexpr bool M16 = CD > 0;
+    constexpr int LS = M16 ? 1 : 2;               // log2(bytes per table entry)
     typedef Geo<S> g_;
     constexpr int WDW = g_::WDW, B = g_::B, LOG2B = g_::LOG2B, POS = g_::POS;
     const PatInfo& pat = a.pat;
     const int rp = RPT >= 0 ? RPT : tc.r, q = tc.q;
-    const uint32_t amask = pat.kmask << 2;
+    const uint32_t amask = pat.kmask << LS;
     // what a lane keeps about its blocks (table entries are mask << 16 | count: the OR of entries is right in its high half,
     // their sum in its low half -- the other halves are garbage that the window arithmetic never looks at)
     uint32_t sfx[B], c0s[B], xf_own = 0;         // OR of this and the lane's later blocks; matches before the block; the lane's OR | matches
@@ -1818,8 +1865,10 @@ TPS_DEV void tile_lc_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
     TPS_PHASE {
         const int span = tid;
         const int p0 = delta + span * POS;        // >= 16: fused tiles are staged behind SEQ_LEAD words
-        const uint32_t sh2 = (uint32_t)((p0 - 1) & 15) * 2u;
-        const int d0 = (p0 - 1) >> 4;
+        // the lane's bases shifted so that position p's k-mer code sits LS bits above bit 2 p: code << LS is the table's byte offset
+        const int bo = 2 * p0 - LS;
+        const uint32_t sh2 = (uint32_t)(bo & 31);
+        const int d0 = bo >> 5;
         uint32_t w[WDW];
         {
             uint32_t prev = l.seq2[d0];
@@ -1883,7 +1932,7 @@ TPS_DEV void tile_lc_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
                 for (int i = 0; i < S; ++i) {
                     if (i < cnt_) {
                         const int p = blk * S + i;
-                        uint32_t h = lut_at(l.lut, v4_at(p), amask);
+                        uint32_t h = M16 ? lut16_at(l.lut, v4_at(p), amask) : lut_at(l.lut, v4_at(p), amask);
                         if (INV) {
                             if (h && invalid_at(l.val, p0 + p, pat.k)) h = 0;   // tiles with non-ACGT letters only
                         }
@@ -1902,12 +1951,12 @@ TPS_DEV void tile_lc_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
                     uint32_t cfb = 0;                     // some pattern occurs at p and again at p + CD, p in this block
                     TPS_UNROLL
                     for (int i = 0; i < S; ++i) cfb |= hc[i] & (i + CD < S ? hc[i + CD] : hn[i + CD - S]);
-                    if (cfb & 0xFFFF0000u) {              // rare: a deleted or inserted base inside a telomeric stretch
+                    if (M16 ? cfb != 0u : (cfb & 0xFFFF0000u) != 0u) {   // rare: a deleted or inserted base inside a telomeric stretch
                         // remember WHERE (one bit per position of the lane); the chains are walked behind the block loop, by one
                         // copy of that code instead of one per unrolled position
                         TPS_UNROLL
                         for (int i = 0; i < S; ++i) {
-                            const uint32_t pr = ((hc[i] & (i + CD < S ? hc[i + CD] : hn[i + CD - S])) >> 16) ? 1u : 0u;
+                            const uint32_t pr = ((hc[i] & (i + CD < S ? hc[i + CD] : hn[i + CD - S])) >> (M16 ? 0 : 16)) ? 1u : 0u;
                             if (blk * S + i < 32) pair_lo |= pr << ((blk * S + i) & 31);
                             else pair_hi |= pr << ((blk * S + i) & 31);
                         }
@@ -1920,12 +1969,12 @@ TPS_DEV void tile_lc_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
                 for (int i = 0; i < S; ++i) {
                     const uint32_t h = hc[i];
                     g |= h;
-                    cnt += h;
+                    cnt = M16 ? cnt + (uint32_t)popc(h) : cnt + h;
                     if (!RZ) {
                         if (i + 1 == rp) { c1 = cnt; pp = run_or | g; }
                     }
                 }
-                xpc[blk] = pack_hi_lo(pp, c1);
+                xpc[blk] = M16 ? ((pp << 16) | c1) : pack_hi_lo(pp, c1);
                 gs[blk] = g;
                 run_or |= g;
                 TPS_UNROLL
@@ -1935,10 +1984,10 @@ TPS_DEV void tile_lc_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
         uint32_t sf = 0;
         TPS_UNROLL
         for (int j = B - 1; j >= 0; --j) {
-            sf |= gs[j];
+            sf = M16 ? ((gs[j] << 16) | sf) : (sf | gs[j]);      // (the window phase wants the masks in the high half)
             sfx[j] = sf;
         }
-        xf_own = pack_hi_lo(sf, cnt);
+        xf_own = M16 ? (sf | cnt) : pack_hi_lo(sf, cnt);
         l.XF[span] = xf_own;
         if constexpr (CD > 0) {
             // the lane's occurrence pairs: the ones that HEAD a chain (no occurrence of the pattern CD before them; what lies
@@ -3085,7 +3134,8 @@ TPS_DEV void binseg_from_lc(const ScanArgs& a, const Lds& l, uint64_t lc_g, cons
 // 2 periods 5 and 6 (one tile_lc_s<.., CD> per period and partial-block position: the host picks the kernel by ScanArgs::pp_d).
 template <int SV, bool SO, bool PAIR = false, bool RAW = true, bool FULL = tile_full_default(SV), int DCLASS = 0>
 TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_t* lut) {
-    const Lds l = SV ? carve_fused<SV ? SV : 5, FULL>(lds_base, lut, a) : carve(lds_base, lut, a);
+    constexpr bool M16K = SV != 0 && SO && !RAW;       // sums-only kernels of self-overlap tables: 16-bit table, XT aliased (lut16 / xt_alias)
+    const Lds l = SV ? carve_fused<SV ? SV : 5, FULL, M16K>(lds_base, lut, a) : carve(lds_base, lut, a);
     const PatInfo& pat = a.pat;
     const tps_params& prm = a.prm;
     // one 16-byte descriptor per read (wave-uniform: a scalar load)
@@ -3163,7 +3213,7 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
             if (fld) {
                 if constexpr (RAW) { TPS_PHASE { trc_count_packed<SO, true>(a, l, st_s, st_e, tid); } }
             } else if (SO) {
-                TPS_PHASE { trc_count_packed<true>(a, l, st_s, st_e, tid); }
+                TPS_PHASE { trc_count_packed<true, M16K ? 2 : 0>(a, l, st_s, st_e, tid); }
             } else {
                 TPS_PHASE { trc_count_packed<false>(a, l, st_s, st_e, tid); }
             }

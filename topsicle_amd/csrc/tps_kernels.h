@@ -27,10 +27,12 @@
         /* workgroup-shared tables: [pair table (PAIR kernels)][single table], both aligned to their size */ \
         uint32_t* lut = lds + ((PAIR) ? a.pair_n : 0);                                                     \
         const int nthr_ = tps::NT * a.wpg;            /* = blockDim.x */                                   \
-        for (int i = (int)threadIdx.x; i < a.lut_n; i += nthr_) {                                          \
-            const uint32_t m_ = a.lut[i];                                                                  \
-            lut[i] = !(SV) ? m_ : ((RAW) && a.lut_fields) ? tps::mask_to_fields(m_)                        \
-                                                          : ((m_ << 16) | (uint32_t)__builtin_popcount(m_));  \
+        if ((SV) != 0) {   /* fused kernels: the host keeps the table in its LDS format (lut_img): a copy in 16-byte pieces */ \
+            const int ndw_ = (int)tps::lut_dw(a);                                                           \
+            for (int c = 4 * (int)threadIdx.x; c < ndw_; c += 4 * nthr_)                                    \
+                *(uint4*)(lut + c) = *(const uint4*)(a.lut_img + c);                                        \
+        } else {                                                                                           \
+            for (int i = (int)threadIdx.x; i < a.lut_n; i += nthr_) lut[i] = a.lut[i];                      \
         }                                                                                                  \
         if (PAIR) {   /* host-built pair table, stored right behind the plain table */                      \
             for (int c = 4 * (int)threadIdx.x; c < a.pair_n; c += 4 * nthr_)                               \
@@ -45,7 +47,10 @@
            readfirstlane: the wave index is uniform -> everything per read lives in SGPRs */              \
         const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));                          \
         const int64_t wave_dw = (tps::lds_dwords(a) + 3) & ~3ll;                                           \
-        uint32_t* slice = lut + ((a.lut_n + 3) & ~3) + wave * wave_dw;                                     \
+        uint32_t* slice = lut + tps::lut_dw(a) + wave * wave_dw;                                           \
+        /* (several reads per wave -- a grid-strided loop here, so that a big table is loaded once per 8 or 16 reads -- was built \
+           in round 4 and dropped: with a loop around it the optimiser hoists the read-invariant arithmetic of scan_read out of  \
+           the loop and keeps it live: _s6so 88 -> 96 VGPRs + scratch, 146 -> 227 spilled SGPRs) */                              \
         const int64_t r = (int64_t)blockIdx.x * a.wpg + wave;                                              \
         if (r < a.n_reads) tps::scan_read<SV, SO, PAIR, RAW, FULL, DCLASS>(a, r, slice, lut);                           \
     }

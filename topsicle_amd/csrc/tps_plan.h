@@ -132,7 +132,7 @@ inline void plan_wpg(ScanArgs& a, int64_t budget_dw) {
     }
     // only multiples of four: a workgroup's waves go round the four SIMDs, and five waves would put two on one of them
     // (measured at k = 6, 10 000 x 25 kb reads: 4 waves per workgroup 0.256 ms, 5: 0.306, 7: 0.251, 8: 0.222)
-    if (a.lut_n * 4 >= 16384) {
+    if (lut_dw(a) * 4 >= 16384) {
         // (ten waves per workgroup -- two workgroups of ten with a 16 KB table each fill the CU's LDS, 5 waves per SIMD -- was
         // measured in round 3: 248 us against 207 us with eight at k = 6: ten waves sit 3 / 3 / 2 / 2 on the four SIMDs)
         const int v = waves_per_cu(WPG_MAX);
@@ -140,6 +140,7 @@ inline void plan_wpg(ScanArgs& a, int64_t budget_dw) {
     }
     a.wpg = best;
 }
+
 
 // Slides that have a specialised kernel instantiation (tps_scan_kernel_s<S>).
 inline bool has_specialised_slide(int s) { return s == 5 || s == 6 || s == 7 || s == 8; }
@@ -196,6 +197,7 @@ inline std::string plan_geometry_core(ScanArgs& a, const tps_params& prm, int k,
                        a.q / 8 + 2 < (XLANES - NT) && max_period <= std::min(prm.slide, 6) &&
                        2 * a.head_dw <= fused_seq_dw(prm.slide);   // the two step-1 heads fit the tile buffer (TileGeo::SEQ)
     a.lc16 = 0; a.tile_cap = 0; a.tw = 0; a.tw_magic = 0; a.pair_n = 0; a.lc_global = 0; a.lc_stride = 0; a.pp_d = -1; a.so_fast = 0; a.seq_alias = 0; a.lut_fields = 0; a.tile_full = 0;
+    a.lut16 = 0; a.xt_alias = 0; a.xt_own = 0;
     if (fused) {
         // per-pattern tiles (tile_pp_s): one-hot 2-bit fields per pattern need distinct k-mers, raw rows of at most 14 bytes
         // (they are staged through 16-byte LDS rows); a lane's 8 blocks hold at
@@ -207,6 +209,13 @@ inline std::string plan_geometry_core(ScanArgs& a, const tps_params& prm, int k,
         if (pp_counts && a.pat.n_periods == 1 && a.pat.period[0] >= 2 && 2 * a.pat.period[0] >= k) a.pp_d = a.pat.period[0];
         a.lut_fields = (a.pp_d >= 0 && (prm.flags & TPS_F_STORE_RAW)) ? 1 : 0;   // the per-pattern tiles will run: table of one-hot fields
         a.so_fast = getenv("TPS_NO_SO_FAST") ? 0 : 1;   // sums only, pp_d > 0: chain-free tiles complete as plain tiles (tile_fused_s<.., CD>)
+        // the sums-only kernels of self-overlap tables (_s*so, _s*sol): 16-bit table, XT aliased onto the staged bases unless the
+        // fallback tile can run (a batch with non-ACGT letters, a table the chain corrections do not take, TPS_NO_SO_FAST)
+        if (a.pat.so_mask != 0 && !(prm.flags & TPS_F_STORE_RAW)) {
+            a.lut16 = 1;
+            a.xt_alias = 1;
+            a.xt_own = (a.val_on || !a.so_fast || a.pp_d <= 0 || getenv("TPS_XT_OWN")) ? 1 : 0;
+        }
         a.variant = prm.slide;
         a.blk_log2 = 3;                            // 8 blocks per lane for every slide
         a.span_dw = 0;                             // lanes start at arbitrary bit offsets (per-lane shift)
@@ -253,6 +262,7 @@ inline std::string plan_geometry_core(ScanArgs& a, const tps_params& prm, int k,
         // does not fit (very long maxlengthtelo: the candidate sums of 4 reads outgrow LDS): the generic kernel,
         // whose tile size adapts, takes over
         a.lc16 = 0; a.tile_cap = 0; a.tw = 0; a.tw_magic = 0; a.pair_n = 0; a.lc_global = 0; a.lc_stride = 0; a.pp_d = -1; a.so_fast = 0; a.seq_alias = 0; a.lut_fields = 0;
+        a.lut16 = 0; a.xt_alias = 0; a.xt_own = 0;
     }
     a.variant = 0;
     // the generic kernel's 32-bit candidate sums go off-chip too (stride counted in 16-bit units)
