@@ -7,15 +7,15 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
 import numpy as np
 from topsicle_amd import hiplib, synth, allsteps
-motif, k, slide = "CCCTAA", 4, 6
+motif, k, slide = "CCCTAA", int(os.environ.get("TPS_STAMP_K", "4")), 6
 pats = allsteps.patterns_to_search(motif, k)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 rl = int(sys.argv[2]) if len(sys.argv) > 2 else 15000
 wpg = int(sys.argv[3]) if len(sys.argv) > 3 else 4
-b, o, _ = synth.make_reads(n, rl, motif, 20250920, errors=synth.ONT, telomeric_fraction=float(os.environ.get("TPS_TELO_FRAC", "1")))
+b, o, _ = synth.make_reads(n, rl, motif, 20250920, errors={"ont": synth.ONT, "hifi": synth.HIFI}[os.environ.get("TPS_STAMP_ERRORS", "ont")], telomeric_fraction=float(os.environ.get("TPS_TELO_FRAC", "1")))
 sc = hiplib.HipScanner(0); sc.set_patterns(pats)
 sc.upload(0, b, o)
-prm = hiplib.make_params(min_len=9000, min_count=allsteps.min_count_for_cutoff(0.7, 1000 / len(motif), 1000), slide=slide, flags=1 | 2 | 4 | 8)
+prm = hiplib.make_params(min_len=9000, min_count=allsteps.min_count_for_cutoff(0.7, 1000 / len(motif), 1000), slide=slide, flags=int(os.environ.get("TPS_STAMP_FLAGS", "15")))
 for _ in range(300):
     sc.scan(0, prm)
 sc.sync()

@@ -416,11 +416,15 @@ def test_emulation_per_pattern_tiles(motif, k, slide, units):
     ("CCCTAA", 6, 6, "CCTAA"),                    # CCTAAC: period 5
     ("TTTAGGG", 7, 7, "TTTAGG"),                  # period 6
 ])
-def test_emulation_chain_free_tiles_hand_over(motif, k, slide, unit):
+@pytest.mark.parametrize("detect_every_tile", [True, False])
+def test_emulation_chain_free_tiles_hand_over(motif, k, slide, unit, detect_every_tile, monkeypatch):
     """Self-overlap table: tiles without a chained occurrence complete as plain tiles (sums only: tile_fused_s<.., CD>; raw rows:
     tile_pp_s<S, 0, CD>), the others go through tile_so_s / tile_pp_s<S, D>.  Chains planted around every tile boundary (before, across, after; 2 to 6 links; both
     tails) check the hand-over in both directions: what a plain tile leaves for a chained successor, and a chained tile
-    followed by a plain one."""
+    followed by a plain one.  detect_every_tile (TPS_SO_FAST=2): the raw-row kernels try the chain-free tile first for EVERY tile (the
+    order of round 3); otherwise a tile that follows a chained one goes straight to the canonical-pick tile (round 4)."""
+    if detect_every_tile:
+        monkeypatch.setenv("TPS_SO_FAST", "2")
     rng = np.random.default_rng(7 * k + slide)
     pats = orc.kmer_table(motif, k)
     flags = hiplib.F_WINDOWS | hiplib.F_BINSEG | hiplib.F_TAILS_IN | hiplib.F_STORE_SUMS
@@ -448,7 +452,7 @@ def test_emulation_chain_free_tiles_hand_over(motif, k, slide, unit):
         fast, slow, redone = lib.emu_counter(fi) - f0, lib.emu_counter(si) - s0, lib.emu_counter(1) - r0
         if raw:
             slow -= fast                                # (counter 0 counts every completed per-pattern tile)
-        assert fast > 0 and slow > 0, (raw, fast, slow)
+        assert slow > 0 and (fast > 0 or (raw and not detect_every_tile)), (raw, fast, slow)
         for i, seq in enumerate(seqs):
             _, counts = orc.window_count_matrix(seq, ["forward", "reverse"][tails[i]], pats, 100, slide, 100, 20000)
             lo, hi = out["win_off"][i], out["win_off"][i + 1]
@@ -572,3 +576,58 @@ def test_emulation_self_overlap_sums_clean_batch_layout(motif, k, slide, units, 
         lo, hi = out["win_off"][i], out["win_off"][i + 1]
         assert np.array_equal(out["sums"][lo:hi], counts.sum(axis=1)), i
         assert out["results"][i]["bkp"] == orc.binseg_l2_exact(counts.sum(axis=1))
+
+
+@pytest.mark.parametrize("window,fast", [(261, True), (262, False), (420, False)])
+def test_emulation_self_overlap_sums_wide_windows(window, fast):
+    """The chain-corrected sums tiles keep a window's matches and pairs in two 8-bit fields of one 16-bit count (round 4): windows
+    of more than 255 start positions (W - k > 255) take the flag-and-recount tile instead -- both exact."""
+    motif, k, slide = "CCCTAA", 6, 6
+    rng = np.random.default_rng(window)
+    pats, seqs = _pp_reads(rng, motif, k, 3, 8000, ["CCTAA", "GGATT"])
+    prm = hiplib.make_params(window=window, slide=slide, trimfirst=100, maxlen=20000,
+                             flags=hiplib.F_WINDOWS | hiplib.F_BINSEG | hiplib.F_TAILS_IN | hiplib.F_STORE_SUMS)
+    L = emu.lib()
+    t0 = L.emu_counter(5) + L.emu_counter(6)
+    out = emu.scan(pats, seqs, prm, tails=[0, 1, 0])
+    assert (L.emu_counter(5) + L.emu_counter(6) - t0 > 0) == fast
+    for i, seq in enumerate(seqs):
+        _, counts = orc.window_count_matrix(seq, ["forward", "reverse", "forward"][i], pats, window, slide, 100, 20000)
+        lo, hi = out["win_off"][i], out["win_off"][i + 1]
+        assert np.array_equal(out["sums"][lo:hi], counts.sum(axis=1)), i
+
+
+@pytest.mark.parametrize("motif,k,unit", [
+    ("CCCTAA", 6, "CCTAA"), ("CCCTAA", 5, "CTAA"), ("TTTAGGG", 7, "TTTAGG"), ("TTAGGG", 5, "TTAG"), ("CCCTAA", 6, "GGATT"),
+])
+def test_emulation_step1_chains_of_every_length(motif, k, unit):
+    """Step 1 on tables with self-overlapping k-mers (round 4: pairs and triples taken off / added back per pattern from the packed
+    bases, chains of four or more recounted): chains of 2 .. 9 elements planted at random places of both heads, across the 16-base
+    chunk boundaries and across the END of the 1000-base head (where only the elements that are start positions of the head
+    count), inside telomere-like repeats with deletions -- per-pattern counts of both ends against the oracle."""
+    rng = np.random.default_rng(1000 * k + len(unit))
+    pats = orc.kmer_table(motif, k)
+    d = len(unit)
+    seqs = []
+    for i in range(48):
+        L = int(rng.integers(1100, 2600)) if i % 4 else int(rng.integers(700, 1000))     # (short reads: the two heads overlap)
+        if i % 3 == 0:
+            body = list((motif * (L // len(motif) + 2))[:L])
+            for _ in range(int(rng.integers(5, 60))):                       # deletions make pairs, close ones chains of three
+                del body[int(rng.integers(0, len(body)))]
+            body += ["ACGT"[x] for x in rng.integers(0, 4, L - len(body))]
+        else:
+            body = ["ACGT"[x] for x in rng.integers(0, 4, L)]
+        for _ in range(int(rng.integers(1, 7))):
+            n = int(rng.integers(2, 10))
+            run = list(unit * (n - 1) + unit[:k])                           # n chained occurrences of the unit's k-mer(s)
+            at = int(rng.choice([rng.integers(0, 40), rng.integers(950, 1010), rng.integers(0, L - len(run)), L - int(rng.integers(950, 1010)), L - len(run) - int(rng.integers(0, 30))]))
+            at = max(0, min(L - len(run), at))
+            body[at:at + len(run)] = run
+        seqs.append("".join(body[:L]))
+    prm = hiplib.make_params(no_bp=1000, min_len=0, min_count=10 ** 6, flags=hiplib.F_STEP1)
+    out = emu.scan(pats, seqs, prm, base_shift=int(rng.integers(16)))
+    for i, seq in enumerate(seqs):
+        cs, ce = orc.trc_counts(seq, pats)
+        assert np.array_equal(out["c_start"][i], cs), (i, len(seq), out["c_start"][i], cs)
+        assert np.array_equal(out["c_end"][i], ce), (i, len(seq), out["c_end"][i], ce)

@@ -744,8 +744,18 @@ TPS_DEV bool trc_packed_ok(const ScanArgs& a, int npos) {
     for (int i = 0; i < a.pat.n_periods; ++i) maxd = a.pat.period[i] > maxd ? a.pat.period[i] : maxd;
     return a.pat.P <= 15 && maxd <= 6 && mp >= 3 && npos <= 255 * mp && iters * ((16 + mp - 1) / mp) <= 15;
 }
-// FMT 1: the table holds one-hot 2-bit fields (LUT_FIELDS): no squaring, and the overlap test runs on fields; FMT 2: 16-bit
-// pattern masks (LUT_M16): the one-hot mask 1 << p squares to the field 1 << 2 p by a plain 24-bit multiply
+// FMT 1: the table holds one-hot 2-bit fields (LUT_FIELDS): no squaring; FMT 2: 16-bit pattern masks (LUT_M16): the one-hot mask
+// 1 << p squares to the field 1 << 2 p by a plain 24-bit multiply.
+// SO_ (round 4): tables with self-overlapping k-mers.  re.finditer counts leftmost non-overlapping occurrences
+// (allsteps.py:182): along a chain of occurrences d apart (d the k-mers' one period) it takes every other one, so a chain of n
+// counts ceil(n / 2) = n - pairs + triples for n <= 3, where a pair / triple = occurrences at j, j + d (, j + 2 d).  Two
+// occurrences d apart ARE k + d bases of period d, so pairs and triples are found on the packed bases themselves, 16 positions at a
+// time: one XOR of the chunk's registers against themselves d bases on, an AND-fold to runs of k equal comparisons, two more ANDs
+// for the triples and the chains of four -- ~30 instructions per chunk and no extra lookups.  Only a chunk that holds a pair
+// (a deleted base inside the telomere: ~15 % of the chunks at ONT error rates) walks its 16 positions again to take the
+// pairs off the lane's per-pattern counts and add the triples back; a chain of FOUR or more (two per thousand bases even there)
+// flags its pattern for the exact recount (trc_publish_occ / trc_walk_occ), as does any overlapping pair in a table with more
+// than one period.  Round 3 flagged every pair: at k = 6 every ONT read took the recount, 60 of a read's 132 thousand clocks.
 template <bool SO_, int FMT = 0>
 TPS_DEV void trc_count_packed(const ScanArgs& a, const Lds& l, const Stage& st_s, const Stage& st_e, int tid, uint32_t* keep = nullptr) {
     const PatInfo& pat = a.pat;
@@ -757,20 +767,11 @@ TPS_DEV void trc_count_packed(const ScanArgs& a, const Lds& l, const Stage& st_s
     const uint32_t amask = pat.kmask << LS;
     const int npos = st_s.n - pat.k + 1;
     const int nchunks = (npos + 15) >> 4;
-    constexpr int LA = SO_ ? 6 : 0;                 // look-ahead entries for the overlap test
-    uint32_t ppd[7];
-    if (SO_) {
-        TPS_UNROLL
-        for (int d = 0; d < 7; ++d) ppd[d] = 0;
-        TPS_NOVEC
-        for (int i = 0; i < pat.n_periods; ++i) {
-            TPS_UNROLL
-            for (int d = 1; d < 7; ++d)
-                if (pat.period[i] == d) ppd[d] |= FLD ? mask_to_fields(pat.period_pat[i]) : M16 ? pat.period_pat[i] : pat.period_pat[i] << 16;
-        }
-    }
+    const int k = pat.k;
+    auto fieldsq = [&](uint32_t h) -> uint32_t { return FLD ? h : M16 ? mul24(h, h) : mulhi32(h, h); };   // table entry -> one-hot 2-bit field
     uint32_t ne = 0, no = 0;                        // per-pattern counts of this lane, nibbles: even / odd patterns
-    uint32_t cf = 0;
+    uint32_t pe = 0, po = 0, te = 0, to = 0;        // SO_: the same for pairs and triples (counted at their first element)
+    uint32_t cf = 0;                                // SO_: entries of the patterns that need the exact recount
     for (int c0 = 0; c0 < nchunks; c0 += 32) {      // uniform trip count
         const int c = c0 + t;
         // the base BEFORE the chunk's first one goes to bit 0 (4-byte entries; 2-byte entries: its high bit): alignbit(.., 2 j) &
@@ -780,50 +781,89 @@ TPS_DEV void trc_count_packed(const ScanArgs& a, const Lds& l, const Stage& st_s
         const uint32_t sh = (uint32_t)(bo & 31);
         const uint32_t d0 = seq2[idx], d1 = seq2[idx + 1], d2 = seq2[idx + 2];
         const uint32_t w0 = alignbit(d1, d0, sh), w1 = alignbit(d2, d1, sh);
-        uint32_t w2 = 0;
-        if (SO_) w2 = alignbit(seq2[idx + 3], d2, sh);
-        uint32_t h[16 + LA];
+        uint32_t h[16];
         TPS_UNROLL
-        for (int j = 0; j < 16 + LA; ++j) {
-            const uint32_t v_ = j == 0 ? w0 : j < 16 ? alignbit(w1, w0, 2u * j) : j == 16 ? w1 : alignbit(w2, w1, 2u * (j - 16));
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t v_ = j == 0 ? w0 : alignbit(w1, w0, 2u * j);
             h[j] = M16 ? lut16_at(l.lut, v_, amask) : lut_at(l.lut, v_, amask);
         }
-        if (16 * (c0 + 32) + LA > npos) {            // uniform: the pass that holds the end of the head
+        const bool last_pass = 16 * (c0 + 32) + 32 > npos;      // uniform: the pass that holds the end of the head
+        if (last_pass) {
             TPS_UNROLL
-            for (int j = 0; j < 16 + LA; ++j)
+            for (int j = 0; j < 16; ++j)
                 if (16 * c + j >= npos) h[j] = 0;
-        }
-        if (SO_) {
-            TPS_UNROLL
-            for (int d = 1; d < 7; ++d) {
-                if (ppd[d]) {                        // uniform
-                    TPS_UNROLL
-                    for (int j = 0; j < 16; ++j) cf |= h[j] & h[j + d] & ppd[d];
-                }
-            }
         }
         TPS_UNROLL
         for (int half = 0; half < 2; ++half) {
             uint32_t x2 = 0;                         // 2-bit fields: <= 3 occurrences of a pattern in 8 positions
             TPS_UNROLL
-            for (int j = 8 * half; j < 8 * half + 8; ++j) x2 += FLD ? h[j] : M16 ? mul24(h[j], h[j]) : mulhi32(h[j], h[j]);
+            for (int j = 8 * half; j < 8 * half + 8; ++j) x2 += fieldsq(h[j]);
             ne += x2 & 0x33333333u;
             no += (x2 >> 2) & 0x33333333u;
+        }
+        if (SO_) {
+            const uint32_t w2 = alignbit(seq2[idx + 3], d2, sh);
+            // the chunk's bases from bit 0 on: positions 0 .. 15 | 16 .. 31 | 32 .. 47 (the last word a fraction of a base short)
+            const uint32_t a0 = alignbit(w1, w0, (uint32_t)LS), a1 = alignbit(w2, w1, (uint32_t)LS), a2 = w2 >> LS;
+            TPS_NOVEC
+            for (int pi = 0; pi < pat.n_periods; ++pi) {            // (one period: every telomere motif tried)
+                const int d = pat.period[pi];
+                const uint32_t x0 = a0 ^ alignbit(a1, a0, 2u * (uint32_t)d), x1 = a1 ^ alignbit(a2, a1, 2u * (uint32_t)d);
+                const uint32_t z0 = ~(x0 | (x0 >> 1)) & 0x55555555u, z1 = ~(x1 | (x1 >> 1)) & 0x55555555u;   // bit 2 i: base i == base i + d
+                uint32_t r0 = z0, r1 = z1;           // bit 2 j: the k-mers at j and j + d are the same (k equal comparisons from j on)
+                TPS_NOVEC
+                for (int u = 1; u < k; ++u) { r0 &= alignbit(z1, z0, 2u * (uint32_t)u); r1 &= z1 >> (2 * u); }
+                // r is known up to position 32 - k; pairs, triples and chains of four by their FIRST element j = 0 .. 15
+                uint32_t pr = r0, tr = 0, qd = 0;
+                if (pat.n_periods == 1) {
+                    tr = r0 & alignbit(r1, r0, 2u * (uint32_t)d);
+                    qd = tr & alignbit(r1, r0, 4u * (uint32_t)d);
+                    const int known = 32 - k - 2 * d;                 // first elements up to here see their whole chain of four
+                    if (known < 15) qd |= tr & ~((known < 0) ? 0u : ((4u << (2 * known)) - 1u));      // (the others: a triple counts as one)
+                } else {
+                    qd = pr;                           // several periods: any overlapping pair sends its pattern to the recount
+                }
+                if (last_pass) {
+                    // both (all three, four) elements are start positions of the head
+                    auto below = [&](int n) -> uint32_t { return n <= 0 ? 0u : n >= 16 ? 0xFFFFFFFFu : ((1u << (2 * n)) - 1u); };
+                    pr &= below(npos - 16 * c - d);
+                    tr &= below(npos - 16 * c - 2 * d);
+                    if (pat.n_periods == 1) qd &= below(npos - 16 * c - 2 * d); else qd &= below(npos - 16 * c - d);
+                }
+                if (pr != 0u) {                        // a pair starts in this chunk (or the bases are periodic without a pattern)
+                    uint32_t xp[2] = {0u, 0u}, xt[2] = {0u, 0u};
+                    TPS_UNROLL
+                    for (int j = 0; j < 16; ++j) {
+                        const uint32_t hp = h[j] & (0u - ((pr >> (2 * j)) & 1u));
+                        const uint32_t ht = h[j] & (0u - ((tr >> (2 * j)) & 1u));
+                        xp[j >> 3] += fieldsq(hp);
+                        xt[j >> 3] += fieldsq(ht);
+                        cf |= h[j] & (0u - ((qd >> (2 * j)) & 1u));
+                    }
+                    TPS_UNROLL
+                    for (int half = 0; half < 2; ++half) {
+                        pe += xp[half] & 0x33333333u; po += (xp[half] >> 2) & 0x33333333u;
+                        te += xt[half] & 0x33333333u; to += (xt[half] >> 2) & 0x33333333u;
+                    }
+                }
+            }
         }
     }
     if (SO_ && cf) {
         uint32_t cm = M16 ? cf : cf >> 16;
-        if (FLD) {                                  // fields -> pattern mask (rare: only a lane that saw an overlapping pair)
+        if (FLD) {                                  // fields -> pattern mask (rare: only a lane that saw a long chain)
             cm = 0;
             while (cf) { cm |= 1u << pp_pattern(ffs0(cf) >> 1); cf &= cf - 1u; }
         }
         lds_or(&l.misc[M_CMASK + side], cm);
     }
     uint32_t* dst = keep ? keep : l.blk + 4 * tid;  // (keep: the caller sums the lanes' words itself -- trc_decide_packed)
-    dst[0] = ne & 0x0F0F0F0Fu;
-    dst[1] = (ne >> 4) & 0x0F0F0F0Fu;
-    dst[2] = no & 0x0F0F0F0Fu;
-    dst[3] = (no >> 4) & 0x0F0F0F0Fu;
+    // bytes per pattern: occurrences - pairs + triples (a lane's pairs are among its occurrences, its triples among its pairs:
+    // no byte borrows)
+    dst[0] = (ne & 0x0F0F0F0Fu) - (pe & 0x0F0F0F0Fu) + (te & 0x0F0F0F0Fu);
+    dst[1] = ((ne >> 4) & 0x0F0F0F0Fu) - ((pe >> 4) & 0x0F0F0F0Fu) + ((te >> 4) & 0x0F0F0F0Fu);
+    dst[2] = (no & 0x0F0F0F0Fu) - (po & 0x0F0F0F0Fu) + (to & 0x0F0F0F0Fu);
+    dst[3] = ((no >> 4) & 0x0F0F0F0Fu) - ((po >> 4) & 0x0F0F0F0Fu) + ((to >> 4) & 0x0F0F0F0Fu);
 }
 // Recount of the (few) patterns with overlapping occurrences, cooperatively: every lane looks its chunks up
 // again and publishes, per conflicting pattern, the 16 occurrence bits of each chunk (u16 per chunk: a
@@ -1817,7 +1857,10 @@ TPS_DEV void tile_lc_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
     constexpr bool M16 = CD > 0;
     constexpr int LS = M16 ? 1 : 2;               // log2(bytes per table entry)
     typedef Geo<S> g_;
-    constexpr int WDW = g_::WDW, B = g_::B, LOG2B = g_::LOG2B, POS = g_::POS;
+    constexpr int B = g_::B, LOG2B = g_::LOG2B, POS = g_::POS;
+    constexpr int LB = CD;                        // CD: the lane's registers start CD positions before its first one (look-back of the pair test)
+    constexpr int WDW = (LB + POS + 13 + 15) / 16;
+    static_assert(CD > 0 || WDW == g_::WDW, "the plain tiles keep Geo's register footprint");
     const PatInfo& pat = a.pat;
     const int rp = RPT >= 0 ? RPT : tc.r, q = tc.q;
     const uint32_t amask = pat.kmask << LS;
@@ -1827,37 +1870,31 @@ TPS_DEV void tile_lc_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
 #ifdef TPS_EMU
     uint32_t sfx_keep[NT][B], c0_keep[NT][B], xf_keep[NT];
 #endif
-    uint32_t lane_chain = 0;                      // CD: this lane found the head of a chain
-    if constexpr (CD > 0) {
-        TPS_PHASE {
-            TPS_UNROLL
-            for (int i = 0; i < B + 1; ++i) l.row[tid + i * NT] = 0;          // the difference array, indexed by padded window
-        }
-        TPS_SYNC();
-    }
-    // (CD) the steps of floor(n / 2) for the chain of pattern mask `pm` whose head is at tile position tp
-    auto chain_steps = [&](int tp, uint32_t pm) {
+    uint32_t lane_chain = 0;                      // CD: this lane found the head of a chain of three or more (it added steps to the difference array)
+    uint32_t pair_lo = 0, pair_hi = 0;            // CD: bit e = some pattern occurs at the lane's position e and CD before it (a pair, filed under its SECOND element)
+#ifdef TPS_EMU
+    uint32_t pair_keep[NT][2];
+#endif
+    // (CD) a chain of three or more occurrences CD apart, first element at tile position tp (it may lie before the tile), pattern
+    // mask pm: the pair count takes n - 1 off a window that holds n consecutive elements, finditer counts ceil(n / 2) = n - (n - 1)
+    // + floor((n - 1) / 2) -- the steps of floor((n - 1) / 2), window by window, go to the difference array (any length, exact)
+    auto long_chain_steps = [&](int tp, uint32_t pm) {
         constexpr int CD = CD_ > 0 ? CD_ : 1;     // (never called for CD_ = 0; keeps the divisions below well-formed)
         const int lw = a.lw;
         auto occ = [&](int pos) -> bool { return (lut_mask(l.lut, l.lshift, pat, v_at(l.seq2, delta + pos)) & pm) != 0; };
         auto w_in = [&](int e) -> int { const int x = e - lw + 1; return x <= 0 ? 0 : (x + S - 1) / S; };     // first window that holds position e
         auto step = [&](int w, uint32_t d) { if (w < NT * B) lds_add(&l.row[w + (w >> LOG2B)], d); };
         const int tend = NT * POS;                                           // positions of the tile
-        int c = 2;
+        int c = 3;
         while (tp + c * CD < tend && occ(tp + c * CD)) ++c;
-        if (c == 2) {
-            const int lo = w_in(tp + CD), hi = tp / S;                       // windows that hold both
-            if (lo <= hi) { step(lo, 1u); step(hi + 1, (uint32_t)-1); }
-            return;
-        }
         int prev = 0;
         const int wb = (tp + (c - 1) * CD) / S + 1;
-        for (int w = w_in(tp); w <= wb && w <= NT * B; ++w) {
+        for (int w = w_in(tp < 0 ? 0 : tp); w <= wb && w <= NT * B; ++w) {
             // chain elements j with w S <= tp + j CD < w S + lw
             const int a0 = w * S - tp, a1 = w * S + lw - 1 - tp;
             int jlo = a0 <= 0 ? 0 : (a0 + CD - 1) / CD, jhi = a1 < 0 ? -1 : a1 / CD;
             if (jhi > c - 1) jhi = c - 1;
-            const int cur = jhi >= jlo ? (jhi - jlo + 1) >> 1 : 0;
+            const int cur = jhi > jlo ? (jhi - jlo) >> 1 : 0;
             if (cur != prev) step(w, (uint32_t)(cur - prev));
             prev = cur;
         }
@@ -1866,7 +1903,7 @@ TPS_DEV void tile_lc_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
         const int span = tid;
         const int p0 = delta + span * POS;        // >= 16: fused tiles are staged behind SEQ_LEAD words
         // the lane's bases shifted so that position p's k-mer code sits LS bits above bit 2 p: code << LS is the table's byte offset
-        const int bo = 2 * p0 - LS;
+        const int bo = 2 * (p0 - LB) - LS;        // (CD: from LB positions before the lane's first one)
         const uint32_t sh2 = (uint32_t)(bo & 31);
         const int d0 = bo >> 5;
         uint32_t w[WDW];
@@ -1879,13 +1916,13 @@ TPS_DEV void tile_lc_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
                 prev = nx;
             }
         }
-        auto v4_at = [&](int p) -> uint32_t {     // the base before position p at bit 0 (p constant after unrolling)
-            const int dw = p >> 4, bit = p & 15;
+        auto v4_at = [&](int p) -> uint32_t {     // the base before position p at bit 0 (p constant after unrolling; p >= -LB)
+            const int dw = (p + LB) >> 4, bit = (p + LB) & 15;
             return bit ? alignbit(dw + 1 < WDW ? w[dw + 1] : 0u, w[dw], 2u * bit) : w[dw];
         };
         uint32_t cnt = 0, run_or = 0;
         uint32_t gs[B];
-        uint32_t pair_lo = 0, pair_hi = 0;        // CD: bit p = some pattern occurs at the lane's position p and again CD further on
+        pair_lo = pair_hi = 0;                    // (per lane)
         uint32_t* xpc = l.XPC + span * (B + 1);
         if constexpr (PAIR) {
             constexpr int NP = S / 2, NH = NP + (S & 1);
@@ -1943,24 +1980,31 @@ TPS_DEV void tile_lc_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
                 }
             };
             fetch(0, hc, S);
+            constexpr int NB_ = CD > 0 ? CD : 1;
+            uint32_t hb[NB_];                             // CD: the entries of the CD positions before the block
+            if constexpr (CD > 0) {
+                TPS_UNROLL
+                for (int i = 0; i < CD; ++i) hb[i] = lut16_at(l.lut, v4_at(i - CD), amask);
+            }
             TPS_UNROLL
             for (int blk = 0; blk < B; ++blk) {
                 if (blk + 1 < B) fetch(blk + 1, hn, S);
-                else if (CD > 0) fetch(B, hn, CD);        // look-ahead past the lane's last block (w[] holds 13 extra bases)
                 if constexpr (CD > 0) {
-                    uint32_t cfb = 0;                     // some pattern occurs at p and again at p + CD, p in this block
+                    uint32_t cfb = 0;                     // some pattern occurs at a position of this block and CD before it
                     TPS_UNROLL
-                    for (int i = 0; i < S; ++i) cfb |= hc[i] & (i + CD < S ? hc[i + CD] : hn[i + CD - S]);
-                    if (M16 ? cfb != 0u : (cfb & 0xFFFF0000u) != 0u) {   // rare: a deleted or inserted base inside a telomeric stretch
-                        // remember WHERE (one bit per position of the lane); the chains are walked behind the block loop, by one
-                        // copy of that code instead of one per unrolled position
+                    for (int i = 0; i < S; ++i) cfb |= hc[i] & (i >= CD ? hc[i - CD] : hb[i]);
+                    if (cfb != 0u) {                      // a deleted or inserted base inside a telomeric stretch
+                        // remember WHERE (one bit per position of the lane): everything about pairs and chains happens behind
+                        // the block loop, on these bits
                         TPS_UNROLL
                         for (int i = 0; i < S; ++i) {
-                            const uint32_t pr = ((hc[i] & (i + CD < S ? hc[i + CD] : hn[i + CD - S])) >> (M16 ? 0 : 16)) ? 1u : 0u;
+                            const uint32_t pr = (hc[i] & (i >= CD ? hc[i - CD] : hb[i])) ? 1u : 0u;
                             if (blk * S + i < 32) pair_lo |= pr << ((blk * S + i) & 31);
                             else pair_hi |= pr << ((blk * S + i) & 31);
                         }
                     }
+                    TPS_UNROLL
+                    for (int i = 0; i < CD; ++i) hb[i] = hc[S - CD + i];
                 }
                 uint32_t g = 0;
                 c0s[blk] = cnt;
@@ -1989,24 +2033,119 @@ TPS_DEV void tile_lc_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
         }
         xf_own = M16 ? (sf | cnt) : pack_hi_lo(sf, cnt);
         l.XF[span] = xf_own;
-        if constexpr (CD > 0) {
-            // the lane's occurrence pairs: the ones that HEAD a chain (no occurrence of the pattern CD before them; what lies
-            // before the tile's first position is in none of its windows) put the chain's steps into the difference array
-            TPS_PIN_V(pair_lo); TPS_PIN_V(pair_hi);
-            while (pair_lo | pair_hi) {
-                int p;
-                if (pair_lo) { p = ffs0(pair_lo); pair_lo &= pair_lo - 1u; }
-                else { p = 32 + ffs0(pair_hi); pair_hi &= pair_hi - 1u; }
-                const int tp = span * POS + p;    // position in the tile
-                const uint32_t pm = lut_mask(l.lut, l.lshift, pat, v_at(l.seq2, delta + tp));
-                const bool head = tp < CD || (lut_mask(l.lut, l.lshift, pat, v_at(l.seq2, delta + tp - CD)) & pm) == 0;
-                if (head) { chain_steps(tp, pm); lane_chain = 1u; }
-            }
-        }
+        if constexpr (CD > 0) { TPS_PIN_V(pair_lo); TPS_PIN_V(pair_hi); }
 #ifdef TPS_EMU
         for (int j = 0; j < B; ++j) { sfx_keep[tid][j] = sfx[j]; c0_keep[tid][j] = c0s[j]; }
         xf_keep[tid] = xf_own;
+        pair_keep[tid][0] = pair_lo; pair_keep[tid][1] = pair_hi;
 #endif
+    }
+    if constexpr (CD > 0) {
+        // Pairs (round 4).  A pair -- the same pattern at e - CD and e, filed under e -- lies inside a window iff
+        // window start + CD <= e < window end: the END is the matches' own, so the pairs ride in the count half of the published
+        // words as a second field (matches in bits 0 .. 7, pairs in bits 8 .. 15: the window phase's differences are exact modulo 2^16
+        // as long as both results fit their fields -- a window has at most lw <= 255 of either, plan_geometry checks), and the START
+        // side is the owning lane's registers:
+        // c0s[j] also takes the pairs before position CD of block j.  A window then counts matches - pairs: exact for chains of
+        // two, the usual case (one deleted base inside a telomeric stretch makes one); chains of three or more get the
+        // difference back through the difference array (long_chain_steps).  Everything here is bit arithmetic on the lanes'
+        // 64-bit pair masks -- no walk over the bases, no table lookups -- and only runs in tiles that hold a pair at all.
+        // (Round 3 walked every chain from its head: five dependent LDS round trips and two atomics per pair, ~30 pairs per
+        // telomeric tile at ONT error rates -- a third of the k = 6 kernel's instructions.)
+        constexpr int PS = 8;
+#ifdef TPS_EMU
+        bool tile_pairs = false;
+        for (int t = 0; t < NT; ++t) tile_pairs = tile_pairs || (pair_keep[t][0] | pair_keep[t][1]) != 0u;
+#else
+        const bool tile_pairs = __builtin_amdgcn_ballot_w64((pair_lo | pair_hi) != 0u) != 0;
+#endif
+        if (tile_pairs) {
+            TPS_SYNC();                               // (every lane's words are published: the atomics below add to them)
+            uint32_t head3_lo = 0, head3_hi = 0;      // second elements of the first pair of a chain of three or more
+#ifdef TPS_EMU
+            uint32_t head3_keep[NT][2];
+#endif
+            TPS_PHASE {
+#ifdef TPS_EMU
+                pair_lo = pair_keep[tid][0]; pair_hi = pair_keep[tid][1];
+                for (int j = 0; j < B; ++j) c0s[j] = c0_keep[tid][j];
+                xf_own = xf_keep[tid];
+#endif
+                const int lane = tid;
+                auto below = [&](int n) -> uint32_t {     // pairs at positions < n (n constant after unrolling, 0 <= n <= 64)
+                    if (n <= 0) return 0u;
+                    if (n >= 64) return (uint32_t)(popc(pair_lo) + popc(pair_hi));
+                    if (n <= 32) return (uint32_t)popc(n == 32 ? pair_lo : (pair_lo & ((1u << n) - 1u)));
+                    return (uint32_t)(popc(pair_lo) + popc(pair_hi & ((1u << (n - 32)) - 1u)));
+                };
+                if ((pair_lo | pair_hi) != 0u) {
+                    uint32_t* xpc = l.XPC + lane * (B + 1);
+                    TPS_UNROLL
+                    for (int blk = 0; blk < B; ++blk) {
+                        const uint32_t pe = below(blk * S + (RZ ? 0 : RPT));      // (RPT is a compile-time constant in these tiles)
+                        if (pe) lds_add(&xpc[blk], pe << PS);
+                        c0s[blk] += below(blk * S + CD) << PS;
+                    }
+                    const uint32_t pt = below(64) << PS;
+                    xf_own += pt;
+                    lds_add(&l.XF[lane], pt);
+                }
+                // chains of three or more: pair bits CD apart.  The neighbours' bits close the lane's ends (nothing before the
+                // tile's first lane: what lies there is in none of its windows; nothing behind the last: nor is that)
+                uint32_t prev_hi, next_lo;
+#ifdef TPS_EMU
+                prev_hi = lane > 0 ? pair_keep[lane - 1][1] : 0u;
+                const uint32_t prev_lo_ = lane > 0 ? pair_keep[lane - 1][0] : 0u;
+                next_lo = lane + 1 < NT ? pair_keep[lane + 1][0] : 0u;
+#else
+                prev_hi = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane + NT - 1) & (NT - 1)) << 2, (int)pair_hi);
+                const uint32_t prev_lo_ = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane + NT - 1) & (NT - 1)) << 2, (int)pair_lo);
+                next_lo = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane + 1) & (NT - 1)) << 2, (int)pair_lo);
+                if (lane == 0) prev_hi = 0u;
+                if (lane == NT - 1) next_lo = 0u;
+#endif
+                const uint64_t pm64 = ((uint64_t)pair_hi << 32) | pair_lo;
+                const uint64_t pv64 = lane > 0 ? (((uint64_t)prev_hi << 32) | prev_lo_) : 0ull;
+                // bit e of `before`: a pair at e - CD (the previous lane's last CD positions for e < CD); of `after`: one at e + CD
+                const uint64_t before = (pm64 << CD) | (pv64 >> (POS - CD));
+                const uint64_t after = (pm64 >> CD) | ((uint64_t)(next_lo & ((1u << CD) - 1u)) << (POS - CD));
+                const uint64_t lim = POS >= 64 ? ~0ull : ((1ull << POS) - 1ull);
+                const uint64_t h3 = pm64 & ~before & after & lim;
+                head3_lo = (uint32_t)h3; head3_hi = (uint32_t)(h3 >> 32);
+#ifdef TPS_EMU
+                for (int j = 0; j < B; ++j) c0_keep[tid][j] = c0s[j];
+                xf_keep[tid] = xf_own;
+                head3_keep[tid][0] = head3_lo; head3_keep[tid][1] = head3_hi;
+#endif
+            }
+#ifdef TPS_EMU
+            bool tile_long = false;
+            for (int t = 0; t < NT; ++t) tile_long = tile_long || (head3_keep[t][0] | head3_keep[t][1]) != 0u;
+#else
+            const bool tile_long = __builtin_amdgcn_ballot_w64((head3_lo | head3_hi) != 0u) != 0;
+#endif
+            if (tile_long) {
+                TPS_PHASE {
+                    TPS_UNROLL
+                    for (int i = 0; i < B + 1; ++i) l.row[tid + i * NT] = 0;      // the difference array, indexed by padded window
+                }
+                TPS_SYNC();
+                TPS_PHASE {
+#ifdef TPS_EMU
+                    head3_lo = head3_keep[tid][0]; head3_hi = head3_keep[tid][1];
+#endif
+                    while (head3_lo | head3_hi) {
+                        int e;
+                        if (head3_lo) { e = ffs0(head3_lo); head3_lo &= head3_lo - 1u; }
+                        else { e = 32 + ffs0(head3_hi); head3_hi &= head3_hi - 1u; }
+                        const int te = tid * POS + e;                             // tile position of the chain's SECOND element
+                        const uint32_t pm = lut_mask(l.lut, l.lshift, pat, v_at(l.seq2, delta + te));
+                        long_chain_steps(te - CD, pm);
+                    }
+                }
+                lane_chain = 1u;                      // (uniform: some lane added steps)
+            }
+        }
     }
     TPS_SYNC();
     if (w0 == 0) TPS_STAMP(6);
@@ -2050,8 +2189,8 @@ TPS_DEV void tile_lc_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
             const bool far_ = !ROTZ && j >= brk;
             const uint32_t e = ev[j], fo = far_ ? orb : orw, fs = far_ ? sumb : sumw;
             const uint32_t m = sfx[j] | e | fo;                 // presence: high halves
-            const uint32_t c = (e - c0s[j] + fs) & 0xFFFFu;     // matches: low halves
-            sw[j] = c + (uint32_t)popc(~m & am);
+            const uint32_t c = (e - c0s[j] + fs) & 0xFFFFu;     // matches: low halves (CD: matches | pairs << 8)
+            sw[j] = (CD > 0 ? (c & 0xFFu) - (c >> 8) : c) + (uint32_t)popc(~m & am);
             run += sw[j];
         }
         ltot = run;
@@ -2064,20 +2203,20 @@ TPS_DEV void tile_lc_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
         // a chain somewhere in the tile: the windows give back what the chains' skipped occurrences added -- the prefix sum of
         // the difference array, lane-contiguous like the windows themselves
 #ifdef TPS_EMU
-        const bool tile_chain = lane_chain != 0;  // (the emulation's phase loop has OR-ed every lane into the one variable)
+        const bool tile_chain = lane_chain != 0;
         if (tile_chain) {
             ++emu_counter(5);
             uint32_t acc = 0;
             for (int t = 0; t < NT; ++t) {
                 uint32_t tot = 0;
-                for (int j = 0; j < B; ++j) { acc += l.row[t * (B + 1) + j]; sw_keep[t][j] -= acc; tot += sw_keep[t][j]; }
+                for (int j = 0; j < B; ++j) { acc += l.row[t * (B + 1) + j]; sw_keep[t][j] += acc; tot += sw_keep[t][j]; }
                 tot_keep[t] = tot;
             }
         } else {
             ++emu_counter(6);
         }
 #else
-        const bool tile_chain = __builtin_amdgcn_ballot_w64(lane_chain != 0) != 0;
+        const bool tile_chain = lane_chain != 0;          // (uniform)
         if (tile_chain) {
             uint32_t pd[B], dt = 0;
             TPS_PHASE {
@@ -2095,7 +2234,7 @@ TPS_DEV void tile_lc_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
             const uint32_t dbase = inc - dt;
             uint32_t run = 0;
             TPS_UNROLL
-            for (int j = 0; j < B; ++j) { sw[j] -= dbase + pd[j]; run += sw[j]; }
+            for (int j = 0; j < B; ++j) { sw[j] += dbase + pd[j]; run += sw[j]; }
             ltot = run;
         }
 #endif
@@ -3312,6 +3451,7 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
             TPS_PIN_S(tw);
             bool pp = false;
             if constexpr (RAW) pp = a.pp_d >= 0 && (SO ? a.pp_d > 0 : (a.pp_d == 0 && a.raw != nullptr));
+            bool pp_expect = a.so_fast != 2;       // per-pattern tiles of a self-overlap table: the previous tile held a chain (the first one is expected to)
             auto tile_stage = [&](int w0_) {
                 const int64_t i0 = (int64_t)w0_ * prm.slide;
                 int64_t n_stage = n_s - i0;
@@ -3396,9 +3536,12 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
                     constexpr int SP = SV ? SV : 5;
                     if (pp && uniform(l.misc[M_INVALID]) == 0) {
                         if constexpr (SO) {
-                            // tiles without a chained occurrence complete as tiles of a table without self-overlap
+                            // tiles without a chained occurrence complete as tiles of a table without self-overlap; a tile that
+                            // follows a chained one skips that attempt (round 4: the telomere is a run of tiles at the start of the
+                            // scanned tail, and at ONT error rates every telomeric tile at k = 6 holds a chain -- the detecting
+                            // pass was phase 1 run twice for them)
                             bool chained = true;
-                            if (a.so_fast) {
+                            if (a.so_fast && !pp_expect) {
                                 switch (a.pp_d) {
                                     case 2: chained = tile_pp_s<SP, 0, 2>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
                                     case 3: chained = tile_pp_s<SP, 0, 3>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
@@ -3407,7 +3550,8 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
                                     default: chained = tile_pp_s<SP, 0, (SP < 6 ? SP : 6)>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
                                 }
                             }
-                            if (!chained) continue;
+                            if (!chained) { pp_expect = false; continue; }
+                            const uint64_t s_before = s_total;
                             switch (a.pp_d) {
                                 case 2: tile_pp_s<SP, 2>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
                                 case 3: tile_pp_s<SP, 3>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
@@ -3415,6 +3559,9 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
                                 case 5: tile_pp_s<SP, 5>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
                                 default: tile_pp_s<SP, (SP < 6 ? SP : 6)>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
                             }
+                            // the next tile comes straight here if this one looks telomeric (a mean S_w well above the P of a window
+                            // without matches; a guess that only decides which exact tile code runs first)
+                            pp_expect = a.so_fast != 2 && (s_total - s_before) > (uint64_t)nw_tile * (uint64_t)(pat.P + 4);
                         } else {
                             tile_pp_s<SP, 0>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total);
                         }

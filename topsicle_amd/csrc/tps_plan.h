@@ -208,7 +208,10 @@ inline std::string plan_geometry_core(ScanArgs& a, const tps_params& prm, int k,
         if (pp_counts && a.pat.n_periods == 0) a.pp_d = 0;
         if (pp_counts && a.pat.n_periods == 1 && a.pat.period[0] >= 2 && 2 * a.pat.period[0] >= k) a.pp_d = a.pat.period[0];
         a.lut_fields = (a.pp_d >= 0 && (prm.flags & TPS_F_STORE_RAW)) ? 1 : 0;   // the per-pattern tiles will run: table of one-hot fields
-        a.so_fast = getenv("TPS_NO_SO_FAST") ? 0 : 1;   // sums only, pp_d > 0: chain-free tiles complete as plain tiles (tile_fused_s<.., CD>)
+        a.so_fast = getenv("TPS_NO_SO_FAST") ? 0 : (getenv("TPS_SO_FAST") && atoi(getenv("TPS_SO_FAST")) == 2) ? 2 : 1;
+        // the chain-corrected sums tiles (tile_lc_s<.., CD>) carry a window's matches and pairs as two 8-bit fields of one 16-bit
+        // count (at most one of either per start position): windows of more than 255 start positions take the flag-and-recount tile
+        if (!(prm.flags & TPS_F_STORE_RAW) && a.pp_d > 0 && a.lw > 255) a.so_fast = 0;   // sums only, pp_d > 0: chain-free tiles complete as plain tiles (tile_fused_s<.., CD>)
         // the sums-only kernels of self-overlap tables (_s*so, _s*sol): 16-bit table, XT aliased onto the staged bases unless the
         // fallback tile can run (a batch with non-ACGT letters, a table the chain corrections do not take, TPS_NO_SO_FAST)
         if (a.pat.so_mask != 0 && !(prm.flags & TPS_F_STORE_RAW)) {
