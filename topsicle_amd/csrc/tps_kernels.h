@@ -50,10 +50,15 @@
         uint32_t* slice = lut + tps::lut_dw(a) + wave * wave_dw;                                           \
         /* (several reads per wave -- a grid-strided loop here, so that a big table is loaded once per 8 or 16 reads -- was built \
            in round 4 and dropped: with a loop around it the optimiser hoists the read-invariant arithmetic of scan_read out of  \
-           the loop and keeps it live: _s6so 88 -> 96 VGPRs + scratch, 146 -> 227 spilled SGPRs) */                              \
+           the loop and keeps it live: _s6so 88 -> 96 VGPRs + scratch, 146 -> 227 spilled SGPRs.  So was requesting the read's      \
+           descriptor and its step-1 heads BEFORE the table load: config 2 57.1 against 57.0 us, k = 6 146.9 against 144.9 --    \
+           with 20 - 24 waves per CU in flight a read's own latency is hidden already) */                                         \
         const int64_t r = (int64_t)blockIdx.x * a.wpg + wave;                                              \
         if (r < a.n_reads) tps::scan_read<SV, SO, PAIR, RAW, FULL, DCLASS>(a, r, slice, lut);                           \
     }
+#ifndef TPS_R_MINW
+#define TPS_R_MINW 3      // waves per SIMD the raw-row kernels of tables without self-overlap are compiled for (5: 96 VGPRs with 6 spilled
+#endif                    // and 28 B of scratch -- k = 4 with raw rows 170 -> 163.5 us, measured in round 4; not taken: no scratch in these kernels)
 #ifndef TPS_SO_MINW
 #define TPS_SO_MINW 5     // waves per SIMD the sums-only self-overlap kernels are compiled for
 #endif
@@ -108,10 +113,10 @@ TPS_SCAN_KERNEL(tps_scan_kernel_s8p, 8, false, true, false, 5)
 #endif
 #if TPS_IN_GROUP(2)
 TPS_SCAN_KERNEL(tps_scan_kernel, 0, false, false, true, 4)          // generic: any slide, up to 31 patterns
-TPS_SCAN_KERNEL(tps_scan_kernel_s5r, 5, false, false, true, 3)       // ... with the per-pattern raw counts (TPS_F_STORE_RAW)
-TPS_SCAN_KERNEL(tps_scan_kernel_s6r, 6, false, false, true, 3)
-TPS_SCAN_KERNEL(tps_scan_kernel_s7r, 7, false, false, true, 3)
-TPS_SCAN_KERNEL(tps_scan_kernel_s8r, 8, false, false, true, 3)
+TPS_SCAN_KERNEL(tps_scan_kernel_s5r, 5, false, false, true, TPS_R_MINW)       // ... with the per-pattern raw counts (TPS_F_STORE_RAW)
+TPS_SCAN_KERNEL(tps_scan_kernel_s6r, 6, false, false, true, TPS_R_MINW)
+TPS_SCAN_KERNEL(tps_scan_kernel_s7r, 7, false, false, true, TPS_R_MINW)
+TPS_SCAN_KERNEL(tps_scan_kernel_s8r, 8, false, false, true, TPS_R_MINW)
 #endif
 #if TPS_IN_GROUP(3)
 TPS_SCAN_KERNEL_D(tps_scan_kernel_s5so, 5, true, false, false, TPS_SO_MINW, 2)      // ... self-overlapping k-mers in the table, sums only (tile_lc_s<.., CD>: plain counts, chains corrected), periods 5 and 6
