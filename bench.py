@@ -116,8 +116,14 @@ def profiled_traffic(workload):
             if r["kernel"].startswith("tps_scan_kernel"):
                 vals[r["counter"]] = float(r["mean_value"])
         if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+            PROFILED_COUNTERS.update(vals)
             return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), os.path.relpath(f, ROOT)
     return None, None
+
+
+PROFILED_COUNTERS = {}            # the scan kernel's per-launch counter means of that profile (SQ_INSTS_VALU, ...)
+N_SIMDS = 256 * 4                 # MI355X: 256 CUs x 4 SIMDs; integer VALU issues one wave-instruction per 4 cycles per SIMD
+ENGINE_CLOCK_HZ = 2.4e9           # MI355X_MICROARCH.md (peak engine clock)
 
 
 def cpu_baseline(seqs, motif, k, prm, budget_s=15.0):
@@ -331,6 +337,23 @@ def main():
     elif n_dev.value < world:
         raise SystemExit(f"--gpus {world} but only {n_dev.value} GPU(s) visible ({lib.tps_last_error().decode()})")
     sc = hiplib.HipScanner(dev)
+    # the GPU this rank really got: its PCI address from the runtime (independent of ROCR_VISIBLE_DEVICES), and -- when a launcher
+    # other than this script started the rank (torch.distributed.run: no TPS_BENCH_CPUS) -- the CPUs of that GPU's NUMA node
+    import re as _re
+    m_pci = _re.search(r"pci=([0-9a-f]{4}:[0-9a-f]{2}:[0-9a-f]{2})", sc.device_info())
+    rank_pci = os.environ.get("TPS_BENCH_PCI") or (m_pci.group(1) + ".0" if m_pci else None)
+    if world > 1 and not os.environ.get("TPS_BENCH_CPUS") and rank_pci:
+        try:
+            cpus = set()
+            for part in open(f"/sys/bus/pci/devices/{rank_pci}/local_cpulist").read().strip().split(","):
+                if part:
+                    lo, _, hi = part.partition("-")
+                    cpus.update(range(int(lo), int(hi or lo) + 1))
+            cpus &= os.sched_getaffinity(0)
+            if cpus:
+                os.sched_setaffinity(0, cpus)
+        except (OSError, ValueError):
+            pass
     sc.set_patterns(pats)
     copies = args.resident_copies or max(2, min(hiplib.MAX_SLOTS, -(-(1 << 30) // max(batch_bases, 1))))
     for s in range(copies):
@@ -395,9 +418,29 @@ def main():
         n_launch, k_mean_ms = sum(x[0] for x in kt), sum(x[2] for x in kt) / len(tables)
     else:
         n_launch, k_total_ms, k_mean_ms = sc.kernel_time_ms()
-    per_rank = grp.gather_objects(dict(rank=rank, device=dev, device_info=sc.device_info(), pci=os.environ.get("TPS_BENCH_PCI"),
+    per_rank = grp.gather_objects(dict(rank=rank, device=dev, device_info=sc.device_info(), pci=rank_pci,
                                        cpus=len(os.sched_getaffinity(0)), ms_per_step=dt_rank / args.steps * 1e3,
                                        kernel_ms_mean=k_mean_ms * len(tables), kernel_launches_timed=n_launch))
+    # the same kernel on a batch four times the size (the reads repeated): the launch ramp and the partly filled last round of wave
+    # slots weigh a quarter as much -- what the kernel does in steady state (rank 0 at N = 1, default workload shapes only)
+    steady = None
+    if world == 1 and len(tables) == 1 and not (args.flags or args.n_reads or args.errors) and copies < hiplib.MAX_SLOTS and \
+            not os.environ.get("TPS_BENCH_NO_STEADY") and batch_bases * 4 <= (3 << 30):
+        try:
+            big_off = np.concatenate([offsets[:-1] + j * batch_bases for j in range(4)] + [np.array([4 * batch_bases], np.int64)])
+            sc.upload(copies, np.tile(bases, 4), big_off)
+            for _ in range(6):
+                sc.scan(copies, prm)
+            sc.sync()
+            sc.kernel_time_reset()
+            n_big = 40
+            for _ in range(n_big):
+                sc.scan(copies, prm)
+            sc.sync()
+            nl_big, _tot, km_big = sc.kernel_time_ms()
+            steady = dict(reads_per_launch=4 * n_reads, kernel_ms_mean=km_big, kernel_launches_timed=nl_big)
+        except Exception as e:                      # (out of device memory on a small GPU must not cost the bench line)
+            steady = {"error": repr(e)}
     lens = np.diff(offsets)
     last = (args.steps - 1) % copies
     alg_total = alg1 = alg2 = alg3 = 0
@@ -485,6 +528,18 @@ def main():
                                    if concurrent else "HIP events around the launch",
             },
         }
+        roof = out["roofline"]
+        if traffic and PROFILED_COUNTERS.get("SQ_INSTS_VALU") and roof_ms > 0:
+            # what really bounds the kernel: integer VALU issue (one wave-instruction per 4 cycles per SIMD), from the committed
+            # counters of the same workload; HBM carries `traffic_frac` of its peak (section 3 of DESIGN.md)
+            roof["valu_busy"] = PROFILED_COUNTERS["SQ_INSTS_VALU"] * 4.0 / (N_SIMDS * ENGINE_CLOCK_HZ * roof_ms * 1e-3)
+            roof["valu_busy_source"] = "SQ_INSTS_VALU of %s x 4 cycles / (%d SIMDs x %.1f GHz x this run's kernel duration)" % (traffic_src, N_SIMDS, ENGINE_CLOCK_HZ / 1e9)
+            roof["limiter"] = "valu-issue"
+        if steady and "kernel_ms_mean" in steady and steady["kernel_ms_mean"] > 0:
+            steady["frac"] = 4 * alg_total / (steady["kernel_ms_mean"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            roof["steady_state_frac"] = steady["frac"]
+        if steady:
+            roof["steady_state"] = steady
         if not args.no_cpu_baseline and world == 1:        # the CPU baseline leg runs at N = 1 only
             n_cpu = min(n_reads, 16384)               # (config 2: the whole batch, ~5 s on 16 cores; the budget inside stops a slow host)
             seqs = synth.split_reads(bases[: offsets[n_cpu]], offsets[: n_cpu + 1])

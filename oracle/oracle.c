@@ -182,13 +182,29 @@ int orc_binseg_l2(const int32_t* sums, int n, int P, int jump, int min_size, dou
  * (main.py:57, 125-133): step 1; if kept, windows of BOTH tails are counted (allsteps.py:279-291) when
  * both_tails != 0, the unchosen one is dropped (294-297), Binseg on the chosen one.
  * out: [0]=pass [1]=tail [2]=best_idx [3]=best_count [4]=n_win [5]=bkp [6]=boundary_bp */
-void orc_read_pipeline(const char* seq, int64_t L, const char* pats, int P, int k, int motif_len, int no_bp, int min_len,
-                       double cutoff, int W, int s, int t, int M, int both_tails, int32_t* out) {
+/* Position-weighted 64-bit checksum of a vector (wrap-around arithmetic): sum over i of (v[i] + 1) * CK_MUL^i.  The GPU tests
+ * compute the same over the kernels' window sums / raw rows of EVERY read (tests/ckutil.py), so the at-scale comparisons are
+ * total instead of sampled. */
+#define CK_MUL 0x9E3779B97F4A7C15ull
+static uint64_t ck_i32(const int32_t* v, int64_t n) {
+    uint64_t h = 0, pw = 1;
+    for (int64_t i = 0; i < n; ++i) { h += ((uint64_t)(uint32_t)v[i] + 1ull) * pw; pw *= CK_MUL; }
+    return h;
+}
+static uint64_t ck_u8(const uint8_t* v, int64_t n) {
+    uint64_t h = 0, pw = 1;
+    for (int64_t i = 0; i < n; ++i) { h += ((uint64_t)v[i] + 1ull) * pw; pw *= CK_MUL; }
+    return h;
+}
+
+void orc_read_pipeline_ck(const char* seq, int64_t L, const char* pats, int P, int k, int motif_len, int no_bp, int min_len,
+                          double cutoff, int W, int s, int t, int M, int both_tails, int32_t* out, uint64_t* ck, int want_raw) {
     int32_t cs[64], ce[64];
     int tail = 0, idx = 0;
     double trc = 0.0;
     memset(out, 0, sizeof(int32_t) * 7);
     out[5] = -1;
+    if (ck) { ck[0] = 0; ck[1] = 0; }
     if (!(L > min_len)) return;
     orc_trc_counts(seq, L, pats, P, k, no_bp, cs, ce);
     int keep = orc_trc_call(cs, ce, P, no_bp, motif_len, cutoff, &tail, &idx, &trc);
@@ -199,8 +215,14 @@ void orc_read_pipeline(const char* seq, int64_t L, const char* pats, int P, int 
     out[4] = (int32_t)nwin;
     if (nwin <= 0) return;
     int32_t* sums = (int32_t*)malloc(sizeof(int32_t) * (size_t)nwin);
+    uint8_t* raw = (ck && want_raw) ? (uint8_t*)malloc((size_t)nwin * (size_t)P) : NULL;
     if (both_tails) orc_window_counts(seq, L, 1 - tail, pats, P, k, W, s, t, M, sums, NULL);
-    orc_window_counts(seq, L, tail, pats, P, k, W, s, t, M, sums, NULL);
+    orc_window_counts(seq, L, tail, pats, P, k, W, s, t, M, sums, raw);
+    if (ck) {
+        ck[0] = ck_i32(sums, nwin);
+        if (raw) ck[1] = ck_u8(raw, nwin * (int64_t)P);
+    }
+    free(raw);
     double g;
     int bkp = orc_binseg_l2(sums, (int)nwin, P, 5, 2, &g);
     out[5] = bkp;
@@ -212,10 +234,16 @@ void orc_read_pipeline(const char* seq, int64_t L, const char* pats, int P, int 
     free(sums);
 }
 
+void orc_read_pipeline(const char* seq, int64_t L, const char* pats, int P, int k, int motif_len, int no_bp, int min_len,
+                       double cutoff, int W, int s, int t, int M, int both_tails, int32_t* out) {
+    orc_read_pipeline_ck(seq, L, pats, P, k, motif_len, no_bp, min_len, cutoff, W, s, t, M, both_tails, out, NULL, 0);
+}
+
 /* ---------------------------------------------------------------- threaded batch driver (cpu_baseline) */
 typedef struct {
     const char* bases; const int64_t* offsets; int64_t n; const char* pats; int P, k, motif_len, no_bp, min_len;
     double cutoff; int W, s, t, M, both_tails; int32_t* out; volatile int64_t* next; double deadline; volatile int64_t* done;
+    uint64_t* ck; int want_raw;
 } job_t;
 
 static double now_s(void) {
@@ -230,8 +258,9 @@ static void* worker(void* arg) {
         if (j->deadline > 0 && now_s() > j->deadline) break;
         int64_t i = __sync_fetch_and_add(j->next, 1);
         if (i >= j->n) break;
-        orc_read_pipeline(j->bases + j->offsets[i], j->offsets[i + 1] - j->offsets[i], j->pats, j->P, j->k, j->motif_len,
-                          j->no_bp, j->min_len, j->cutoff, j->W, j->s, j->t, j->M, j->both_tails, j->out + 7 * i);
+        orc_read_pipeline_ck(j->bases + j->offsets[i], j->offsets[i + 1] - j->offsets[i], j->pats, j->P, j->k, j->motif_len,
+                             j->no_bp, j->min_len, j->cutoff, j->W, j->s, j->t, j->M, j->both_tails, j->out + 7 * i,
+                             j->ck ? j->ck + 2 * i : NULL, j->want_raw);
         __sync_fetch_and_add(j->done, 1);
     }
     return NULL;
@@ -240,13 +269,15 @@ static void* worker(void* arg) {
 /* Runs the per-read pipeline over reads [0,n) with `threads` workers, in read order of a shared
  * counter; stops early after budget_s seconds (0 = no limit).  Returns the number of reads
  * completed (a prefix of the batch, up to thread skew); *elapsed receives wall seconds. */
-int64_t orc_batch(const char* bases, const int64_t* offsets, int64_t n, const char* pats, int P, int k, int motif_len,
-                  int no_bp, int min_len, double cutoff, int W, int s, int t, int M, int both_tails, int threads,
-                  double budget_s, int32_t* out, double* elapsed) {
+/* orc_batch_ck: the same, plus per read ck[2 i] = checksum of its window sums, ck[2 i + 1] = of its raw rows (want_raw), 0 for
+ * a read that does not pass */
+int64_t orc_batch_ck(const char* bases, const int64_t* offsets, int64_t n, const char* pats, int P, int k, int motif_len,
+                     int no_bp, int min_len, double cutoff, int W, int s, int t, int M, int both_tails, int threads,
+                     double budget_s, int32_t* out, double* elapsed, uint64_t* ck, int want_raw) {
     volatile int64_t next = 0, done = 0;
     double t0 = now_s();
     job_t j = {bases, offsets, n, pats, P, k, motif_len, no_bp, min_len, cutoff, W, s, t, M, both_tails, out, &next,
-               budget_s > 0 ? t0 + budget_s : 0.0, &done};
+               budget_s > 0 ? t0 + budget_s : 0.0, &done, ck, want_raw};
     if (threads < 1) threads = 1;
     pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)threads);
     for (int i = 0; i < threads; ++i) pthread_create(&th[i], NULL, worker, &j);
@@ -254,4 +285,10 @@ int64_t orc_batch(const char* bases, const int64_t* offsets, int64_t n, const ch
     free(th);
     if (elapsed) *elapsed = now_s() - t0;
     return done;
+}
+int64_t orc_batch(const char* bases, const int64_t* offsets, int64_t n, const char* pats, int P, int k, int motif_len,
+                  int no_bp, int min_len, double cutoff, int W, int s, int t, int M, int both_tails, int threads,
+                  double budget_s, int32_t* out, double* elapsed) {
+    return orc_batch_ck(bases, offsets, n, pats, P, k, motif_len, no_bp, min_len, cutoff, W, s, t, M, both_tails, threads, budget_s,
+                        out, elapsed, NULL, 0);
 }

@@ -42,6 +42,8 @@ def lib():
         L.orc_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p,
                                 C.POINTER(C.c_double)]
+        L.orc_batch_ck.restype = C.c_int64
+        L.orc_batch_ck.argtypes = L.orc_batch.argtypes + [C.c_void_p, C.c_int]
         _lib = L
     return _lib
 
@@ -82,6 +84,54 @@ def binseg_l2_y(y, jump=5, min_size=2):
     g = C.c_double(0)
     b = lib().orc_binseg_l2_y(a.ctypes.data, len(a), jump, min_size, C.byref(g))
     return (None if b < 0 else b), g.value
+
+
+CK_MUL = 0x9E3779B97F4A7C15
+
+
+def checksum_weights(n: int) -> np.ndarray:
+    """CK_MUL^i mod 2^64 for i < n (oracle.c: ck_i32 / ck_u8)."""
+    w = np.empty(max(n, 1), np.uint64)
+    w[0] = 1
+    if n > 1:
+        with np.errstate(over="ignore"):
+            w[1:] = np.cumprod(np.full(n - 1, CK_MUL, np.uint64))
+    return w
+
+
+def checksums(values: np.ndarray, starts: np.ndarray) -> np.ndarray:
+    """Per-segment checksum sum((v + 1) * CK_MUL^i) mod 2^64 of `values` cut at `starts` (n + 1 offsets), vectorised: what
+    oracle.c computes per read (ck_i32 over window sums, ck_u8 over raw rows); 0 for an empty segment."""
+    starts = np.asarray(starts, np.int64)
+    n = len(starts) - 1
+    lens = np.diff(starts)
+    out = np.zeros(n, np.uint64)
+    if n == 0 or starts[-1] == starts[0]:
+        return out
+    v = np.asarray(values)[starts[0]:starts[-1]].astype(np.uint64) + np.uint64(1)
+    idx = np.arange(len(v), dtype=np.int64) - np.repeat(starts[:-1] - starts[0], lens)
+    with np.errstate(over="ignore"):
+        prod = v * checksum_weights(int(lens.max()))[idx]
+        nz = np.nonzero(lens)[0]
+        out[nz] = np.add.reduceat(prod, (starts[:-1] - starts[0])[nz])
+    return out
+
+
+def batch_ck(bases: np.ndarray, offsets: np.ndarray, patterns, motif_len, no_bp, min_len, cutoff, W, s, t, M,
+             both_tails=False, threads=1, want_raw=False):
+    """batch() plus per-read checksums of the window sums (and of the raw rows): (out[n,7], ck[n,2] uint64)."""
+    blob, P, k = _pats(patterns)
+    bases = np.ascontiguousarray(bases, np.uint8)
+    offsets = np.ascontiguousarray(offsets, np.int64)
+    n = len(offsets) - 1
+    out = np.zeros((n, 7), np.int32)
+    ck = np.zeros((n, 2), np.uint64)
+    el = C.c_double(0)
+    done = lib().orc_batch_ck(bases.ctypes.data, offsets.ctypes.data, n, blob, P, k, motif_len, no_bp, min_len, cutoff,
+                              W, s, t, M, 1 if both_tails else 0, threads, 0.0, out.ctypes.data, C.byref(el), ck.ctypes.data,
+                              1 if want_raw else 0)
+    assert done == n
+    return out, ck
 
 
 def batch(bases: np.ndarray, offsets: np.ndarray, patterns, motif_len, no_bp, min_len, cutoff, W, s, t, M,

@@ -10,4 +10,4 @@ for mode in ("own", "zlib"):
         env["TPS_IO_BGZF_ZLIB"] = "1"
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env).stdout.strip().splitlines()[-1]
     d = json.loads(out)
-    print(mode, {k: (round(v["value"] / 1e9, 3), v["seconds_best"]) for k, v in d.items()})
+    print(mode, {k: (round(v["value"] / 1e9, 3), v["seconds_median"]) for k, v in d.items()})

@@ -33,8 +33,10 @@ def make_file(rng, path):
             plus = b"+" + (name if rng.random() < 0.1 else b"")
             out.append(b"@" + name + nl + seq + nl + plus + nl + qual + nl)
         else:
-            w = int(rng.choice([60, 80, 10 ** 9]))
+            w = int(rng.choice([60, 80, 10 ** 9, int(rng.integers(1, 150))]))       # (round 4: any line width -- wrapped FASTA takes the thread-team decoder)
             lines = [seq[j:j + w] for j in range(0, len(seq), w)] or [b""]
+            if rng.random() < 0.03 and len(lines) > 1:
+                lines.insert(int(rng.integers(1, len(lines))), b"")                 # a blank line inside a record
             out.append(b">" + name + nl + nl.join(lines) + nl)
         if rng.random() < 0.05:
             out.append(nl)
@@ -110,7 +112,20 @@ def run(cases=300, seed=0):
         try:
             for pb in seqio.read_batches_packed(p, pool):
                 for i in range(pb.n):
-                    got_p.append((pb.read_id(i), pb.head(i), bytes(pb.seq_bytes(i)).decode("latin1")))
+                    sq = bytes(pb.seq_bytes(i))
+                    got_p.append((pb.read_id(i), pb.head(i), sq.decode("latin1")))
+                    # what was PACKED is that sequence (2-bit codes (c >> 1) & 3, invalid mask = not one of acgtACGT)
+                    w0, L = int(pb.desc["word_off"][i]), int(pb.desc["len"][i])
+                    assert L == len(sq), (case, p, i, L, len(sq))
+                    nw = (L + 15) // 16
+                    words = np.asarray(pb.seq2[w0:w0 + nw], np.uint32)
+                    codes = ((words[:, None] >> (2 * np.arange(16, dtype=np.uint32))) & 3).reshape(-1)[:L]
+                    raw = np.frombuffer(sq, np.uint8)
+                    assert np.array_equal(codes, (raw >> 1) & 3), (case, p, i, "packed bases differ from the record's sequence")
+                    if pb.inv is not None:
+                        iv = np.asarray(pb.inv[w0:w0 + nw], np.uint16)
+                        bad = ((iv[:, None] >> np.arange(16, dtype=np.uint16)) & 1).reshape(-1)[:L].astype(bool)
+                        assert np.array_equal(bad, ~np.isin(raw, np.frombuffer(b"ACGTacgt", np.uint8))), (case, p, i, "invalid mask")
                 pb.release()
         except RuntimeError as e:                                 # a read larger than the (deliberately small) upload buffers
             if "does not fit" not in str(e):

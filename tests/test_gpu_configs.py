@@ -61,13 +61,21 @@ def _check_reads_vs_oracle(bases, offsets, res, sums, win_off, pats, motif, slid
 
 
 def _float64_pipeline(bases, offsets, pats, motif, slide, cutoff):
-    out, done, _ = oracle_c.batch(bases, offsets, pats, len(motif), 1000, 9000, cutoff, 100, slide, 100, 20000,
-                                  both_tails=False, threads=oracle_c.usable_cores())
-    assert done == len(offsets) - 1
-    return out          # [pass, tail, best_idx, best_count, n_win, bkp (float64 Binseg), boundary_bp]
+    """Every read through oracle.c: rows [pass, tail, best_idx, best_count, n_win, bkp (float64 Binseg), boundary_bp] and, per read,
+    the checksum of its window sums (round 4: the at-scale comparisons cover EVERY window of every read, not a sample)."""
+    out, ck = oracle_c.batch_ck(bases, offsets, pats, len(motif), 1000, 9000, cutoff, 100, slide, 100, 20000,
+                                both_tails=False, threads=oracle_c.usable_cores())
+    return out, ck
 
 
-def _assert_equals_float64_pipeline(res, out):
+def _assert_equals_float64_pipeline(res, out_ck, sums=None, win_off=None):
+    out, ck = out_ck
+    if sums is not None:
+        p_ = res["pass"].astype(bool)
+        got = oracle_c.checksums(sums, win_off)
+        bad = np.nonzero(got[p_] != ck[p_, 0])[0]
+        print(f"window sums: GPU vs oracle.c checksums on {int(p_.sum())} reads ({int(np.diff(win_off)[p_].sum())} windows): {len(bad)} differ")
+        assert len(bad) == 0, bad[:10]
     assert np.array_equal(res["pass"], out[:, 0])
     p = res["pass"].astype(bool)
     assert np.array_equal(res["tail"][p], out[p, 1])
@@ -121,7 +129,7 @@ def test_config3_full_shard_properties_and_float64_binseg(sc):
     # float64 Binseg (oracle.c) on a 4000-read slice of the same batch
     m = 4000
     out = _float64_pipeline(bases[: offsets[m]], offsets[: m + 1], pats, motif, slide, 0.7)
-    _assert_equals_float64_pipeline(res[:m], out)
+    _assert_equals_float64_pipeline(res[:m], out, sums, win_off[: m + 1])
 
 
 # --------------------------------------------------------------------------------------------- configs[3]
@@ -139,7 +147,7 @@ def test_config4_ont_30kb_vs_oracle_and_float64_binseg(sc):
     assert (res["n_win"][res["pass"] == 1] == 3301).all()
     _check_reads_vs_oracle(bases, offsets, res, sums, win_off, pats, motif, slide, cutoff, range(0, n, 47))
     out = _float64_pipeline(bases, offsets, pats, motif, slide, cutoff)
-    _assert_equals_float64_pipeline(res, out)
+    _assert_equals_float64_pipeline(res, out, sums, win_off)
     # the sweep itself is a host-side threshold on the step-1 counts: same reads as a scan at each cutoff
     best = np.where(res["tail"] == 0, res["best_start"], res["best_end"])
     for c in (0.3, 0.4, 0.5, 0.6, 0.7, 0.8):
@@ -155,10 +163,10 @@ def test_config2_float64_binseg_at_scale(sc):
     pats = orc.kmer_table(motif, k)
     sc.set_patterns(pats)
     bases, offsets, _ = synth.make_reads(10000, 15000, motif, seed=20250919 + 1)
-    res, _, _ = _scan(sc, 0, bases, offsets, _params(motif, slide))
+    res, sums, win_off = _scan(sc, 0, bases, offsets, _params(motif, slide))
     assert "tps_scan_kernel_s6p " in sc.kernel_info(0) + " "
     out = _float64_pipeline(bases, offsets, pats, motif, slide, 0.7)
-    _assert_equals_float64_pipeline(res, out)
+    _assert_equals_float64_pipeline(res, out, sums, win_off)
 
 
 @pytest.mark.parametrize("k", [5, 6])
@@ -167,9 +175,9 @@ def test_config5_float64_binseg_self_overlap_tables(sc, k):
     pats = orc.kmer_table(motif, k)
     sc.set_patterns(pats)
     bases, offsets, _ = synth.make_reads(2000, 25000, motif, seed=20250919 + 4)
-    res, _, _ = _scan(sc, 0, bases, offsets, _params(motif, slide))
+    res, sums, win_off = _scan(sc, 0, bases, offsets, _params(motif, slide))
     out = _float64_pipeline(bases, offsets, pats, motif, slide, 0.7)
-    _assert_equals_float64_pipeline(res, out)
+    _assert_equals_float64_pipeline(res, out, sums, win_off)
 
 
 def _write_fastq(path, bases, offsets, prefix="r"):

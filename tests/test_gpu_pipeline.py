@@ -74,9 +74,8 @@ def test_ragged_batch_at_scale_vs_oracle(sc, motif, k, slide, raw):
     sums, win_off = sc.window_sums(0)
     rows = sc.window_raw(0)[0] if raw else None
     # every read against the float64 pipeline (what allsteps.py:310-311 computes), all reads
-    out, done, _ = oracle_c.batch(bases, offsets, pats, len(motif), 1000, min_len, cutoff, 100, slide, 100, 20000,
-                                  both_tails=False, threads=oracle_c.usable_cores())
-    assert done == n
+    out, ck = oracle_c.batch_ck(bases, offsets, pats, len(motif), 1000, min_len, cutoff, 100, slide, 100, 20000,
+                                both_tails=False, threads=oracle_c.usable_cores(), want_raw=raw)
     assert np.array_equal(res["pass"], out[:, 0])
     p = res["pass"].astype(bool)
     assert 0.5 * n < p.sum() < n
@@ -88,6 +87,10 @@ def test_ragged_batch_at_scale_vs_oracle(sc, motif, k, slide, raw):
     assert len(differ) == 0, (differ[:10], res["bkp"][p][differ[:10]], out[p, 5][differ[:10]])
     nw = np.array([hiplib.window_count(int(x), 100, slide, 100, 20000) for x in lens])
     assert np.array_equal(np.diff(win_off), nw)                  # (the layout holds windows for every read, passing or not)
+    # EVERY window of every passing read (round 4): per-read checksums of the sums (and of the raw rows) against oracle.c's
+    assert np.array_equal(oracle_c.checksums(sums, win_off)[p], ck[p, 0])
+    if raw:
+        assert np.array_equal(oracle_c.checksums(rows.reshape(-1), win_off * len(pats))[p], ck[p, 1])
     # window by window: every 50th read, plus the shortest and the longest passing ones
     idx = set(range(0, n, 50)) | {int(np.nonzero(p)[0][np.argmin(lens[p])]), int(np.argmax(lens))}
     checked = 0

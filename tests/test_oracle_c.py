@@ -5,6 +5,7 @@ import pytest
 
 import oracle_c
 import topsicle_oracle as orc
+from topsicle_amd import synth
 
 
 def test_c_counts_on_goldens(synth_cases):
@@ -51,3 +52,28 @@ def test_c_demo_pipeline(demo_records, gold_dir):
     gold = list(csv.reader(open(os.path.join(gold_dir, "demo_telolengths_all.csv"))))[1:]
     got = [(demo_records[i][0], int(out[i, 6]), f"{out[i, 3] / (1000 / 7):.3f}") for i in range(len(demo_records)) if out[i, 0]]
     assert got == [(g[3], int(g[4]), g[2]) for g in gold]
+
+
+def test_batch_checksums_equal_the_vectorised_ones():
+    """oracle.c's per-read checksums of the window sums / raw rows (orc_batch_ck) = oracle_c.checksums over the same vectors laid out
+    read after read -- what the -m gpu tests compare the kernels' outputs with, every window of every read."""
+    motif, k = "CCCTAA", 6
+    pats = orc.kmer_table(motif, k)
+    bases, offsets, _ = synth.make_reads(24, 10500, motif, seed=5)
+    out, ck = oracle_c.batch_ck(bases, offsets, pats, 6, 1000, 9000, 0.5, 100, 6, 100, 20000, threads=3, want_raw=True)
+    sums, rows, wo = [], [], [0]
+    for i in range(24):
+        s_c = np.zeros(0, np.int32)
+        r_c = np.zeros((0, len(pats)), np.uint8)
+        if out[i, 0]:
+            s_c, r_c = oracle_c.window_counts(bytes(bases[offsets[i]:offsets[i + 1]]).decode(), ["forward", "reverse"][out[i, 1]], pats, 100, 6, 100, 20000)
+        sums.append(s_c)
+        rows.append(r_c.reshape(-1))
+        wo.append(wo[-1] + len(s_c))
+    wo = np.array(wo)
+    assert out[:, 0].sum() >= 12
+    assert np.array_equal(oracle_c.checksums(np.concatenate(sums), wo), ck[:, 0])
+    assert np.array_equal(oracle_c.checksums(np.concatenate(rows), wo * len(pats)), ck[:, 1])
+    s2 = np.concatenate(sums).copy()
+    s2[[5, 6]] = s2[[6, 5]] if s2[5] != s2[6] else s2[[5, 6]] + [1, 0]      # a swap (or a change) of two windows is seen
+    assert not np.array_equal(oracle_c.checksums(s2, wo), ck[:, 0])

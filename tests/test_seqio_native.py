@@ -378,3 +378,79 @@ def test_differential_fuzz_against_the_python_parser():
     import reader_fuzz
     same, prefix = reader_fuzz.run(60, seed=4)
     assert same >= 60 and same + prefix == 120
+
+
+@pytest.mark.skipif(seqio._load_io() is None, reason="libtopsicle_io.so not built")
+def test_bgzf_window_that_ends_at_a_quality_line_stays_packed(tmp_path, monkeypatch):
+    """a window of inflated text that ends exactly behind a record's last quality character (its line end is the first
+    byte of the next window) used to be accepted as a whole record; the next window then began with the left-over newline, the
+    packed decoder gave up and the REST of the file went through the one-thread streaming decoder (correct records, silent large
+    slow-down).  Every BGZF block here ends at such a place and every group is one block: all batches must still be packed ones."""
+    rng = np.random.default_rng(5)
+    recs, text, cuts = [], b"", []
+    for i in range(120):
+        seq = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), int(rng.integers(800, 1200))))
+        qual = bytes(rng.integers(33, 74, len(seq), dtype=np.uint8))
+        text += b"@r%d\n" % i + seq + b"\n+\n" + qual
+        if i % 4 == 3:
+            cuts.append(len(text))                       # the block ends behind the quality line, in front of its "\n"
+        text += b"\n"
+        recs.append(("r%d" % i, seq.decode()))
+    p = tmp_path / "cut.fastq.gz"
+    _write_bgzf(str(p), text, splits=cuts)
+    monkeypatch.setenv("TPS_IO_BGZF_GROUP", "1")          # one block per group
+    pool = seqio.BufferPool(3, 1024, 64)
+    got, kinds = [], []
+    for pb in seqio.read_batches_packed(str(p), pool):
+        kinds.append("packed" if pb.spans is not None else "ascii")
+        got += [(pb.read_id(i), pb.seq_bytes(i).decode()) for i in range(pb.n)]
+        pb.release()
+    assert got == recs
+    assert set(kinds) == {"packed"} and len(kinds) > 5, kinds
+
+
+@pytest.mark.skipif(seqio._load_io() is None, reason="libtopsicle_io.so not built")
+@pytest.mark.parametrize("nl", [b"\n", b"\r\n"])
+def test_wrapped_fasta_takes_the_thread_team_decoder(tmp_path, monkeypatch, nl):
+    """Round 4: FASTA records whose sequence is wrapped (60 / 80 / any columns; blank lines in between) are joined line by line and
+    packed by the thread team, plain, gzip'ed and bgzip'ed -- the same records, bases and 2-bit words as the same reads on one line
+    each; a record with padded lines still goes to the streaming decoder."""
+    monkeypatch.setenv("TPS_IO_PACK_MIN_SPAN", "2000")    # the team on small files
+    monkeypatch.setenv("TPS_IO_PARGZ_MIN", "0")
+    monkeypatch.setenv("TPS_IO_THREADS", "5")
+    rng = np.random.default_rng(11)
+    seqs = [bytes(rng.choice(np.frombuffer(b"ACGTacgtN", np.uint8), int(L))) for L in list(rng.integers(0, 4000, 150)) + [60, 61, 120, 1]]
+    one, wrapped = b"", b""
+    for i, s in enumerate(seqs):
+        one += b">r%d d\n" % i + s + b"\n"
+        w = [60, 80, 7, 1000][i % 4]
+        lines = [s[j:j + w] for j in range(0, len(s), w)] or [b""]
+        if i % 9 == 0 and len(lines) > 2:
+            lines.insert(2, b"")
+        wrapped += b">r%d d" % i + nl + nl.join(lines) + nl
+    import gzip
+
+    def packed(path):
+        pool = seqio.BufferPool(3, 1 << 16, 4096)
+        out, kinds = [], set()
+        for pb in seqio.read_batches_packed(str(path), pool):
+            kinds.add("packed" if pb.spans is not None else "ascii")
+            for i in range(pb.n):
+                w0, L = int(pb.desc["word_off"][i]), int(pb.desc["len"][i])
+                out.append((pb.head(i), pb.seq_bytes(i), pb.qual_bytes(i), np.asarray(pb.seq2[w0:w0 + (L + 15) // 16]).tobytes(),
+                            int(pb.desc["flags"][i])))
+            pb.release()
+        return out, kinds
+    (tmp_path / "one.fasta").write_bytes(one)
+    want, kinds = packed(tmp_path / "one.fasta")
+    assert kinds == {"packed"} and [x[1] for x in want] == seqs and all(x[2] is None for x in want)
+    (tmp_path / "w.fasta").write_bytes(wrapped)
+    (tmp_path / "w.fasta.gz").write_bytes(gzip.compress(wrapped, 4))
+    _write_bgzf(str(tmp_path / "wb.fasta.gz"), wrapped, block=3001)
+    for name in ("w.fasta", "w.fasta.gz", "wb.fasta.gz"):
+        got, kinds = packed(tmp_path / name)
+        assert kinds == {"packed"}, (name, kinds)
+        assert got == want, name
+    (tmp_path / "pad.fasta").write_bytes(b">a\nACGT \n  AC\n>b\nTTTT\n")
+    got, kinds = packed(tmp_path / "pad.fasta")
+    assert [x[1] for x in got] == [b"ACGTAC", b"TTTT"] and kinds == {"ascii"}

@@ -417,7 +417,9 @@ struct Fast {
     size_t win_hi = 0;                         // end of the indexed window
     bool whole = false;                        // the window reaches the end of the file
     int threads = 1;
-    struct Rec { uint64_t h0, hl, s0, sl, q0; };
+    // h0 / hl: header text (without '@' / '>'), s0: first base, sl: bases, q0: first quality character (FASTQ) or the end of the
+    // record's sequence text (FASTA); wrapped: the sequence is spread over several lines (FASTA)
+    struct Rec { uint64_t h0, hl, s0, sl, q0; bool wrapped; };
     std::vector<Rec> recs;
 
     ~Fast() {
@@ -535,7 +537,7 @@ struct Fast {
                 if (recs.empty()) return -2;
                 break;
             }
-            recs.push_back(Rec{h0 + 1, (uint64_t)hl, s0, (uint64_t)sl, q0});
+            recs.push_back(Rec{h0 + 1, (uint64_t)hl, s0, (uint64_t)sl, q0, false});
             nb += sl;
             nh += hl;
             offsets[recs.size()] = nb;
@@ -553,9 +555,13 @@ struct Fast {
     // the byte behind it is looked at -- its own bytes are never read.
     bool fasta = false;                        // two-line FASTA records ('>' header, the whole sequence on one line) instead of FASTQ
     bool final_window() const { return !src || src->eof(); }      // the text in hand reaches the end of the input
-    // One FASTA record whose sequence is ONE line (what read sets converted from FASTQ look like): 0 = well formed, 1 = anything
-    // else (wrapped sequence, blank line, text that ends inside the record): the streaming decoder takes those.
-    int parse_fasta_at(size_t s, Rec& r, size_t& next) const {
+    // One FASTA record: the header line, then sequence lines up to the next line that begins with '>' (or the end of the input).
+    // 0 = well formed (r filled, next = start of the following record), 1 = not this decoder's business (a line with leading /
+    // trailing blanks, which the streaming decoder strips; text that ends inside the record while the source has more).  A
+    // sequence on ONE line is packed from the text itself; a wrapped one (60 / 80 columns, what most FASTA files look like) is
+    // joined line by line into `dewrap` (the calling thread's scratch) and packed from there -- round 4: wrapped FASTA used to go
+    // to the one-thread streaming decoder (6.6e8 against 2.4e9 bases/s for the same reads on one line each).
+    int parse_fasta_at(size_t s, Rec& r, size_t& next, std::vector<uint8_t>* dewrap = nullptr) const {
         if (s >= size || data[s] != '>') return 1;
         const char* e0p = (const char*)memchr(data + s, '\n', size - s);
         if (!e0p) return 1;
@@ -563,29 +569,34 @@ struct Fast {
         const size_t h1 = (e0 > s && data[e0 - 1] == '\r') ? e0 - 1 : e0;
         if (h1 <= s) return 1;
         const size_t s0 = e0 + 1;
-        if (s0 >= size) return 1;
-        const char* e1p = (const char*)memchr(data + s0, '\n', size - s0);
-        size_t e1, s1;
-        if (e1p) {
-            e1 = (size_t)(e1p - data);
-            s1 = (e1 > s0 && data[e1 - 1] == '\r') ? e1 - 1 : e1;
-            next = e1 + 1;
-        } else {
-            if (!final_window()) return 1;                      // (the line may go on in the next group of blocks)
-            e1 = s1 = size;
-            if (s1 > s0 && data[s1 - 1] == '\r') --s1;
-            next = size;
+        size_t p = s0, first_a = 0, first_b = 0;       // the first non-empty sequence line
+        uint64_t sl = 0;
+        int nlines = 0;
+        for (;;) {
+            if (p >= size) { if (!final_window()) return 1; next = size; break; }       // (the record may go on in the next group of blocks)
+            if (data[p] == '>') { next = p; break; }
+            const char* ep = (const char*)memchr(data + p, '\n', size - p);
+            if (!ep && !final_window()) return 1;
+            const size_t e = ep ? (size_t)(ep - data) : size;
+            const size_t l1 = (e > p && data[e - 1] == '\r') ? e - 1 : e;
+            if (l1 > p) {
+                if (data[p] == ' ' || data[p] == '\t' || data[l1 - 1] == ' ' || data[l1 - 1] == '\t') return 1;
+                if (nlines == 0) { first_a = p; first_b = l1; }
+                else if (dewrap) {
+                    if (nlines == 1) dewrap->assign((const uint8_t*)data + first_a, (const uint8_t*)data + first_b);
+                    dewrap->insert(dewrap->end(), (const uint8_t*)data + p, (const uint8_t*)data + l1);
+                }
+                sl += l1 - p;
+                ++nlines;
+            }
+            p = ep ? e + 1 : size;
         }
-        // the next line has to open the next record: a wrapped sequence or a blank line is not this decoder's business
-        if (next < size ? data[next] != '>' : !final_window()) return 1;
-        const size_t sl = s1 - s0;
         if (sl > 0x7FFFFFFFull) return 1;
-        if (sl && (data[s0] == ' ' || data[s0] == '\t' || data[s1 - 1] == ' ' || data[s1 - 1] == '\t' || data[s0] == '>')) return 1;
-        r = Rec{s + 1, (uint64_t)(h1 - s - 1), s0, (uint64_t)sl, 0};
+        r = Rec{s + 1, (uint64_t)(h1 - s - 1), nlines ? first_a : s0, sl, next, nlines > 1};
         return 0;
     }
-    int parse_at(size_t s, Rec& r, size_t& next) const {
-        if (fasta) return parse_fasta_at(s, r, next);
+    int parse_at(size_t s, Rec& r, size_t& next, std::vector<uint8_t>* dewrap = nullptr) const {
+        if (fasta) return parse_fasta_at(s, r, next, dewrap);
         if (s >= size || data[s] != '@') return 1;
         const char* e0p = (const char*)memchr(data + s, '\n', size - s);
         if (!e0p) return 1;
@@ -609,7 +620,12 @@ struct Fast {
             else if (data[q1] == '\n') next = q1 + 1;
             else return 1;                                      // more (or fewer) quality characters than bases
         } else {
-            next = size;                                        // last line without a newline
+            // the quality line ends exactly where the text in hand ends: the last line of the input without a newline -- or, in a
+            // window of inflated text, a record whose line end is the first byte of the NEXT window (accepting it here
+            // left that newline at the head of the next window, the packed decoder gave up there and the rest of the file went
+            // through the one-thread streaming decoder): the record waits for the next window
+            if (!final_window()) return 1;
+            next = size;
         }
         // A quality line SHORTER than the sequence puts q1 inside the next record; that is only mistaken for a line end if that
         // record's header happens to end exactly there -- and then what follows is not a record start.  Scanning every quality
@@ -619,7 +635,7 @@ struct Fast {
         if (next < size && data[next] != '@' && memchr(data + q0, '\n', sl)) return 1;
         if (sl > 0x7FFFFFFFull) return 1;
         if (sl && (data[s0] == ' ' || data[s0] == '\t' || data[s1 - 1] == ' ' || data[s1 - 1] == '\t')) return 1;
-        r = Rec{s + 1, (uint64_t)(h1 - s - 1), s0, (uint64_t)sl, q0};
+        r = Rec{s + 1, (uint64_t)(h1 - s - 1), s0, (uint64_t)sl, q0, false};
         return 0;
     }
     // What one thread of the team found in its stretch of the text: the records that START there, already packed into
@@ -630,6 +646,7 @@ struct Fast {
         std::vector<uint16_t> inv;
         std::vector<uint8_t> bad;                  // per record: has an invalid base
         std::vector<int64_t> woff;                 // per record: word offset inside the staging
+        std::vector<uint8_t> dewrap;               // a wrapped FASTA sequence joined into one stretch (the record being packed)
         size_t first = 0, end = 0;                 // start of the first record, start of the record after the last
         bool odd = false;                          // stopped at something that is not a plain 4-line record (at `end`)
         int64_t base_rec = 0, base_word = 0, base_head = 0, take = 0;
@@ -663,7 +680,7 @@ struct Fast {
         const size_t p = pos;
         if (p >= size || only_blank(p)) return 0;
         // text that yields at most words_cap words if it were nothing but sequence + quality lines
-        size_t span = std::min<size_t>(size - p, (size_t)std::max<int64_t>(words_cap, 1024) * 32);
+        size_t span = std::min<size_t>(size - p, (size_t)std::max<int64_t>(words_cap, 1024) * (fasta ? 17 : 32));      // (FASTA: no quality lines)
         static const size_t min_span = getenv("TPS_IO_PACK_MIN_SPAN") ? (size_t)atoll(getenv("TPS_IO_PACK_MIN_SPAN")) : (size_t)4 << 20;   // (tests: team on small files)
         const int T = span < min_span ? 1 : threads;
         if (chunks.empty()) take_spare();
@@ -691,11 +708,12 @@ struct Fast {
             c.seq2.reserve((b - a) / 28 + 1024);
             if (inv) c.inv.reserve((b - a) / 28 + 1024);
             while (s < b) {
-                if (parse_at(s, r, nx) != 0) { c.odd = true; break; }
+                if (parse_at(s, r, nx, &c.dewrap) != 0) { c.odd = true; break; }
                 const int64_t w = tps::packed_words((int64_t)r.sl), at = (int64_t)c.seq2.size();
                 c.seq2.resize((size_t)(at + w));
                 if (inv) c.inv.resize((size_t)(at + w));
-                const bool bad = tps::pack_one((const uint8_t*)data + r.s0, (int64_t)r.sl, c.seq2.data() + at, inv ? c.inv.data() + at : nullptr);
+                const uint8_t* bases = r.wrapped ? c.dewrap.data() : (const uint8_t*)data + r.s0;
+                const bool bad = tps::pack_one(bases, (int64_t)r.sl, c.seq2.data() + at, inv ? c.inv.data() + at : nullptr);
                 c.recs.push_back(r);
                 c.bad.push_back(bad ? 1 : 0);
                 c.woff.push_back(at);

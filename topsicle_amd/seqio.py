@@ -389,12 +389,22 @@ class PackedBatch:
 
     def seq_bytes(self, i: int) -> bytes:
         if self.spans is not None:
-            s0 = int(self.spans[i, 2])
-            return self.text[s0:s0 + int(self.desc["len"][i])]
+            s0, n = int(self.spans[i, 2]), int(self.desc["len"][i])
+            if self.fmt == "fasta":
+                # FASTA spans: [first base, end of the record's sequence text); a wrapped sequence is joined here (the few records
+                # that are written back out), exactly as the reader joined it for packing: line ends dropped, nothing else
+                raw = self.text[s0:int(self.spans[i, 3])]
+                head = raw[:n]
+                if b"\n" in head or b"\r" in head:    # wrapped (a sequence on one line has its n bases in front of the first line end)
+                    raw = b"".join(ln[:-1] if ln.endswith(b"\r") else ln for ln in raw.split(b"\n"))
+                return raw[:n]
+            return self.text[s0:s0 + n]
         b = self.ascii_batch
         return b.bases[int(b.offsets[i]):int(b.offsets[i + 1])].tobytes()
 
     def qual_bytes(self, i: int):
+        if self.fmt == "fasta":
+            return None                       # (a FASTA span's fourth entry is the end of the sequence text, not a quality offset)
         if self.spans is not None:
             q0 = int(self.spans[i, 3])
             return self.text[q0:q0 + int(self.desc["len"][i])]
@@ -411,7 +421,7 @@ class PackedBatch:
         of a batch that was packed straight from a mmap'ed plain FASTQ file leave through the native writer: writev from the
         mapping, no copy in user space (tps_write_fastq_spans)."""
         import numpy as np
-        if fmt == "fastq" and self.spans is not None and self.text is not None and len(indices):
+        if fmt == "fastq" and self.fmt == "fastq" and self.spans is not None and self.text is not None and len(indices):
             lib = _load_io()
             try:
                 fd = handle.fileno()                  # (an in-memory handle has none: the Python loop below serves it)
@@ -524,7 +534,9 @@ def read_batches_packed(filepath: str, pool: BufferPool, max_records: int = 1 <<
             if n == 0:
                 return
             if n == -4:
-                packed_mode = False          # compressed / FASTA / odd records: ASCII batches from here on
+                packed_mode = False          # multi-line FASTQ / odd records: ASCII batches from here on
+                logging.info("%s: records the thread-team decoder does not take (multi-line FASTQ, blank or padded lines, lone CRs): "
+                             "the one-thread streaming decoder reads the rest", filepath)
             elif n == -2:
                 raise RuntimeError("a single read does not fit the upload buffers; raise the batch size")
             else:
