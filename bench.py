@@ -554,6 +554,11 @@ def main():
                 out["e2e"] = e2e.measure(bases, offsets, motif, k, cfg["slide"], device=dev)
             except Exception as e:                  # a full /tmp must not cost the bench line
                 out["e2e"] = {"error": repr(e)}
+            if args.workload == "config2" and not os.environ.get("TPS_BENCH_NO_WGS"):
+                try:                                # the step-1-dominated regime end to end: 30 kb reads, 1 % telomeric, one-pass against two-pass upload
+                    out["e2e"]["wgs_1pct"] = e2e.measure_wgs(device=dev)
+                except Exception as e:
+                    out["e2e"]["wgs_1pct"] = {"error": repr(e)}
         print(json.dumps(out))
     sc.close()
     grp.close()

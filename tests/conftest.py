@@ -64,3 +64,14 @@ def demo_records():
             h.readline()
             recs.append((head[1:].split()[0], seq))
     return recs
+
+
+@pytest.fixture
+def emu_engine_factory():
+    """() -> two engines with HipScanner's interface backed by the host emulation of the kernels (tests/emu): the host-side
+    pipeline (batch.EnginePool) without a GPU."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import emu_driver
+    emu_driver.build()
+    from emu_engine import EmuEngine
+    return lambda: [EmuEngine(), EmuEngine()]

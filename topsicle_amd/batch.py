@@ -47,6 +47,7 @@ def upload_batch(engine, recs, slot: int = 0):
     """A seqio.PackedBatch is uploaded as it is (3 bits per base); a seqio.RecordBatch or a list of records goes up as
     ASCII and is packed on the device."""
     if hasattr(recs, "seq2"):
+        recs.uploaded_bytes = 4 * len(recs.seq2) + (2 * len(recs.inv) if recs.any_invalid else 0) + 16 * len(recs.desc)
         engine.upload_packed(slot, recs.seq2, recs.inv if recs.any_invalid else None, recs.desc)
     elif hasattr(recs, "bases"):
         engine.upload(slot, recs.bases, recs.offsets)
@@ -54,13 +55,132 @@ def upload_batch(engine, recs, slot: int = 0):
         engine.upload(slot, *hiplib.pack_reads([r.seq for r in recs]))
 
 
+TWO_PASS_MAX_PASSING = 0.25      # heads mode stays on while at most this share of a batch's reads passes step 1
+
+
+def scan_jobs_heads(engine, recs, jobs, slot: int = 0):
+    """Two passes over a batch that came in HEADS mode (seqio.PackedBatch.full_len: only the first + last no_bp bases of every read
+    were packed and uploaded -- all that step 1, allsteps.py:174-198, looks at):
+      A  step 1 on the heads, one launch per job (table);
+      B  the reads that pass -- in real WGS data well under 1 % (the reference's README: "> 20 GB and / or > 1 million reads") -- get
+         the part of them step 2 scans, their first / last min(L, maxlengthtelo) bases (allsteps.py:263-271), packed from the batch's
+         text (seqio.pack_spans) and uploaded as a small batch of its own with the tails step 1 chose; windows + change point there.
+    The rows that come back are those of the one-pass scan (tests/test_two_pass.py: equal field by field); sums / raw rows are
+    laid out over ALL reads of the batch with no windows for the reads that do not pass.  PCIe bytes per input base, 30 kb reads of
+    which 1 % pass: 0.375 -> 0.028.  Same return value as scan_jobs."""
+    import numpy as np
+    concurrent = len(jobs) > 1 and hasattr(engine, "helper") and os.environ.get("TOPSICLE_SEQUENTIAL_TABLES", "0") != "1"
+    engines = [engine] + ([engine.helper(j) for j in range(len(jobs) - 1)] if concurrent else [engine] * (len(jobs) - 1))
+    slot_b = slot + 1
+    full = np.asarray(recs.full_len, np.int64)
+    out = []
+    try:
+        upload_batch(engine, recs, slot)
+        prm_a = []
+        for job in jobs:
+            p = hiplib.Params.from_buffer_copy(job.prm)
+            p.flags = hiplib.F_STEP1
+            p.min_len = 0                              # (the pseudo-reads are short: the length filter is applied to full_len below)
+            prm_a.append(p)
+        res_a = []
+        if concurrent:
+            for eng, job, p in zip(engines, jobs, prm_a):
+                if eng is not engine:
+                    eng.share(slot, engine, slot)
+                if getattr(eng, "patterns", None) != job.patterns:
+                    eng.set_patterns(job.patterns)
+                eng.scan(slot, p)
+        for n, (eng, job, p) in enumerate(zip(engines, jobs, prm_a)):
+            if not concurrent:
+                if len(jobs) > 1 or getattr(eng, "patterns", None) != job.patterns:
+                    eng.set_patterns(job.patterns)
+                eng.scan(slot, p)
+            eng.sync()
+            res_a.append(eng.results(slot))
+        recs.release()                                 # the heads are on the device: the staging buffers go back to the reader
+        uploaded, holds = {}, {}                       # (passing reads, tails, maxlen) -> the engine that uploaded them; engine -> what its slot_b holds
+        for n, (eng, job, ra) in enumerate(zip(engines, jobs, res_a)):
+            res = ra.copy()
+            passing = (ra["pass"] != 0) & (full > job.prm.min_len)
+            res["pass"] = passing
+            res["n_win"] = 0
+            res["bkp"] = -1
+            res["gain"] = 0.0
+            res["flags"] = 0
+            idx = np.nonzero(passing)[0]
+            sums = raw = None
+            win_off = np.zeros(len(res) + 1, np.int64)
+            want_b = (job.prm.flags & (hiplib.F_WINDOWS | hiplib.F_BINSEG)) != 0
+            if len(idx) and want_b:
+                tails = ra["tail"][idx].astype(np.uint8)
+                key = (idx.tobytes(), tails.tobytes(), int(job.prm.maxlen))
+                if not concurrent and len(jobs) > 1 and getattr(eng, "patterns", None) != job.patterns:
+                    eng.set_patterns(job.patterns)
+                if holds.get(id(eng)) != key:
+                    owner = uploaded.get(key)
+                    if owner is not None and owner is not eng and holds.get(id(owner)) == key and hasattr(eng, "share"):
+                        eng.share(slot_b, owner, slot_b)           # another table's context holds exactly these reads already
+                    else:
+                        seq2, inv, desc = _pack_passing(recs, idx, tails, int(job.prm.maxlen))
+                        eng.upload_packed(slot_b, seq2, inv if (desc["flags"] & 1).any() else None, desc)
+                        recs.uploaded_bytes += 4 * len(seq2) + (2 * len(inv) if (desc["flags"] & 1).any() else 0) + 16 * len(desc)
+                        uploaded[key] = eng
+                    holds[id(eng)] = key
+                eng.set_tails(slot_b, tails)
+                p = hiplib.Params.from_buffer_copy(job.prm)
+                p.flags = (job.prm.flags & ~hiplib.F_STEP1) | hiplib.F_TAILS_IN | (hiplib.F_STORE_SUMS if job.want_sums else 0) | \
+                          (hiplib.F_STORE_RAW if job.want_raw else 0)
+                p.min_len = 0
+                eng.scan(slot_b, p)
+                eng.sync()
+                rb = eng.results(slot_b)
+                if p.flags & hiplib.F_BINSEG:
+                    hiplib.resolve_ties(eng, slot_b, rb, len(job.patterns), p.jump, p.min_size)
+                for f in ("n_win", "bkp", "gain", "flags"):
+                    res[f][idx] = rb[f]
+                np.cumsum(np.where(passing, res["n_win"], 0), out=win_off[1:])
+                if job.want_sums:
+                    sums, wo_b = eng.window_sums(slot_b)
+                    assert int(wo_b[-1]) == int(win_off[-1])
+                if job.want_raw:
+                    raw, wo_b = eng.window_raw(slot_b)
+                    assert int(wo_b[-1]) == int(win_off[-1])
+            else:
+                if job.want_sums:
+                    sums = np.zeros(0, np.int32)
+                if job.want_raw:
+                    raw = np.zeros((0, len(job.patterns)), np.uint8)
+            out.append((res, sums, raw, win_off if (job.want_sums or job.want_raw) else None))
+    except BaseException:
+        for eng in dict.fromkeys(engines):
+            try:
+                eng.sync()
+            except Exception:
+                pass
+        recs.release()
+        raise
+    return out
+
+
+def _pack_passing(recs, idx, tails, maxlen):
+    """The scanned part of the passing reads as a packed batch of its own: from the text the batch's spans point into, or -- a
+    batch that has none (ASCII batches of odd inputs never come in heads mode) -- an error."""
+    from . import seqio
+    if recs.spans is None or recs.text is None:
+        raise RuntimeError("heads-mode batch without text spans")
+    return seqio.pack_spans(recs, idx, tails, maxlen)
+
+
 def scan_jobs(engine, recs, jobs, slot: int = 0):
     """Upload once, then one fused scan per job.  Returns [(results, sums, raw, win_off), ...] in job order.
+    A batch in heads mode (PackedBatch.full_len) takes the two-pass route: scan_jobs_heads.
 
     Several jobs (pattern tables) on a HipScanner run AT THE SAME TIME: job j > 0 goes to the engine's j-th helper context,
     which borrows the resident batch (tps_batch_share) and keeps its own table -- no table switch per batch, and the launches
     of the k passes overlap on the GPU (measured: 603 vs 785 us per 10 000 x 25 kb batch for k = 4, 5, 6).
     TOPSICLE_SEQUENTIAL_TABLES=1 scans them back to back on the one context instead (the A/B switch)."""
+    if getattr(recs, "full_len", None) is not None:
+        return scan_jobs_heads(engine, recs, jobs, slot)
     out = []
     concurrent = len(jobs) > 1 and hasattr(engine, "helper") and os.environ.get("TOPSICLE_SEQUENTIAL_TABLES", "0") != "1"
     engines = [engine] + ([engine.helper(j) for j in range(len(jobs) - 1)] if concurrent else [engine] * (len(jobs) - 1))
@@ -117,8 +237,11 @@ class EnginePool:
     upload / launch ramp / result download of one batch with the scan of another).  Batches go to whichever context is
     free next; results come back in input order."""
 
-    def __init__(self, engines, patterns=None):
+    def __init__(self, engines, patterns=None, two_pass="auto"):
+        """two_pass: "auto" (heads mode while few reads pass step 1: see _heads_mode), "on", "off"."""
         self.engines = list(engines)
+        self.two_pass = os.environ.get("TOPSICLE_TWO_PASS", two_pass)
+        self.stats = {"batches": 0, "heads_batches": 0, "upload_bytes": 0, "input_bases": 0}
         if not self.engines:
             raise ValueError("no engines")
         self.patterns = None if patterns is None else list(patterns)
@@ -135,8 +258,9 @@ class EnginePool:
         words_cap = max(max_bases // 16, 1024)                 # (a read's padding to whole 64-base quads counts too)
         reads_cap = min(BATCH_READS, max(64, max_bases // 256))
         pool = self._staging_pool(words_cap, reads_cap)
-        return self._single(self._run(seqio.read_batches_packed(filepath, pool, max_records=reads_cap),
-                                      [Job(self.patterns, prm, want_sums, want_raw)], pool))
+        jobs = [Job(self.patterns, prm, want_sums, want_raw)]
+        return self._single(self._run(seqio.read_batches_packed(filepath, pool, max_records=reads_cap, heads_bp=self._heads_mode(jobs)),
+                                      jobs, pool))
 
     def scan_file_jobs(self, filepath, jobs, max_bases=None):
         """One pass over the file for several jobs (pattern tables): yields (PackedBatch, [(results, sums, raw, win_off) per job])."""
@@ -145,7 +269,38 @@ class EnginePool:
         words_cap = max(max_bases // 16, 1024)
         reads_cap = min(BATCH_READS, max(64, max_bases // 256))
         pool = self._staging_pool(words_cap, reads_cap)
-        return self._run(seqio.read_batches_packed(filepath, pool, max_records=reads_cap), list(jobs), pool)
+        jobs = list(jobs)
+        return self._run(seqio.read_batches_packed(filepath, pool, max_records=reads_cap, heads_bp=self._heads_mode(jobs)), jobs, pool)
+
+    def _heads_mode(self, jobs):
+        """The reader's heads_bp for the next batch of one file (a callable: seqio.read_batches_packed asks before every batch).
+        Heads mode needs step 1 in every job and the same no_bp; "auto" keeps it while the batches seen so far say that it pays:
+        reads several times longer than the two heads, and few of them passing step 1 (real WGS input: < 1 % telomeric).  A
+        telomere-enriched file (the demo, the synthetic benchmarks: every read passes) drops to the one-pass route after its
+        first batch -- there the second pass would upload what the first one spared."""
+        mode = self.two_pass
+        no_bp = {int(j.prm.no_bp) for j in jobs}
+        ok = mode in ("auto", "on") and len(no_bp) == 1 and all(j.prm.flags & hiplib.F_STEP1 for j in jobs) and min(no_bp) > 0
+        self._hm = {"bp": min(no_bp) if ok else 0, "auto": mode == "auto"}
+        return lambda: self._hm["bp"]
+
+    def _heads_feedback(self, pb, outs):
+        """Called by the workers with every finished batch: the statistics, and auto mode's decision."""
+        hm = getattr(self, "_hm", None)
+        st = self.stats
+        st["batches"] += 1
+        st["input_bases"] += int(pb.n_bases)
+        if getattr(pb, "full_len", None) is None:
+            st["upload_bytes"] += int(getattr(pb, "uploaded_bytes", pb.n_bases * 3 // 8))
+            return
+        st["heads_batches"] += 1
+        import numpy as np
+        full = np.asarray(pb.full_len, np.int64)
+        frac = max((float(np.mean(o[0]["pass"] != 0)) if len(o[0]) else 0.0) for o in outs)
+        st["upload_bytes"] += int(getattr(pb, "uploaded_bytes", 0))
+        if hm and hm["auto"] and hm["bp"] and len(full) >= 8:
+            if frac > TWO_PASS_MAX_PASSING or float(full.mean()) < 4 * hm["bp"]:
+                hm["bp"] = 0                            # the rest of the file goes up whole
 
     def _staging_pool(self, words_cap, reads_cap):
         """The pinned staging buffers of this engine set: allocated ONCE per (engine set, geometry) and kept on the first engine,
@@ -208,7 +363,9 @@ class EnginePool:
                     if item is None:
                         return
                     i, b = item
-                    q_out.put(("batch", i, (b, scan_jobs(eng, b, jobs, 0))))
+                    outs = scan_jobs(eng, b, jobs, 0)
+                    self._heads_feedback(b, outs)
+                    q_out.put(("batch", i, (b, outs)))
             except BaseException as e:
                 stop.set()
                 q_out.put(("error", None, e))

@@ -647,6 +647,7 @@ struct Fast {
         std::vector<uint8_t> bad;                  // per record: has an invalid base
         std::vector<int64_t> woff;                 // per record: word offset inside the staging
         std::vector<uint8_t> dewrap;               // a wrapped FASTA sequence joined into one stretch (the record being packed)
+        std::vector<uint8_t> ends;                 // heads mode: the first + last heads_bp bases of the record being packed
         size_t first = 0, end = 0;                 // start of the first record, start of the record after the last
         bool odd = false;                          // stopped at something that is not a plain 4-line record (at `end`)
         int64_t base_rec = 0, base_word = 0, base_head = 0, take = 0;
@@ -665,8 +666,12 @@ struct Fast {
         std::lock_guard<std::mutex> lk(spare_mu());
         if (spare().size() < 2) { spare().emplace_back(); spare().back().swap(chunks); }
     }
+    // heads_bp > 0 ("heads mode", round 4): a read longer than 2 heads_bp is packed as its first heads_bp + its last heads_bp bases
+    // only -- all step 1 looks at (allsteps.py:176-177); desc[i].len is that pseudo-read's length and full_len[i] the read's own.
+    // The caller uploads ~2 kb per read instead of the whole read, runs step 1, and packs the scanned part of the FEW reads that
+    // pass from their spans afterwards (tps_pack_spans).
     int64_t next_packed(uint32_t* seq2, uint16_t* inv, int64_t words_cap, tps_read_desc* desc, int64_t max_records, char* heads,
-                        int64_t heads_cap, int64_t* head_off, int64_t* spans) {
+                        int64_t heads_cap, int64_t* head_off, int64_t* spans, int32_t heads_bp = 0, int32_t* full_len = nullptr) {
         // The text from the first unconsumed record on is cut into one stretch per thread; a thread finds the first record
         // that starts in its stretch (a line that begins with '@', is followed by a sequence line, a '+' line and a quality
         // line of the sequence's length -- a quality line that happens to begin with '@' fails that test), then decodes
@@ -709,11 +714,19 @@ struct Fast {
             if (inv) c.inv.reserve((b - a) / 28 + 1024);
             while (s < b) {
                 if (parse_at(s, r, nx, &c.dewrap) != 0) { c.odd = true; break; }
-                const int64_t w = tps::packed_words((int64_t)r.sl), at = (int64_t)c.seq2.size();
+                const uint8_t* bases = r.wrapped ? c.dewrap.data() : (const uint8_t*)data + r.s0;
+                int64_t pl = (int64_t)r.sl;                                 // bases packed for this record
+                if (heads_bp > 0 && pl > 2 * (int64_t)heads_bp) {
+                    c.ends.resize((size_t)(2 * heads_bp));
+                    memcpy(c.ends.data(), bases, (size_t)heads_bp);
+                    memcpy(c.ends.data() + heads_bp, bases + r.sl - heads_bp, (size_t)heads_bp);
+                    bases = c.ends.data();
+                    pl = 2 * (int64_t)heads_bp;
+                }
+                const int64_t w = tps::packed_words(pl), at = (int64_t)c.seq2.size();
                 c.seq2.resize((size_t)(at + w));
                 if (inv) c.inv.resize((size_t)(at + w));
-                const uint8_t* bases = r.wrapped ? c.dewrap.data() : (const uint8_t*)data + r.s0;
-                const bool bad = tps::pack_one(bases, (int64_t)r.sl, c.seq2.data() + at, inv ? c.inv.data() + at : nullptr);
+                const bool bad = tps::pack_one(bases, pl, c.seq2.data() + at, inv ? c.inv.data() + at : nullptr);
                 c.recs.push_back(r);
                 c.bad.push_back(bad ? 1 : 0);
                 c.woff.push_back(at);
@@ -735,14 +748,17 @@ struct Fast {
             }
             if (c.first != cur) break;                        // mis-framed stretch: the next call starts at `cur`, a known record start
             for (size_t i = 0; i < c.recs.size(); ++i) {
-                const int64_t w = tps::packed_words((int64_t)c.recs[i].sl), hl = (int64_t)c.recs[i].hl;
+                const int64_t sl_full = (int64_t)c.recs[i].sl;
+                const int64_t pl = (heads_bp > 0 && sl_full > 2 * (int64_t)heads_bp) ? 2 * (int64_t)heads_bp : sl_full;
+                const int64_t w = tps::packed_words(pl), hl = (int64_t)c.recs[i].hl;
                 if (n >= max_records || nw + w > words_cap || nh + hl > heads_cap) {
                     too_big = n == 0 && (w > words_cap || hl > heads_cap);
                     stop = true;
                     break;
                 }
                 desc[n].word_off = nw;
-                desc[n].len = (int32_t)c.recs[i].sl;
+                desc[n].len = (int32_t)pl;
+                if (full_len) full_len[n] = (int32_t)sl_full;
                 desc[n].flags = c.bad[i] ? TPS_RD_HAS_INVALID : 0;
                 nw += w; nh += hl; ++n;
                 head_off[n] = nh;
@@ -1025,8 +1041,9 @@ int64_t tps_reader_next(void* hv, uint8_t* bases, int64_t bases_cap, int64_t* of
 // the end of the input), -1 on an error, -2 if one record does not fit into empty buffers, -4 if this input cannot be read
 // in packed mode (compressed, FASTA, wrapped or odd records from here on): the caller continues with tps_reader_next at
 // the same record and packs with tps_pack_reads.  *n_words receives the words used in seq2 / inv.
-int64_t tps_reader_next_packed(void* hv, uint32_t* seq2, uint16_t* inv, int64_t words_cap, tps_read_desc* desc, int64_t max_records,
-                               char* heads, int64_t heads_cap, int64_t* head_off, int64_t* spans, int64_t* n_words) {
+static int64_t reader_next_packed(void* hv, uint32_t* seq2, uint16_t* inv, int64_t words_cap, tps_read_desc* desc, int64_t max_records,
+                                  char* heads, int64_t heads_cap, int64_t* head_off, int64_t* spans, int64_t* n_words, int32_t heads_bp,
+                                  int32_t* full_len) {
     Handle* h = (Handle*)hv;
     if (!h || !seq2 || !desc || !heads || !head_off || !n_words) { g_err = "null argument"; return -1; }
     *n_words = 0;
@@ -1038,7 +1055,7 @@ int64_t tps_reader_next_packed(void* hv, uint32_t* seq2, uint16_t* inv, int64_t 
         f->top_up((size_t)std::max<int64_t>(words_cap, 1024) * 32);      // (a batch's worth of text in the window, if it can still grow)
         if (f->src->failed) return -1;
     }
-    int64_t n = f->next_packed(seq2, inv, words_cap, desc, max_records, heads, heads_cap, head_off, spans);
+    int64_t n = f->next_packed(seq2, inv, words_cap, desc, max_records, heads, heads_cap, head_off, spans, heads_bp, full_len);
     // compressed input: the window ends in an incomplete record (or is used up) while the source has more -- the next group
     // of blocks is inflated into a new window behind the unconsumed tail.  (An unconsumed stretch longer than any record that
     // yields nothing is not an incomplete record: the streaming decoder judges it.)
@@ -1046,11 +1063,78 @@ int64_t tps_reader_next_packed(void* hv, uint32_t* seq2, uint16_t* inv, int64_t 
         f->fill_target = (size_t)std::max<int64_t>(words_cap, 1024) * 32 + (f->size - f->pos);
         f->index_window();
         if (f->src->failed) return -1;
-        n = f->next_packed(seq2, inv, words_cap, desc, max_records, heads, heads_cap, head_off, spans);
+        n = f->next_packed(seq2, inv, words_cap, desc, max_records, heads, heads_cap, head_off, spans, heads_bp, full_len);
     }
     if (n == -3) return -4;                 // (the position is unchanged: tps_reader_next re-reads this record its own way)
     if (n > 0) *n_words = desc[n - 1].word_off + tps::packed_words(desc[n - 1].len);
     return n;
+}
+
+int64_t tps_reader_next_packed(void* hv, uint32_t* seq2, uint16_t* inv, int64_t words_cap, tps_read_desc* desc, int64_t max_records,
+                               char* heads, int64_t heads_cap, int64_t* head_off, int64_t* spans, int64_t* n_words) {
+    return reader_next_packed(hv, seq2, inv, words_cap, desc, max_records, heads, heads_cap, head_off, spans, n_words, 0, nullptr);
+}
+// Heads mode (see Fast::next_packed): reads longer than 2 heads_bp are packed as their first + last heads_bp bases; full_len[i]
+// receives every read's own length.
+int64_t tps_reader_next_heads(void* hv, int32_t heads_bp, uint32_t* seq2, uint16_t* inv, int64_t words_cap, tps_read_desc* desc,
+                              int64_t max_records, char* heads, int64_t heads_cap, int64_t* head_off, int64_t* spans, int32_t* full_len,
+                              int64_t* n_words) {
+    if (heads_bp < 1 || !full_len) { g_err = "bad heads_bp / full_len"; return -1; }
+    return reader_next_packed(hv, seq2, inv, words_cap, desc, max_records, heads, heads_cap, head_off, spans, n_words, heads_bp, full_len);
+}
+
+// Second pass of the heads mode: packs, for the n reads idx[0 .. n) of a batch whose spans point into `text`, the part of the
+// read a scan of tail tails[j] (0 = forward, 1 = reverse) touches -- its first / last min(length, maxlen) bases, as a read of its
+// own (allsteps.py:263-271: s = seq[t:min(L, M)], or the same of the reversed read).  fasta: spans[4 i + 3] is the end of the
+// record's sequence text (a wrapped sequence is joined first).  seq2 / inv / desc as tps_pack_reads fills them; returns the words
+// used, -2 if words_cap is too small, -1 on a bad span.
+int64_t tps_pack_spans(const char* text, int64_t text_len, int32_t fasta, const int64_t* spans, const int32_t* full_len, const int64_t* idx,
+                       const uint8_t* tails, int64_t n, int32_t maxlen, uint32_t* seq2, uint16_t* inv, tps_read_desc* desc, int64_t words_cap) {
+    if (!text || !spans || !full_len || (n > 0 && (!idx || !tails)) || !seq2 || !desc || maxlen < 0) { g_err = "null argument"; return -1; }
+    int64_t nw = 0;
+    for (int64_t j = 0; j < n; ++j) {
+        const int64_t L = full_len[idx[j]], m = std::min<int64_t>(L, maxlen);
+        desc[j].word_off = nw;
+        desc[j].len = (int32_t)m;
+        desc[j].flags = 0;
+        nw += tps::packed_words(m);
+    }
+    if (nw > words_cap) { g_err = "the passing reads do not fit the buffers"; return -2; }
+    std::atomic<int> bad{0};
+    const int T = nw * 16 < (4 << 20) ? 1 : io_threads();
+    team(T, [&](int t, int nt) {
+        std::vector<uint8_t> joined;
+        const int64_t a = n * (int64_t)t / nt, b = n * (int64_t)(t + 1) / nt;
+        for (int64_t j = a; j < b; ++j) {
+            const int64_t i = idx[j], L = full_len[i], m = desc[j].len, s0 = spans[4 * i + 2];
+            const uint8_t* src = (const uint8_t*)text + s0;
+            if (s0 < 0 || s0 > text_len) { bad = 1; return; }
+            if (fasta) {
+                const int64_t se = spans[4 * i + 3];
+                if (se < s0 || se > text_len) { bad = 1; return; }
+                const size_t look = (size_t)std::min<int64_t>(L, se - s0);      // a sequence on one line has its L bases in front of the first line end
+                if (se - s0 > L && (memchr(text + s0, '\n', look) || memchr(text + s0, '\r', look))) {
+                    // wrapped: join the lines (line ends dropped, a trailing CR with them: what the reader packed)
+                    joined.clear();
+                    const char* p = text + s0;
+                    const char* e = text + se;
+                    while (p < e) {
+                        const char* q = (const char*)memchr(p, '\n', (size_t)(e - p));
+                        const char* le = q ? q : e;
+                        const char* l1 = (le > p && le[-1] == '\r') ? le - 1 : le;
+                        joined.insert(joined.end(), (const uint8_t*)p, (const uint8_t*)l1);
+                        p = q ? q + 1 : e;
+                    }
+                    if ((int64_t)joined.size() != L) { bad = 1; return; }
+                    src = joined.data();
+                } else if (s0 + L > text_len) { bad = 1; return; }
+            } else if (s0 + L > text_len) { bad = 1; return; }
+            if (tps::pack_one(src + (tails[j] & 1 ? L - m : 0), m, seq2 + desc[j].word_off, inv ? inv + desc[j].word_off : nullptr))
+                desc[j].flags |= TPS_RD_HAS_INVALID;
+        }
+    });
+    if (bad.load()) { g_err = "record span outside the text"; return -1; }
+    return nw;
 }
 
 // The text the spans of the LAST packed batch point into, for a compressed input (for a plain file the caller maps the file

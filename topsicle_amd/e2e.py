@@ -278,6 +278,51 @@ def measure(bases, offsets, motif: str, k: int, slide: int, device: int = 0, con
     return out
 
 
+def measure_wgs(motif: str = "CCCTAA", k: int = 4, slide: int = 6, n_reads: int = 6000, read_len: int = 30000, telomeric_fraction: float = 0.01,
+                device: int = 0, contexts_per_gpu: int = 2, repeats: int = 4, workdir: str | None = None) -> dict:
+    """The step-1-dominated regime end to end: a FASTQ file of `read_len`-base reads of which
+    `telomeric_fraction` are telomeric, file -> results with the one-pass upload (every read whole: 3 bits per base) and with the
+    two-pass route (batch.scan_jobs_heads: the two 1000-base ends of every read, then the scanned part of the reads that pass).
+    Reports both rates (median run) and the bytes that crossed PCIe per input base."""
+    from . import allsteps, batch, hiplib, synth
+    tmp = tempfile.mkdtemp(prefix="tps_e2e_wgs_", dir=workdir)
+    out = {"reads": n_reads, "read_len": read_len, "telomeric_fraction": telomeric_fraction}
+    try:
+        bases, offsets, _ = synth.make_reads(n_reads, read_len, motif, seed=20250919 + 33, telomeric_fraction=telomeric_fraction)
+        n_bases = int(offsets[-1])
+        fq = os.path.join(tmp, "wgs.fastq")
+        write_fastq(fq, bases, offsets)
+        del bases
+        pats = allsteps.patterns_to_search(motif, k)
+        prm = hiplib.make_params(no_bp=1000, min_len=9000, min_count=allsteps.min_count_for_cutoff(0.7, 1000 / len(motif), 1000),
+                                 window=100, slide=slide, trimfirst=100, maxlen=20000)
+        engines = [hiplib.HipScanner(device) for _ in range(contexts_per_gpu)]
+        try:
+            rows = {}
+            for mode in ("off", "auto"):
+                ep = batch.EnginePool(engines, pats, two_pass=mode)
+                times = []
+                for rep in range(repeats + 1):
+                    for key in ep.stats:
+                        ep.stats[key] = 0
+                    t0 = time.perf_counter()
+                    got = []
+                    for pb, res, _s, _r, _w in ep.scan_file(fq, prm):
+                        got.append(res[["pass", "tail", "best_start", "best_end", "n_win", "bkp"]].copy())
+                    times.append(time.perf_counter() - t0)
+                rows[mode] = np.concatenate(got)
+                out["two_pass_" + mode] = _leg(times[1:], n_bases, upload_bytes_per_input_base=ep.stats["upload_bytes"] / n_bases,
+                                               heads_batches=ep.stats["heads_batches"], batches=ep.stats["batches"],
+                                               reads_passing=int(rows[mode]["pass"].sum()))
+            out["rows_equal"] = bool(np.array_equal(rows["off"], rows["auto"]))
+        finally:
+            for e in engines:
+                e.close()
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
 def _quiet(fn, argv):
     """Run the CLI with its stdout chatter sent to /dev/null (the log file still gets everything)."""
     import contextlib

@@ -122,7 +122,7 @@ def process_file_multi(args, seq_loc, phrases, engines):
     npz = getattr(args, "rawcountformat", "csv") == "npz"
     raw_npz = [{"read_id": [], "tail": [], "n_win": [], "counts": []} if npz else None for _ in phrases]
     csv_path = f"{args.outputDir}/telolengths_all.csv"
-    pool = batch.EnginePool(engines)
+    pool = batch.EnginePool(engines, two_pass=getattr(args, "twopass", "auto"))
     # the passing records are written by a helper thread, batch by batch in file order, while the next batches are scanned
     # (the native writer releases the GIL: writev straight from the mapped input)
     wq: "queue.Queue" = queue.Queue(maxsize=4)
@@ -200,6 +200,10 @@ def process_file_multi(args, seq_loc, phrases, engines):
             _write_rawcount_npz(args, file_name, telo_phrase, pattern, sliding_val, raw_npz[n])
     if out_handle is not None:
         tprint(f"Temporary fasta file with TRC more than {min_cutoff}:", fasta_temp)
+    st = pool.stats
+    if st["heads_batches"]:
+        tprint(f"{base_name}: {st['heads_batches']} of {st['batches']} batches scanned in two passes (read ends first, then the reads that pass): "
+               f"{st['upload_bytes']} bytes uploaded for {st['input_bases']} bases")
     return rows
 
 
@@ -428,6 +432,9 @@ def build_parser():
     # MI355X build only
     parser.add_argument("--gpus", metavar="INT", type=int, default=1, help="GPUs of this node to shard reads over")
     parser.add_argument("--device", metavar="INT", type=int, default=0, help="index of the first GPU to use")
+    parser.add_argument("--twopass", choices=["auto", "on", "off"], default="auto",
+                        help="MI355X build: upload only the two 1000-base ends of every read for the TRC filter and the scanned part of the "
+                             "reads that pass afterwards (auto: while few reads of a batch pass, as in whole-genome read sets)")
     return parser
 
 

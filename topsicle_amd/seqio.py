@@ -198,6 +198,12 @@ def _load_io():
         lib.tps_reader_next_packed.restype = C.c_int64
         lib.tps_reader_next_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
                                                C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+        lib.tps_reader_next_heads.restype = C.c_int64
+        lib.tps_reader_next_heads.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+                                              C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
+        lib.tps_pack_spans.restype = C.c_int64
+        lib.tps_pack_spans.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                       C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
         lib.tps_pack_reads.restype = C.c_int64
         lib.tps_pack_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
         lib.tps_packed_words_total.restype = C.c_int64
@@ -305,6 +311,7 @@ class BufferSet:
         self.heads = np.empty(self.heads_cap, np.uint8)
         self.head_off = np.empty(self.reads_cap + 1, np.int64)
         self.spans = np.empty((self.reads_cap, 4), np.int64)
+        self.full_len = np.empty(self.reads_cap, np.int32)          # (heads mode: every read's own length)
 
 
 class BufferPool:
@@ -351,11 +358,15 @@ class PackedBatch:
     """A batch of reads in the packed upload format, plus what is needed to write single records back out: either the
     records' spans in the mmap'ed input file (plain FASTQ, nothing was copied) or the ASCII RecordBatch it was packed from."""
 
-    def __init__(self, seq2, inv, desc, heads, head_off, fmt, spans=None, text=None, ascii_batch=None, bufset=None, pool=None):
+    def __init__(self, seq2, inv, desc, heads, head_off, fmt, spans=None, text=None, ascii_batch=None, bufset=None, pool=None, full_len=None):
         self.seq2, self.inv, self.desc, self.heads, self.head_off, self.fmt = seq2, inv, desc, heads, head_off, fmt
         self.spans, self.text, self.ascii_batch = spans, text, ascii_batch
+        # heads mode (read_batches_packed(heads_bp=...)): seq2 / desc hold every read's first + last heads_bp bases only (all that
+        # step 1 looks at); full_len = the reads' own lengths.  batch.scan_jobs runs step 1 on them and packs the scanned part of the
+        # reads that pass from their spans (pack_spans).  After release() desc["len"] is the read's own length, as for any batch.
+        self.full_len = full_len
         self.n = len(desc)
-        self.n_bases = int(desc["len"].sum(dtype="int64")) if self.n else 0
+        self.n_bases = int((desc["len"] if full_len is None else full_len).sum(dtype="int64")) if self.n else 0
         self._bufset, self._pool = bufset, pool
         self._ids = None
 
@@ -371,6 +382,8 @@ class PackedBatch:
         if self._pool is not None and self._bufset is not None:
             import numpy as np
             self.desc = np.array(self.desc)               # lengths stay available for the writers
+            if self.full_len is not None:
+                self.desc["len"] = self.full_len          # (heads mode: from here on the batch describes the whole reads)
             self.seq2 = self.inv = None
             self._pool.put(self._bufset)
             self._bufset = None
@@ -387,9 +400,12 @@ class PackedBatch:
     def read_id(self, i: int) -> str:
         return self._ids[i] if self._ids is not None else _first_token(self.head(i))
 
+    def read_len(self, i: int) -> int:
+        return int(self.desc["len"][i] if self.full_len is None else self.full_len[i])
+
     def seq_bytes(self, i: int) -> bytes:
         if self.spans is not None:
-            s0, n = int(self.spans[i, 2]), int(self.desc["len"][i])
+            s0, n = int(self.spans[i, 2]), self.read_len(i)
             if self.fmt == "fasta":
                 # FASTA spans: [first base, end of the record's sequence text); a wrapped sequence is joined here (the few records
                 # that are written back out), exactly as the reader joined it for packing: line ends dropped, nothing else
@@ -407,7 +423,7 @@ class PackedBatch:
             return None                       # (a FASTA span's fourth entry is the end of the sequence text, not a quality offset)
         if self.spans is not None:
             q0 = int(self.spans[i, 3])
-            return self.text[q0:q0 + int(self.desc["len"][i])]
+            return self.text[q0:q0 + self.read_len(i)]
         b = self.ascii_batch
         return None if b.quals is None else b.quals[int(b.offsets[i]):int(b.offsets[i + 1])].tobytes()
 
@@ -431,7 +447,7 @@ class PackedBatch:
                 handle.flush()
                 text = np.frombuffer(self.text.buffer() if hasattr(self.text, "buffer") else self.text, dtype=np.uint8)
                 idx = np.ascontiguousarray(indices, dtype=np.int64)
-                lens = np.ascontiguousarray(self.desc["len"], dtype=np.int32)
+                lens = np.ascontiguousarray(self.desc["len"] if self.full_len is None else self.full_len, dtype=np.int32)
                 spans = np.ascontiguousarray(self.spans, dtype=np.int64)
                 got = lib.tps_write_fastq_spans(fd, text.ctypes.data, len(text), spans.ctypes.data, lens.ctypes.data, idx.ctypes.data, len(idx))
                 if got < 0:
@@ -490,10 +506,36 @@ class _HeldText:
             pass
 
 
-def read_batches_packed(filepath: str, pool: BufferPool, max_records: int = 1 << 20):
+def pack_spans(pb: "PackedBatch", idx, tails, maxlen: int):
+    """Second pass of the heads mode: (seq2, inv, desc) of the part of reads idx[j] of `pb` a scan of tail tails[j] touches -- the
+    first (tail 0) / last (tail 1) min(length, maxlen) bases, each as a read of its own -- packed by the native team from the
+    batch's text (tps_pack_spans).  Plain arrays (a few reads: the ones that passed step 1)."""
+    import ctypes as C
+    import numpy as np
+    from . import hiplib
+    lib = _load_io()
+    idx = np.ascontiguousarray(idx, np.int64)
+    tails = np.ascontiguousarray(tails, np.uint8)
+    full = np.ascontiguousarray(pb.full_len if pb.full_len is not None else pb.desc["len"], np.int32)
+    m = np.minimum(full[idx].astype(np.int64), int(maxlen))
+    words = int((((m + 63) // 64) * 4).sum())
+    seq2 = np.zeros(max(words, 4), np.uint32)
+    inv = np.zeros(max(words, 4), np.uint16)
+    desc = np.zeros(len(idx), hiplib.DESC_DTYPE)
+    text = np.frombuffer(pb.text.buffer() if hasattr(pb.text, "buffer") else pb.text, dtype=np.uint8)
+    spans = np.ascontiguousarray(pb.spans, np.int64)
+    got = lib.tps_pack_spans(text.ctypes.data, len(text), 1 if pb.fmt == "fasta" else 0, spans.ctypes.data, full.ctypes.data, idx.ctypes.data,
+                             tails.ctypes.data, len(idx), int(maxlen), seq2.ctypes.data, inv.ctypes.data, desc.ctypes.data, len(seq2))
+    if got < 0:
+        raise RuntimeError(lib.tps_io_last_error().decode())
+    return seq2[:got], inv[:got], desc
+
+
+def read_batches_packed(filepath: str, pool: BufferPool, max_records: int = 1 << 20, heads_bp=0):
     """Generator of PackedBatch over a FASTA/FASTQ(.gz) file.  Plain FASTQ is packed straight from the mmap'ed file by
     the native thread team (no ASCII copy, qualities untouched); other inputs are decoded to ASCII batches first
-    (read_batches) and packed by the same team.  Every batch owns one BufferSet of `pool` until `release()`."""
+    (read_batches) and packed by the same team.  Every batch owns one BufferSet of `pool` until `release()`.
+    heads_bp (an int, or a callable asked before every batch): > 0 = heads mode, see PackedBatch.full_len."""
     import ctypes as C
     import mmap
     import numpy as np
@@ -513,8 +555,14 @@ def read_batches_packed(filepath: str, pool: BufferPool, max_records: int = 1 <<
             bs = pool.get()
             heads, head_off, spans = bs.heads, bs.head_off, bs.spans
             nw = C.c_int64(0)
-            n = lib.tps_reader_next_packed(h, bs.seq2.ctypes.data, bs.inv.ctypes.data, bs.words_cap, bs.desc.ctypes.data, nrec_cap,
-                                           heads.ctypes.data, bs.heads_cap, head_off.ctypes.data, spans.ctypes.data, C.byref(nw))
+            hb = int(heads_bp() if callable(heads_bp) else heads_bp)
+            if hb > 0:
+                n = lib.tps_reader_next_heads(h, hb, bs.seq2.ctypes.data, bs.inv.ctypes.data, bs.words_cap, bs.desc.ctypes.data, nrec_cap,
+                                              heads.ctypes.data, bs.heads_cap, head_off.ctypes.data, spans.ctypes.data, bs.full_len.ctypes.data,
+                                              C.byref(nw))
+            else:
+                n = lib.tps_reader_next_packed(h, bs.seq2.ctypes.data, bs.inv.ctypes.data, bs.words_cap, bs.desc.ctypes.data, nrec_cap,
+                                               heads.ctypes.data, bs.heads_cap, head_off.ctypes.data, spans.ctypes.data, C.byref(nw))
             if n > 0:
                 # the text the spans point into: the mapped file itself, or -- compressed input -- the reader's window of inflated
                 # text, which this batch keeps alive (tps_reader_text_hold) until it is gone
@@ -528,7 +576,8 @@ def read_batches_packed(filepath: str, pool: BufferPool, max_records: int = 1 <<
                         mm = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
                     text = mm
                 yield PackedBatch(bs.seq2[:nw.value], bs.inv[:nw.value], bs.desc[:n], heads[:int(head_off[n])].copy(), head_off[:n + 1].copy(),
-                                  fmt, spans=spans[:n].copy(), text=text, bufset=bs, pool=pool)
+                                  fmt, spans=spans[:n].copy(), text=text, bufset=bs, pool=pool,
+                                  full_len=bs.full_len[:n].copy() if hb > 0 else None)
                 continue
             pool.put(bs)
             if n == 0:
