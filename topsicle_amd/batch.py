@@ -281,8 +281,16 @@ class EnginePool:
         mode = self.two_pass
         no_bp = {int(j.prm.no_bp) for j in jobs}
         ok = mode in ("auto", "on") and len(no_bp) == 1 and all(j.prm.flags & hiplib.F_STEP1 for j in jobs) and min(no_bp) > 0
-        self._hm = {"bp": min(no_bp) if ok else 0, "auto": mode == "auto"}
-        return lambda: self._hm["bp"]
+        hm = self._hm = {"bp": min(no_bp) if ok else 0, "auto": mode == "auto", "asked": 0, "first": threading.Event()}
+
+        def ask():
+            # auto: the reader hands out ONE heads batch and then waits for the verdict on it (a few milliseconds, once per file)
+            # instead of running several batches ahead in a mode that may not pay
+            hm["asked"] += 1
+            if hm["auto"] and hm["bp"] and hm["asked"] == 2:
+                hm["first"].wait(timeout=10.0)
+            return hm["bp"]
+        return ask
 
     def _heads_feedback(self, pb, outs):
         """Called by the workers with every finished batch: the statistics, and auto mode's decision."""
@@ -292,6 +300,8 @@ class EnginePool:
         st["input_bases"] += int(pb.n_bases)
         if getattr(pb, "full_len", None) is None:
             st["upload_bytes"] += int(getattr(pb, "uploaded_bytes", pb.n_bases * 3 // 8))
+            if hm:
+                hm["first"].set()
             return
         st["heads_batches"] += 1
         import numpy as np
@@ -301,6 +311,8 @@ class EnginePool:
         if hm and hm["auto"] and hm["bp"] and len(full) >= 8:
             if frac > TWO_PASS_MAX_PASSING or float(full.mean()) < 4 * hm["bp"]:
                 hm["bp"] = 0                            # the rest of the file goes up whole
+        if hm:
+            hm["first"].set()
 
     def _staging_pool(self, words_cap, reads_cap):
         """The pinned staging buffers of this engine set: allocated ONCE per (engine set, geometry) and kept on the first engine,

@@ -1862,7 +1862,11 @@ TPS_DEV void tile_lc_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
     constexpr int WDW = (LB + POS + 13 + 15) / 16;
     static_assert(CD > 0 || WDW == g_::WDW, "the plain tiles keep Geo's register footprint");
     const PatInfo& pat = a.pat;
-    const int rp = RPT >= 0 ? RPT : tc.r, q = tc.q;
+    int rp = RPT >= 0 ? RPT : tc.r, q = tc.q;
+    // opaque per tile: what derives from q (the far-end choice of each of a lane's 8 windows, the lane distances) is recomputed on
+    // the scalar unit per tile instead of being hoisted out of the tile loop and kept in -- spilled -- SGPR pairs across the read
+    TPS_PIN_S(q);
+    if (RPT < 0) TPS_PIN_S(rp);
     const uint32_t amask = pat.kmask << LS;
     // what a lane keeps about its blocks (table entries are mask << 16 | count: the OR of entries is right in its high half,
     // their sum in its low half -- the other halves are garbage that the window arithmetic never looks at)

@@ -30,9 +30,42 @@ PLOT_THREADS = []                 # quadratic-fit PNGs being rendered off the cr
 
 
 def wait_for_plots():
-    """Block until every summary PNG of earlier runs is on disk."""
-    while PLOT_THREADS:
-        PLOT_THREADS.pop().join()
+    """Block until every summary PNG of earlier runs is on disk; an exception inside a drawing is reported here (it used to
+    be lost in its thread and a missing quadfit_*.png went unnoticed)."""
+    _PLOT_JOBS.join()
+    errs, PLOT_ERRORS[:] = list(PLOT_ERRORS), []
+    for path, err in errs:
+        tprint(f"summary plot {path} failed: {err!r}")
+    return errs
+
+
+# The summary pictures are drawn by ONE worker thread, one after the other (ADVICE r3: one thread per k-mer length rendered them
+# concurrently -- Agg rendering with shared font caches is only safe on recent matplotlib)
+import queue as _queue  # noqa: E402
+
+_PLOT_JOBS: "_queue.Queue" = _queue.Queue()
+PLOT_ERRORS: list = []
+
+
+def _plot_worker():
+    while True:
+        fn, fargs, path = _PLOT_JOBS.get()
+        try:
+            fn(*fargs)
+        except BaseException as e:                                   # reported by wait_for_plots()
+            PLOT_ERRORS.append((path, e))
+        finally:
+            _PLOT_JOBS.task_done()
+
+
+def _submit_plot(fn, fargs, path):
+    if not PLOT_THREADS:                       # the one worker, started with the first picture; a process that ends waits for its queue
+        import atexit
+        t = threading.Thread(target=_plot_worker, daemon=True)
+        t.start()
+        PLOT_THREADS.append(t)
+        atexit.register(wait_for_plots)
+    _PLOT_JOBS.put((fn, fargs, path))
 
 
 def warm_up_plotting():
@@ -393,10 +426,8 @@ def summarize(args, phrase_to_telo, phrase_to_trc):
         median_trc = np.median(trc)
         fit_x, fit_y, coeffs = allsteps.fit_quadratic_and_find_vertex(list(trc), list(telo), inputtrc=inputtrc, median_trc=median_trc)
         # the picture is drawn on a helper thread: the numbers below do not wait for it (0.2 s of a 0.4 s run on 10 000 reads)
-        t = threading.Thread(target=allsteps.plot_quadratic_fit,
-                             args=(trc, telo, coeffs, fit_x, fit_y, os.path.join(args.outputDir, f"quadfit_{phrase}mer_{args.pattern}.png")))
-        t.start()
-        PLOT_THREADS.append(t)
+        png = os.path.join(args.outputDir, f"quadfit_{phrase}mer_{args.pattern}.png")
+        _submit_plot(allsteps.plot_quadratic_fit, (trc, telo, coeffs, fit_x, fit_y, png), png)
         cutoff, notes = recommend_cutoff(fit_x, float(trc.max()), median_trc, inputtrc)
         for line in notes:
             tprint(line)
@@ -443,7 +474,9 @@ def main(argv=None):
     args = build_parser().parse_args(argv)
     tprint.logfile = get_log_path(args)
     warm_up_plotting()
-    analysis_run(args, wait_plots=False)          # (the summary PNGs may still be rendering: the interpreter waits for them at exit)
+    analysis_run(args, wait_plots=False)
+    # the elapsed time is that of the ANALYSIS: the summary PNGs may still be rendering on the plot thread -- the process waits
+    # for them when it ends (atexit), a caller of main() can call wait_for_plots() itself
     print(f"Elapsed time(s): {time.time() - start_time:.2f} seconds")
 
 
