@@ -267,6 +267,9 @@ def main():
     ap.add_argument("--no-store-sums", action="store_true", help="do not write S_w to HBM (boundary-only run)")
     ap.add_argument("--n-reads", type=int, default=0, help="diagnostic: override the batch size (NOT the metric's workload)")
     ap.add_argument("--flags", type=int, default=0, help="diagnostic: override the scan flags (partial pipelines are NOT the metric)")
+    ap.add_argument("--steady", action="store_true", help="also time the kernel on a batch four times the size (steady state: the launch ramp and the "
+                    "last round of wave slots weigh a quarter); NOT part of the default run -- its launches would sit in a rocprofv3 "
+                    "average of the same command -- the default line quotes the committed profiles/*/steady_state.json instead")
     ap.add_argument("--resident-copies", type=int, default=0, help="copies of the batch kept in HBM (0 = enough for >1 GB)")
     ap.add_argument("--errors", default="", choices=["", "ont", "hifi", "none"], help="diagnostic: override the workload's per-base error profile (NOT the metric's workload)")
     args = ap.parse_args()
@@ -424,8 +427,8 @@ def main():
     # the same kernel on a batch four times the size (the reads repeated): the launch ramp and the partly filled last round of wave
     # slots weigh a quarter as much -- what the kernel does in steady state (rank 0 at N = 1, default workload shapes only)
     steady = None
-    if world == 1 and len(tables) == 1 and not (args.flags or args.n_reads or args.errors) and copies < hiplib.MAX_SLOTS and \
-            not os.environ.get("TPS_BENCH_NO_STEADY") and batch_bases * 4 <= (3 << 30):
+    if args.steady and world == 1 and len(tables) == 1 and not (args.flags or args.n_reads or args.errors) and copies < hiplib.MAX_SLOTS and \
+            batch_bases * 4 <= (3 << 30):
         try:
             big_off = np.concatenate([offsets[:-1] + j * batch_bases for j in range(4)] + [np.array([4 * batch_bases], np.int64)])
             sc.upload(copies, np.tile(bases, 4), big_off)
@@ -537,9 +540,18 @@ def main():
             roof["limiter"] = "valu-issue"
         if steady and "kernel_ms_mean" in steady and steady["kernel_ms_mean"] > 0:
             steady["frac"] = 4 * alg_total / (steady["kernel_ms_mean"] * 1e-3) / 1e9 / HBM_PEAK_GBS
-            roof["steady_state_frac"] = steady["frac"]
+            steady["workload"] = args.workload
+        if steady is None and traffic_src:            # the committed measurement of the same profile directory (bench.py --steady)
+            try:
+                st_ = json.load(open(os.path.join(ROOT, os.path.dirname(traffic_src), "steady_state.json")))
+                if st_.get("workload") == args.workload:
+                    steady = dict(st_, source=os.path.join(os.path.dirname(traffic_src), "steady_state.json"))
+            except (OSError, ValueError):
+                pass
         if steady:
             roof["steady_state"] = steady
+            if "frac" in steady:
+                roof["steady_state_frac"] = steady["frac"]
         if not args.no_cpu_baseline and world == 1:        # the CPU baseline leg runs at N = 1 only
             n_cpu = min(n_reads, 16384)               # (config 2: the whole batch, ~5 s on 16 cores; the budget inside stops a slow host)
             seqs = synth.split_reads(bases[: offsets[n_cpu]], offsets[: n_cpu + 1])
