@@ -95,8 +95,9 @@ def test_two_pass_rows_equal_one_pass_emulation(tmp_path, emu_engine_factory, fm
     _check(emu_engine_factory, tmp_path, fmt, ks, raw, sums, max_bases)
 
 
-def test_auto_mode_drops_to_one_pass_when_many_reads_pass(tmp_path, emu_engine_factory):
+def test_auto_mode_drops_to_one_pass_when_many_reads_pass(tmp_path, emu_engine_factory, monkeypatch):
     """auto: a file of telomeric reads (every read passes) is scanned in heads mode for its first batch only."""
+    monkeypatch.setattr(batch, "AUTO_MIN_FILE_BYTES", 0)          # (auto mode leaves small files alone)
     b, o, _ = synth.make_reads(60, 9500, "CCCTAA", seed=5)
     path = str(tmp_path / "telo.fastq")
     _write(path, [bytes(b[o[i]:o[i + 1]]) for i in range(60)], "fastq")

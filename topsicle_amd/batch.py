@@ -56,6 +56,9 @@ def upload_batch(engine, recs, slot: int = 0):
 
 
 TWO_PASS_MAX_PASSING = 0.25      # heads mode stays on while at most this share of a batch's reads passes step 1
+PROBE_READS = 64                 # auto mode: reads of the probe batch that opens a file
+AUTO_MIN_FILE_BYTES = 1 << 30    # auto mode only probes files of at least this size (a quarter of it for .gz): the probe costs ~0.5 ms per
+                                 # file, and what two passes save on a small file is less than that
 
 
 def scan_jobs_heads(engine, recs, jobs, slot: int = 0):
@@ -259,8 +262,9 @@ class EnginePool:
         reads_cap = min(BATCH_READS, max(64, max_bases // 256))
         pool = self._staging_pool(words_cap, reads_cap)
         jobs = [Job(self.patterns, prm, want_sums, want_raw)]
-        return self._single(self._run(seqio.read_batches_packed(filepath, pool, max_records=reads_cap, heads_bp=self._heads_mode(jobs)),
-                                      jobs, pool))
+        hb = self._heads_mode(jobs, filepath)
+        return self._single(self._run(seqio.read_batches_packed(filepath, pool, max_records=reads_cap, heads_bp=hb,
+                                                                first_batch_records=self._probe_records()), jobs, pool))
 
     def scan_file_jobs(self, filepath, jobs, max_bases=None):
         """One pass over the file for several jobs (pattern tables): yields (PackedBatch, [(results, sums, raw, win_off) per job])."""
@@ -270,25 +274,40 @@ class EnginePool:
         reads_cap = min(BATCH_READS, max(64, max_bases // 256))
         pool = self._staging_pool(words_cap, reads_cap)
         jobs = list(jobs)
-        return self._run(seqio.read_batches_packed(filepath, pool, max_records=reads_cap, heads_bp=self._heads_mode(jobs)), jobs, pool)
+        hb = self._heads_mode(jobs, filepath)
+        return self._run(seqio.read_batches_packed(filepath, pool, max_records=reads_cap, heads_bp=hb, first_batch_records=self._probe_records()),
+                         jobs, pool)
 
-    def _heads_mode(self, jobs):
+    def _probe_records(self):
+        """auto mode: the file's first batch is a small probe (its verdict decides the mode of the rest; a whole 64-Mbase batch scanned
+        in two passes for nothing cost a third of the 300 MB benchmark file's run)."""
+        hm = getattr(self, "_hm", None)
+        return PROBE_READS if hm and hm["auto"] and hm["bp"] else 0
+
+    def _heads_mode(self, jobs, filepath=None):
         """The reader's heads_bp for the next batch of one file (a callable: seqio.read_batches_packed asks before every batch).
         Heads mode needs step 1 in every job and the same no_bp; "auto" keeps it while the batches seen so far say that it pays:
         reads several times longer than the two heads, and few of them passing step 1 (real WGS input: < 1 % telomeric).  A
         telomere-enriched file (the demo, the synthetic benchmarks: every read passes) drops to the one-pass route after its
         first batch -- there the second pass would upload what the first one spared."""
         mode = self.two_pass
+        if mode == "auto" and filepath is not None:
+            try:
+                small = os.path.getsize(filepath) < (AUTO_MIN_FILE_BYTES // 4 if str(filepath).endswith(".gz") else AUTO_MIN_FILE_BYTES)
+            except OSError:
+                small = False
+            if small:
+                mode = "off"
         no_bp = {int(j.prm.no_bp) for j in jobs}
         ok = mode in ("auto", "on") and len(no_bp) == 1 and all(j.prm.flags & hiplib.F_STEP1 for j in jobs) and min(no_bp) > 0
         hm = self._hm = {"bp": min(no_bp) if ok else 0, "auto": mode == "auto", "asked": 0, "first": threading.Event()}
 
         def ask():
-            # auto: the reader hands out ONE heads batch and then waits for the verdict on it (a few milliseconds, once per file)
-            # instead of running several batches ahead in a mode that may not pay
+            # auto: the file opens with a small probe batch in heads mode (_probe_records); until the verdict on it is in, the reader
+            # goes on with ordinary whole-read batches (valid in either mode: nothing waits), then with what the verdict says
             hm["asked"] += 1
-            if hm["auto"] and hm["bp"] and hm["asked"] == 2:
-                hm["first"].wait(timeout=10.0)
+            if hm["auto"] and hm["bp"] and hm["asked"] > 1 and not hm["first"].is_set():
+                return 0
             return hm["bp"]
         return ask
 

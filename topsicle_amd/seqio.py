@@ -531,11 +531,12 @@ def pack_spans(pb: "PackedBatch", idx, tails, maxlen: int):
     return seq2[:got], inv[:got], desc
 
 
-def read_batches_packed(filepath: str, pool: BufferPool, max_records: int = 1 << 20, heads_bp=0):
+def read_batches_packed(filepath: str, pool: BufferPool, max_records: int = 1 << 20, heads_bp=0, first_batch_records: int = 0):
     """Generator of PackedBatch over a FASTA/FASTQ(.gz) file.  Plain FASTQ is packed straight from the mmap'ed file by
     the native thread team (no ASCII copy, qualities untouched); other inputs are decoded to ASCII batches first
     (read_batches) and packed by the same team.  Every batch owns one BufferSet of `pool` until `release()`.
-    heads_bp (an int, or a callable asked before every batch): > 0 = heads mode, see PackedBatch.full_len."""
+    heads_bp (an int, or a callable asked before every batch): > 0 = heads mode, see PackedBatch.full_len.
+    first_batch_records > 0: the first batch holds at most that many records (a small probe: batch.EnginePool's auto mode)."""
     import ctypes as C
     import mmap
     import numpy as np
@@ -551,6 +552,8 @@ def read_batches_packed(filepath: str, pool: BufferPool, max_records: int = 1 <<
         fmt = {1: "fasta", 2: "fastq"}.get(lib.tps_reader_format(h), "fasta")
         packed_mode = True
         nrec_cap = min(max_records, pool.reads_cap)
+        if first_batch_records > 0:
+            nrec_full, nrec_cap = nrec_cap, min(nrec_cap, int(first_batch_records))
         while packed_mode:
             bs = pool.get()
             heads, head_off, spans = bs.heads, bs.head_off, bs.spans
@@ -578,6 +581,8 @@ def read_batches_packed(filepath: str, pool: BufferPool, max_records: int = 1 <<
                 yield PackedBatch(bs.seq2[:nw.value], bs.inv[:nw.value], bs.desc[:n], heads[:int(head_off[n])].copy(), head_off[:n + 1].copy(),
                                   fmt, spans=spans[:n].copy(), text=text, bufset=bs, pool=pool,
                                   full_len=bs.full_len[:n].copy() if hb > 0 else None)
+                if first_batch_records > 0:
+                    nrec_cap, first_batch_records = nrec_full, 0
                 continue
             pool.put(bs)
             if n == 0:
