@@ -67,6 +67,18 @@ def test_kernel_emulation_under_asan_ubsan():
     import emu_driver
     emu_driver.build(asan=True)
     out = _run_under_sanitizers(["tests/test_emulation.py", "-k",
-                                 "synthetic_goldens or random_vs_oracle or multi_tile or per_pattern_tiles or wide_windows or demo_reads"],
+                                 "synthetic_goldens or random_vs_oracle or multi_tile or per_pattern_tiles or wide_windows or demo_reads or "
+                                 "clean_batch_layout or chains_of_every_length or hand_over"],
                                 {"TPS_EMU_ASAN": "1"})
+    assert " passed" in out
+
+
+def test_two_pass_route_under_asan_ubsan():
+    """The heads-mode reader (tps_reader_next_heads), the second pass's packer (tps_pack_spans: spans into mapped / inflated text,
+    wrapped FASTA joined on the fly) and the emulation's scan of both passes, on the sanitizer builds."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import emu_driver
+    emu_driver.build(asan=True)
+    lib = _build_io_asan()
+    out = _run_under_sanitizers(["tests/test_two_pass.py"], {"TPS_EMU_ASAN": "1", "TOPSICLE_IO_LIB": lib})
     assert " passed" in out

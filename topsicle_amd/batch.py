@@ -316,6 +316,10 @@ class EnginePool:
         hm = getattr(self, "_hm", None)
         st = self.stats
         st["batches"] += 1
+        if not hasattr(pb, "n_bases"):              # (a list of records / an ASCII batch: scan_stream)
+            if hm:
+                hm["first"].set()
+            return
         st["input_bases"] += int(pb.n_bases)
         if getattr(pb, "full_len", None) is None:
             st["upload_bytes"] += int(getattr(pb, "uploaded_bytes", pb.n_bases * 3 // 8))
