@@ -87,7 +87,9 @@ extern "C" int emu_scan(const char* pats, int P, int k, const uint8_t* bases, co
     // the workgroup-shared tables (read-only for the waves): [pair table][single table]
     std::vector<uint32_t> lutbuf((size_t)a.pair_n + lut.size());
     uint32_t* lut1 = lutbuf.data() + a.pair_n;
-    if (a.lut16) {                                 // sums-only kernels of self-overlap tables: 16-bit pattern masks
+    if (a.lut16 && a.lut_fields) {                 // raw rows of a big self-overlap table: 16-bit field indices (LUT_F16)
+        for (size_t i = 0; i < lut.size(); ++i) ((uint16_t*)lut1)[i] = lut[i] ? (uint16_t)(1u << tps::pp_field(__builtin_ctz(lut[i]))) : (uint16_t)0;
+    } else if (a.lut16) {                          // sums-only kernels of self-overlap tables: 16-bit pattern masks
         for (size_t i = 0; i < lut.size(); ++i) ((uint16_t*)lut1)[i] = (uint16_t)lut[i];
     } else
     for (size_t i = 0; i < lut.size(); ++i)
@@ -108,7 +110,8 @@ extern "C" int emu_scan(const char* pats, int P, int k, const uint8_t* bases, co
         // the library's kernel families: plain, pair table, raw rows, self-overlap sums, self-overlap raw
 #define EMU_CASE(S)                                                                                              \
         case S:                                                                                                  \
-            if (so && want_raw) tps::scan_read<S, true, false, true>(a, r, lds.data(), lut1);                    \
+            if (so && want_raw && a.lut16) tps::scan_read<S, true, false, true, tps::tile_full_default(S), 3>(a, r, lds.data(), lut1); \
+            else if (so && want_raw) tps::scan_read<S, true, false, true>(a, r, lds.data(), lut1);               \
             else if (so) tps::scan_read<S, true, false, false>(a, r, lds.data(), lut1);                          \
             else if (want_raw) tps::scan_read<S, false, false, true>(a, r, lds.data(), lut1);                    \
             else if (a.pair_n) tps::scan_read<S, false, true, false>(a, r, lds.data(), lut1);                    \

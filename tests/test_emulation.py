@@ -631,3 +631,31 @@ def test_emulation_step1_chains_of_every_length(motif, k, unit):
         cs, ce = orc.trc_counts(seq, pats)
         assert np.array_equal(out["c_start"][i], cs), (i, len(seq), out["c_start"][i], cs)
         assert np.array_equal(out["c_end"][i], ce), (i, len(seq), out["c_end"][i], ce)
+
+
+@pytest.mark.parametrize("motif,k,slide,units", [
+    ("CCCTAA", 4, 6, []),                          # 12-byte rows, no self-overlap
+    ("CCCTAA", 6, 6, ["CCTAA", "GGATT"]),          # 12-byte rows, period 5
+    ("AAACCCT", 5, 7, []),                         # 14-byte rows: padded to 16 bytes in LDS, 18 lanes per pass
+    ("TTAGGG", 5, 5, ["TTAG"]),
+])
+def test_emulation_raw_rows_clean_batch_layout(motif, k, slide, units, monkeypatch):
+    """The raw-row kernels on a batch without non-ACGT letters (round 4): no XF / XT words in the exchange region -- the per-pattern
+    tiles keep their lane totals in the pad words of END, the row staging buffer is XPC alone -- the LDS layout the planner picks
+    for a clean batch on the device (xt_alias = 2 without xt_own).  Rows, sums and change point against the oracle."""
+    monkeypatch.setenv("TPS_EMU_VAL_OFF", "1")
+    rng = np.random.default_rng(7 + 10 * k + slide)
+    pats, seqs = _pp_reads(rng, motif, k, 4, 8000, units)
+    prm = hiplib.make_params(window=100, slide=slide, trimfirst=100, maxlen=20000,
+                             flags=hiplib.F_WINDOWS | hiplib.F_BINSEG | hiplib.F_TAILS_IN | hiplib.F_STORE_SUMS | hiplib.F_STORE_RAW)
+    L = emu.lib()
+    t0 = L.emu_counter(0)
+    tails = [0, 1, 1, 0]
+    out = emu.scan(pats, seqs, prm, tails=tails, base_shift=int(rng.integers(16)))
+    assert L.emu_counter(0) - t0 >= 8
+    for i, seq in enumerate(seqs):
+        _, counts = orc.window_count_matrix(seq, ["forward", "reverse"][tails[i]], pats, 100, slide, 100, 20000)
+        lo, hi = out["win_off"][i], out["win_off"][i + 1]
+        assert np.array_equal(out["raw"][lo:hi], counts), i
+        assert np.array_equal(out["sums"][lo:hi], counts.sum(axis=1)), i
+        assert out["results"][i]["bkp"] == orc.binseg_l2_exact(counts.sum(axis=1))

@@ -186,7 +186,7 @@ struct tps_ctx {
     hipDeviceProp_t prop{};
     // dev: [4^k masks][pair table, k <= 4][ready-made LDS images of the table for the fused kernels, each a multiple of 4 dwords:
     // mask << 16 | count, one-hot fields, 16-bit masks -- a workgroup copies its image in 16-byte pieces instead of converting it]
-    struct Table { DevBuf dev; int P = 0, k = 0; std::string key; tps::PatInfo pat{}; size_t off_e32 = 0, off_fld = 0, off_m16 = 0; };
+    struct Table { DevBuf dev; int P = 0, k = 0; std::string key; tps::PatInfo pat{}; size_t off_e32 = 0, off_fld = 0, off_m16 = 0, off_f16 = 0; };
     std::deque<Table> tables;         // resident pattern tables (deque: pointers to elements stay valid)
     Table* lut_cur = nullptr;
     size_t table_rr = 0;
@@ -384,7 +384,7 @@ int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm) {
     a.desc = (const tps_read_desc*)sl.desc.p;
     a.tails_in = ((prm.flags & TPS_F_TAILS_IN) && !(prm.flags & TPS_F_STEP1)) ? (const uint8_t*)sl.tails.p : nullptr;
     a.lut = (const uint32_t*)c->lut_cur->dev.p;
-    a.lut_img = a.lut + (a.lut16 ? c->lut_cur->off_m16 : a.lut_fields ? c->lut_cur->off_fld : c->lut_cur->off_e32);
+    a.lut_img = a.lut + ((a.lut16 && a.lut_fields) ? c->lut_cur->off_f16 : a.lut16 ? c->lut_cur->off_m16 : a.lut_fields ? c->lut_cur->off_fld : c->lut_cur->off_e32);
     a.results = c->zero_copy ? sl.h_results : (tps_read_result*)sl.results.p;
     a.c_start = a.c_end = nullptr;
     if (prm.flags & TPS_F_STEP1) {
@@ -450,12 +450,14 @@ int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm) {
                                  {(const void*)tps_scan_kernel_s7so, "tps_scan_kernel_s7so"}, {(const void*)tps_scan_kernel_s8so, "tps_scan_kernel_s8so"}};
         static const K sork[4] = {{(const void*)tps_scan_kernel_s5sor, "tps_scan_kernel_s5sor"}, {(const void*)tps_scan_kernel_s6sor, "tps_scan_kernel_s6sor"},
                                   {(const void*)tps_scan_kernel_s7sor, "tps_scan_kernel_s7sor"}, {(const void*)tps_scan_kernel_s8sor, "tps_scan_kernel_s8sor"}};
+        static const K sorhk[4] = {{(const void*)tps_scan_kernel_s5sorh, "tps_scan_kernel_s5sorh"}, {(const void*)tps_scan_kernel_s6sorh, "tps_scan_kernel_s6sorh"},
+                                   {(const void*)tps_scan_kernel_s7sorh, "tps_scan_kernel_s7sorh"}, {(const void*)tps_scan_kernel_s8sorh, "tps_scan_kernel_s8sorh"}};
         static const K solk[4] = {{(const void*)tps_scan_kernel_s5sol, "tps_scan_kernel_s5sol"}, {(const void*)tps_scan_kernel_s6sol, "tps_scan_kernel_s6sol"},
                                   {(const void*)tps_scan_kernel_s7sol, "tps_scan_kernel_s7sol"}, {(const void*)tps_scan_kernel_s8sol, "tps_scan_kernel_s8sol"}};
         if (a.variant >= 5 && a.variant <= 8) {
             // sums only, self-overlap table: periods 2 .. 4 have their own kernels (96 registers, 5 waves per SIMD)
-            const int fam = so ? (want_raw ? 4 : (a.pp_d >= 2 && a.pp_d <= 4) ? 5 : 3) : want_raw ? 2 : pair ? 1 : 0;
-            const K* tab[6] = {plain, pairk, rawk, sok, sork, solk};
+            const int fam = so ? (want_raw ? (a.lut16 ? 6 : 4) : (a.pp_d >= 2 && a.pp_d <= 4) ? 5 : 3) : want_raw ? 2 : pair ? 1 : 0;
+            const K* tab[7] = {plain, pairk, rawk, sok, sork, solk, sorhk};
             const K& k = tab[fam][a.variant - 5];
             kfn = k.fn;
             sl.kernel_name = k.name;
@@ -625,18 +627,21 @@ int tps_set_patterns(tps_ctx* c, const char* pats, int32_t P, int32_t k) {
             lut[n1 + cc] = ((m1 | m2) << 16) | (uint32_t)(__builtin_popcount(m1) + __builtin_popcount(m2));
         }
     }
-    size_t off_e32 = 0, off_fld = 0, off_m16 = 0;
+    size_t off_e32 = 0, off_fld = 0, off_m16 = 0, off_f16 = 0;
     if (!pi.hash_shift) {
         const size_t n1 = (size_t)1 << (2 * k), n4 = (n1 + 3) & ~(size_t)3, n16 = ((n1 + 1) / 2 + 3) & ~(size_t)3;
         off_e32 = (lut.size() + 3) & ~(size_t)3;       // (16-byte aligned: the kernels copy uint4)
         off_fld = off_e32 + n4;
         off_m16 = off_fld + n4;
-        lut.resize(off_m16 + n16, 0u);
+        off_f16 = off_m16 + n16;
+        lut.resize(off_f16 + n16, 0u);
         for (size_t i = 0; i < n1; ++i) {
             const uint32_t m = lut[i];
             lut[off_e32 + i] = (m << 16) | (uint32_t)__builtin_popcount(m);
             lut[off_fld + i] = tps::mask_to_fields(m);
             ((uint16_t*)&lut[off_m16])[i] = (uint16_t)m;
+            // (field index of THE pattern: tables with duplicate k-mers never take the kernels that read this image)
+            ((uint16_t*)&lut[off_f16])[i] = m ? (uint16_t)(1u << tps::pp_field(__builtin_ctz(m))) : (uint16_t)0;
         }
     }
     HIP_TRY(hipStreamSynchronize(c->stream));          // no launch may still be reading the table that gets recycled
@@ -647,7 +652,7 @@ int tps_set_patterns(tps_ctx* c, const char* pats, int32_t P, int32_t k) {
     HIP_TRY(hipMemcpyAsync(slot->dev.p, lut.data(), lut.size() * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     slot->P = P; slot->k = k; slot->key = key; slot->pat = pi;
-    slot->off_e32 = off_e32; slot->off_fld = off_fld; slot->off_m16 = off_m16;
+    slot->off_e32 = off_e32; slot->off_fld = off_fld; slot->off_m16 = off_m16; slot->off_f16 = off_f16;
     c->lut_cur = slot;
     c->pat = pi;
     c->have_pat = true;

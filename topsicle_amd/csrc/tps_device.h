@@ -322,7 +322,8 @@ struct ScanArgs {
                                  // 2-bit fields (1 << 2 p for pattern p) instead of mask << 16 | count
     int32_t lut16;               // sums-only kernels of self-overlap tables: the LDS table holds 16-bit pattern masks (LUT_M16), half the
                                  // bytes of mask << 16 | count -- at k = 6 that is 8 KB instead of 16 KB per workgroup; counts come from v_bcnt
-    int32_t xt_alias;            // ... and their XT words (written behind a tile's window phase) share LDS with the head of the staged bases
+    int32_t xt_alias;            // 1: ... and their XT words (written behind a tile's window phase) share LDS with the head of the staged bases;
+                                 // 2: the raw-row kernels -- the per-pattern tiles keep their lane totals in END's pad words and need no XF / XT
     int32_t xt_own;              // xt_alias kernels whose fallback tile may run (non-ACGT letters in the batch, TPS_NO_SO_FAST): XT gets its own words
 };
 
@@ -369,8 +370,8 @@ struct Lds {
     uint32_t* misc;
 };
 constexpr int XLANES = NT + 16;                  // most lanes an exchange row can hold: NT + halo lanes read past the tile end
-TPS_HD int64_t xchg_dw(const ScanArgs& a) {      // fused path: XPC (9 words per lane), XF, XT (xt_alias: XT lives elsewhere)
-    return 9ll * NT + (a.xt_alias ? 1ll : 2ll) * XLANES;
+TPS_HD int64_t xchg_dw(const ScanArgs& a) {      // fused path: XPC (9 words per lane), XF, XT (xt_alias 1: XT lives elsewhere, 2: both do)
+    return 9ll * NT + (a.xt_alias == 1 ? 1ll : a.xt_alias == 2 ? 0ll : 2ll) * XLANES;
 }
 // dwords of the workgroup's LDS table: 4^k entries of 4 bytes, or of 2 (lut16)
 TPS_HD int64_t lut_dw(const ScanArgs& a) { return a.lut16 ? ((((int64_t)a.lut_n + 1) / 2 + 3) & ~3ll) : (((int64_t)a.lut_n + 3) & ~3ll); }
@@ -417,7 +418,7 @@ TPS_DEV Lds carve(uint32_t* base, uint32_t* lut, const ScanArgs& a) {
 }
 TPS_HD int64_t lds_dwords(const ScanArgs& a) {
     return (int64_t)a.blk_dw + (a.seq_alias ? 0 : a.seq_dw) + val_dw(a) + a.tot_dw + lc_dw(a) + row_dw(a) + MISC_DW +
-           ((a.xt_alias && a.xt_own) ? XLANES : 0);   // per wave; + the table per workgroup
+           ((a.xt_alias && a.xt_own) ? (a.xt_alias == 2 ? 2 : 1) * XLANES : 0);   // per wave; + the table per workgroup
 }
 // LDS dwords of a whole workgroup: the shared table + WPG wave slices (each rounded to 16 bytes)
 TPS_HD int64_t wg_lds_dwords(const ScanArgs& a) { return a.pair_n + lut_dw(a) + (int64_t)(a.wpg > 0 ? a.wpg : WPG) * ((lds_dwords(a) + 3) & ~3ll); }
@@ -605,6 +606,8 @@ TPS_DEV bool invalid_at(const uint16_t* val, int q, int k) {
 // without duplicate k-mers: what the per-pattern tiles and the packed step 1 add up, without the squaring).
 constexpr int LUT_FIELDS = 32;
 constexpr int LUT_M16 = 48;                       // 16-bit entries: the pattern mask alone (ScanArgs::lut16)
+constexpr int LUT_F16 = 64;                       // 16-bit entries: 1 << (field index of THE pattern), pp_field -- squared, the one-hot 2-bit field of
+                                                  // LUT_FIELDS (the raw-row kernels of big self-overlap tables, k >= 6: half the LDS table)
 // Which of the sixteen 2-bit fields belongs to list pattern p.  The per-pattern tiles widen fields to nibbles (even / odd
 // fields: two words) and nibbles to bytes (four words, pp_expand); with THIS assignment the four byte words come out in ROW
 // order -- word p / 4, byte p % 4 holds pattern p -- so a raw row is the words as they are (no byte transposition: 8 v_perm per
@@ -628,6 +631,7 @@ TPS_DEV uint32_t lut_mask(const uint32_t* lut, int lshift, const PatInfo& pat, u
     }
     if (lshift == LUT_FIELDS) return field_to_mask(lut[code]);
     if (lshift == LUT_M16) return ((const uint16_t*)lut)[code];
+    if (lshift == LUT_F16) { const uint32_t m = ((const uint16_t*)lut)[code]; return m ? 1u << pp_pattern(ffs0(m)) : 0u; }
     return lut[code] >> lshift;
 }
 // mask of list patterns whose k-mer starts at position q
@@ -762,7 +766,7 @@ TPS_DEV void trc_count_packed(const ScanArgs& a, const Lds& l, const Stage& st_s
     const int side = tid >> 5, t = tid & 31;
     const int delta = side ? st_e.delta : st_s.delta;
     const uint32_t* seq2 = l.seq2 + side * a.head_dw;
-    constexpr bool FLD = FMT == 1, M16 = FMT == 2;
+    constexpr bool FLD = FMT == 1, M16 = FMT == 2 || FMT == 3, F16 = FMT == 3;   // (3: LUT_F16 -- 16-bit entries that square to fields in ROW order)
     constexpr int LS = M16 ? 1 : 2;                 // log2(bytes per table entry)
     const uint32_t amask = pat.kmask << LS;
     const int npos = st_s.n - pat.k + 1;
@@ -851,9 +855,9 @@ TPS_DEV void trc_count_packed(const ScanArgs& a, const Lds& l, const Stage& st_s
     }
     if (SO_ && cf) {
         uint32_t cm = M16 ? cf : cf >> 16;
-        if (FLD) {                                  // fields -> pattern mask (rare: only a lane that saw a long chain)
+        if (FLD || F16) {                           // fields / field indices -> pattern mask (rare: only a lane that saw a long chain)
             cm = 0;
-            while (cf) { cm |= 1u << pp_pattern(ffs0(cf) >> 1); cf &= cf - 1u; }
+            while (cf) { cm |= 1u << pp_pattern(F16 ? ffs0(cf) : ffs0(cf) >> 1); cf &= cf - 1u; }
         }
         lds_or(&l.misc[M_CMASK + side], cm);
     }
@@ -934,7 +938,7 @@ TPS_DEV void trc_sum_packed(const ScanArgs& a, const Lds& l, const Stage& st_s, 
     if (p < a.pat.P) {
         // byte of pattern p in a lane's 16 parked bytes: fields in list order (mask tables, squared entries) put it in word
         // [0, 2, 1, 3][p & 3], byte p >> 2; ready-made fields (LUT_FIELDS tables: pp_field) in row order, byte p
-        const int pbyte = l.lshift == LUT_FIELDS ? p : 4 * (((p & 1) << 1) | ((p >> 1) & 1)) + (p >> 2);
+        const int pbyte = (l.lshift == LUT_FIELDS || l.lshift == LUT_F16) ? p : 4 * (((p & 1) << 1) | ((p >> 1) & 1)) + (p >> 2);
         const uint8_t* src = (const uint8_t*)(l.blk + 4 * 32 * side) + pbyte;
         uint32_t sm = 0;
         TPS_UNROLL
@@ -1269,9 +1273,12 @@ constexpr bool tile_full_default(int s) { return s >= 1; }
 // (tile_lc_s<.., CD>: the lanes' registers and the chain walks).  80 dwords per wave less: with the 16-bit table that is the fifth
 // 4-wave workgroup per CU at k = 6 (8 192 + 4 x 5 856 B = 31 616 <= 32 000).  The fallback tile (tile_fused_s: recounts read the
 // bases AFTER it has rewritten XT) gets XT words of its own behind everything else whenever it can run (ScanArgs::xt_own).
-template <int S, bool FULL, bool XTA = false>
+// XM = 2 (the raw-row kernels, ScanArgs::xt_alias == 2): no XF / XT at all in the exchange region -- tile_pp_s keeps the lanes'
+// totals in the pad words of END; the fallback tile gets both behind everything else whenever it can run (xt_own).
+template <int S, bool FULL, int XM = 0>
 TPS_DEV Lds carve_fused(uint32_t* base, uint32_t* lut, const ScanArgs& a) {
-    constexpr int BLK = 9 * NT + (XTA ? 1 : 2) * XLANES, ROW = NT * Geo<S>::B + NT, SEQ = TileGeo<S, FULL>::SEQ;
+    constexpr bool XTA = XM == 1;
+    constexpr int BLK = 9 * NT + (XM == 0 ? 2 : XM == 1 ? 1 : 0) * XLANES, ROW = NT * Geo<S>::B + NT, SEQ = TileGeo<S, FULL>::SEQ;
     const int VAL = a.val_on ? ((SEQ + 4 + 3) / 4) * 2 : 0;
     static_assert(BLK % 4 == 0 && ROW % 4 == 0 && MISC_DW % 4 == 0 && SEQ % 4 == 0, "seq2 must be 16-byte aligned");
     // seq_alias: the staged bases live in the LAST SEQ dwords of row[].  A tile's lanes read them into registers at the very
@@ -1283,7 +1290,7 @@ TPS_DEV Lds carve_fused(uint32_t* base, uint32_t* lut, const ScanArgs& a) {
     Lds l;
     l.lut2 = lut - a.pair_n;
     l.lut = lut;
-    l.lshift = XTA ? LUT_M16 : a.lut_fields ? LUT_FIELDS : 16;     // (the XTA kernels are the LUT_M16 kernels)
+    l.lshift = XTA ? LUT_M16 : (a.lut_fields && a.lut16) ? LUT_F16 : a.lut_fields ? LUT_FIELDS : 16;     // (the XTA kernels are the LUT_M16 kernels)
     l.blk = base;
     l.XPC = base;
     l.XF = base + 9 * NT;
@@ -1305,6 +1312,10 @@ TPS_DEV Lds carve_fused(uint32_t* base, uint32_t* lut, const ScanArgs& a) {
     l.Lc16 = (uint16_t*)p;
     l.Tc = p + ((a.lc16 && a.lc_global) ? 0 : ((a.lc_cap + 3) / 4) * 2);
     if (XTA) l.XT = a.xt_own ? p + lc_dw(a) : l.seq2;
+    if (XM == 2) {                             // (only the fallback tile reads these; without xt_own it cannot run)
+        l.XF = p + lc_dw(a);
+        l.XT = l.XF + XLANES;
+    }
     return l;
 }
 
@@ -1430,7 +1441,12 @@ TPS_DEV void tile_fused_s(const ScanArgs& a, const TileConst& tc, const Lds& l, 
                             h = lut_at(l.lut, v4, amask);
                         }
                         if constexpr (INV && RAW) {
-                            if (a.lut_fields) h = field_to_entry(h);    // (a tile with non-ACGT letters of a batch on the per-pattern tiles)
+                            if (a.lut_fields && a.lut16) {              // (16-bit field-index table: the entry read above is not one)
+                                const uint32_t m16 = lut16_at(l.lut, v4 >> 1, amask >> 1);
+                                h = m16 ? ((1u << (16 + pp_pattern(ffs0(m16)))) | 1u) : 0u;
+                            } else if (a.lut_fields) {
+                                h = field_to_entry(h);                  // (a tile with non-ACGT letters of a batch on the per-pattern tiles)
+                            }
                         }
                         if (INV) {
                             if (h && invalid_at(l.val, p0 + p, pat.k)) h = 0;   // tiles with non-ACGT letters only
@@ -2366,7 +2382,7 @@ TPS_DEV void pp_expand(uint32_t ne, uint32_t no, uint32_t* b) {   // nibble word
 // lane saw a pattern occur at p and again at p + CD inside the tile it returns true right after phase 1 (nothing but its own
 // exchange words written) and the caller runs tile_pp_s<S, CD> on the tile; otherwise every window's per-pattern count is
 // the plain prefix difference and the tile completes here (see tile_fused_s<.., CD> for the argument and the hand-over).
-template <int S, int D, int CD = 0>
+template <int S, int D, int CD = 0, bool F16 = false>
 TPS_DEV bool tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int delta, int w0, int tile, int nw_tile,
                        int64_t out_base, uint64_t& s_total) {
     static_assert(CD == 0 || (D == 0 && CD <= 6), "chain detection runs on the tile without self-overlap logic");
@@ -2380,11 +2396,14 @@ TPS_DEV bool tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
     const PatInfo& pat = a.pat;
     int rp = tc.r, q = tc.q;
     TPS_PIN_S(rp); TPS_PIN_S(q);                  // opaque per tile: what derives from them is recomputed (scalar) per tile, not kept in SGPRs across the read
-    const uint32_t amask = pat.kmask << 2;
+    constexpr int LS = F16 ? 1 : 2;               // log2(bytes per table entry): F16 = the 16-bit field-index table (LUT_F16)
+    const uint32_t amask = pat.kmask << LS;
     uint32_t* ende = l.XPC;                       // END, even patterns (padded block index)
     uint32_t* endo = l.row;                       // END, odd patterns; S_w takes the place after phase 2
-    uint32_t* tne = l.XF;                         // per lane: nibble totals
-    uint32_t* tno = l.XT;
+    // per lane: its nibble totals, kept in the PAD word of the lane's 9-word group of END (round 4: the per-pattern tiles need no
+    // XF / XT words of their own any more -- 160 dwords per wave less in the raw-row kernels' LDS slices)
+    uint32_t* tne = ende + B;                     // lane t's total: tne[t * (B + 1)]
+    uint32_t* tno = endo + B;
     uint32_t* carry = l.misc + M_SCAN;            // [0, 6): picks of the D positions before the next tile's first; [6]: uncertain
     const int cblk = a.tw & (B - 1), clane = a.tw >> 3;
     // the state at THIS tile's first position (one lane overwrites `carry` for the next tile during phase 1)
@@ -2407,8 +2426,9 @@ TPS_DEV bool tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
     TPS_PHASE {
         const int span = tid;
         const int p0 = delta + span * POS;        // >= 16
-        const uint32_t sh2 = (uint32_t)((p0 - 1 - LBK) & 15) * 2u;
-        const int d0 = (p0 - 1 - LBK) >> 4;       // the lane's registers start LBK positions before its first one (p0 >= 64)
+        const int bo = 2 * (p0 - LBK) - LS;       // the lane's registers start LBK positions before its first one (p0 >= 64)
+        const uint32_t sh2 = (uint32_t)(bo & 31);
+        const int d0 = bo >> 5;
         uint32_t w[WDW];
         {
             uint32_t prev = l.seq2[d0];
@@ -2423,6 +2443,10 @@ TPS_DEV bool tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
         auto look = [&](int p) -> uint32_t {
             const int idx = p + LBK, dw = idx >> 4, bit = idx & 15;
             const uint32_t v4 = bit ? alignbit(dw + 1 < WDW ? w[dw + 1] : 0u, w[dw], 2u * bit) : w[dw];
+            if constexpr (F16) {
+                const uint32_t m = lut16_at(l.lut, v4, amask);
+                return mul24(m, m);                     // 1 << field index -> the one-hot 2-bit field
+            }
             const uint32_t h = lut_at(l.lut, v4, amask);
             return h;                                   // (the table of these kernels holds the fields ready-made)
         };
@@ -2528,8 +2552,8 @@ TPS_DEV bool tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
             TPS_UNROLL
             for (int i = 0; i < CD; ++i) chain_any |= look(POS + i) & pk[POS + i - CD];   // pairs that reach into the next lane's positions
         }
-        tne[span] = pe;
-        tno[span] = po;
+        tne[span * (B + 1)] = pe;
+        tno[span * (B + 1)] = po;
         TPS_PIN_V(chm); TPS_PIN_V(chw); TPS_PIN_V(unc);
         TPS_UNROLL
         for (int i = 0; i < B; ++i) { TPS_PIN_V(ve[i]); TPS_PIN_V(vo[i]); }
@@ -2615,13 +2639,13 @@ TPS_DEV bool tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
             TPS_NOVEC
             for (int t = 0; t < dl0; ++t) {
                 uint32_t x[4];
-                pp_expand(tne[lane + t], tno[lane + t], x);
+                pp_expand(tne[(lane + t) * (B + 1)], tno[(lane + t) * (B + 1)], x);
                 TPS_UNROLL
                 for (int i = 0; i < NW; ++i) fa[i] += x[i];
             }
             {
                 uint32_t x[4];
-                pp_expand(tne[lane + dl0], tno[lane + dl0], x);
+                pp_expand(tne[(lane + dl0) * (B + 1)], tno[(lane + dl0) * (B + 1)], x);
                 TPS_UNROLL
                 for (int i = 0; i < NW; ++i) {
                     fa[i] -= PP_BIAS * 0x01010101u;   // the bias of V; the running sums below are whole-word arithmetic
@@ -2687,7 +2711,7 @@ TPS_DEV bool tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
         // Raw rows leave through LDS: a lane's 8 rows are 8 P contiguous bytes in HBM, LPP lanes per pass mirror a
         // contiguous stretch of the output in the (now free) END / totals area, and all 64 lanes copy it out in
         // 16-byte pieces -- full cache lines instead of 64 scattered 12-byte writes per store instruction.
-        constexpr int LPP = 22;                   // 22 lanes x 8 rows x <= 12 bytes = 2112 <= 2944 bytes (XPC + XF + XT)
+        constexpr int LPP = 22;                   // 22 lanes x 8 rows x <= 12 bytes = 2112 <= 2304 bytes (XPC)
         const int pd = pat.P >> 2;                // dwords per row: 1, 2 or 3
         uint32_t* buf = l.XPC;
         uint32_t* gout = (uint32_t*)(a.raw + (out_base + w0) * (int64_t)pat.P);
@@ -2731,7 +2755,7 @@ TPS_DEV bool tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
             TPS_SYNC();
         }
     } else if (staged16) {
-        constexpr int LPP = 22;                   // 22 lanes x 8 rows x 16 bytes = 2816 <= 2944 bytes
+        constexpr int LPP = 18;                   // 18 lanes x 8 rows x 16 bytes = 2304 bytes = XPC (the raw-row kernels have no XF / XT behind it)
         const int ph = pat.P >> 1;                // 16-bit units per row: 1, 3, 5 or 7
         const uint32_t ph_magic = ph ? (65536u + (uint32_t)ph - 1u) / (uint32_t)ph : 0u;    // u / ph = (u * magic) >> 16 for u < 2^15
         uint32_t* buf = l.XPC;
@@ -3278,7 +3302,9 @@ TPS_DEV void binseg_from_lc(const ScanArgs& a, const Lds& l, uint64_t lc_g, cons
 template <int SV, bool SO, bool PAIR = false, bool RAW = true, bool FULL = tile_full_default(SV), int DCLASS = 0>
 TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_t* lut) {
     constexpr bool M16K = SV != 0 && SO && !RAW;       // sums-only kernels of self-overlap tables: 16-bit table, XT aliased (lut16 / xt_alias)
-    const Lds l = SV ? carve_fused<SV ? SV : 5, FULL, M16K>(lds_base, lut, a) : carve(lds_base, lut, a);
+    constexpr int XM = M16K ? 1 : (SV != 0 && RAW) ? 2 : 0;
+    constexpr bool F16K = SV != 0 && SO && RAW && DCLASS == 3;     // raw rows of a big self-overlap table: 16-bit field-index table (_s*sorh)
+    const Lds l = SV ? carve_fused<SV ? SV : 5, FULL, XM>(lds_base, lut, a) : carve(lds_base, lut, a);
     const PatInfo& pat = a.pat;
     const tps_params& prm = a.prm;
     // one 16-byte descriptor per read (wave-uniform: a scalar load)
@@ -3354,7 +3380,7 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
             bool fld = false;
             if constexpr (RAW) fld = a.lut_fields != 0;
             if (fld) {
-                if constexpr (RAW) { TPS_PHASE { trc_count_packed<SO, true>(a, l, st_s, st_e, tid); } }
+                if constexpr (RAW) { TPS_PHASE { trc_count_packed<SO, F16K ? 3 : 1>(a, l, st_s, st_e, tid); } }
             } else if (SO) {
                 TPS_PHASE { trc_count_packed<true, M16K ? 2 : 0>(a, l, st_s, st_e, tid); }
             } else {
@@ -3547,21 +3573,21 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
                             bool chained = true;
                             if (a.so_fast && !pp_expect) {
                                 switch (a.pp_d) {
-                                    case 2: chained = tile_pp_s<SP, 0, 2>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
-                                    case 3: chained = tile_pp_s<SP, 0, 3>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
-                                    case 4: chained = tile_pp_s<SP, 0, 4>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
-                                    case 5: chained = tile_pp_s<SP, 0, 5>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
-                                    default: chained = tile_pp_s<SP, 0, (SP < 6 ? SP : 6)>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
+                                    case 2: chained = tile_pp_s<SP, 0, 2, F16K>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
+                                    case 3: chained = tile_pp_s<SP, 0, 3, F16K>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
+                                    case 4: chained = tile_pp_s<SP, 0, 4, F16K>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
+                                    case 5: chained = tile_pp_s<SP, 0, 5, F16K>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
+                                    default: chained = tile_pp_s<SP, 0, (SP < 6 ? SP : 6), F16K>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
                                 }
                             }
                             if (!chained) { pp_expect = false; continue; }
                             const uint64_t s_before = s_total;
                             switch (a.pp_d) {
-                                case 2: tile_pp_s<SP, 2>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
-                                case 3: tile_pp_s<SP, 3>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
-                                case 4: tile_pp_s<SP, 4>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
-                                case 5: tile_pp_s<SP, 5>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
-                                default: tile_pp_s<SP, (SP < 6 ? SP : 6)>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
+                                case 2: tile_pp_s<SP, 2, 0, F16K>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
+                                case 3: tile_pp_s<SP, 3, 0, F16K>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
+                                case 4: tile_pp_s<SP, 4, 0, F16K>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
+                                case 5: tile_pp_s<SP, 5, 0, F16K>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
+                                default: tile_pp_s<SP, (SP < 6 ? SP : 6), 0, F16K>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
                             }
                             // the next tile comes straight here if this one looks telomeric (a mean S_w well above the P of a window
                             // without matches; a guess that only decides which exact tile code runs first)

@@ -65,7 +65,7 @@
 #define TPS_SCAN_KERNEL(NAME, SV, SO, PAIR, RAW, MINW) TPS_SCAN_KERNEL_F(NAME, SV, SO, PAIR, RAW, MINW, tps::tile_full_default(SV), 0)
 #define TPS_SCAN_KERNEL_D(NAME, SV, SO, PAIR, RAW, MINW, DCLASS) TPS_SCAN_KERNEL_F(NAME, SV, SO, PAIR, RAW, MINW, tps::tile_full_default(SV), DCLASS)
 
-#define TPS_KGROUPS 11
+#define TPS_KGROUPS 15
 #ifdef TPS_KGROUP
 #define TPS_IN_GROUP(g) (TPS_KGROUP == (g))
 #else
@@ -98,6 +98,10 @@ TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s5sor)
 TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s6sor)
 TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s7sor)
 TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s8sor)
+TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s5sorh)
+TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s6sorh)
+TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s7sorh)
+TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s8sorh)
 
 #if TPS_IN_GROUP(0)
 TPS_SCAN_KERNEL(tps_scan_kernel_s5, 5, false, false, false, 5)       // specialised: compile-time slide, <= 15 patterns
@@ -137,6 +141,20 @@ TPS_SCAN_KERNEL(tps_scan_kernel_s7sor, 7, true, false, true, 5)
 #endif
 #if TPS_IN_GROUP(8)
 TPS_SCAN_KERNEL(tps_scan_kernel_s8sor, 8, true, false, true, 5)
+#endif
+// ... the same for tables of 4^6 and more k-mers: the LDS table holds 16-bit field indices (LUT_F16: 8 KB instead of 16 KB at k = 6, one
+// multiply per position more) -- with the slim exchange region five 4-wave workgroups fit a CU instead of two 8-wave ones
+#if TPS_IN_GROUP(11)
+TPS_SCAN_KERNEL_D(tps_scan_kernel_s5sorh, 5, true, false, true, 5, 3)
+#endif
+#if TPS_IN_GROUP(12)
+TPS_SCAN_KERNEL_D(tps_scan_kernel_s6sorh, 6, true, false, true, 5, 3)
+#endif
+#if TPS_IN_GROUP(13)
+TPS_SCAN_KERNEL_D(tps_scan_kernel_s7sorh, 7, true, false, true, 5, 3)
+#endif
+#if TPS_IN_GROUP(14)
+TPS_SCAN_KERNEL_D(tps_scan_kernel_s8sorh, 8, true, false, true, 5, 3)
 #endif
 #if TPS_IN_GROUP(9)
 TPS_SCAN_KERNEL_D(tps_scan_kernel_s5sol, 5, true, false, false, 5, 1)     // ... the same for self-overlap periods 2 .. 4

@@ -219,6 +219,14 @@ inline std::string plan_geometry_core(ScanArgs& a, const tps_params& prm, int k,
             a.xt_alias = 1;
             a.xt_own = (a.val_on || !a.so_fast || a.pp_d <= 0 || getenv("TPS_XT_OWN")) ? 1 : 0;
         }
+        // the raw-row kernels (_s*r, _s*sor): no XF / XT in the exchange region (tile_pp_s keeps its lane totals in END's pad words);
+        // the fallback tile -- a batch with non-ACGT letters, a table the per-pattern tiles do not take -- gets them back
+        if (prm.flags & TPS_F_STORE_RAW) {
+            // ... and a self-overlap table of 4^6 k-mers or more goes into LDS as 16-bit field indices (LUT_F16, kernels _s*sorh)
+            if (a.lut_fields && a.pat.so_mask != 0 && a.pp_d > 0 && a.lut_n >= 4096 && !getenv("TPS_NO_F16")) a.lut16 = 1;
+            a.xt_alias = 2;
+            a.xt_own = (a.val_on || (a.pat.so_mask != 0 ? a.pp_d <= 0 : a.pp_d != 0) || getenv("TPS_XT_OWN")) ? 1 : 0;
+        }
         a.variant = prm.slide;
         a.blk_log2 = 3;                            // 8 blocks per lane for every slide
         a.span_dw = 0;                             // lanes start at arbitrary bit offsets (per-lane shift)
