@@ -50,8 +50,8 @@ for i in range(nb):
     f = (end >= lo) & (end < hi)
     md = dur[s].mean() / 1e3 if s.any() else 0
     print(f"{lo / 1e3:10.2f}  {inflight:8d}  {int(s.sum()):8d}  {int(f.sum()):8d}  {md:10.2f}")
-names = {14: "table barrier", 0: "scan_read entry", 1: "misc zeroed", 2: "heads staged", 3: "trc counted", 4: "decided", 5: "tile0 staged", 6: "t0 ph1", 7: "t0 xt", 11: "t0 ph2",
-         12: "t0 rowscan/ph2", 8: "t0 done", 9: "tiles done", 10: "result"}
+names = {14: "table barrier", 0: "scan_read entry", 1: "misc zeroed", 2: "heads staged", 3: "trc counted", 4: "decided", 5: "tile0 staged", 6: "t0 ph1", 7: "t0 xt / pp windows", 11: "t0 ph2 / pp rows out",
+         12: "t0 rowscan/ph2 / pp candidates", 8: "t0 done", 9: "tiles done", 10: "result"}
 order = [13, 14, 0, 1, 2, 3, 4, 5, 6, 7, 11, 12, 8, 9, 10]
 early = start < np.percentile(start, 30)
 for label, sel in (("reads started early (first 30 %)", early), ("reads started late", ~early)):

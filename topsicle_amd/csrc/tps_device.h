@@ -247,6 +247,12 @@ constexpr int clog2(int x) { return x <= 1 ? 0 : 1 + clog2(x / 2); }
 #else
 #define TPS_STAMP(i) do { if (a.stamps && (threadIdx.x & 63u) == 0) a.stamps[r * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
 #endif
+// ... inside the per-pattern tiles (first tile of a read only): 6 = phase 1 done, 7 = windows done, 11 = rows out, 12 = candidates done
+#if defined(TPS_EMU) || !defined(TPS_STAMPS)
+#define TPS_PP_STAMP(i) ((void)0)
+#else
+#define TPS_PP_STAMP(i) do { if (w0 == 0 && a.stamps && (threadIdx.x & 63u) == 0) a.stamps[tc.rd * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#endif
 
 // ------------------------------------------------------------------ kernel arguments
 struct PatInfo {
@@ -1227,11 +1233,13 @@ struct TileConst {
     uint32_t jump, jump_magic, lc_cap, lc16;
     uint64_t lc_g;               // this read's off-chip candidate sums: Lc16, or absolute 32-bit sums (0 = they live in LDS)
     uint16_t* sw16;              // this read's window sums (16-bit, ScanArgs::sums16)
+    int64_t rd;                  // (diagnostics build: the read index, for the clock stamps of the per-pattern tiles)
 };
 TPS_DEV TileConst tile_const(const ScanArgs& a, int64_t r) {
     TileConst t;
     t.lc_g = a.lc_global ? (uint64_t)(uintptr_t)(a.lc_scratch + r * (int64_t)a.lc_stride) : 0ull;
     t.sw16 = a.sums16 + (a.win_off16 ? a.win_off16[r] : 0);
+    t.rd = r;
     t.q = (int32_t)uniform((uint32_t)a.q); t.r = (int32_t)uniform((uint32_t)a.r);
     t.jump = uniform((uint32_t)a.prm.jump); t.jump_magic = uniform(a.jump_magic);
     t.lc_cap = uniform((uint32_t)a.lc_cap); t.lc16 = uniform((uint32_t)a.lc16);
@@ -2564,6 +2572,7 @@ TPS_DEV bool tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
 #endif
     }
     TPS_SYNC();
+    TPS_PP_STAMP(6);
     if constexpr (CD > 0) {
 #ifdef TPS_EMU
         const bool chained = chain_any != 0;      // (the emulation's phase loop has OR-ed every lane into the one variable)
@@ -2689,30 +2698,16 @@ TPS_DEV bool tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
         else windows(IntC<4>{});
         g_store_sw8(tc.sw16 + w0, lane, nw_tile, swv);     // (0 for the windows past the tile: dropped by the range check)
     }
-    TPS_SYNC();                                   // every END word has been read: S_w takes the place of the odd half
-    TPS_PHASE {
-        TPS_UNROLL
-        for (int j = 0; j < B; ++j) {
-#ifdef TPS_EMU
-            swv[j] = sw_keep[tid][j];
-#endif
-            l.row[tid * (B + 1) + j] = swv[j];
-        }
-        if constexpr (CD > 0) {
-            // what a chained successor wants from this (chain-free) tile: no pick before its first position matters -- a pair
-            // across that position would lie inside this tile -- and nothing is uncertain
-            if (tid == clane) {
-                TPS_UNROLL
-                for (int i = 0; i < 7; ++i) carry[i] = 0u;
-            }
-        }
-    }
+    TPS_SYNC();                                   // every END word has been read: both halves of END are free
+    TPS_PP_STAMP(7);
     if (staged) {
         // Raw rows leave through LDS: a lane's 8 rows are 8 P contiguous bytes in HBM, LPP lanes per pass mirror a
         // contiguous stretch of the output in the (now free) END / totals area, and all 64 lanes copy it out in
         // 16-byte pieces -- full cache lines instead of 64 scattered 12-byte writes per store instruction.
-        constexpr int LPP = 22;                   // 22 lanes x 8 rows x <= 12 bytes = 2112 <= 2304 bytes (XPC)
+        // (round 4: the buffer is END's even AND odd half -- XPC and row[], contiguous in the raw-row kernels' slices, 1152 dwords --
+        // and S_w moves into row[] only afterwards: 48 lanes of 12-byte rows per pass instead of 22, two passes per tile instead of three)
         const int pd = pat.P >> 2;                // dwords per row: 1, 2 or 3
+        const int LPP = pd == 3 ? 48 : NT;
         uint32_t* buf = l.XPC;
         uint32_t* gout = (uint32_t*)(a.raw + (out_base + w0) * (int64_t)pat.P);
         for (int l0 = 0; l0 < NT; l0 += LPP) {
@@ -2755,7 +2750,7 @@ TPS_DEV bool tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
             TPS_SYNC();
         }
     } else if (staged16) {
-        constexpr int LPP = 18;                   // 18 lanes x 8 rows x 16 bytes = 2304 bytes = XPC (the raw-row kernels have no XF / XT behind it)
+        constexpr int LPP = 36;                   // 36 lanes x 8 rows x 16 bytes = 4608 bytes = XPC + row[] (see above)
         const int ph = pat.P >> 1;                // 16-bit units per row: 1, 3, 5 or 7
         const uint32_t ph_magic = ph ? (65536u + (uint32_t)ph - 1u) / (uint32_t)ph : 0u;    // u / ph = (u * magic) >> 16 for u < 2^15
         uint32_t* buf = l.XPC;
@@ -2806,9 +2801,26 @@ TPS_DEV bool tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
             }
             TPS_SYNC();
         }
-    } else {
-        TPS_SYNC();
     }
+    // S_w takes the place of END's odd half (the candidate phase and the repairs read it there)
+    TPS_PHASE {
+        TPS_UNROLL
+        for (int j = 0; j < B; ++j) {
+#ifdef TPS_EMU
+            swv[j] = sw_keep[tid][j];
+#endif
+            l.row[tid * (B + 1) + j] = swv[j];
+        }
+        if constexpr (CD > 0) {
+            // what a chained successor wants from this (chain-free) tile: no pick before its first position matters -- a pair
+            // across that position would lie inside this tile -- and nothing is uncertain
+            if (tid == clane) {
+                TPS_UNROLL
+                for (int i = 0; i < 7; ++i) carry[i] = 0u;
+            }
+        }
+    }
+    TPS_SYNC();
     if (D > 0) {
         // Repairs (rare, lane-divergent): results are in memory by now -- S_w in row[] and HBM, raw rows in HBM.
 #ifndef TPS_EMU
@@ -2877,7 +2889,9 @@ TPS_DEV bool tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
         }
         TPS_SYNC();
     }
+    TPS_PP_STAMP(11);
     tile_candidates(tc, l, w0, tile, nw_tile, s_total);
+    TPS_PP_STAMP(12);
     return false;
 }
 
