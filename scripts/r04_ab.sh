@@ -12,7 +12,7 @@ for item in $LIST; do
   ENVS=""; base=$item
   if [[ "$item" == *@* ]]; then ENVS=${item#*@}; base=${item%%@*}; fi
   W=${base%%:*}; FL=""; [[ "$base" == *:* ]] && FL="--flags ${base##*:}"
-  name=$(echo "$item" | tr ':@=,' '____')
+  name=$(echo "$item" | tr ':@=,/' '_____')
   ( for kv in ${ENVS//,/ }; do export "$kv"; done
     python3 bench.py --workload $W $FL --steps ${STEPS:-300} --warmup 5 --no-cpu-baseline --no-e2e > $OUT/$name.json 2> $OUT/$name.err )
   python3 - <<PY

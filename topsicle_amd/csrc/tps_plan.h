@@ -253,6 +253,17 @@ inline std::string plan_geometry_core(ScanArgs& a, const tps_params& prm, int k,
         // absolute 32-bit sums: 4 bytes per candidate instead of the 2 of the tile-relative 16-bit form, but the
         // change-point step then needs no per-candidate tile lookup (mul, mulhi, LDS read, add) and no Tc array in LDS.
         // TPS_LC16 / TPS_LC_IN_LDS select the older layouts (experiments).
+        // Round 4, the 40 MB this round trip adds to a config-2 launch's 128 MB at the memory side -- three ways around it, measured
+        // (A/B on one box each, us per launch) and dropped:  (i) the block indexed by the HARDWARE WAVE SLOT (s_getreg HW_ID / XCC_ID:
+        // 12 MB rewritten in place launch after launch instead of 20 MB per batch): 55.3 -> 54.4, config 4's sample 67.7 -> 66.7 -- but
+        // WRITE_SIZE does not move (71.3 -> 71.2 MB; FETCH_SIZE x 2: 57.1 -> 52.4 MB): ~7 MB of streaming traffic pass through an
+        // XCD's 4 MB L2 between two reads of a slot, the lines are gone either way; and a wave restored into another slot after a
+        // queue preemption would share its block with a newcomer unnoticed -- 1.5 % are not worth a checksum-and-fallback.
+        // (ii) ... with the bases as non-temporal loads, so that the scratch lines outlive them in the L2: 54.8 -> 55.5 (54.0 with (i)
+        // alone on that box; WRITE_SIZE 67.4 MB).  (iii) the sums in 16 VGPRs per lane -- register (tile, pass), a wave-uniform index:
+        // a scalar branch to one v_mov per pass; 57 -> 73 VGPRs, still six waves per SIMD; emulation and all GPU tests green --
+        // 58.2 against 54.8 (and 56.6 with the registers compiled in but switched off): the longer live ranges and the 16-way uniform
+        // dispatch in the tile loop and the change-point step cost more than the round trip, which rides the Infinity Cache.
         a.lc16 = (getenv("TPS_LC16") || getenv("TPS_LC_IN_LDS")) && a.pat.dup_mask == 0 && (int64_t)a.tw * (a.lw + P) < 65536 ? 1 : 0;
         a.lc_global = getenv("TPS_LC_IN_LDS") ? 0 : 1;
         a.lc_stride = a.lc16 ? ((a.lc_cap + 1) & ~1) : 2 * ((a.lc_cap + 1) & ~1);        // in 16-bit units
