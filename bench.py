@@ -17,6 +17,15 @@ torch.distributed (gloo) is used only for the barrier and the max-over-ranks tim
 before this process has touched a GPU -- and relays rank 0's JSON line; it fails if fewer than N GPUs are visible
 (TPS_BENCH_SHARE_GPU=1 lets ranks share devices: the launcher test on a 1-GPU box).
 
+Two timed regions of K steps each, both bracketed by barrier + device sync (round 4):
+  1. strictly one launch after the other on one context -> the kernel's own duration (HIP events), `roofline`, `single_stream`;
+  2. the same K steps with consecutive batches on `--streams` (default 2) contexts, each with its own stream, as the file pipeline
+     issues them (batch.EnginePool keeps two contexts per GPU) -> `value`, `ms_per_step`, `pipelined`.  A 10 000-read launch is
+     1.63 rounds of the chip's 6 144 wave slots: alone, its last third runs on a draining GPU (the roofline says what that costs:
+     frac 0.84 against steady_state_frac 0.99); with the next batch's launch already queued on the other stream its drain is the
+     neighbour's ramp.  `--streams 1` skips region 2 (`value` = `single_stream.value`): the command for a rocprofv3 --stats summary
+     whose average duration is that of an undisturbed launch (overlapping launches stretch each other: `pipelined.kernel_ms_mean_while_overlapping`).
+
 Prints ONE JSON line (rank 0).
 """
 import argparse
@@ -270,6 +279,9 @@ def main():
     ap.add_argument("--steady", action="store_true", help="also time the kernel on a batch four times the size (steady state: the launch ramp and the "
                     "last round of wave slots weigh a quarter); NOT part of the default run -- its launches would sit in a rocprofv3 "
                     "average of the same command -- the default line quotes the committed profiles/*/steady_state.json instead")
+    ap.add_argument("--streams", type=int, default=2, help="contexts (streams) the batches of the `value` region alternate between: 2 = the pipeline's "
+                    "own shape (batch.EnginePool: two contexts per GPU) -- the ramp of one launch fills the drain of the previous one; 1 = strictly one "
+                    "launch after the other.  The kernel's own duration and the roofline are measured on serialised launches either way")
     ap.add_argument("--resident-copies", type=int, default=0, help="copies of the batch kept in HBM (0 = enough for >1 GB)")
     ap.add_argument("--errors", default="", choices=["", "ont", "hifi", "none"], help="diagnostic: override the workload's per-base error profile (NOT the metric's workload)")
     args = ap.parse_args()
@@ -421,8 +433,40 @@ def main():
         n_launch, k_mean_ms = sum(x[0] for x in kt), sum(x[2] for x in kt) / len(tables)
     else:
         n_launch, k_total_ms, k_mean_ms = sc.kernel_time_ms()
+    # The same K steps again with consecutive batches on alternating contexts (each its own stream), as the file pipeline issues them
+    # (batch.EnginePool keeps two contexts per GPU): a launch's ramp fills the drain of the one before it.  This region gives `value`;
+    # the serialised region above gives the kernel's own duration (the roofline) and `single_stream`.
+    dt_serial = dt
+    piped = None
+    if len(tables) == 1 and args.streams > 1:
+        pipe = [sc] + [sc.helper(j) for j in range(args.streams - 1)]
+        for eng in pipe[1:]:
+            eng.set_patterns(pats)
+            for s in range(copies):
+                eng.share(s, sc, s)
+        def sync_pipe():
+            for eng in pipe:
+                eng.sync()
+        for i in range(max(args.warmup, 4 * len(pipe))):
+            pipe[i % len(pipe)].scan(i % copies, prm)
+        sync_pipe()
+        grp.barrier()
+        for eng in pipe:
+            eng.kernel_time_reset()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            pipe[i % len(pipe)].scan(i % copies, prm)
+        sync_pipe()
+        dt_rank_p = time.perf_counter() - t0
+        dt = grp.max(dt_rank_p)
+        grp.barrier()
+        ktp = [eng.kernel_time_ms() for eng in pipe]
+        piped = dict(streams=len(pipe), ms_per_step=dt / args.steps * 1e3,
+                     kernel_ms_mean_while_overlapping=sum(x[1] for x in ktp) / max(1, sum(x[0] for x in ktp)))
+        dt_rank = dt_rank_p
     per_rank = grp.gather_objects(dict(rank=rank, device=dev, device_info=sc.device_info(), pci=rank_pci,
                                        cpus=len(os.sched_getaffinity(0)), ms_per_step=dt_rank / args.steps * 1e3,
+                                       ms_per_step_single_stream=dt_serial / args.steps * 1e3,
                                        kernel_ms_mean=k_mean_ms * len(tables), kernel_launches_timed=n_launch))
     # the same kernel on a batch four times the size (the reads repeated): the launch ramp and the partly filled last round of wave
     # slots weigh a quarter as much -- what the kernel does in steady state (rank 0 at N = 1, default workload shapes only)
@@ -492,6 +536,9 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            "streams": piped["streams"] if piped else (len(tables) if concurrent else 1),
+            # strictly one launch after the other (the region the roofline's kernel duration comes from)
+            "single_stream": {"value": touched * world * args.steps / dt_serial, "ms_per_step": dt_serial / args.steps * 1e3},
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -528,10 +575,15 @@ def main():
                 "kernel_launches_timed": n_launch,
                 "duration_ms": roof_ms,
                 "duration_source": ("wall time of one step: %d launches (one per table) overlapping on %d streams" % (len(tables), len(tables)))
-                                   if concurrent else "HIP events around the launch",
+                                   if concurrent else "HIP events around the launch, serialised launches (the `single_stream` region)",
             },
         }
         roof = out["roofline"]
+        if piped:
+            # what the overlap recovers of the launch's ramp and drain: bytes per second over the two-stream region against the HBM peak
+            # (can exceed 1: the contract's ALGORITHMIC bytes, 367 MB per config-2 launch, against the 128 MB the fused kernel really moves)
+            piped["algorithmic_hbm_frac"] = alg_total / (piped["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            out["pipelined"] = piped
         if traffic and PROFILED_COUNTERS.get("SQ_INSTS_VALU") and roof_ms > 0:
             # what really bounds the kernel: integer VALU issue (one wave-instruction per 4 cycles per SIMD), from the committed
             # counters of the same workload; HBM carries `traffic_frac` of its peak (section 3 of DESIGN.md)

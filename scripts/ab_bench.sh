@@ -18,7 +18,7 @@ for rep in $(seq 1 $REPS); do
     lib=$ROOT/topsicle_amd/libtopsicle_hip_$name.so
     [ "$name" == "main" ] && lib=$ROOT/topsicle_amd/libtopsicle_hip.so
     label=$(echo "$v" | tr ':=,' '___')
-    env TOPSICLE_HIP_LIB=$lib $envs python3 $ROOT/bench.py $BARGS --no-cpu-baseline --no-e2e > $OUT/${label}_$rep.json 2> $OUT/${label}_$rep.err
+    env TOPSICLE_HIP_LIB=$lib $envs python3 $ROOT/bench.py $BARGS --no-cpu-baseline --no-e2e --streams 1 > $OUT/${label}_$rep.json 2> $OUT/${label}_$rep.err
     python3 - "$OUT/${label}_$rep.json" "$label" <<'EOF'
 import json, sys
 try:

@@ -19,7 +19,7 @@ for v in "$@"; do
   i=0
   for G in "$G1" "$G2" "$G3" "FETCH_SIZE" "WRITE_SIZE"; do
     i=$((i+1))
-    rocprofv3 --pmc $G --output-format csv -d $OUT/${v}_g$i -- python3 $ROOT/bench.py $BARGS --steps 4 --warmup 1 --no-cpu-baseline --no-e2e > $OUT/${v}_g$i.log 2>&1
+    rocprofv3 --pmc $G --output-format csv -d $OUT/${v}_g$i -- python3 $ROOT/bench.py $BARGS --steps 4 --warmup 1 --no-cpu-baseline --no-e2e --streams 1 > $OUT/${v}_g$i.log 2>&1
     echo "$v group $i rc=$?"
   done
 done

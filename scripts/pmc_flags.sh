@@ -4,7 +4,7 @@
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}; cd /tmp; export TMPDIR=/tmp
 for fl in 1 11 15; do
 OUT=$ROOT/gpurun_out/pmcf$fl; rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT -- python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-e2e --flags $fl ${1:-} > $OUT/log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT -- python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-e2e --streams 1 --flags $fl ${1:-} > $OUT/log 2>&1
 python3 - <<PY
 import csv,glob,collections
 acc=collections.defaultdict(list)

@@ -7,7 +7,7 @@ for kv in $2; do
   for C in FETCH_SIZE WRITE_SIZE; do
     OUT=$ROOT/gpurun_out/pmct; rm -rf $OUT; mkdir -p $OUT
     ( [ "$kv" != "-" ] && for e in ${kv//,/ }; do export "$e"; done
-      rocprofv3 --pmc $C --output-format csv -d $OUT -- python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-e2e --workload $W > $OUT/log 2>&1 )
+      rocprofv3 --pmc $C --output-format csv -d $OUT -- python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-e2e --streams 1 --workload $W > $OUT/log 2>&1 )
     python3 - <<PY
 import csv,glob,collections
 acc=collections.defaultdict(list)

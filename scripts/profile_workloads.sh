@@ -14,13 +14,13 @@ for item in $LIST; do
   OUT=$ROOT/gpurun_out/profw_$TAG/${W}${SEQ}_f$F
   rm -rf $OUT; mkdir -p $OUT
   FL=""; [ "$F" != "0" ] && FL="--flags $F"
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 400 --warmup 3 --no-cpu-baseline --no-e2e --workload $W $FL > $OUT/bench.json 2> $OUT/trace.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 400 --warmup 3 --no-cpu-baseline --no-e2e --streams 1 --workload $W $FL > $OUT/bench.json 2> $OUT/trace.err
   echo "$item trace rc=$?"
   for C in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -- python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-e2e --workload $W $FL > $OUT/pmc_$C.log 2>&1
+    rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -- python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-e2e --streams 1 --workload $W $FL > $OUT/pmc_$C.log 2>&1
     echo "$item pmc $C rc=$?"
   done
-  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmc_sq -- python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-e2e --workload $W $FL > $OUT/pmc_sq.log 2>&1
+  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmc_sq -- python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-e2e --streams 1 --workload $W $FL > $OUT/pmc_sq.log 2>&1
   echo "$item pmc sq rc=$?"
   # keep only the small summaries (the raw traces are tens of MB)
   find $OUT -name "*_kernel_trace.csv" -delete

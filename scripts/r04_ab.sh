@@ -14,13 +14,13 @@ for item in $LIST; do
   W=${base%%:*}; FL=""; [[ "$base" == *:* ]] && FL="--flags ${base##*:}"
   name=$(echo "$item" | tr ':@=,/' '_____')
   ( for kv in ${ENVS//,/ }; do export "$kv"; done
-    python3 bench.py --workload $W $FL --steps ${STEPS:-300} --warmup 5 --no-cpu-baseline --no-e2e > $OUT/$name.json 2> $OUT/$name.err )
+    python3 bench.py --workload $W $FL --steps ${STEPS:-300} --warmup 5 --no-cpu-baseline --no-e2e ${STREAMS:+--streams $STREAMS} > $OUT/$name.json 2> $OUT/$name.err )
   python3 - <<PY
 import json
 try:
     d = [json.loads(l) for l in open("$OUT/$name.json") if l.startswith("{")][-1]
     r = d["roofline"]
-    print("%-44s step %.4f ms  kernel %.4f ms  frac %.3f  %s" % ("$item", d["ms_per_step"], r["kernel_ms_mean"], r["frac"], r["kernel_launch"]))
+    print("%-44s step %.4f ms (single stream %.4f)  kernel %.4f ms  frac %.3f  %s" % ("$item", d["ms_per_step"], d["single_stream"]["ms_per_step"], r["kernel_ms_mean"], r["frac"], r["kernel_launch"]))
 except Exception as e:
     print("$item FAILED", e, open("$OUT/$name.err").read()[-400:])
 PY

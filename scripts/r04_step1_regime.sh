@@ -10,11 +10,11 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $ROOT
 for W in config4_1pct config4_01pct config4_sample; do
-  python3 bench.py --workload $W --steps 400 --warmup 5 --no-cpu-baseline --no-e2e > $OUT/bench_$W.json 2> $OUT/bench_$W.err
+  python3 bench.py --workload $W --steps 400 --warmup 5 --no-cpu-baseline --no-e2e --streams 1 > $OUT/bench_$W.json 2> $OUT/bench_$W.err
   echo "bench $W rc=$?"
 done
 for N in 40000 100000; do
-  python3 bench.py --workload config4_1pct --n-reads $N --steps 100 --warmup 5 --no-cpu-baseline --no-e2e > $OUT/bench_config4_1pct_n$N.json 2> $OUT/bench_config4_1pct_n$N.err
+  python3 bench.py --workload config4_1pct --n-reads $N --steps 100 --warmup 5 --no-cpu-baseline --no-e2e --streams 1 > $OUT/bench_config4_1pct_n$N.json 2> $OUT/bench_config4_1pct_n$N.err
   echo "bench 1pct n=$N rc=$?"
 done
 bash scripts/profile_workloads.sh ${TAG} "config4_1pct config4_01pct" > $OUT/workloads.csv 2> $OUT/profile_workloads.err

@@ -298,6 +298,9 @@ def test_bench_launches_its_own_ranks():
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and sorted(x["rank"] for x in out["ranks"]) == [0, 1]
+    # `value` comes from the two-stream region, the kernel's own duration from the serialised one
+    assert out["streams"] == 2 and out["pipelined"]["streams"] == 2 and out["single_stream"]["ms_per_step"] > 0
+    assert out["ms_per_step"] == pytest.approx(out["pipelined"]["ms_per_step"])
     assert out["value"] > 0 and out["roofline"]["kernel"].startswith("tps_scan_kernel")
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

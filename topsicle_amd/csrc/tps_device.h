@@ -1807,6 +1807,12 @@ TPS_DEV void tile_candidates(const TileConst& tc, const Lds& l, int w0, int tile
 // Against tile_fused_s per tile and lane: 17 LDS stores instead of 35 (no XS, no rewritten XF / XT, no second copy of
 // S_w for the scan), 13 + the table gathers LDS loads instead of 37 + the gathers, three wave barriers instead of six,
 // two 16-byte stores to HBM instead of eight dword stores.
+#ifndef TPS_DIAG_SKIP_PAIR
+#define TPS_DIAG_SKIP_PAIR 0
+#endif
+#ifndef TPS_XPAD
+#define TPS_XPAD 1          // (0: the default kernels keep XF / XT arrays in the exchange region -- A/B builds, with TPS_NO_XPAD=1 in the environment)
+#endif
 #ifndef TPS_LC_TILE
 #define TPS_LC_TILE 1
 #endif
@@ -1880,7 +1886,12 @@ TPS_DEV void tile_lc_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
     // the published words keep the layout mask << 16 | count
     constexpr bool M16 = CD > 0;
     constexpr int LS = M16 ? 1 : 2;               // log2(bytes per table entry)
+    // XPAD (the default kernels, round 4): a lane's OR | matches (XF) and its exclusive prefix in the tile (XT) live in the pad words of
+    // its XPC and row[] rows (9 words per lane, the ninth unused) -- no XF / XT arrays in the wave's slice (carve_fused<.., XM = 2>)
+    constexpr bool XPAD = CD == 0 && TPS_XPAD != 0;
     typedef Geo<S> g_;
+    auto xf_at = [&](int lane_) -> uint32_t& { return XPAD ? l.XPC[lane_ * (g_::B + 1) + g_::B] : l.XF[lane_]; };
+    auto xt_at = [&](int lane_) -> uint32_t& { return XPAD ? l.row[lane_ * (g_::B + 1) + g_::B] : l.XT[lane_]; };
     constexpr int B = g_::B, LOG2B = g_::LOG2B, POS = g_::POS;
     constexpr int LB = CD;                        // CD: the lane's registers start CD positions before its first one (look-back of the pair test)
     constexpr int WDW = (LB + POS + 13 + 15) / 16;
@@ -1953,7 +1964,7 @@ TPS_DEV void tile_lc_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
         pair_lo = pair_hi = 0;                    // (per lane)
         uint32_t* xpc = l.XPC + span * (B + 1);
         if constexpr (PAIR) {
-            constexpr int NP = S / 2, NH = NP + (S & 1);
+            constexpr int NP = S / 2 - TPS_DIAG_SKIP_PAIR, NH = NP + (S & 1);
             const uint32_t amask2 = (pat.kmask << 4) | 0xCu;
             const int rpe = rp & ~1;
             uint32_t hc[NH], hn[NH];
@@ -2060,7 +2071,7 @@ TPS_DEV void tile_lc_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
             sfx[j] = sf;
         }
         xf_own = M16 ? (sf | cnt) : pack_hi_lo(sf, cnt);
-        l.XF[span] = xf_own;
+        xf_at(span) = xf_own;
         if constexpr (CD > 0) { TPS_PIN_V(pair_lo); TPS_PIN_V(pair_hi); }
 #ifdef TPS_EMU
         for (int j = 0; j < B; ++j) { sfx_keep[tid][j] = sfx[j]; c0_keep[tid][j] = c0s[j]; }
@@ -2116,7 +2127,7 @@ TPS_DEV void tile_lc_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
                     }
                     const uint32_t pt = below(64) << PS;
                     xf_own += pt;
-                    lds_add(&l.XF[lane], pt);
+                    lds_add(&xf_at(lane), pt);
                 }
                 // chains of three or more: pair bits CD apart.  The neighbours' bits close the lane's ends (nothing before the
                 // tile's first lane: what lies there is in none of its windows; nothing behind the last: nor is that)
@@ -2200,13 +2211,13 @@ TPS_DEV void tile_lc_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
         uint32_t orw = 0, sumw = xf_own;
         TPS_NOVEC
         for (int t = 1; t < dl0; ++t) {
-            const uint32_t v = l.XF[lane + t];
+            const uint32_t v = xf_at(lane + t);
             orw |= v;
             sumw += v;
         }
         uint32_t orb = orw, sumb = sumw;
         if (!ROTZ) {
-            const uint32_t vb = l.XF[lane + dl0];
+            const uint32_t vb = xf_at(lane + dl0);
             orb |= vb;
             sumb += vb;
         }
@@ -2299,12 +2310,12 @@ TPS_DEV void tile_lc_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
         uint32_t run = 0;
         TPS_UNROLL
         for (int j = 0; j < B; ++j) { pr[j] = run; run += sw[j]; }
-        l.XT[lane] = lexc;
+        xt_at(lane) = lexc;
     }
     TPS_SYNC();
     if (w0 == 0) TPS_STAMP(12);
     // the tile's total = the prefix at its first window that is NOT part of it (nw_tile <= 512 - q - 1: a written entry)
-    const uint32_t gsum = uniform(l.row[nw_tile + (nw_tile >> LOG2B)] + l.XT[nw_tile >> LOG2B]);
+    const uint32_t gsum = uniform(l.row[nw_tile + (nw_tile >> LOG2B)] + xt_at(nw_tile >> LOG2B));
     {
         // change-point candidates of this tile: c with w0 <= c * jump < w0 + nw_tile, 64 per pass
         const uint32_t jump = tc.jump;
@@ -2321,7 +2332,7 @@ TPS_DEV void tile_lc_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
             TPS_NOVEC
             for (int t = 0; t < passes; ++t) {
                 if (c < c_hi) {
-                    const uint32_t pre = l.row[w + (w >> LOG2B)] + l.XT[w >> LOG2B];
+                    const uint32_t pre = l.row[w + (w >> LOG2B)] + xt_at((int)(w >> LOG2B));
                     if (tc.lc16) {
                         if (tc.lc_g) g16_store(tc.lc_g, c, pre);
                         else l.Lc16[c] = (uint16_t)pre;
@@ -3316,7 +3327,8 @@ TPS_DEV void binseg_from_lc(const ScanArgs& a, const Lds& l, uint64_t lc_g, cons
 template <int SV, bool SO, bool PAIR = false, bool RAW = true, bool FULL = tile_full_default(SV), int DCLASS = 0>
 TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_t* lut) {
     constexpr bool M16K = SV != 0 && SO && !RAW;       // sums-only kernels of self-overlap tables: 16-bit table, XT aliased (lut16 / xt_alias)
-    constexpr int XM = M16K ? 1 : (SV != 0 && RAW) ? 2 : 0;
+    // (XM = 2 also for the default kernels: every tile of theirs is a tile_lc_s<.., CD = 0>, which keeps XF / XT in the pad words too)
+    constexpr int XM = M16K ? 1 : (SV != 0 && (RAW || (!SO && TPS_LC_TILE != 0 && TPS_XPAD != 0))) ? 2 : 0;
     constexpr bool F16K = SV != 0 && SO && RAW && DCLASS == 3;     // raw rows of a big self-overlap table: 16-bit field-index table (_s*sorh)
     const Lds l = SV ? carve_fused<SV ? SV : 5, FULL, XM>(lds_base, lut, a) : carve(lds_base, lut, a);
     const PatInfo& pat = a.pat;

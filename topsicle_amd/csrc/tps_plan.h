@@ -227,6 +227,8 @@ inline std::string plan_geometry_core(ScanArgs& a, const tps_params& prm, int k,
             a.xt_alias = 2;
             a.xt_own = (a.val_on || (a.pat.so_mask != 0 ? a.pp_d <= 0 : a.pp_d != 0) || getenv("TPS_XT_OWN")) ? 1 : 0;
         }
+        // ... and so do the default kernels (no self-overlap, sums only: every tile is a tile_lc_s<.., CD = 0>, lane totals in the pad words)
+        if (a.pat.so_mask == 0 && !(prm.flags & TPS_F_STORE_RAW) && !getenv("TPS_NO_XPAD")) { a.xt_alias = 2; a.xt_own = 0; }
         a.variant = prm.slide;
         a.blk_log2 = 3;                            // 8 blocks per lane for every slide
         a.span_dw = 0;                             // lanes start at arbitrary bit offsets (per-lane shift)
