@@ -13,6 +13,9 @@ dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 os.makedirs(dst, exist_ok=True)
 for f in glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
     shutil.copyfile(f, os.path.join(dst, "kernel_stats.csv"))
+# the default command (two contexts issuing consecutive batches): the launches overlap and stretch each other
+for f in glob.glob(os.path.join(src, "trace_default", "*", "*_kernel_stats.csv")):
+    shutil.copyfile(f, os.path.join(dst, "kernel_stats_default_command_two_streams.csv"))
 rows = []
 for f in sorted(glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv"))):
     acc = collections.defaultdict(list)

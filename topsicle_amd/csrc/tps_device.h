@@ -1807,9 +1807,6 @@ TPS_DEV void tile_candidates(const TileConst& tc, const Lds& l, int w0, int tile
 // Against tile_fused_s per tile and lane: 17 LDS stores instead of 35 (no XS, no rewritten XF / XT, no second copy of
 // S_w for the scan), 13 + the table gathers LDS loads instead of 37 + the gathers, three wave barriers instead of six,
 // two 16-byte stores to HBM instead of eight dword stores.
-#ifndef TPS_DIAG_SKIP_PAIR
-#define TPS_DIAG_SKIP_PAIR 0
-#endif
 #ifndef TPS_XPAD
 #define TPS_XPAD 1          // (0: the default kernels keep XF / XT arrays in the exchange region -- A/B builds, with TPS_NO_XPAD=1 in the environment)
 #endif
@@ -1964,7 +1961,7 @@ TPS_DEV void tile_lc_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
         pair_lo = pair_hi = 0;                    // (per lane)
         uint32_t* xpc = l.XPC + span * (B + 1);
         if constexpr (PAIR) {
-            constexpr int NP = S / 2 - TPS_DIAG_SKIP_PAIR, NH = NP + (S & 1);
+            constexpr int NP = S / 2, NH = NP + (S & 1);
             const uint32_t amask2 = (pat.kmask << 4) | 0xCu;
             const int rpe = rp & ~1;
             uint32_t hc[NH], hn[NH];
