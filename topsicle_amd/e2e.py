@@ -279,7 +279,7 @@ def measure(bases, offsets, motif: str, k: int, slide: int, device: int = 0, con
 
 
 def measure_wgs(motif: str = "CCCTAA", k: int = 4, slide: int = 6, n_reads: int = 6000, read_len: int = 30000, telomeric_fraction: float = 0.01,
-                device: int = 0, contexts_per_gpu: int = 2, repeats: int = 4, workdir: str | None = None) -> dict:
+                device: int = 0, contexts_per_gpu: int = 2, repeats: int = 9, workdir: str | None = None) -> dict:
     """The step-1-dominated regime end to end: a FASTQ file of `read_len`-base reads of which
     `telomeric_fraction` are telomeric, file -> results with the one-pass upload (every read whole: 3 bits per base) and with the
     two-pass route (batch.scan_jobs_heads: the two 1000-base ends of every read, then the scanned part of the reads that pass).
