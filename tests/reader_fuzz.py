@@ -31,7 +31,12 @@ def make_file(rng, path):
         if fastq:
             qual = bytes(rng.integers(33, 75, L, dtype=np.uint8)) if L else b""      # ('@' = 64 and '+' = 43 occur, also first)
             plus = b"+" + (name if rng.random() < 0.1 else b"")
-            out.append(b"@" + name + nl + seq + nl + plus + nl + qual + nl)
+            if L and rng.random() < 0.3:           # (round 4) a multi-line record: sequence and quality wrapped at their own widths
+                ws, wq = (int(rng.choice([60, 80, int(rng.integers(1, 150))])) for _ in range(2))
+                out.append(b"@" + name + nl + nl.join(seq[j:j + ws] for j in range(0, L, ws)) + nl + plus + nl +
+                           nl.join(qual[j:j + wq] for j in range(0, L, wq)) + nl)
+            else:
+                out.append(b"@" + name + nl + seq + nl + plus + nl + qual + nl)
         else:
             w = int(rng.choice([60, 80, 10 ** 9, int(rng.integers(1, 150))]))       # (round 4: any line width -- wrapped FASTA takes the thread-team decoder)
             lines = [seq[j:j + w] for j in range(0, len(seq), w)] or [b""]
@@ -103,17 +108,18 @@ def run(cases=300, seed=0):
             os.environ.pop("TPS_IO_BGZF_GROUP", None)
         if os.environ.get("RD_FUZZ_VERBOSE"):
             print("case", case, p, flush=True)
-        want = [(r.id, r.description, r.seq.upper() if False else r.seq) for r in seqio.read_records(p)]
+        want = [(r.id, r.description, r.seq, r.qual) for r in seqio.read_records(p)]
         got_a = []
         for b in seqio.read_batches(p, max_bases=int(rng.choice([1 << 12, 1 << 16, 1 << 24])), max_records=int(rng.choice([3, 64, 1 << 20]))):
-            got_a += [(r.id, r.description, r.seq) for r in (b.record(i) for i in range(len(b)))]
+            got_a += [(r.id, r.description, r.seq, r.qual) for r in (b.record(i) for i in range(len(b)))]
         got_p = []
         pool = seqio.BufferPool(2, int(rng.choice([1 << 14, 1 << 18])), int(rng.choice([8, 4096])))
         try:
             for pb in seqio.read_batches_packed(p, pool):
                 for i in range(pb.n):
                     sq = bytes(pb.seq_bytes(i))
-                    got_p.append((pb.read_id(i), pb.head(i), sq.decode("latin1")))
+                    ql = pb.qual_bytes(i)
+                    got_p.append((pb.read_id(i), pb.head(i), sq.decode("latin1"), None if ql is None else bytes(ql).decode("latin1")))
                     # what was PACKED is that sequence (2-bit codes (c >> 1) & 3, invalid mask = not one of acgtACGT)
                     w0, L = int(pb.desc["word_off"][i]), int(pb.desc["len"][i])
                     assert L == len(sq), (case, p, i, L, len(sq))
@@ -134,8 +140,8 @@ def run(cases=300, seed=0):
         for name, got in (("ascii", got_a), ("packed", got_p)):
             if got is None:
                 continue
-            g = [(a, b, c.upper()) for a, b, c in got] if name == "packed" else got
-            w = [(a, b, c.upper()) for a, b, c in want] if name == "packed" else want
+            g = [(a, b, c.upper(), d) for a, b, c, d in got] if name == "packed" else got
+            w = [(a, b, c.upper(), d) for a, b, c, d in want] if name == "packed" else want
             if g == w:
                 same += 1
             else:

@@ -454,3 +454,61 @@ def test_wrapped_fasta_takes_the_thread_team_decoder(tmp_path, monkeypatch, nl):
     (tmp_path / "pad.fasta").write_bytes(b">a\nACGT \n  AC\n>b\nTTTT\n")
     got, kinds = packed(tmp_path / "pad.fasta")
     assert [x[1] for x in got] == [b"ACGTAC", b"TTTT"] and kinds == {"ascii"}
+
+
+@pytest.mark.skipif(seqio._load_io() is None, reason="libtopsicle_io.so not built")
+@pytest.mark.parametrize("nl", [b"\n", b"\r\n"])
+def test_multiline_fastq_takes_the_thread_team_decoder(tmp_path, monkeypatch, nl):
+    """Round 4: FASTQ records whose sequence and quality are spread over several lines -- each at its own
+    width, quality lines that begin with '@' or '+', a name repeated on the '+' line -- are joined and packed by the thread team,
+    plain, gzip'ed and bgzip'ed: the same records, qualities and 2-bit words as the same reads written four lines each; the
+    record writer puts them out in Biopython's four-line layout; a record with a blank line inside still goes to the streaming
+    decoder."""
+    monkeypatch.setenv("TPS_IO_PACK_MIN_SPAN", "2000")    # the team on small files
+    monkeypatch.setenv("TPS_IO_PARGZ_MIN", "0")
+    monkeypatch.setenv("TPS_IO_THREADS", "5")
+    rng = np.random.default_rng(12)
+    seqs = [bytes(rng.choice(np.frombuffer(b"ACGTacgtN", np.uint8), int(L))) for L in list(rng.integers(1, 4000, 150)) + [60, 61, 120, 1, 2]]
+    quals = [bytes(rng.choice(np.frombuffer(b"@+I#5", np.uint8), len(s))) for s in seqs]
+    four, multi = b"", b""
+    for i, (s, q) in enumerate(zip(seqs, quals)):
+        plus = b"+r%d d" % i if i % 7 == 0 else b"+"
+        four += b"@r%d d\n" % i + s + b"\n+\n" + q + b"\n"
+        ws, wq = [60, 80, 7, 1000][i % 4], [60, 61, 13, 999][i % 4]
+        multi += (b"@r%d d" % i + nl + nl.join(s[j:j + ws] for j in range(0, len(s), ws)) + nl + plus + nl +
+                  nl.join(q[j:j + wq] for j in range(0, len(q), wq)) + nl)
+    import gzip
+
+    def packed(path, write_to=None):
+        pool = seqio.BufferPool(3, 1 << 16, 4096)
+        out, kinds = [], set()
+        for pb in seqio.read_batches_packed(str(path), pool):
+            kinds.add("packed" if pb.spans is not None else "ascii")
+            for i in range(pb.n):
+                w0, L = int(pb.desc["word_off"][i]), int(pb.desc["len"][i])
+                out.append((pb.head(i), bytes(pb.seq_bytes(i)), bytes(pb.qual_bytes(i)), np.asarray(pb.seq2[w0:w0 + (L + 15) // 16]).tobytes(),
+                            int(pb.desc["flags"][i])))
+            if write_to is not None:
+                pb.write_records(write_to, list(range(0, pb.n, 2)), "fastq")
+            pb.release()
+        return out, kinds
+    (tmp_path / "four.fastq").write_bytes(four)
+    want, kinds = packed(tmp_path / "four.fastq")
+    assert kinds == {"packed"} and [x[1] for x in want] == seqs and [x[2] for x in want] == quals
+    (tmp_path / "m.fastq").write_bytes(multi)
+    (tmp_path / "m.fastq.gz").write_bytes(gzip.compress(multi, 4))
+    _write_bgzf(str(tmp_path / "mb.fastq.gz"), multi, block=3001)
+    for name in ("m.fastq", "m.fastq.gz", "mb.fastq.gz"):
+        with open(tmp_path / ("out_" + name + ".fq"), "wb") as h:
+            got, kinds = packed(tmp_path / name, write_to=h)
+        assert kinds == {"packed"}, (name, kinds)
+        assert got == want, name
+        written = list(seqio.read_records(str(tmp_path / ("out_" + name + ".fq"))))
+        assert len(written) >= len(seqs) // 2 and all(b"\n" not in r.seq.encode() for r in written)
+        by_id = {"r%d" % i: (s.decode(), q.decode()) for i, (s, q) in enumerate(zip(seqs, quals))}
+        assert all((r.seq, r.qual) == by_id[r.id] for r in written)
+        assert (tmp_path / ("out_" + name + ".fq")).read_bytes().count(b"\n") == 4 * len(written)
+    (tmp_path / "blank.fastq").write_bytes(b"@a\nACGT\n\nAC\n+\nIIII\nII\n@b\nTTTT\n+\n####\n")
+    got, kinds = packed(tmp_path / "blank.fastq")
+    py = list(seqio.read_records(str(tmp_path / "blank.fastq")))
+    assert [(x[1].decode(), x[2].decode()) for x in got] == [(r.seq, r.qual) for r in py] and kinds == {"ascii"}

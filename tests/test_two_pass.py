@@ -34,6 +34,10 @@ def _write(path, seqs, fmt):
         for i, s in enumerate(seqs):
             if fmt == "fastq":
                 h.write(b"@r%d x\n" % i + s + b"\n+\n" + b"I" * len(s) + b"\n")
+            elif fmt == "fastqw":                   # multi-line FASTQ: sequence and quality wrapped at different widths
+                q = (b"@+I" * (len(s) // 3 + 1))[:len(s)]
+                h.write(b"@r%d x\n" % i + b"\n".join(s[j:j + 70] for j in range(0, len(s), 70)) + b"\n+\n" +
+                        b"\n".join(q[j:j + 80] for j in range(0, len(s), 80)) + b"\n")
             else:
                 h.write(b">r%d x\n" % i + b"\n".join(s[j:j + 70] for j in range(0, len(s), 70)) + b"\n")
 
@@ -66,7 +70,7 @@ def _run(engines, path, jobs, two_pass, max_bases=None):
 
 def _check(engines_factory, tmp_path, fmt, ks, raw, sums, max_bases=None):
     seqs = _reads(3)
-    path = str(tmp_path / ("reads." + fmt))
+    path = str(tmp_path / ("reads." + ("fastq" if fmt == "fastqw" else fmt)))
     _write(path, seqs, fmt)
     jobs = _jobs(ks, raw, sums)
     one, st1 = _run(engines_factory(), path, jobs, "off", max_bases)
@@ -90,7 +94,7 @@ def _check(engines_factory, tmp_path, fmt, ks, raw, sums, max_bases=None):
 
 
 @pytest.mark.parametrize("fmt,ks,raw,sums,max_bases", [("fastq", [4], False, True, None), ("fasta", [6], True, False, None),
-                                                       ("fastq", [4, 5, 6], True, True, 300000)])
+                                                       ("fastq", [4, 5, 6], True, True, 300000), ("fastqw", [4], False, True, None)])
 def test_two_pass_rows_equal_one_pass_emulation(tmp_path, emu_engine_factory, fmt, ks, raw, sums, max_bases):
     _check(emu_engine_factory, tmp_path, fmt, ks, raw, sums, max_bases)
 

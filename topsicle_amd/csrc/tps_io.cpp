@@ -11,7 +11,8 @@
 //   * plain (uncompressed) 4-line FASTQ: the file is mmap'ed; newline positions of a window are indexed
 //     by a team of threads (memchr), records are validated ('@', '+', equal sequence / quality length)
 //     and their sequence, quality and header bytes are copied into the batch buffers by the same team.
-//     Anything unexpected (wrapped lines, blank lines, length mismatch) hands the rest of the file to
+//     Anything unexpected (blank or padded lines inside a record, length mismatch; in ASCII mode also wrapped lines) hands the
+//     rest of the file to
 //   * the streaming decoder on zlib (gz or plain, FASTA or FASTQ, wrapped lines), single-threaded.
 //
 // Packed mode (tps_reader_next_packed): plain FASTQ records are 2-bit packed straight from the mmap'ed file into the
@@ -595,6 +596,59 @@ struct Fast {
         r = Rec{s + 1, (uint64_t)(h1 - s - 1), nlines ? first_a : s0, sl, next, nlines > 1};
         return 0;
     }
+    // A FASTQ record whose sequence (and quality) is spread over several lines (round 4; it used to end the packed decoding of the
+    // file): header at s (ends at h1), sequence lines from s0 up to the first line that begins with '+', then quality lines until
+    // they hold as many characters as the sequence -- which has to happen exactly at a line end ('@' and '+' may begin a quality
+    // line: lengths decide, as in Biopython's FastqGeneralIterator).  The sequence is joined into `dewrap` like a wrapped FASTA
+    // record's; r.q0 is the first quality character (consumers join the quality lines by count).  1 = not this decoder's business:
+    // blank or padded lines inside the record, a sequence line that begins with '@' (a mis-framed candidate), text that ends inside
+    // the record.
+    int parse_fastq_multiline_at(size_t s, size_t h1, size_t s0, Rec& r, size_t& next, std::vector<uint8_t>* dewrap) const {
+        size_t p = s0, first_a = 0, first_b = 0;
+        uint64_t sl = 0;
+        int nlines = 0;
+        for (;;) {                                     // sequence lines
+            if (p >= size) return 1;
+            if (data[p] == '+') break;
+            if (data[p] == '@') return 1;
+            const char* ep = (const char*)memchr(data + p, '\n', size - p);
+            if (!ep) return 1;
+            const size_t e = (size_t)(ep - data);
+            const size_t l1 = (e > p && data[e - 1] == '\r') ? e - 1 : e;
+            if (l1 == p) return 1;                     // a blank line inside a record: the streaming decoder judges that
+            if (data[p] == ' ' || data[p] == '\t' || data[l1 - 1] == ' ' || data[l1 - 1] == '\t') return 1;
+            if (nlines == 0) { first_a = p; first_b = l1; }
+            else if (dewrap) {
+                if (nlines == 1) dewrap->assign((const uint8_t*)data + first_a, (const uint8_t*)data + first_b);
+                dewrap->insert(dewrap->end(), (const uint8_t*)data + p, (const uint8_t*)data + l1);
+            }
+            sl += l1 - p;
+            ++nlines;
+            p = e + 1;
+        }
+        if (nlines == 0 || sl > 0x7FFFFFFFull) return 1;         // (an empty sequence has its '+' right behind the header: the 4-line path)
+        const char* epl = (const char*)memchr(data + p, '\n', size - p);
+        if (!epl) return 1;
+        size_t q = (size_t)(epl - data) + 1;
+        const size_t q0 = q;
+        uint64_t ql = 0;
+        while (ql < sl) {                              // quality lines
+            if (q >= size) return 1;
+            const char* ep = (const char*)memchr(data + q, '\n', size - q);
+            if (!ep && !final_window()) return 1;
+            const size_t e = ep ? (size_t)(ep - data) : size;
+            const size_t l1 = (e > q && data[e - 1] == '\r') ? e - 1 : e;
+            if (l1 == q) return 1;
+            ql += l1 - q;
+            if (!ep) { if (ql != sl) return 1; q = size; break; }
+            q = e + 1;
+        }
+        if (ql != sl) return 1;
+        if (q < size && data[q] != '@' && !only_blank(q)) return 1;      // what follows has to be a record (or the end of the input)
+        next = q;
+        r = Rec{s + 1, (uint64_t)(h1 - s - 1), first_a, sl, q0, nlines > 1};
+        return 0;
+    }
     int parse_at(size_t s, Rec& r, size_t& next, std::vector<uint8_t>* dewrap = nullptr) const {
         if (fasta) return parse_fasta_at(s, r, next, dewrap);
         if (s >= size || data[s] != '@') return 1;
@@ -609,7 +663,8 @@ struct Fast {
         if (!e1p) return 1;
         const size_t e1 = (size_t)(e1p - data);
         const size_t s1 = (e1 > s0 && data[e1 - 1] == '\r') ? e1 - 1 : e1;
-        if (e1 + 1 >= size || data[e1 + 1] != '+') return 1;
+        if (e1 + 1 >= size) return 1;
+        if (data[e1 + 1] != '+') return parse_fastq_multiline_at(s, h1, s0, r, next, dewrap);
         const char* e2p = (const char*)memchr(data + e1 + 1, '\n', size - (e1 + 1));
         if (!e2p) return 1;
         const size_t q0 = (size_t)(e2p - data) + 1, sl = s1 - s0;
@@ -1129,6 +1184,21 @@ int64_t tps_pack_spans(const char* text, int64_t text_len, int32_t fasta, const 
                     src = joined.data();
                 } else if (s0 + L > text_len) { bad = 1; return; }
             } else if (s0 + L > text_len) { bad = 1; return; }
+            else if (memchr(text + s0, '\n', (size_t)L) || memchr(text + s0, '\r', (size_t)L)) {
+                // a multi-line FASTQ record: the first L bytes from s0 on that are not line ends
+                joined.clear();
+                int64_t p = s0;
+                while ((int64_t)joined.size() < L) {
+                    if (p >= text_len) { bad = 1; return; }
+                    const char* q = (const char*)memchr(text + p, '\n', (size_t)(text_len - p));
+                    const int64_t le = q ? (int64_t)(q - text) : text_len;
+                    const int64_t l1 = (le > p && text[le - 1] == '\r') ? le - 1 : le;
+                    const int64_t take = std::min<int64_t>(L - (int64_t)joined.size(), l1 - p);
+                    joined.insert(joined.end(), (const uint8_t*)text + p, (const uint8_t*)text + p + take);
+                    p = le + 1;
+                }
+                src = joined.data();
+            }
             if (tps::pack_one(src + (tails[j] & 1 ? L - m : 0), m, seq2 + desc[j].word_off, inv ? inv + desc[j].word_off : nullptr))
                 desc[j].flags |= TPS_RD_HAS_INVALID;
         }
@@ -1254,8 +1324,27 @@ int64_t tps_write_fastq_spans(int fd, const char* text, int64_t text_len, const 
         if (verbatim) {
             push(text + h0 - 1, (size_t)(q0 + sl + 1 - (h0 - 1)));
         } else {
-            push(&at, 1); push(text + h0, (size_t)hl); push(&nl, 1); push(text + s0, (size_t)sl);
-            push(plus, 3); push(text + q0, (size_t)sl); push(&nl, 1);
+            // (a multi-line record: its sl bases / quality characters are the first sl bytes that are not line ends)
+            auto push_joined = [&](int64_t from) -> bool {
+                if (!memchr(text + from, '\n', (size_t)sl) && !memchr(text + from, '\r', (size_t)sl)) { push(text + from, (size_t)sl); return true; }
+                int64_t p = from, need = sl;
+                while (need > 0) {
+                    if (p >= text_len) return false;
+                    const char* q = (const char*)memchr(text + p, '\n', (size_t)(text_len - p));
+                    const int64_t le = q ? (int64_t)(q - text) : text_len;
+                    const int64_t l1 = (le > p && text[le - 1] == '\r') ? le - 1 : le;
+                    const int64_t take = std::min<int64_t>(need, l1 - p);
+                    push(text + p, (size_t)take);
+                    need -= take;
+                    p = le + 1;
+                }
+                return true;
+            };
+            push(&at, 1); push(text + h0, (size_t)hl); push(&nl, 1);
+            if (!push_joined(s0)) { g_err = "record span outside the text"; return -1; }
+            push(plus, 3);
+            if (!push_joined(q0)) { g_err = "record span outside the text"; return -1; }
+            push(&nl, 1);
         }
         if (iov.size() > 1000 && !flush()) return -1;
     }

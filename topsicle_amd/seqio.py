@@ -414,16 +414,24 @@ class PackedBatch:
                 if b"\n" in head or b"\r" in head:    # wrapped (a sequence on one line has its n bases in front of the first line end)
                     raw = b"".join(ln[:-1] if ln.endswith(b"\r") else ln for ln in raw.split(b"\n"))
                 return raw[:n]
-            return self.text[s0:s0 + n]
+            return self._joined(s0, n)
         b = self.ascii_batch
         return b.bases[int(b.offsets[i]):int(b.offsets[i + 1])].tobytes()
+
+    def _joined(self, off: int, n: int) -> bytes:
+        """n sequence / quality characters of a FASTQ record from text offset `off` on: the n bytes themselves, or -- a multi-line
+        record (the reader joined it the same way for packing) -- the first n bytes that are not line ends."""
+        raw = self.text[off:off + n]
+        if b"\n" not in raw and b"\r" not in raw:
+            return raw
+        raw = self.text[off:off + 3 * n + 16]         # (at worst one character per CRLF line)
+        return raw.replace(b"\r", b"").replace(b"\n", b"")[:n]
 
     def qual_bytes(self, i: int):
         if self.fmt == "fasta":
             return None                       # (a FASTA span's fourth entry is the end of the sequence text, not a quality offset)
         if self.spans is not None:
-            q0 = int(self.spans[i, 3])
-            return self.text[q0:q0 + self.read_len(i)]
+            return self._joined(int(self.spans[i, 3]), self.read_len(i))
         b = self.ascii_batch
         return None if b.quals is None else b.quals[int(b.offsets[i]):int(b.offsets[i + 1])].tobytes()
 
@@ -588,8 +596,8 @@ def read_batches_packed(filepath: str, pool: BufferPool, max_records: int = 1 <<
             if n == 0:
                 return
             if n == -4:
-                packed_mode = False          # multi-line FASTQ / odd records: ASCII batches from here on
-                logging.info("%s: records the thread-team decoder does not take (multi-line FASTQ, blank or padded lines, lone CRs): "
+                packed_mode = False          # odd records: ASCII batches from here on
+                logging.info("%s: records the thread-team decoder does not take (blank or padded lines inside a record, lone CRs): "
                              "the one-thread streaming decoder reads the rest", filepath)
             elif n == -2:
                 raise RuntimeError("a single read does not fit the upload buffers; raise the batch size")
