@@ -512,3 +512,49 @@ def test_multiline_fastq_takes_the_thread_team_decoder(tmp_path, monkeypatch, nl
     got, kinds = packed(tmp_path / "blank.fastq")
     py = list(seqio.read_records(str(tmp_path / "blank.fastq")))
     assert [(x[1].decode(), x[2].decode()) for x in got] == [(r.seq, r.qual) for r in py] and kinds == {"ascii"}
+
+
+@pytest.mark.skipif(seqio._load_io() is None, reason="libtopsicle_io.so not built")
+def test_compressed_windows_are_inflated_and_indexed_only_for_who_uses_them(tmp_path):
+    """an ASCII consumer of bgzip'ed FASTA -- which the thread-team decoder does not serve -- used to inflate and
+    line-index a whole first window at open and throw it away; the packed decoder line-indexed every window it never looked at by
+    lines.  Now the first window is built by the first call that wants records, and the line index only for Fast::next.  The
+    library's own timing lines (TPS_IO_TIMING, a fresh process: the switch is read once) say what ran."""
+    import subprocess
+    import sys
+    rng = np.random.default_rng(5)
+    fa = b"".join(b">r%d\n" % i + bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), 3000)) + b"\n" for i in range(300))
+    fq = b"".join(b"@r%d\n" % i + bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), 3000)) + b"\n+\n" + b"I" * 3000 + b"\n" for i in range(300))
+    _write_bgzf(str(tmp_path / "a.fasta.gz"), fa)
+    _write_bgzf(str(tmp_path / "q.fastq.gz"), fq)
+    code = """
+import sys
+sys.path.insert(0, %r)
+from topsicle_amd import seqio
+mode, path = sys.argv[1], sys.argv[2]
+n = 0
+if mode == "ascii":
+    for b in seqio.read_batches(path):
+        n += len(b)
+else:
+    pool = seqio.BufferPool(2, 1 << 18, 4096)
+    for pb in seqio.read_batches_packed(path, pool):
+        assert pb.spans is not None
+        n += pb.n
+        pb.release()
+print("records", n)
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(mode, name):
+        r = subprocess.run([sys.executable, "-c", code, mode, str(tmp_path / name)], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, TPS_IO_TIMING="1"))
+        assert r.returncode == 0 and "records 300" in r.stdout, r.stdout + r.stderr
+        return r.stderr
+    err = run("ascii", "a.fasta.gz")
+    assert "bgzf group" not in err and "[tps_io] index" not in err, err       # nothing inflated by the team, nothing indexed
+    err = run("packed", "a.fasta.gz")
+    assert "bgzf group" in err and "[tps_io] index" not in err, err
+    err = run("packed", "q.fastq.gz")
+    assert "bgzf group" in err and "[tps_io] index" not in err, err
+    err = run("ascii", "q.fastq.gz")
+    assert "bgzf group" in err and "[tps_io] index" in err, err               # Fast::next works on the line index

@@ -453,7 +453,24 @@ struct Fast {
             size = hold->buf.size();
         }
     }
+    // ASCII consumers (next) want the line index of every window; the packed decoder (next_packed) never looks at it -- a window
+    // of inflated text is then only refilled (round 4: indexing 128 MB of lines per window for nothing).  `lazy`: a
+    // compressed source's FIRST window is inflated by the first call that wants records, not by tps_reader_open -- an ASCII consumer
+    // of compressed FASTA, which this decoder does not serve, no longer inflates a window it throws away.
+    bool want_lines = true, lines_valid = false, lazy = false;
+    void first_window() {
+        if (!lazy) return;
+        lazy = false;
+        index_window();                                  // first group of blocks; leading blank lines skipped like the streaming decoder does
+        while (pos < size && (data[pos] == '\n' || data[pos] == '\r' || data[pos] == ' ')) ++pos;
+        if (pos && want_lines) index_lines();
+    }
     void index_window() {
+        refill();
+        if (want_lines) { index_lines(); return; }
+        nl.clear(); nl_i = 0; lines_valid = false; whole = false; win_hi = size;
+    }
+    void refill() {
         if (src) {
             // a NEW buffer for the next group of blocks (batches already handed out keep pointing into the old one): the
             // unconsumed tail (a partial record) is copied to its front, the group is inflated behind it
@@ -474,6 +491,8 @@ struct Fast {
             data = hold->buf.data();
             size = hold->buf.size();
         }
+    }
+    void index_lines() {
         const double t_ix = io_timing() ? now_s() : 0.0;
         const size_t lo = pos, span = src ? size - lo : std::min<size_t>(size - lo, (size_t)512 << 20);
         win_hi = lo + span;
@@ -497,12 +516,17 @@ struct Fast {
         for (auto& v : part) nl.insert(nl.end(), v.begin(), v.end());
         if (whole && size && data[size - 1] != '\n') nl.push_back(size);      // last line without a newline
         nl_i = 0;
+        lines_valid = true;
         if (io_timing()) fprintf(stderr, "[tps_io] index %.2f ms: %zu bytes, %zu lines, %d threads\n", 1e3 * (now_s() - t_ix), span, nl.size(), T);
     }
     // >= 0: records decoded; -3: not plain 4-line FASTQ here -> caller switches to the streaming decoder at `pos`
     int64_t next(uint8_t* bases, int64_t bases_cap, int64_t* offsets, int64_t max_records, char* heads, int64_t heads_cap,
                  int64_t* head_off, uint8_t* quals) {
         if (fasta) return -3;                          // (ASCII batches of FASTA: the streaming decoder, from this byte on)
+        want_lines = true;
+        first_window();
+        if (src && src->failed) return -1;
+        if (!lines_valid) index_lines();               // (the packed decoder had the window before: same text, now with its lines)
         recs.clear();
         int64_t nb = 0, nh = 0;
         offsets[0] = 0;
@@ -964,11 +988,8 @@ int tps_reader_open(const char* path, void** out) {
                     f->src = z;
                     f->threads = z->threads;
                     f->pos = 0;
-                    f->index_window();                   // first group of blocks; leading blank lines skipped like the streaming decoder does
-                    while (f->pos < f->size && (f->data[f->pos] == '\n' || f->data[f->pos] == '\r' || f->data[f->pos] == ' ')) ++f->pos;
-                    if (f->pos) f->index_window();
+                    f->lazy = true;                      // (the first group of blocks is inflated by the first call that wants records)
                     h->fast = f;
-                    if (z->failed) { delete h; return -1; }        // (g_err says why; `f` owns `z`)
                     z = nullptr;
                 }
             }
@@ -997,11 +1018,8 @@ int tps_reader_open(const char* path, void** out) {
                 f->src = z;
                 f->threads = z->z.threads;
                 f->pos = 0;
-                f->index_window();
-                while (f->pos < f->size && (f->data[f->pos] == '\n' || f->data[f->pos] == '\r' || f->data[f->pos] == ' ')) ++f->pos;
-                if (f->pos) f->index_window();
+                f->lazy = true;
                 h->fast = f;
-                if (z->failed) { delete h; return -1; }            // (g_err says why; `f` owns `z`)
                 z = nullptr;
             }
         }
@@ -1106,6 +1124,9 @@ static int64_t reader_next_packed(void* hv, uint32_t* seq2, uint16_t* inv, int64
     if (!h->format) return 0;
     if (!h->fast) return -4;
     Fast* f = h->fast;
+    f->want_lines = false;
+    f->first_window();
+    if (f->src && f->src->failed) return -1;
     if (f->src) {
         f->top_up((size_t)std::max<int64_t>(words_cap, 1024) * 32);      // (a batch's worth of text in the window, if it can still grow)
         if (f->src->failed) return -1;
