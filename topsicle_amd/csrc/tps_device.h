@@ -184,14 +184,29 @@ TPS_DEV uint32_t lut_at_tile(const uint32_t* lut, uint32_t v4, uint32_t amask) {
 #endif
 #endif
 
+#ifndef TPS_WIDE16_MODE
+#define TPS_WIDE16_MODE 1         // (0: A/B builds without the pin of lut16_at_wide)
+#endif
 // 16-bit table entry (LUT_M16 tables: one pattern mask per k-mer code) at byte offset `off2` (already masked to the table size)
 #ifdef TPS_EMU
 TPS_DEV uint32_t lut16_at(const uint32_t* lut, uint32_t v2, uint32_t amask1) { return *(const uint16_t*)((const char*)lut + (v2 & amask1)); }
+#define lut16_at_wide lut16_at
 #else
 TPS_DEV uint32_t lut16_at(const uint32_t* lut, uint32_t v2, uint32_t amask1) {
     typedef const __attribute__((address_space(3))) uint16_t* lptr16_t;
     const uint32_t base = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t*)lut;
     return *(lptr16_t)(uintptr_t)((v2 & amask1) | base);      // ds_read_u16: zero-extended
+}
+// ... for the sums tiles of the self-overlap tables (tile_lc_s<.., CD>), opaque to the optimiser: it otherwise narrows everything
+// computed from these values to 16-bit arithmetic and legalises that with one `v_and_b32 0xffff` per entry -- 6 of a block's 57 VALU
+// instructions (k = 5 sums 107.4 -> 105.7 us, k = 6 142.5 -> 140.6; the raw-row tiles' look-ups are better off without:
+// `_s6sorh` 211.6 -> 219.2 us with it, the waits move up to the loads)
+TPS_DEV uint32_t lut16_at_wide(const uint32_t* lut, uint32_t v2, uint32_t amask1) {
+    uint32_t h = lut16_at(lut, v2, amask1);
+#if TPS_WIDE16_MODE == 1
+    asm("" : "+v"(h));
+#endif
+    return h;
 }
 #endif
 
@@ -2005,7 +2020,7 @@ TPS_DEV void tile_lc_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
                 for (int i = 0; i < S; ++i) {
                     if (i < cnt_) {
                         const int p = blk * S + i;
-                        uint32_t h = M16 ? lut16_at(l.lut, v4_at(p), amask) : lut_at(l.lut, v4_at(p), amask);
+                        uint32_t h = M16 ? lut16_at_wide(l.lut, v4_at(p), amask) : lut_at(l.lut, v4_at(p), amask);
                         if (INV) {
                             if (h && invalid_at(l.val, p0 + p, pat.k)) h = 0;   // tiles with non-ACGT letters only
                         }
@@ -2020,7 +2035,7 @@ TPS_DEV void tile_lc_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
             uint32_t hb[NB_];                             // CD: the entries of the CD positions before the block
             if constexpr (CD > 0) {
                 TPS_UNROLL
-                for (int i = 0; i < CD; ++i) hb[i] = lut16_at(l.lut, v4_at(i - CD), amask);
+                for (int i = 0; i < CD; ++i) hb[i] = lut16_at_wide(l.lut, v4_at(i - CD), amask);
             }
             TPS_UNROLL
             for (int blk = 0; blk < B; ++blk) {
