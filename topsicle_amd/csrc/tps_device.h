@@ -1929,25 +1929,34 @@ TPS_DEV void tile_lc_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
     // (CD) a chain of three or more occurrences CD apart, first element at tile position tp (it may lie before the tile), pattern
     // mask pm: the pair count takes n - 1 off a window that holds n consecutive elements, finditer counts ceil(n / 2) = n - (n - 1)
     // + floor((n - 1) / 2) -- the steps of floor((n - 1) / 2), window by window, go to the difference array (any length, exact)
-    auto long_chain_steps = [&](int tp, uint32_t pm) {
+    // One chain at a time, its windows spread over the wave's lanes (round 4: the lane that found a chain used to walk its ~20
+    // windows alone, ~400 instructions with 63 lanes masked off -- two such chains per telomeric tile at k = 6 and ONT error rates
+    // made that tile's first phase twice as long as any other's): chain_len() is wave-uniform, chain_window() is lane `ln`'s share.
+    auto chain_len = [&](int tp, uint32_t pm) -> int {
         constexpr int CD = CD_ > 0 ? CD_ : 1;     // (never called for CD_ = 0; keeps the divisions below well-formed)
-        const int lw = a.lw;
-        auto occ = [&](int pos) -> bool { return (lut_mask(l.lut, l.lshift, pat, v_at(l.seq2, delta + pos)) & pm) != 0; };
-        auto w_in = [&](int e) -> int { const int x = e - lw + 1; return x <= 0 ? 0 : (x + S - 1) / S; };     // first window that holds position e
-        auto step = [&](int w, uint32_t d) { if (w < NT * B) lds_add(&l.row[w + (w >> LOG2B)], d); };
+        auto occ = [&](int pos) -> bool { return uniform(lut_mask(l.lut, l.lshift, pat, v_at(l.seq2, delta + pos)) & pm) != 0u; };
         const int tend = NT * POS;                                           // positions of the tile
         int c = 3;
         while (tp + c * CD < tend && occ(tp + c * CD)) ++c;
-        int prev = 0;
-        const int wb = (tp + (c - 1) * CD) / S + 1;
-        for (int w = w_in(tp < 0 ? 0 : tp); w <= wb && w <= NT * B; ++w) {
+        return c;
+    };
+    auto chain_windows = [&](int tp, int c, int ln) {
+        constexpr int CD = CD_ > 0 ? CD_ : 1;
+        const int lw = a.lw;
+        auto w_in = [&](int e) -> int { const int x = e - lw + 1; return x <= 0 ? 0 : (x + S - 1) / S; };     // first window that holds position e
+        auto cur_of = [&](int w) -> int {
             // chain elements j with w S <= tp + j CD < w S + lw
             const int a0 = w * S - tp, a1 = w * S + lw - 1 - tp;
             int jlo = a0 <= 0 ? 0 : (a0 + CD - 1) / CD, jhi = a1 < 0 ? -1 : a1 / CD;
             if (jhi > c - 1) jhi = c - 1;
-            const int cur = jhi > jlo ? (jhi - jlo) >> 1 : 0;
-            if (cur != prev) step(w, (uint32_t)(cur - prev));
-            prev = cur;
+            return jhi > jlo ? (jhi - jlo) >> 1 : 0;
+        };
+        const int wf = w_in(tp < 0 ? 0 : tp);
+        int wb = (tp + (c - 1) * CD) / S + 1;     // the first window behind the chain: the last step (back to 0)
+        if (wb > NT * B - 1) wb = NT * B - 1;     // (steps at or behind the tile's last window slot are nobody's)
+        for (int w = wf + ln; w <= wb; w += NT) {
+            const int cur = cur_of(w), prev = w == wf ? 0 : cur_of(w - 1);
+            if (cur != prev) lds_add(&l.row[w + (w >> LOG2B)], (uint32_t)(cur - prev));
         }
     };
     TPS_PHASE {
@@ -2181,19 +2190,33 @@ TPS_DEV void tile_lc_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
                     for (int i = 0; i < B + 1; ++i) l.row[tid + i * NT] = 0;      // the difference array, indexed by padded window
                 }
                 TPS_SYNC();
-                TPS_PHASE {
-#ifdef TPS_EMU
-                    head3_lo = head3_keep[tid][0]; head3_hi = head3_keep[tid][1];
-#endif
-                    while (head3_lo | head3_hi) {
+                // every chain in turn (owner lane by owner lane, bit by bit: all of it wave-uniform), its windows lane-parallel
+                auto one_owner = [&](int src, uint32_t h_lo, uint32_t h_hi, auto&& each_lane) {
+                    while (h_lo | h_hi) {
                         int e;
-                        if (head3_lo) { e = ffs0(head3_lo); head3_lo &= head3_lo - 1u; }
-                        else { e = 32 + ffs0(head3_hi); head3_hi &= head3_hi - 1u; }
-                        const int te = tid * POS + e;                             // tile position of the chain's SECOND element
-                        const uint32_t pm = lut_mask(l.lut, l.lshift, pat, v_at(l.seq2, delta + te));
-                        long_chain_steps(te - CD, pm);
+                        if (h_lo) { e = ffs0(h_lo); h_lo &= h_lo - 1u; }
+                        else { e = 32 + ffs0(h_hi); h_hi &= h_hi - 1u; }
+                        const int te = src * POS + e;                             // tile position of the chain's SECOND element
+                        const uint32_t pm = uniform(lut_mask(l.lut, l.lshift, pat, v_at(l.seq2, delta + te)));
+                        const int c = chain_len(te - CD, pm);
+                        each_lane(te - CD, c);
+                    }
+                };
+#ifdef TPS_EMU
+                for (int src = 0; src < NT; ++src)
+                    one_owner(src, head3_keep[src][0], head3_keep[src][1], [&](int tp, int c) { for (int ln = 0; ln < NT; ++ln) chain_windows(tp, c, ln); });
+#else
+                {
+                    const int ln = tps_fresh_lane();
+                    uint64_t owners = __builtin_amdgcn_ballot_w64((head3_lo | head3_hi) != 0u);
+                    while (owners) {
+                        const int src = __builtin_ctzll(owners);
+                        owners &= owners - 1ull;
+                        const uint32_t h_lo = (uint32_t)__builtin_amdgcn_readlane((int)head3_lo, src), h_hi = (uint32_t)__builtin_amdgcn_readlane((int)head3_hi, src);
+                        one_owner(src, h_lo, h_hi, [&](int tp, int c) { chain_windows(tp, c, ln); });
                     }
                 }
+#endif
                 lane_chain = 1u;                      // (uniform: some lane added steps)
             }
         }
