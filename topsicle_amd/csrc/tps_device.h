@@ -161,7 +161,10 @@ TPS_DEV uint32_t bitrev32(uint32_t x) { return __builtin_bitreverse32(x); }     
 
 // table entry at byte offset `off` (already masked to the table size).  The table starts at the
 // workgroup's LDS offset 0, i.e. it is aligned to any power of two, so base | off == base + off and the
-// mask + base fold into one v_and_or_b32.
+// mask + base fold into one v_and_or_b32 -- where the base is a known 0 (every kernel's first table) into one v_and; with mask and
+// base both in SGPRs (the single table of the pair-table kernels: 8 lookups per tile at odd r, step 1's) it comes out as v_and +
+// v_or, a VOP3 instruction reading one scalar register only on gfx9.  The base pinned into a VGPR gives the one instruction, 6 VALU
+// per tile less -- and measures nothing at config 2 (55.0 / 54.8 against 54.8 / 55.0 us), +1 % on the kernels whose base is 0: not kept.
 #ifdef TPS_EMU
 TPS_DEV uint32_t lut_at(const uint32_t* lut, uint32_t v4, uint32_t amask) { return *(const uint32_t*)((const char*)lut + (v4 & amask)); }
 #define lut_at_tile lut_at
