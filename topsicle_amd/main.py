@@ -153,7 +153,7 @@ def process_file_multi(args, seq_loc, phrases, engines):
     rows = [[] for _ in phrases]
     image_num = [1] * len(phrases)
     npz = getattr(args, "rawcountformat", "csv") == "npz"
-    raw_npz = [{"read_id": [], "tail": [], "n_win": [], "counts": []} if npz else None for _ in phrases]
+    raw_npz = [_RawNpz(args, file_name, telo_phrase, pattern, sliding_val) if npz else None for telo_phrase, pattern, sliding_val in phrases]
     csv_path = f"{args.outputDir}/telolengths_all.csv"
     pool = batch.EnginePool(engines, two_pass=getattr(args, "twopass", "auto"))
     # the passing records are written by a helper thread, batch by batch in file order, while the next batches are scanned
@@ -213,10 +213,7 @@ def process_file_multi(args, seq_loc, phrases, engines):
                         if args.rawcountpattern:
                             block = raw[win_off[i]:win_off[i + 1]]
                             if raw_npz[n] is not None:
-                                raw_npz[n]["read_id"].append(ids[j])
-                                raw_npz[n]["tail"].append(tail)
-                                raw_npz[n]["n_win"].append(block.shape[0])
-                                raw_npz[n]["counts"].append(np.array(block, dtype=np.uint8))
+                                raw_npz[n].add(ids[j], tail, block)
                             else:
                                 _write_rawcount(args, telo_phrase, image_num[n] + j, pattern, sliding_val, block, tail)
                 image_num[n] += len(idx)
@@ -227,10 +224,13 @@ def process_file_multi(args, seq_loc, phrases, engines):
         if out_handle is not None:
             out_handle.close()
     if werr:
+        for w in raw_npz:
+            if w is not None:
+                w.discard()
         raise werr[0]
-    for n, (telo_phrase, pattern, sliding_val) in enumerate(phrases):
-        if raw_npz[n] is not None and raw_npz[n]["read_id"]:
-            _write_rawcount_npz(args, file_name, telo_phrase, pattern, sliding_val, raw_npz[n])
+    for w in raw_npz:
+        if w is not None:
+            w.finish()
     if out_handle is not None:
         tprint(f"Temporary fasta file with TRC more than {min_cutoff}:", fasta_temp)
     st = pool.stats
@@ -253,17 +253,59 @@ def _write_rawcount(args, telo_phrase, image_num, pattern, slide, block, tail):
     df.to_csv(f"{args.outputDir}/rawcount_{telo_phrase}_{image_num}.csv")
 
 
-def _write_rawcount_npz(args, file_name, telo_phrase, pattern, slide, acc):
+class _RawNpz:
     """--rawcountformat npz (an extension, not an upstream flag): ONE columnar file per input file and k instead of
     one 1.2 MB CSV per read -- the same numbers: counts[win_off[i]:win_off[i+1], p] is read i's count of pattern p in
     the window that starts at position (w - win_off[i]) * slide (the CSV volume is what bounds the
-    raw-count workload end to end)."""
-    n_win = np.array(acc["n_win"], dtype=np.int64)
-    win_off = np.zeros(len(n_win) + 1, dtype=np.int64)
-    np.cumsum(n_win, out=win_off[1:])
-    counts = np.concatenate(acc["counts"], axis=0) if len(acc["counts"]) else np.zeros((0, len(pattern)), np.uint8)
-    np.savez(f"{args.outputDir}/rawcount_{telo_phrase}_{file_name}.npz", read_id=np.array(acc["read_id"]), tail=np.array(acc["tail"]),
-             win_off=win_off, counts=counts, pattern=np.array(pattern), slide=np.int64(slide))
+    raw-count workload end to end).  The rows go to a spool file beside the output as the batches arrive and are copied into
+    the archive at the end (round 4: a file's rows used to stay in memory until then -- 14 GB resident for BASELINE configs[4]'s
+    per-GPU shard with three k); what stays in memory is one id, one tail and one length per passing read."""
+
+    def __init__(self, args, file_name, telo_phrase, pattern, slide):
+        self.path = f"{args.outputDir}/rawcount_{telo_phrase}_{file_name}.npz"
+        self.pattern, self.slide = list(pattern), int(slide)
+        self.read_id, self.tail, self.n_win = [], [], []
+        self.spool = None
+        self.rows = 0
+
+    def add(self, read_id, tail, block):
+        if self.spool is None:
+            self.spool = open(self.path + ".rows", "w+b")
+        b = np.ascontiguousarray(block, dtype=np.uint8)
+        self.spool.write(memoryview(b).cast("B"))
+        self.read_id.append(read_id)
+        self.tail.append(tail)
+        self.n_win.append(b.shape[0])
+        self.rows += b.shape[0]
+
+    def discard(self):
+        if self.spool is not None:
+            self.spool.close()
+            os.unlink(self.path + ".rows")
+            self.spool = None
+
+    def finish(self):
+        """The archive np.savez would write (stored, not deflated): small members through numpy, `counts` streamed from the spool."""
+        if not self.read_id:
+            self.discard()
+            return
+        import shutil
+        import zipfile
+        n_win = np.array(self.n_win, dtype=np.int64)
+        win_off = np.zeros(len(n_win) + 1, dtype=np.int64)
+        np.cumsum(n_win, out=win_off[1:])
+        small = dict(read_id=np.array(self.read_id), tail=np.array(self.tail), win_off=win_off, pattern=np.array(self.pattern),
+                     slide=np.int64(self.slide))
+        with zipfile.ZipFile(self.path, "w", zipfile.ZIP_STORED, allowZip64=True) as z:
+            for name, arr in small.items():
+                with z.open(name + ".npy", "w", force_zip64=True) as h:
+                    np.lib.format.write_array(h, np.asanyarray(arr), allow_pickle=False)
+            with z.open("counts.npy", "w", force_zip64=True) as h:
+                np.lib.format.write_array_header_1_0(h, {"descr": "|u1", "fortran_order": False, "shape": (int(self.rows), len(self.pattern))})
+                self.spool.flush()
+                self.spool.seek(0)
+                shutil.copyfileobj(self.spool, h, 16 << 20)
+        self.discard()
 
 
 def analysis_run(args, engines=None, engine_factory=None, wait_plots=True):
