@@ -817,9 +817,11 @@ TPS_DEV void trc_count_packed(const ScanArgs& a, const Lds& l, const Stage& st_s
         }
         const bool last_pass = 16 * (c0 + 32) + 32 > npos;      // uniform: the pass that holds the end of the head
         if (last_pass) {
+            int nv = npos - 16 * c;                  // start positions of the head in this lane's chunk (<= 0: none)
+            TPS_PIN_V(nv);                           // (one subtraction, then compares against constants -- not an add per position)
             TPS_UNROLL
             for (int j = 0; j < 16; ++j)
-                if (16 * c + j >= npos) h[j] = 0;
+                if (j >= nv) h[j] = 0;
         }
         TPS_UNROLL
         for (int half = 0; half < 2; ++half) {
