@@ -438,18 +438,26 @@ def main():
     # the serialised region above gives the kernel's own duration (the roofline) and `single_stream`.
     dt_serial = dt
     piped = None
+    pipe, pipe_err = None, None
     if len(tables) == 1 and args.streams > 1:
-        pipe = [sc] + [sc.helper(j) for j in range(args.streams - 1)]
-        for eng in pipe[1:]:
-            eng.set_patterns(pats)
-            for s in range(copies):
-                eng.share(s, sc, s)
+        try:                                       # (a rank that cannot set its second context up must not leave the others in a barrier)
+            pipe = [sc] + [sc.helper(j) for j in range(args.streams - 1)]
+            for eng in pipe[1:]:
+                eng.set_patterns(pats)
+                for s in range(copies):
+                    eng.share(s, sc, s)
+            for i in range(max(args.warmup, 4 * len(pipe))):
+                pipe[i % len(pipe)].scan(i % copies, prm)
+            for eng in pipe:
+                eng.sync()
+        except Exception as e:
+            pipe_err = repr(e)
+        if grp.max(1.0 if pipe_err else 0.0) > 0.0:       # every rank or none
+            pipe = None
+    if pipe is not None:
         def sync_pipe():
             for eng in pipe:
                 eng.sync()
-        for i in range(max(args.warmup, 4 * len(pipe))):
-            pipe[i % len(pipe)].scan(i % copies, prm)
-        sync_pipe()
         grp.barrier()
         for eng in pipe:
             eng.kernel_time_reset()
@@ -539,6 +547,7 @@ def main():
             "streams": piped["streams"] if piped else (len(tables) if concurrent else 1),
             # strictly one launch after the other (the region the roofline's kernel duration comes from)
             "single_stream": {"value": touched * world * args.steps / dt_serial, "ms_per_step": dt_serial / args.steps * 1e3},
+            **({"pipelined_error": pipe_err} if pipe_err else {}),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
