@@ -95,6 +95,10 @@ extern "C" int emu_scan(const char* pats, int P, int k, const uint8_t* bases, co
     for (size_t i = 0; i < lut.size(); ++i)
         lut1[i] = !a.variant ? lut[i] : a.lut_fields ? tps::mask_to_fields(lut[i])                 // raw-count kernels on the per-pattern tiles: one-hot fields
                                                      : ((lut[i] << 16) | (uint32_t)__builtin_popcount(lut[i]));   // fused kernels: mask << 16 | count
+    if (a.pair16) {                                // k = 5 pair-table kernels (_s*q): 4^(k+1) 16-bit masks, the two positions' masks ORed
+        for (int c = 0; c < 2 * a.pair_n; ++c)
+            ((uint16_t*)lutbuf.data())[c] = (uint16_t)(lut[(size_t)(c & (int)a.pat.kmask)] | lut[(size_t)((c >> 2) & (int)a.pat.kmask)]);
+    } else
     for (int c = 0; c < a.pair_n; ++c) {
         const uint32_t e1 = lut1[c & a.pat.kmask], e2 = lut1[(c >> 2) & a.pat.kmask];
         lutbuf[(size_t)c] = ((e1 | e2) & 0xFFFF0000u) | ((e1 + e2) & 0xFFFFu);
@@ -114,6 +118,7 @@ extern "C" int emu_scan(const char* pats, int P, int k, const uint8_t* bases, co
             else if (so && want_raw) tps::scan_read<S, true, false, true>(a, r, lds.data(), lut1);               \
             else if (so) tps::scan_read<S, true, false, false>(a, r, lds.data(), lut1);                          \
             else if (want_raw) tps::scan_read<S, false, false, true>(a, r, lds.data(), lut1);                    \
+            else if (a.pair_n && a.pair16) tps::scan_read<S, false, true, false, tps::tile_full_default(S), 4>(a, r, lds.data(), lut1); \
             else if (a.pair_n) tps::scan_read<S, false, true, false>(a, r, lds.data(), lut1);                    \
             else tps::scan_read<S, false, false, false>(a, r, lds.data(), lut1);                                 \
             break;

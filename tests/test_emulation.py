@@ -659,3 +659,44 @@ def test_emulation_raw_rows_clean_batch_layout(motif, k, slide, units, monkeypat
         assert np.array_equal(out["raw"][lo:hi], counts), i
         assert np.array_equal(out["sums"][lo:hi], counts.sum(axis=1)), i
         assert out["results"][i]["bkp"] == orc.binseg_l2_exact(counts.sum(axis=1))
+
+
+@pytest.mark.parametrize("motif,slide,W", [("AAACCCT", 7, 100), ("CCCTAAA", 6, 100), ("AAACCCT", 5, 100), ("CCCTAAA", 8, 260), ("TTTAGGG", 6, 101)])
+def test_emulation_k5_pair_table_of_16_bit_masks(motif, slide, W, monkeypatch):
+    """Round 4: k = 5 tables without self-overlap (the plant-type 7-mer motifs at the reference's default k) take two positions per
+    lookup from a 16-bit pair table (ScanArgs::pair16, kernels _s*q; the single table in the same format).  On the device the planner
+    picks it by itself (8-wave workgroups); the emulation's slices are bigger, so the test forces it.  Step 1, window sums and the
+    boundary against the oracle -- reads of several tiles, both strands, a read with N, lower case."""
+    monkeypatch.setenv("TPS_FORCE_PAIR", "1")
+    k = 5
+    pats = orc.kmer_table(motif, k)
+    prm = hiplib.make_params(no_bp=1000, min_len=0, min_count=-1, window=W, slide=slide, trimfirst=100, maxlen=20000,
+                             flags=hiplib.F_STEP1 | hiplib.F_WINDOWS | hiplib.F_BINSEG | hiplib.F_STORE_SUMS)
+    pl = emu.plan_table(pats, prm, 3000)
+    assert pl["variant"] == slide and pl["pair_n"] == 4 ** (k + 1) // 2, pl
+    rng = np.random.default_rng(slide * 13 + W)
+    comp = str.maketrans("ACGTacgt", "TGCAtgca")
+    seqs = []
+    for i in range(5):
+        L = int(rng.integers(4000, 9000))
+        tract = int(rng.integers(600, 3500))
+        body = list((motif * (tract // len(motif) + 2))[:tract] + "".join("ACGT"[x] for x in rng.integers(0, 4, L - tract)))
+        for p in rng.integers(0, L, L // 14):
+            body[p] = "ACGT"[int(rng.integers(4))]
+        if i == 3:
+            body[int(rng.integers(1200, L))] = "N"
+        if i == 4:
+            body[50:400] = [c.lower() for c in body[50:400]]
+        sq = "".join(body)
+        seqs.append(sq if i % 2 == 0 else sq[::-1].translate(comp))
+    out = emu.scan(pats, seqs, prm)
+    for i, seq in enumerate(seqs):
+        cs, ce = orc.trc_counts(seq, pats, 1000)
+        assert out["c_start"][i].tolist() == cs and out["c_end"][i].tolist() == ce, i
+        r = out["results"][i]
+        tail = "forward" if r["tail"] == 0 else "reverse"
+        _, counts = orc.window_count_matrix(seq, tail, pats, W, slide, 100, 20000)
+        lo, hi = out["win_off"][i], out["win_off"][i + 1]
+        assert hi - lo == counts.shape[0] and hi - lo > 500
+        assert np.array_equal(out["sums"][lo:hi], counts.sum(axis=1)), i
+        assert r["bkp"] == orc.binseg_l2_exact(counts.sum(axis=1)), i

@@ -186,7 +186,7 @@ struct tps_ctx {
     hipDeviceProp_t prop{};
     // dev: [4^k masks][pair table, k <= 4][ready-made LDS images of the table for the fused kernels, each a multiple of 4 dwords:
     // mask << 16 | count, one-hot fields, 16-bit masks -- a workgroup copies its image in 16-byte pieces instead of converting it]
-    struct Table { DevBuf dev; int P = 0, k = 0; std::string key; tps::PatInfo pat{}; size_t off_e32 = 0, off_fld = 0, off_m16 = 0, off_f16 = 0; };
+    struct Table { DevBuf dev; int P = 0, k = 0; std::string key; tps::PatInfo pat{}; size_t off_e32 = 0, off_fld = 0, off_m16 = 0, off_f16 = 0, off_p16 = 0; };
     std::deque<Table> tables;         // resident pattern tables (deque: pointers to elements stay valid)
     Table* lut_cur = nullptr;
     size_t table_rr = 0;
@@ -209,7 +209,7 @@ struct tps_ctx {
     int zero_copy = 1;       // per-read results are written by the kernel straight into mapped pinned host memory
     int force_generic = 0;
     int64_t lds_target_dw = 32 * 256;
-    size_t lds_set_v[32] = {0};
+    size_t lds_set_v[40] = {0};
     uint32_t* h_flag = nullptr;      // mapped host word the pack kernel raises when a read has a non-ACGT letter
     hipEvent_t share_ev = nullptr;   // tps_batch_share: orders this context's stream behind the lender's upload
 };
@@ -384,6 +384,7 @@ int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm) {
     a.desc = (const tps_read_desc*)sl.desc.p;
     a.tails_in = ((prm.flags & TPS_F_TAILS_IN) && !(prm.flags & TPS_F_STEP1)) ? (const uint8_t*)sl.tails.p : nullptr;
     a.lut = (const uint32_t*)c->lut_cur->dev.p;
+    a.pair_img = a.lut + (a.pair16 ? c->lut_cur->off_p16 : (size_t)a.lut_n);      // (the 32-bit pair table follows the 4^k masks)
     a.lut_img = a.lut + ((a.lut16 && a.lut_fields) ? c->lut_cur->off_f16 : a.lut16 ? c->lut_cur->off_m16 : a.lut_fields ? c->lut_cur->off_fld : c->lut_cur->off_e32);
     a.results = c->zero_copy ? sl.h_results : (tps_read_result*)sl.results.p;
     a.c_start = a.c_end = nullptr;
@@ -452,12 +453,14 @@ int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm) {
                                   {(const void*)tps_scan_kernel_s7sor, "tps_scan_kernel_s7sor"}, {(const void*)tps_scan_kernel_s8sor, "tps_scan_kernel_s8sor"}};
         static const K sorhk[4] = {{(const void*)tps_scan_kernel_s5sorh, "tps_scan_kernel_s5sorh"}, {(const void*)tps_scan_kernel_s6sorh, "tps_scan_kernel_s6sorh"},
                                    {(const void*)tps_scan_kernel_s7sorh, "tps_scan_kernel_s7sorh"}, {(const void*)tps_scan_kernel_s8sorh, "tps_scan_kernel_s8sorh"}};
+        static const K pairqk[4] = {{(const void*)tps_scan_kernel_s5q, "tps_scan_kernel_s5q"}, {(const void*)tps_scan_kernel_s6q, "tps_scan_kernel_s6q"},
+                                    {(const void*)tps_scan_kernel_s7q, "tps_scan_kernel_s7q"}, {(const void*)tps_scan_kernel_s8q, "tps_scan_kernel_s8q"}};
         static const K solk[4] = {{(const void*)tps_scan_kernel_s5sol, "tps_scan_kernel_s5sol"}, {(const void*)tps_scan_kernel_s6sol, "tps_scan_kernel_s6sol"},
                                   {(const void*)tps_scan_kernel_s7sol, "tps_scan_kernel_s7sol"}, {(const void*)tps_scan_kernel_s8sol, "tps_scan_kernel_s8sol"}};
         if (a.variant >= 5 && a.variant <= 8) {
             // sums only, self-overlap table: periods 2 .. 4 have their own kernels (96 registers, 5 waves per SIMD)
-            const int fam = so ? (want_raw ? (a.lut16 ? 6 : 4) : (a.pp_d >= 2 && a.pp_d <= 4) ? 5 : 3) : want_raw ? 2 : pair ? 1 : 0;
-            const K* tab[7] = {plain, pairk, rawk, sok, sork, solk, sorhk};
+            const int fam = so ? (want_raw ? (a.lut16 ? 6 : 4) : (a.pp_d >= 2 && a.pp_d <= 4) ? 5 : 3) : want_raw ? 2 : (pair && a.pair16) ? 7 : pair ? 1 : 0;
+            const K* tab[8] = {plain, pairk, rawk, sok, sork, solk, sorhk, pairqk};
             const K& k = tab[fam][a.variant - 5];
             kfn = k.fn;
             sl.kernel_name = k.name;
@@ -627,7 +630,7 @@ int tps_set_patterns(tps_ctx* c, const char* pats, int32_t P, int32_t k) {
             lut[n1 + cc] = ((m1 | m2) << 16) | (uint32_t)(__builtin_popcount(m1) + __builtin_popcount(m2));
         }
     }
-    size_t off_e32 = 0, off_fld = 0, off_m16 = 0, off_f16 = 0;
+    size_t off_e32 = 0, off_fld = 0, off_m16 = 0, off_f16 = 0, off_p16 = 0;
     if (!pi.hash_shift) {
         const size_t n1 = (size_t)1 << (2 * k), n4 = (n1 + 3) & ~(size_t)3, n16 = ((n1 + 1) / 2 + 3) & ~(size_t)3;
         off_e32 = (lut.size() + 3) & ~(size_t)3;       // (16-byte aligned: the kernels copy uint4)
@@ -643,6 +646,15 @@ int tps_set_patterns(tps_ctx* c, const char* pats, int32_t P, int32_t k) {
             // (field index of THE pattern: tables with duplicate k-mers never take the kernels that read this image)
             ((uint16_t*)&lut[off_f16])[i] = m ? (uint16_t)(1u << tps::pp_field(__builtin_ctz(m))) : (uint16_t)0;
         }
+        if (k == 5 && P <= 16) {
+            // 16-bit pair table of the _s*q kernels (ScanArgs::pair16): entry of the (k+1)-mer code c = the masks of the k-mers at p
+            // and p + 1 ORed (counts are popcounts: the planner takes it for tables without self-overlap only)
+            const size_t n2 = n1 * 4;
+            off_p16 = lut.size();                       // (a multiple of 4 dwords)
+            lut.resize(off_p16 + n2 / 2, 0u);
+            for (size_t cc = 0; cc < n2; ++cc)
+                ((uint16_t*)&lut[off_p16])[cc] = (uint16_t)(lut[cc & (n1 - 1)] | lut[(cc >> 2) & (n1 - 1)]);
+        }
     }
     HIP_TRY(hipStreamSynchronize(c->stream));          // no launch may still be reading the table that gets recycled
     tps_ctx::Table* slot = nullptr;
@@ -652,7 +664,7 @@ int tps_set_patterns(tps_ctx* c, const char* pats, int32_t P, int32_t k) {
     HIP_TRY(hipMemcpyAsync(slot->dev.p, lut.data(), lut.size() * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     slot->P = P; slot->k = k; slot->key = key; slot->pat = pi;
-    slot->off_e32 = off_e32; slot->off_fld = off_fld; slot->off_m16 = off_m16; slot->off_f16 = off_f16;
+    slot->off_e32 = off_e32; slot->off_fld = off_fld; slot->off_m16 = off_m16; slot->off_f16 = off_f16; slot->off_p16 = off_p16;
     c->lut_cur = slot;
     c->pat = pi;
     c->have_pat = true;

@@ -295,6 +295,7 @@ struct ScanArgs {
     const uint8_t* tails_in;     // n, or nullptr
     const uint32_t* lut;         // 4^k masks over the pattern list (+ the pair table behind them)
     const uint32_t* lut_img;     // fused kernels: the table as it sits in LDS (mask << 16 | count, one-hot fields or 16-bit masks: lut_dw(a) dwords)
+    const uint32_t* pair_img;    // pair-table kernels: the pair table as it sits in LDS (pair_n dwords: mask << 16 | count per (k+1)-mer, or -- pair16 -- 16-bit masks)
     tps_read_result* results;    // n
     int32_t* c_start;            // n*P or nullptr
     int32_t* c_end;              // n*P or nullptr
@@ -349,6 +350,8 @@ struct ScanArgs {
     int32_t xt_alias;            // 1: ... and their XT words (written behind a tile's window phase) share LDS with the head of the staged bases;
                                  // 2: the raw-row kernels -- the per-pattern tiles keep their lane totals in END's pad words and need no XF / XT
     int32_t xt_own;              // xt_alias kernels whose fallback tile may run (non-ACGT letters in the batch, TPS_NO_SO_FAST): XT gets its own words
+    int32_t pair16;              // k = 5 tables without self-overlap, sums only (kernels _s*q): BOTH tables as 16-bit pattern masks -- the pair table of
+                                 // 4^6 (k+1)-mers is 8 KB instead of 16, shared by the 8 waves of a workgroup (lut16 is set as well)
 };
 
 struct BinsegArgs {
@@ -993,9 +996,10 @@ TPS_DEV void trc_sum_packed(const ScanArgs& a, const Lds& l, const Stage& st_s, 
 // instead of parking 16 bytes per lane in LDS, a barrier, 32 byte reads by each of P lanes, an LDS atomic max, another barrier
 // and two uniform reads (a fifth of step 1's latency, which every read pays before its first tile can be requested).
 // Returns the keys count << 5 | (31 - p) of the first pattern with the largest count, per side.
+template <int FMT = 0>
 TPS_DEV void trc_decide_packed(const ScanArgs& a, const Lds& l, const Stage& st_s, const Stage& st_e, int64_t r, uint32_t& ks, uint32_t& ke) {
     uint32_t x[4];
-    TPS_PHASE { trc_count_packed<false, false>(a, l, st_s, st_e, tid, x); }
+    TPS_PHASE { trc_count_packed<false, FMT>(a, l, st_s, st_e, tid, x); }
     uint32_t s0[4], s1[4];
     TPS_UNROLL
     for (int w = 0; w < 4; ++w) {
@@ -1891,17 +1895,19 @@ TPS_DEV void g_store16_clamped(uint32_t* base, int n_dw, int cdw, const u32x4& t
 // first window that holds both and -1 behind the last.  Tiles with a chain (most telomeric tiles at k = 6, few elsewhere)
 // then prefix-sum the array and subtract.  This replaces the canonical-pick tile of round 2 (tile_so_s: one dependent pick
 // per position in every lane of every chained tile, 2.3 x a plain tile) and its chain-parity repairs.
-template <int S, bool INV, int RPT, bool PAIR, bool ROTZ, int CD_ = 0>
+template <int S, bool INV, int RPT, bool PAIR, bool ROTZ, int CD_ = 0, bool P16_ = false>
 TPS_DEV void tile_lc_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int delta, int w0, int tile, int nw_tile,
                        int64_t out_base, uint64_t& s_total, int64_t r) {
     static_assert(!(PAIR && INV), "pair lookups need per-position independence");
     constexpr int CD = CD_;
     static_assert(CD == 0 || (!PAIR && !INV && CD <= S), "chain corrections: single lookups on clean tiles, period <= slide");
+    static_assert(!(P16_ && CD_ > 0), "the 16-bit pair table is for tables without self-overlap");
     constexpr bool RZ = RPT == 0;
     // M16: the kernels that run the chain-corrected tiles keep their LDS table as 16-bit pattern masks (ScanArgs::lut16): a block's
     // OR is the masks' OR, its match count their popcounts added up (v_bcnt_u32_b32: one instruction, like the add it replaces);
     // the published words keep the layout mask << 16 | count
-    constexpr bool M16 = CD > 0;
+    // (P16_: the pair-table kernels of k = 5 tables -- pair and single table both in that format, ScanArgs::pair16)
+    constexpr bool M16 = CD > 0 || P16_;
     constexpr int LS = M16 ? 1 : 2;               // log2(bytes per table entry)
     // XPAD (the default kernels, round 4): a lane's OR | matches (XF) and its exclusive prefix in the tile (XT) live in the pad words of
     // its XPC and row[] rows (9 words per lane, the ninth unused) -- no XF / XT arrays in the wave's slice (carve_fused<.., XM = 2>)
@@ -1991,13 +1997,13 @@ TPS_DEV void tile_lc_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
         uint32_t* xpc = l.XPC + span * (B + 1);
         if constexpr (PAIR) {
             constexpr int NP = S / 2, NH = NP + (S & 1);
-            const uint32_t amask2 = (pat.kmask << 4) | 0xCu;
+            const uint32_t amask2 = M16 ? ((pat.kmask << 3) | 0x6u) : ((pat.kmask << 4) | 0xCu);     // the (k+1)-mer's code << LS
             const int rpe = rp & ~1;
             uint32_t hc[NH], hn[NH];
             auto fetch = [&](int blk, uint32_t* hh) {
                 TPS_UNROLL
-                for (int j = 0; j < NP; ++j) hh[j] = lut_at_tile(l.lut2, v4_at(blk * S + 2 * j), amask2);
-                if (S & 1) hh[NP] = lut_at_tile(l.lut, v4_at(blk * S + S - 1), amask);
+                for (int j = 0; j < NP; ++j) hh[j] = M16 ? lut16_at(l.lut2, v4_at(blk * S + 2 * j), amask2) : lut_at_tile(l.lut2, v4_at(blk * S + 2 * j), amask2);
+                if (S & 1) hh[NP] = M16 ? lut16_at(l.lut, v4_at(blk * S + S - 1), amask) : lut_at_tile(l.lut, v4_at(blk * S + S - 1), amask);
             };
             fetch(0, hc);
             TPS_UNROLL
@@ -2005,22 +2011,22 @@ TPS_DEV void tile_lc_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
                 if (blk + 1 < B) fetch(blk + 1, hn);
                 uint32_t g = 0;
                 c0s[blk] = cnt;
-                if (RZ) xpc[blk] = pack_hi_lo(run_or, cnt);
+                if (RZ) xpc[blk] = M16 ? ((run_or << 16) | cnt) : pack_hi_lo(run_or, cnt);
                 TPS_UNROLL
                 for (int j = 0; j < NH; ++j) {
                     if (!RZ) {
                         if (2 * j == rpe) {
                             uint32_t c1 = cnt, pp = run_or | g;
                             if (rp & 1) {
-                                const uint32_t h1 = lut_at(l.lut, v4_at(blk * S + 2 * j), amask);
-                                c1 += h1;
+                                const uint32_t h1 = M16 ? lut16_at(l.lut, v4_at(blk * S + 2 * j), amask) : lut_at(l.lut, v4_at(blk * S + 2 * j), amask);
+                                c1 = M16 ? c1 + (uint32_t)popc(h1) : c1 + h1;
                                 pp |= h1;
                             }
-                            xpc[blk] = pack_hi_lo(pp, c1);
+                            xpc[blk] = M16 ? ((pp << 16) | c1) : pack_hi_lo(pp, c1);
                         }
                     }
                     g |= hc[j];
-                    cnt += hc[j];
+                    cnt = M16 ? cnt + (uint32_t)popc(hc[j]) : cnt + hc[j];     // (a pair entry: the two positions' masks ORed -- never the same pattern twice)
                 }
                 gs[blk] = g;
                 run_or |= g;
@@ -3370,7 +3376,10 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
     // (XM = 2 also for the default kernels: every tile of theirs is a tile_lc_s<.., CD = 0>, which keeps XF / XT in the pad words too)
     constexpr int XM = M16K ? 1 : (SV != 0 && (RAW || (!SO && TPS_LC_TILE != 0 && TPS_XPAD != 0))) ? 2 : 0;
     constexpr bool F16K = SV != 0 && SO && RAW && DCLASS == 3;     // raw rows of a big self-overlap table: 16-bit field-index table (_s*sorh)
-    const Lds l = SV ? carve_fused<SV ? SV : 5, FULL, XM>(lds_base, lut, a) : carve(lds_base, lut, a);
+    constexpr bool P16K = SV != 0 && !SO && !RAW && PAIR && DCLASS == 4;      // pair-table kernels of k = 5 tables: 16-bit pair + single table (_s*q)
+    Lds l_ = SV ? carve_fused<SV ? SV : 5, FULL, XM>(lds_base, lut, a) : carve(lds_base, lut, a);
+    if constexpr (P16K) l_.lshift = LUT_M16;
+    const Lds l = l_;
     const PatInfo& pat = a.pat;
     const tps_params& prm = a.prm;
     // one 16-byte descriptor per read (wave-uniform: a scalar load)
@@ -3435,7 +3444,7 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
 #if !defined(TPS_EMU) && !defined(TPS_NO_DECIDE_FAST)           /* (TPS_NO_DECIDE_FAST: A/B builds) */
         if constexpr (SV != 0 && !SO && !RAW) {
             if (packed1) {
-                trc_decide_packed(a, l, st_s, st_e, r, ks, ke);
+                trc_decide_packed<P16K ? 2 : 0>(a, l, st_s, st_e, r, ks, ke);
                 decided = true;
                 TPS_STAMP(3);
             }
@@ -3450,7 +3459,7 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
             } else if (SO) {
                 TPS_PHASE { trc_count_packed<true, M16K ? 2 : 0>(a, l, st_s, st_e, tid); }
             } else {
-                TPS_PHASE { trc_count_packed<false>(a, l, st_s, st_e, tid); }
+                TPS_PHASE { trc_count_packed<false, P16K ? 2 : 0>(a, l, st_s, st_e, tid); }
             }
             TPS_SYNC();
             if (SO && (uniform(l.misc[M_CMASK]) | uniform(l.misc[M_CMASK + 1]))) {
@@ -3690,15 +3699,15 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
                 constexpr int SF = SV ? SV : 1;
                 constexpr bool LC = TPS_LC_TILE != 0 && !SO && !RAW;     // the default kernels: lane-contiguous windows (tile_lc_s)
                 if (uniform(l.misc[M_INVALID]) != 0) {
-                    if constexpr (LC) tile_lc_s<SF, true, -1, false, false>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r);
+                    if constexpr (LC) tile_lc_s<SF, true, -1, false, false, 0, P16K>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r);
                     else tile_fused_s<SF, SO, true, -1, false, RAW>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r);
                 } else if constexpr (SO || RAW) {
                     // (these kernels reach the plain tile only as a fallback: one instantiation with r read at run time)
                     if (tc.r == 0) tile_fused_s<SF, SO, false, 0, PAIR, RAW>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r);
                     else tile_fused_s<SF, SO, false, -1, PAIR, RAW>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r);
                 } else {
-#define TPS_TILE_RP(N) case N: if constexpr (N < SF) { if constexpr (LC) { if ((tc.q & 7) == 0) tile_lc_s<SF, false, (N < SF ? N : 0), PAIR, true>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r); \
-                                                                          else tile_lc_s<SF, false, (N < SF ? N : 0), PAIR, false>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r); } \
+#define TPS_TILE_RP(N) case N: if constexpr (N < SF) { if constexpr (LC) { if ((tc.q & 7) == 0) tile_lc_s<SF, false, (N < SF ? N : 0), PAIR, true, 0, P16K>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r); \
+                                                                          else tile_lc_s<SF, false, (N < SF ? N : 0), PAIR, false, 0, P16K>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r); } \
                                                        else tile_fused_s<SF, SO, false, (N < SF ? N : 0), PAIR, RAW>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r); } break;
                     switch (tc.r) {
                         TPS_TILE_RP(0) TPS_TILE_RP(1) TPS_TILE_RP(2) TPS_TILE_RP(3) TPS_TILE_RP(4) TPS_TILE_RP(5) TPS_TILE_RP(6) TPS_TILE_RP(7)

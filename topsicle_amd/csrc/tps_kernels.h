@@ -36,7 +36,7 @@
         }                                                                                                  \
         if (PAIR) {   /* host-built pair table, stored right behind the plain table */                      \
             for (int c = 4 * (int)threadIdx.x; c < a.pair_n; c += 4 * nthr_)                               \
-                *(uint4*)(lds + c) = *(const uint4*)(a.lut + a.lut_n + c);                                 \
+                *(uint4*)(lds + c) = *(const uint4*)(a.pair_img + c);                                 \
         }                                                                                                  \
         __syncthreads();                                                                                   \
         TPS_KSTAMP(14);                                                                                    \
@@ -65,7 +65,7 @@
 #define TPS_SCAN_KERNEL(NAME, SV, SO, PAIR, RAW, MINW) TPS_SCAN_KERNEL_F(NAME, SV, SO, PAIR, RAW, MINW, tps::tile_full_default(SV), 0)
 #define TPS_SCAN_KERNEL_D(NAME, SV, SO, PAIR, RAW, MINW, DCLASS) TPS_SCAN_KERNEL_F(NAME, SV, SO, PAIR, RAW, MINW, tps::tile_full_default(SV), DCLASS)
 
-#define TPS_KGROUPS 15
+#define TPS_KGROUPS 16
 #ifdef TPS_KGROUP
 #define TPS_IN_GROUP(g) (TPS_KGROUP == (g))
 #else
@@ -102,6 +102,10 @@ TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s5sorh)
 TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s6sorh)
 TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s7sorh)
 TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s8sorh)
+TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s5q)
+TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s6q)
+TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s7q)
+TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s8q)
 
 #if TPS_IN_GROUP(0)
 TPS_SCAN_KERNEL(tps_scan_kernel_s5, 5, false, false, false, 5)       // specialised: compile-time slide, <= 15 patterns
@@ -155,6 +159,14 @@ TPS_SCAN_KERNEL_D(tps_scan_kernel_s7sorh, 7, true, false, true, 5, 3)
 #endif
 #if TPS_IN_GROUP(14)
 TPS_SCAN_KERNEL_D(tps_scan_kernel_s8sorh, 8, true, false, true, 5, 3)
+#endif
+// ... k = 5 tables without self-overlap, sums only: pair AND single table as 16-bit pattern masks (ScanArgs::pair16) -- the 4^6-entry
+// pair table is 8 KB, shared by the 8 waves of a workgroup (three per CU: the same 24 waves as the k = 4 pair kernels)
+#if TPS_IN_GROUP(15)
+TPS_SCAN_KERNEL_D(tps_scan_kernel_s5q, 5, false, true, false, 5, 4)
+TPS_SCAN_KERNEL_D(tps_scan_kernel_s6q, 6, false, true, false, 5, 4)
+TPS_SCAN_KERNEL_D(tps_scan_kernel_s7q, 7, false, true, false, 5, 4)
+TPS_SCAN_KERNEL_D(tps_scan_kernel_s8q, 8, false, true, false, 5, 4)
 #endif
 #if TPS_IN_GROUP(9)
 TPS_SCAN_KERNEL_D(tps_scan_kernel_s5sol, 5, true, false, false, 5, 1)     // ... the same for self-overlap periods 2 .. 4

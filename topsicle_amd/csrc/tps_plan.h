@@ -132,7 +132,7 @@ inline void plan_wpg(ScanArgs& a, int64_t budget_dw) {
     }
     // only multiples of four: a workgroup's waves go round the four SIMDs, and five waves would put two on one of them
     // (measured at k = 6, 10 000 x 25 kb reads: 4 waves per workgroup 0.256 ms, 5: 0.306, 7: 0.251, 8: 0.222)
-    if (lut_dw(a) * 4 >= 16384) {
+    if (lut_dw(a) * 4 >= 16384 || (a.pair_n + lut_dw(a)) * 4 >= 8192) {
         // (ten waves per workgroup -- two workgroups of ten with a 16 KB table each fill the CU's LDS, 5 waves per SIMD -- was
         // measured in round 3: 248 us against 207 us with eight at k = 6: ten waves sit 3 / 3 / 2 / 2 on the four SIMDs)
         const int v = waves_per_cu(WPG_MAX);
@@ -197,7 +197,7 @@ inline std::string plan_geometry_core(ScanArgs& a, const tps_params& prm, int k,
                        a.q / 8 + 2 < (XLANES - NT) && max_period <= std::min(prm.slide, 6) &&
                        2 * a.head_dw <= fused_seq_dw(prm.slide);   // the two step-1 heads fit the tile buffer (TileGeo::SEQ)
     a.lc16 = 0; a.tile_cap = 0; a.tw = 0; a.tw_magic = 0; a.pair_n = 0; a.lc_global = 0; a.lc_stride = 0; a.pp_d = -1; a.so_fast = 0; a.seq_alias = 0; a.lut_fields = 0; a.tile_full = 0;
-    a.lut16 = 0; a.xt_alias = 0; a.xt_own = 0;
+    a.lut16 = 0; a.xt_alias = 0; a.xt_own = 0; a.pair16 = 0;
     if (fused) {
         // per-pattern tiles (tile_pp_s): one-hot 2-bit fields per pattern need distinct k-mers, raw rows of at most 14 bytes
         // (they are staged through 16-byte LDS rows); a lane's 8 blocks hold at
@@ -271,22 +271,41 @@ inline std::string plan_geometry_core(ScanArgs& a, const tps_params& prm, int k,
         a.lc_stride = a.lc16 ? ((a.lc_cap + 1) & ~1) : 2 * ((a.lc_cap + 1) & ~1);        // in 16-bit units
         // pair table (two positions per lookup) while it is small: k <= 4 -> at most 4 KB per workgroup
         a.pair_n = (a.pat.so_mask == 0 && k <= 4 && !(prm.flags & TPS_F_STORE_RAW) && !getenv("TPS_NO_PAIR")) ? (1 << (2 * (k + 1))) : 0;   // (the raw-count kernels use single lookups)
+        // ... and at k = 5 as 16-bit pattern masks (round 4; the single table likewise: kernels _s*q): 4^6 entries = 8 KB per workgroup,
+        // which plan_wpg then shares among 8 waves -- the plant-type 7-mer motifs (CCCTAAA at the reference's default k = 5) get two
+        // positions per lookup like the 6-mer motifs at k = 4
+        a.pair16 = 0;
+        if (a.pat.so_mask == 0 && a.pat.dup_mask == 0 && k == 5 && P <= 15 && !(prm.flags & TPS_F_STORE_RAW) && !getenv("TPS_NO_PAIR") && !getenv("TPS_NO_PAIR16")) {
+            a.pair16 = 1;
+            a.lut16 = 1;
+            a.pair_n = (1 << (2 * (k + 1))) / 2;       // dwords
+        }
         a.blk_dw = (int32_t)blk_region_dw(a);
         if (a.pair_n && !getenv("TPS_FORCE_PAIR")) {
             // ... unless it costs a resident workgroup where one is scarce: LDS is handed out in 1280-byte granules,
             // 128 per CU.  Measured at config 2 (ms per batch): 4 workgroups + pair 0.096 vs 5 + single lookups 0.092;
             // 5 + pair 0.089 vs 6 + single lookups 0.091 -- so the pair table stays if 5 workgroups still fit.
-            auto wgs_per_cu = [](int64_t dwords) { return (int)std::min<int64_t>(8, 128 / std::max<int64_t>(1, (dwords * 4 + 1279) / 1280)); };
-            const int with_pair = wgs_per_cu(wg_lds_dwords(a));
+            // (in waves per CU since round 4: the 8 KB table of the k = 5 kernels is planned for 8-wave workgroups, plan_wpg below)
+            auto waves_per_cu = [&](int w) {
+                const int32_t w0 = a.wpg;
+                a.wpg = w;
+                const int64_t dw = wg_lds_dwords(a);
+                a.wpg = w0;
+                if (dw > budget_dw) return 0;
+                return (int)(std::min<int64_t>(8, 128 / std::max<int64_t>(1, (dw * 4 + 1279) / 1280)) * w);
+            };
+            const int with_pair = a.pair16 ? std::max(waves_per_cu(WPG), waves_per_cu(WPG_MAX)) : waves_per_cu(WPG);
             const int32_t keep = a.pair_n;
+            const int32_t keep16 = a.pair16;
             a.pair_n = 0;
-            if (with_pair >= 5 || wgs_per_cu(wg_lds_dwords(a)) <= with_pair) a.pair_n = keep;
+            if (keep16) { a.lut16 = 0; a.pair16 = 0; }        // (without: the 32-bit single table)
+            if (with_pair >= 5 * WPG || waves_per_cu(WPG) <= with_pair) { a.pair_n = keep; if (keep16) { a.pair16 = 1; a.lut16 = 1; } }
         }
         if (wg_lds_dwords(a) <= budget_dw) return "";
         // does not fit (very long maxlengthtelo: the candidate sums of 4 reads outgrow LDS): the generic kernel,
         // whose tile size adapts, takes over
         a.lc16 = 0; a.tile_cap = 0; a.tw = 0; a.tw_magic = 0; a.pair_n = 0; a.lc_global = 0; a.lc_stride = 0; a.pp_d = -1; a.so_fast = 0; a.seq_alias = 0; a.lut_fields = 0;
-        a.lut16 = 0; a.xt_alias = 0; a.xt_own = 0;
+        a.lut16 = 0; a.xt_alias = 0; a.xt_own = 0; a.pair16 = 0;
     }
     a.variant = 0;
     // the generic kernel's 32-bit candidate sums go off-chip too (stride counted in 16-bit units)
