@@ -482,3 +482,47 @@ def test_full_size_raw_count_properties(sc, k):
         seq = bytes(bases[offsets[i]:offsets[i + 1]]).decode()
         _, counts = orc.window_count_matrix(seq, ["forward", "reverse"][int(res["tail"][i])], pats, 100, 6, 100, 20000)
         assert np.array_equal(raw[win_off[i]:win_off[i + 1]], counts)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("motif,slide,W", [("AAACCCT", 7, 100), ("CCCTAAA", 6, 100), ("AAACCCT", 5, 100), ("CCCTAAA", 8, 260)])
+def test_k5_pair_table_kernels(sc, motif, slide, W):
+    """k = 5 tables without self-overlap, sums only: the planner picks the 16-bit pair table and 8-wave workgroups (kernels _s*q);
+    step 1, window sums and the boundary bit-exact against the oracle -- reads of several tiles, both strands, N and lower case."""
+    k = 5
+    pats = orc.kmer_table(motif, k)
+    sc.set_patterns(pats)
+    rng = np.random.default_rng(slide * 17 + W)
+    comp = str.maketrans("ACGTacgt", "TGCAtgca")
+    seqs = []
+    for i in range(48):
+        L = int(rng.integers(3000, 12000))
+        tract = int(rng.integers(600, 2900))
+        body = list((motif * (tract // len(motif) + 2))[:tract] + "".join("ACGT"[x] for x in rng.integers(0, 4, L - tract)))
+        for p in rng.integers(0, L, L // 14):
+            body[p] = "ACGT"[int(rng.integers(4))]
+        if i % 5 == 3:
+            body[int(rng.integers(1200, L))] = "N"
+        if i % 7 == 4:
+            body[50:400] = [c.lower() for c in body[50:400]]
+        sq = "".join(body)
+        seqs.append(sq if i % 2 == 0 else sq[::-1].translate(comp))
+    bases, offsets = hiplib.pack_reads(seqs)
+    sc.upload(6, bases, offsets)
+    prm = hiplib.make_params(min_len=0, min_count=-1, window=W, slide=slide,
+                             flags=hiplib.F_STEP1 | hiplib.F_WINDOWS | hiplib.F_BINSEG | hiplib.F_STORE_SUMS)
+    sc.scan(6, prm)
+    sc.sync()
+    info = sc.kernel_info(6)
+    assert info.startswith("tps_scan_kernel_s%dq " % slide) and "waves_per_wg=8" in info, info
+    res = sc.results(6).copy()
+    sums, win_off = sc.window_sums(6)
+    cs_all, ce_all = sc.batch_trc_counts(6)
+    for i, seq in enumerate(seqs):
+        cs, ce = orc.trc_counts(seq, pats)
+        assert cs_all[i].tolist() == cs and ce_all[i].tolist() == ce, i
+        tail = ["forward", "reverse"][res["tail"][i]]
+        _, counts = orc.window_count_matrix(seq, tail, pats, W, slide, 100, 20000)
+        assert np.array_equal(sums[win_off[i]:win_off[i + 1]], counts.sum(axis=1)), i
+        want = orc.binseg_l2_exact(counts.sum(axis=1)) if counts.shape[0] >= 7 else None
+        assert res["bkp"][i] == (-1 if want is None else want), i
