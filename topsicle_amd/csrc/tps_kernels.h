@@ -59,6 +59,9 @@
 #ifndef TPS_R_MINW
 #define TPS_R_MINW 3      // waves per SIMD the raw-row kernels of tables without self-overlap are compiled for (5: 96 VGPRs with 6 spilled
 #endif                    // and 28 B of scratch -- k = 4 with raw rows 170 -> 163.5 us, measured in round 4; not taken: no scratch in these kernels)
+#ifndef TPS_S8SOR_MINW
+#define TPS_S8SOR_MINW 4  // ... of the slide-8 self-overlap raw-row kernel: 113 VGPRs; compiled for 5 it spills 94 VGPRs to 68 B of scratch (k = 5 at slide 8: 168.6 -> 163.8 us)
+#endif
 #ifndef TPS_SO_MINW
 #define TPS_SO_MINW 5     // waves per SIMD the sums-only self-overlap kernels are compiled for
 #endif
@@ -144,7 +147,7 @@ TPS_SCAN_KERNEL(tps_scan_kernel_s6sor, 6, true, false, true, 5)
 TPS_SCAN_KERNEL(tps_scan_kernel_s7sor, 7, true, false, true, 5)
 #endif
 #if TPS_IN_GROUP(8)
-TPS_SCAN_KERNEL(tps_scan_kernel_s8sor, 8, true, false, true, 5)
+TPS_SCAN_KERNEL(tps_scan_kernel_s8sor, 8, true, false, true, TPS_S8SOR_MINW)
 #endif
 // ... the same for tables of 4^6 and more k-mers: the LDS table holds 16-bit field indices (LUT_F16: 8 KB instead of 16 KB at k = 6, one
 // multiply per position more) -- with the slim exchange region five 4-wave workgroups fit a CU instead of two 8-wave ones
@@ -158,7 +161,7 @@ TPS_SCAN_KERNEL_D(tps_scan_kernel_s6sorh, 6, true, false, true, 5, 3)
 TPS_SCAN_KERNEL_D(tps_scan_kernel_s7sorh, 7, true, false, true, 5, 3)
 #endif
 #if TPS_IN_GROUP(14)
-TPS_SCAN_KERNEL_D(tps_scan_kernel_s8sorh, 8, true, false, true, 5, 3)
+TPS_SCAN_KERNEL_D(tps_scan_kernel_s8sorh, 8, true, false, true, 5, 3)      // (compiled for 4 waves per SIMD: 185.6 -> 191.0 us, k = 6 at slide 8)
 #endif
 // ... k = 5 tables without self-overlap, sums only: pair AND single table as 16-bit pattern masks (ScanArgs::pair16) -- the 4^6-entry
 // pair table is 8 KB, shared by the 8 waves of a workgroup (three per CU: the same 24 waves as the k = 4 pair kernels)
