@@ -526,3 +526,24 @@ def test_k5_pair_table_kernels(sc, motif, slide, W):
         assert np.array_equal(sums[win_off[i]:win_off[i + 1]], counts.sum(axis=1)), i
         want = orc.binseg_l2_exact(counts.sum(axis=1)) if counts.shape[0] >= 7 else None
         assert res["bkp"][i] == (-1 if want is None else want), i
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,flags,kernel", [(4, 0, "tps_scan_kernel_s6p lds=23936 wgs_per_cu=6 waves_per_wg=4"),
+                                           (4, hiplib.F_STORE_RAW, "tps_scan_kernel_s6r lds=23168 wgs_per_cu=6 waves_per_wg=4"),
+                                           (5, 0, "tps_scan_kernel_s6sol lds=25472 wgs_per_cu=6 waves_per_wg=4"),
+                                           (5, hiplib.F_STORE_RAW, "tps_scan_kernel_s6sor lds=26240 wgs_per_cu=6 waves_per_wg=4"),
+                                           (6, 0, "tps_scan_kernel_s6so lds=31616 wgs_per_cu=5 waves_per_wg=4"),
+                                           (6, hiplib.F_STORE_RAW, "tps_scan_kernel_s6sorh lds=30336 wgs_per_cu=5 waves_per_wg=4")])
+def test_planned_launch_shapes_of_the_benchmark_tables(sc, k, flags, kernel):
+    """The kernel, LDS bytes and workgroup shape the planner picks for CCCTAA at k = 4, 5, 6 on a clean batch (BASELINE configs[1] and
+    [4]): what the profiles and DESIGN quote.  (A planner edit for the k = 5 pair tables once moved the 8 KB tables of the k = 6
+    kernels to 8-wave workgroups unnoticed: 493 -> 530 us per three-k step.)"""
+    sc.set_patterns(orc.kmer_table("CCCTAA", k))
+    bases, offsets, _ = synth.make_reads(64, 12000, "CCCTAA", seed=3)
+    sc.upload(7, bases, offsets)
+    prm = hiplib.make_params(min_len=0, min_count=-1, window=100, slide=6,
+                             flags=hiplib.F_STEP1 | hiplib.F_WINDOWS | hiplib.F_BINSEG | hiplib.F_STORE_SUMS | flags)
+    sc.scan(7, prm)
+    sc.sync()
+    assert sc.kernel_info(7) == kernel

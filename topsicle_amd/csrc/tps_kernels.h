@@ -57,8 +57,9 @@
         if (r < a.n_reads) tps::scan_read<SV, SO, PAIR, RAW, FULL, DCLASS>(a, r, slice, lut);                           \
     }
 #ifndef TPS_R_MINW
-#define TPS_R_MINW 3      // waves per SIMD the raw-row kernels of tables without self-overlap are compiled for (5: 96 VGPRs with 6 spilled
-#endif                    // and 28 B of scratch -- k = 4 with raw rows 170 -> 163.5 us, measured in round 4; not taken: no scratch in these kernels)
+#define TPS_R_MINW 5      // waves per SIMD the raw-row kernels of tables without self-overlap are compiled for: 96 VGPRs with 7 spilled and 32 B
+#endif                    // of scratch instead of 106 and none -- k = 4 with raw rows 171.2 -> 165.8 us (143.4 against 149.6 per batch on two streams);
+                          // the fifth wave is worth more than the spills cost, as in the self-overlap raw kernels.  Slide 8 would spill 64: it stays at 3
 #ifndef TPS_S8SOR_MINW
 #define TPS_S8SOR_MINW 4  // ... of the slide-8 self-overlap raw-row kernel: 113 VGPRs; compiled for 5 it spills 94 VGPRs to 68 B of scratch (k = 5 at slide 8: 168.6 -> 163.8 us)
 #endif
@@ -127,7 +128,7 @@ TPS_SCAN_KERNEL(tps_scan_kernel, 0, false, false, true, 4)          // generic: 
 TPS_SCAN_KERNEL(tps_scan_kernel_s5r, 5, false, false, true, TPS_R_MINW)       // ... with the per-pattern raw counts (TPS_F_STORE_RAW)
 TPS_SCAN_KERNEL(tps_scan_kernel_s6r, 6, false, false, true, TPS_R_MINW)
 TPS_SCAN_KERNEL(tps_scan_kernel_s7r, 7, false, false, true, TPS_R_MINW)
-TPS_SCAN_KERNEL(tps_scan_kernel_s8r, 8, false, false, true, TPS_R_MINW)
+TPS_SCAN_KERNEL(tps_scan_kernel_s8r, 8, false, false, true, 3)
 #endif
 #if TPS_IN_GROUP(3)
 TPS_SCAN_KERNEL_D(tps_scan_kernel_s5so, 5, true, false, false, TPS_SO_MINW, 2)      // ... self-overlapping k-mers in the table, sums only (tile_lc_s<.., CD>: plain counts, chains corrected), periods 5 and 6

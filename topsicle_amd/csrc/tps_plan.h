@@ -132,7 +132,7 @@ inline void plan_wpg(ScanArgs& a, int64_t budget_dw) {
     }
     // only multiples of four: a workgroup's waves go round the four SIMDs, and five waves would put two on one of them
     // (measured at k = 6, 10 000 x 25 kb reads: 4 waves per workgroup 0.256 ms, 5: 0.306, 7: 0.251, 8: 0.222)
-    if (lut_dw(a) * 4 >= 16384 || (a.pair_n + lut_dw(a)) * 4 >= 8192) {
+    if (lut_dw(a) * 4 >= 16384 || (a.pair16 && (a.pair_n + lut_dw(a)) * 4 >= 8192)) {      // (the 8 KB tables of the k = 6 self-overlap kernels run better in five 4-wave workgroups)
         // (ten waves per workgroup -- two workgroups of ten with a 16 KB table each fill the CU's LDS, 5 waves per SIMD -- was
         // measured in round 3: 248 us against 207 us with eight at k = 6: ten waves sit 3 / 3 / 2 / 2 on the four SIMDs)
         const int v = waves_per_cu(WPG_MAX);
