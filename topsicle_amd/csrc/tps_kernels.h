@@ -63,6 +63,12 @@
 #ifndef TPS_S8SOR_MINW
 #define TPS_S8SOR_MINW 4  // ... of the slide-8 self-overlap raw-row kernel: 113 VGPRs; compiled for 5 it spills 94 VGPRs to 68 B of scratch (k = 5 at slide 8: 168.6 -> 163.8 us)
 #endif
+#ifndef TPS_SOR_MINW
+#define TPS_SOR_MINW 5
+#endif
+#ifndef TPS_SOL_MINW
+#define TPS_SOL_MINW 6     // waves per SIMD the sums kernels of self-overlap periods 2 .. 4 (k = 5) are compiled for: 80 VGPRs without a spill, and their LDS (25 472 B per workgroup) allows the sixth: k = 5 sums 106.0 -> 102.0 us, 97 -> 90 per batch on two streams
+#endif
 #ifndef TPS_SO_MINW
 #define TPS_SO_MINW 5     // waves per SIMD the sums-only self-overlap kernels are compiled for
 #endif
@@ -142,7 +148,7 @@ TPS_SCAN_KERNEL_D(tps_scan_kernel_s8so, 8, true, false, false, TPS_SO_MINW, 2)
 TPS_SCAN_KERNEL(tps_scan_kernel_s5sor, 5, true, false, true, 5)      // ... the same with the per-pattern raw counts (tile_pp_s)
 #endif
 #if TPS_IN_GROUP(6)
-TPS_SCAN_KERNEL(tps_scan_kernel_s6sor, 6, true, false, true, 5)
+TPS_SCAN_KERNEL(tps_scan_kernel_s6sor, 6, true, false, true, TPS_SOR_MINW)
 #endif
 #if TPS_IN_GROUP(7)
 TPS_SCAN_KERNEL(tps_scan_kernel_s7sor, 7, true, false, true, 5)
@@ -173,10 +179,10 @@ TPS_SCAN_KERNEL_D(tps_scan_kernel_s7q, 7, false, true, false, 5, 4)
 TPS_SCAN_KERNEL_D(tps_scan_kernel_s8q, 8, false, true, false, 5, 4)
 #endif
 #if TPS_IN_GROUP(9)
-TPS_SCAN_KERNEL_D(tps_scan_kernel_s5sol, 5, true, false, false, 5, 1)     // ... the same for self-overlap periods 2 .. 4
-TPS_SCAN_KERNEL_D(tps_scan_kernel_s6sol, 6, true, false, false, 5, 1)
+TPS_SCAN_KERNEL_D(tps_scan_kernel_s5sol, 5, true, false, false, TPS_SOL_MINW, 1)     // ... the same for self-overlap periods 2 .. 4
+TPS_SCAN_KERNEL_D(tps_scan_kernel_s6sol, 6, true, false, false, TPS_SOL_MINW, 1)
 #endif
 #if TPS_IN_GROUP(10)
-TPS_SCAN_KERNEL_D(tps_scan_kernel_s7sol, 7, true, false, false, 5, 1)
-TPS_SCAN_KERNEL_D(tps_scan_kernel_s8sol, 8, true, false, false, 5, 1)
+TPS_SCAN_KERNEL_D(tps_scan_kernel_s7sol, 7, true, false, false, TPS_SOL_MINW, 1)
+TPS_SCAN_KERNEL_D(tps_scan_kernel_s8sol, 8, true, false, false, TPS_SOL_MINW, 1)
 #endif
