@@ -167,6 +167,7 @@ def run_cli(path, outdir, cfg, device):
         v = np.array([x[1] for x in samples])
         d.update({"rss_mb_peak": round(float(v.max()), 1), "rss_samples": len(v),
                   "rss_mb_at_25_50_75_100_pct_of_the_run": [round(float(v[int(f * (len(v) - 1))]), 1) for f in (0.25, 0.5, 0.75, 1.0)]})
+        d["rss_series_s_mb"] = [[round(t, 2), round(m)] for t, m in samples]       # (one sample per 0.2 s: where a peak sits in the run)
     log = os.path.join(outdir, "topsicle_run.log")
     if os.path.exists(log):
         d["two_pass_line"] = [ln.strip() for ln in open(log) if "two passes" in ln][:1]

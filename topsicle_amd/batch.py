@@ -368,11 +368,18 @@ class EnginePool:
         q_in: queue.Queue = queue.Queue(maxsize=n + 1)
         q_out: queue.Queue = queue.Queue()
         stop = threading.Event()
+        # At most n + 3 batches between the reader and the consumer: a batch's results (raw rows: hundreds of MB per batch and k) wait
+        # in `pending` until the consumer has dealt with the batches before it, and a consumer slower than the GPUs -- the CLI writing
+        # raw rows -- let them pile up (configs[4]'s shard: 9.9 GB resident one second into the run).  The reader takes the tokens, in
+        # batch order, so the batch the consumer waits for always has one.
+        in_flight = threading.Semaphore(n + 3)
 
         def reader():
             count = 0
             try:
                 for b in batches:
+                    while not stop.is_set() and not in_flight.acquire(timeout=0.2):
+                        pass
                     while not stop.is_set():
                         try:
                             q_in.put((count, b), timeout=0.2)
@@ -421,6 +428,7 @@ class EnginePool:
                 while nxt in pending:
                     yield pending.pop(nxt)
                     nxt += 1
+                    in_flight.release()                # (the consumer came back for more: it is done with that batch)
         finally:
             stop.set()
             if pool is not None:
