@@ -2080,6 +2080,24 @@ TPS_DEV void tile_lc_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
                 uint32_t g = 0;
                 c0s[blk] = cnt;
                 uint32_t c1 = cnt, pp = run_or;
+                // CD >= S - 1 (k = 6 at slide 6: CD = 5): a pattern occurs at most twice in a block -- its occurrences are CD apart
+                // (the table's one period) or at least k > CD, so only positions 0 and S - 1 can share one -- and every position
+                // matches at most one pattern (no duplicate k-mers in these tables): the block's matches are the popcount of its OR
+                // plus that one possible pair, 2 instructions instead of a popcount and an add per position
+                constexpr bool CNT_OR = CD > 0 && CD >= S - 1;
+                if constexpr (CNT_OR) {
+                    uint32_t g_rp = 0;
+                    TPS_UNROLL
+                    for (int i = 0; i < S; ++i) {
+                        g |= hc[i];
+                        if (!RZ) {
+                            if (i + 1 == rp) g_rp = g;
+                        }
+                    }
+                    if (!RZ) { pp = run_or | g_rp; c1 = cnt + (uint32_t)popc(g_rp); }
+                    cnt += (uint32_t)popc(g);
+                    if (CD == S - 1) cnt += (uint32_t)popc(hc[S - 1] & hc[0]);
+                } else {
                 TPS_UNROLL
                 for (int i = 0; i < S; ++i) {
                     const uint32_t h = hc[i];
@@ -2088,6 +2106,7 @@ TPS_DEV void tile_lc_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
                     if (!RZ) {
                         if (i + 1 == rp) { c1 = cnt; pp = run_or | g; }
                     }
+                }
                 }
                 xpc[blk] = M16 ? ((pp << 16) | c1) : pack_hi_lo(pp, c1);
                 gs[blk] = g;
