@@ -700,3 +700,41 @@ def test_emulation_k5_pair_table_of_16_bit_masks(motif, slide, W, monkeypatch):
         assert hi - lo == counts.shape[0] and hi - lo > 500
         assert np.array_equal(out["sums"][lo:hi], counts.sum(axis=1)), i
         assert r["bkp"] == orc.binseg_l2_exact(counts.sum(axis=1)), i
+
+
+@pytest.mark.parametrize("k,slide", [(5, 6), (6, 6), (5, 5), (6, 7), (5, 7)])
+def test_emulation_self_overlap_sums_blocks_with_a_pattern_twice(k, slide):
+    """The sums tiles of the self-overlap tables count a block's matches as popcount(OR of its entries) + the few pairs of positions
+    that can hold the SAME pattern (CD apart, or the block's first and last position).  Reads built to put a pattern twice into a
+    block in every such way: runs of one k-mer repeated back to back (occurrences k apart: adjacent, not overlapping), (CCTAA)n /
+    (CCTA)n runs (occurrences CD apart: the chains), telomeric stretches with deletions, all at every phase to the blocks."""
+    motif = "CCCTAA"
+    pats = orc.kmer_table(motif, k)
+    rng = np.random.default_rng(k * 10 + slide)
+    seqs = []
+    for r in range(6):
+        parts = ["".join("ACGT"[x] for x in rng.integers(0, 4, 150 + r))]
+        for rep in range(40):
+            kind = int(rng.integers(4))
+            if kind == 0:
+                p = pats[int(rng.integers(len(pats)))]
+                parts.append(p * int(rng.integers(2, 9)))                     # the same k-mer k apart
+            elif kind == 1:
+                unit = motif[1:] if k == 6 else motif[2:]                     # CCTAA (period 5) / CTAA-type period-4 unit
+                parts.append((unit * 12)[: int(rng.integers(k + 2, 50))])
+            elif kind == 2:
+                t = list(motif * int(rng.integers(3, 12)))
+                for _ in range(int(rng.integers(0, 4))):
+                    del t[int(rng.integers(len(t)))]
+                parts.append("".join(t))
+            else:
+                parts.append("".join("ACGT"[x] for x in rng.integers(0, 4, int(rng.integers(1, 40)))))
+        seqs.append("".join(parts))
+    prm = hiplib.make_params(window=100, slide=slide, trimfirst=100, maxlen=20000,
+                             flags=hiplib.F_WINDOWS | hiplib.F_BINSEG | hiplib.F_TAILS_IN | hiplib.F_STORE_SUMS)
+    out = emu.scan(pats, seqs, prm, tails=[0] * len(seqs))
+    for i, seq in enumerate(seqs):
+        _, counts = orc.window_count_matrix(seq, "forward", pats, 100, slide, 100, 20000)
+        lo, hi = out["win_off"][i], out["win_off"][i + 1]
+        assert hi - lo == counts.shape[0] > 50
+        assert np.array_equal(out["sums"][lo:hi], counts.sum(axis=1)), (k, slide, i)

@@ -2080,23 +2080,31 @@ TPS_DEV void tile_lc_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
                 uint32_t g = 0;
                 c0s[blk] = cnt;
                 uint32_t c1 = cnt, pp = run_or;
-                // CD >= S - 1 (k = 6 at slide 6: CD = 5): a pattern occurs at most twice in a block -- its occurrences are CD apart
-                // (the table's one period) or at least k > CD, so only positions 0 and S - 1 can share one -- and every position
-                // matches at most one pattern (no duplicate k-mers in these tables): the block's matches are the popcount of its OR
-                // plus that one possible pair, 2 instructions instead of a popcount and an add per position
-                constexpr bool CNT_OR = CD > 0 && CD >= S - 1;
+                // CD >= S - 2 (slide 6: k = 6 with CD = 5, k = 5 with CD = 4): two occurrences of a pattern are CD apart (the table's one
+                // period) or at least k > CD, so a block of S <= CD + 2 positions holds a pattern at most twice -- CD apart, or at its
+                // positions 0 and S - 1 -- and every position matches at most one pattern (no duplicate k-mers in these tables): the
+                // block's matches are the popcount of its OR plus those few possible pairs (whose ANDs the pair test below needs
+                // anyway), instead of a popcount and an add per position
+                constexpr bool CNT_OR = CD > 0 && CD >= S - 2;
                 if constexpr (CNT_OR) {
-                    uint32_t g_rp = 0;
+                    uint32_t g_rp = 0, dup = 0, dup_rp = 0;
                     TPS_UNROLL
                     for (int i = 0; i < S; ++i) {
                         g |= hc[i];
                         if (!RZ) {
                             if (i + 1 == rp) g_rp = g;
                         }
+                        if (i >= CD) {
+                            const uint32_t t = (uint32_t)popc(hc[i] & hc[i - CD]);
+                            dup += t;
+                            if (!RZ) {
+                                if (i < rp) dup_rp += t;
+                            }
+                        }
                     }
-                    if (!RZ) { pp = run_or | g_rp; c1 = cnt + (uint32_t)popc(g_rp); }
-                    cnt += (uint32_t)popc(g);
-                    if (CD == S - 1) cnt += (uint32_t)popc(hc[S - 1] & hc[0]);
+                    if (CD == S - 2) dup += (uint32_t)popc(hc[S - 1] & hc[0]);
+                    if (!RZ) { pp = run_or | g_rp; c1 = cnt + (uint32_t)popc(g_rp) + dup_rp; }
+                    cnt += (uint32_t)popc(g) + dup;
                 } else {
                 TPS_UNROLL
                 for (int i = 0; i < S; ++i) {
