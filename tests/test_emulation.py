@@ -67,7 +67,7 @@ def test_emulation_synthetic_goldens(synth_cases, force_generic):
 
 def test_plan_picks_specialised_kernels_for_the_baseline_configs():
     for k, P, slide, nwin, variant in [(4, 12, 6, 2467, 6), (5, 14, 7, 2829, 7), (4, 12, 6, 3301, 6), (5, 12, 6, 3301, 6),
-                                       (6, 12, 6, 3301, 6), (3, 10, 5, 3000, 5), (6, 16, 8, 2400, 0), (4, 12, 11, 1000, 0)]:
+                                       (6, 12, 6, 3301, 6), (3, 10, 5, 3000, 5), (6, 16, 8, 2400, 0), (4, 12, 11, 1000, 11), (4, 12, 13, 1000, 0), (4, 12, 3, 1000, 0)]:
         pl = emu.plan(k, P, hiplib.make_params(slide=slide), nwin)
         assert pl["variant"] == variant, (k, P, slide, pl)
         assert pl["lds_bytes"] <= 160 * 1024
@@ -738,3 +738,43 @@ def test_emulation_self_overlap_sums_blocks_with_a_pattern_twice(k, slide):
         lo, hi = out["win_off"][i], out["win_off"][i + 1]
         assert hi - lo == counts.shape[0] > 50
         assert np.array_equal(out["sums"][lo:hi], counts.sum(axis=1)), (k, slide, i)
+
+
+@pytest.mark.parametrize("slide", [4, 9, 10, 11, 12])
+@pytest.mark.parametrize("force_pair", [False, True])
+def test_emulation_default_kernels_other_slides(slide, force_pair, monkeypatch):
+    """Round 4: the default kernels (sums only, no self-overlapping k-mer) are instantiated for slides 4 and 9 .. 12 as well -- those
+    took the generic kernel before, three to five times slower per window.  Step 1, window sums and the boundary against the oracle;
+    with and without the pair table (the emulation's planner drops it where its bigger slices make it cost a workgroup)."""
+    if force_pair:
+        monkeypatch.setenv("TPS_FORCE_PAIR", "1")
+    motif, k, W = "CCCTAA", 4, 100
+    pats = orc.kmer_table(motif, k)
+    prm = hiplib.make_params(no_bp=1000, min_len=0, min_count=-1, window=W, slide=slide, trimfirst=100, maxlen=20000,
+                             flags=hiplib.F_STEP1 | hiplib.F_WINDOWS | hiplib.F_BINSEG | hiplib.F_STORE_SUMS)
+    pl = emu.plan_table(pats, prm, 5000)
+    assert pl["variant"] == slide and (pl["pair_n"] == 1024 or not force_pair), pl
+    rng = np.random.default_rng(slide * 7 + force_pair)
+    comp = str.maketrans("ACGTacgt", "TGCAtgca")
+    seqs = []
+    for i in range(5):
+        L = int(rng.integers(6000, 15000))
+        tract = int(rng.integers(800, 5000))
+        body = list((motif * (tract // len(motif) + 2))[:tract] + "".join("ACGT"[x] for x in rng.integers(0, 4, L - tract)))
+        for p in rng.integers(0, L, L // 12):
+            body[p] = "ACGT"[int(rng.integers(4))]
+        if i == 3:
+            body[int(rng.integers(1500, L))] = "N"
+        sq = "".join(body)
+        seqs.append(sq if i % 2 == 0 else sq[::-1].translate(comp))
+    out = emu.scan(pats, seqs, prm)
+    for i, seq in enumerate(seqs):
+        cs, ce = orc.trc_counts(seq, pats, 1000)
+        assert out["c_start"][i].tolist() == cs and out["c_end"][i].tolist() == ce, i
+        r = out["results"][i]
+        tail = "forward" if r["tail"] == 0 else "reverse"
+        _, counts = orc.window_count_matrix(seq, tail, pats, W, slide, 100, 20000)
+        lo, hi = out["win_off"][i], out["win_off"][i + 1]
+        assert hi - lo == counts.shape[0] and hi - lo > 400
+        assert np.array_equal(out["sums"][lo:hi], counts.sum(axis=1)), i
+        assert r["bkp"] == orc.binseg_l2_exact(counts.sum(axis=1)), i

@@ -547,3 +547,46 @@ def test_planned_launch_shapes_of_the_benchmark_tables(sc, k, flags, kernel):
     sc.scan(7, prm)
     sc.sync()
     assert sc.kernel_info(7) == kernel
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("slide,k,motif", [(4, 4, "CCCTAA"), (9, 4, "CCCTAA"), (10, 4, "CCCTAA"), (11, 4, "TTAGGG"), (12, 4, "CCCTAA"), (10, 5, "AAACCCT"), (12, 3, "TTAGG")])
+def test_default_kernels_other_slides(sc, slide, k, motif):
+    """Slides 4 and 9 .. 12 on the default kernels (sums only, no self-overlapping k-mer; `_s<slide>` / `_s<slide>p`): step 1, window
+    sums and the boundary bit-exact against the oracle -- several tiles, both strands, N and lower case."""
+    pats = orc.kmer_table(motif, k)
+    sc.set_patterns(pats)
+    rng = np.random.default_rng(slide * 19 + k)
+    comp = str.maketrans("ACGTacgt", "TGCAtgca")
+    seqs = []
+    for i in range(40):
+        L = int(rng.integers(3000, 16000))
+        tract = int(rng.integers(600, 2900))
+        body = list((motif * (tract // len(motif) + 2))[:tract] + "".join("ACGT"[x] for x in rng.integers(0, 4, L - tract)))
+        for p in rng.integers(0, L, L // 14):
+            body[p] = "ACGT"[int(rng.integers(4))]
+        if i % 5 == 3:
+            body[int(rng.integers(1200, L))] = "N"
+        if i % 7 == 4:
+            body[50:400] = [c.lower() for c in body[50:400]]
+        sq = "".join(body)
+        seqs.append(sq if i % 2 == 0 else sq[::-1].translate(comp))
+    bases, offsets = hiplib.pack_reads(seqs)
+    sc.upload(6, bases, offsets)
+    prm = hiplib.make_params(min_len=0, min_count=-1, window=100, slide=slide,
+                             flags=hiplib.F_STEP1 | hiplib.F_WINDOWS | hiplib.F_BINSEG | hiplib.F_STORE_SUMS)
+    sc.scan(6, prm)
+    sc.sync()
+    info = sc.kernel_info(6)
+    assert info.startswith("tps_scan_kernel_s%d" % slide) and not info.startswith("tps_scan_kernel "), info
+    res = sc.results(6).copy()
+    sums, win_off = sc.window_sums(6)
+    cs_all, ce_all = sc.batch_trc_counts(6)
+    for i, seq in enumerate(seqs):
+        cs, ce = orc.trc_counts(seq, pats)
+        assert cs_all[i].tolist() == cs and ce_all[i].tolist() == ce, i
+        tail = ["forward", "reverse"][res["tail"][i]]
+        _, counts = orc.window_count_matrix(seq, tail, pats, 100, slide, 100, 20000)
+        assert np.array_equal(sums[win_off[i]:win_off[i + 1]], counts.sum(axis=1)), i
+        want = orc.binseg_l2_exact(counts.sum(axis=1)) if counts.shape[0] >= 7 else None
+        assert res["bkp"][i] == (-1 if want is None else want), i

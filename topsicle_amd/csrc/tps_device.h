@@ -3738,6 +3738,7 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
                                                        else tile_fused_s<SF, SO, false, (N < SF ? N : 0), PAIR, RAW>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r); } break;
                     switch (tc.r) {
                         TPS_TILE_RP(0) TPS_TILE_RP(1) TPS_TILE_RP(2) TPS_TILE_RP(3) TPS_TILE_RP(4) TPS_TILE_RP(5) TPS_TILE_RP(6) TPS_TILE_RP(7)
+                        TPS_TILE_RP(8) TPS_TILE_RP(9) TPS_TILE_RP(10) TPS_TILE_RP(11)
                         default: break;
                     }
 #undef TPS_TILE_RP

@@ -75,7 +75,7 @@
 #define TPS_SCAN_KERNEL(NAME, SV, SO, PAIR, RAW, MINW) TPS_SCAN_KERNEL_F(NAME, SV, SO, PAIR, RAW, MINW, tps::tile_full_default(SV), 0)
 #define TPS_SCAN_KERNEL_D(NAME, SV, SO, PAIR, RAW, MINW, DCLASS) TPS_SCAN_KERNEL_F(NAME, SV, SO, PAIR, RAW, MINW, tps::tile_full_default(SV), DCLASS)
 
-#define TPS_KGROUPS 16
+#define TPS_KGROUPS 18
 #ifdef TPS_KGROUP
 #define TPS_IN_GROUP(g) (TPS_KGROUP == (g))
 #else
@@ -112,6 +112,16 @@ TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s5sorh)
 TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s6sorh)
 TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s7sorh)
 TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s8sorh)
+TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s4)
+TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s4p)
+TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s9)
+TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s9p)
+TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s10)
+TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s10p)
+TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s11)
+TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s11p)
+TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s12)
+TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s12p)
 TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s5q)
 TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s6q)
 TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s7q)
@@ -177,6 +187,22 @@ TPS_SCAN_KERNEL_D(tps_scan_kernel_s5q, 5, false, true, false, 5, 4)
 TPS_SCAN_KERNEL_D(tps_scan_kernel_s6q, 6, false, true, false, 5, 4)
 TPS_SCAN_KERNEL_D(tps_scan_kernel_s7q, 7, false, true, false, 5, 4)
 TPS_SCAN_KERNEL_D(tps_scan_kernel_s8q, 8, false, true, false, 5, 4)
+#endif
+// ... the default (sums only, no self-overlap) kernels for the other slides a window of 100 allows (round 4: slides outside 5 .. 8 took
+// the generic kernel, three to five times slower per window); the raw-row and self-overlap families keep slides 5 .. 8
+#if TPS_IN_GROUP(16)
+TPS_SCAN_KERNEL(tps_scan_kernel_s4, 4, false, false, false, 5)
+TPS_SCAN_KERNEL(tps_scan_kernel_s9, 9, false, false, false, 5)
+TPS_SCAN_KERNEL(tps_scan_kernel_s10, 10, false, false, false, 5)
+TPS_SCAN_KERNEL(tps_scan_kernel_s11, 11, false, false, false, 5)
+TPS_SCAN_KERNEL(tps_scan_kernel_s12, 12, false, false, false, 5)
+#endif
+#if TPS_IN_GROUP(17)
+TPS_SCAN_KERNEL(tps_scan_kernel_s4p, 4, false, true, false, 5)
+TPS_SCAN_KERNEL(tps_scan_kernel_s9p, 9, false, true, false, 5)
+TPS_SCAN_KERNEL(tps_scan_kernel_s10p, 10, false, true, false, 5)
+TPS_SCAN_KERNEL(tps_scan_kernel_s11p, 11, false, true, false, 5)
+TPS_SCAN_KERNEL(tps_scan_kernel_s12p, 12, false, true, false, 5)
 #endif
 #if TPS_IN_GROUP(9)
 TPS_SCAN_KERNEL_D(tps_scan_kernel_s5sol, 5, true, false, false, TPS_SOL_MINW, 1)     // ... the same for self-overlap periods 2 .. 4

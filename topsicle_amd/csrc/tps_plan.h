@@ -144,6 +144,8 @@ inline void plan_wpg(ScanArgs& a, int64_t budget_dw) {
 
 // Slides that have a specialised kernel instantiation (tps_scan_kernel_s<S>).
 inline bool has_specialised_slide(int s) { return s == 5 || s == 6 || s == 7 || s == 8; }
+// ... and the slides only the default kernels (sums only, no self-overlapping k-mer) are also instantiated for
+inline bool has_default_only_slide(int s) { return s == 4 || (s >= 9 && s <= 12); }
 
 // Geometry of one scan: fills variant, lut_n, lw/q/r, span_dw, blk_log2, spans_per_tile, nblk_cap,
 // rec_rs, seq_dw, head_dw, tot_dw, blk_dw, lc_cap, jump_magic.  budget_dw = LDS dwords one workgroup (WPG waves +
@@ -193,7 +195,7 @@ inline std::string plan_geometry_core(ScanArgs& a, const tps_params& prm, int k,
     int max_period = 0;                            // self-overlap periods of the table (0 = none)
     for (int i = 0; i < a.pat.n_periods; ++i) max_period = std::max(max_period, a.pat.period[i]);
     const bool sw16_ok = (int64_t)P * ((a.lw + k - 1) / k + 1) < 65536;        // the fused kernels keep S_w in 16 bits
-    const bool fused = !force_generic && spans_pref <= 0 && k <= TPS_DIRECT_K && has_specialised_slide(prm.slide) && P <= 15 && a.q >= 8 && sw16_ok &&
+    const bool fused = !force_generic && spans_pref <= 0 && k <= TPS_DIRECT_K && (has_specialised_slide(prm.slide) || (has_default_only_slide(prm.slide) && a.pat.so_mask == 0 && !(prm.flags & TPS_F_STORE_RAW) && !getenv("TPS_NO_EXT_SLIDES"))) && P <= 15 && a.q >= 8 && sw16_ok &&
                        a.q / 8 + 2 < (XLANES - NT) && max_period <= std::min(prm.slide, 6) &&
                        2 * a.head_dw <= fused_seq_dw(prm.slide);   // the two step-1 heads fit the tile buffer (TileGeo::SEQ)
     a.lc16 = 0; a.tile_cap = 0; a.tw = 0; a.tw_magic = 0; a.pair_n = 0; a.lc_global = 0; a.lc_stride = 0; a.pp_d = -1; a.so_fast = 0; a.seq_alias = 0; a.lut_fields = 0; a.tile_full = 0;
@@ -275,7 +277,7 @@ inline std::string plan_geometry_core(ScanArgs& a, const tps_params& prm, int k,
         // which plan_wpg then shares among 8 waves -- the plant-type 7-mer motifs (CCCTAAA at the reference's default k = 5) get two
         // positions per lookup like the 6-mer motifs at k = 4
         a.pair16 = 0;
-        if (a.pat.so_mask == 0 && a.pat.dup_mask == 0 && k == 5 && P <= 15 && !(prm.flags & TPS_F_STORE_RAW) && !getenv("TPS_NO_PAIR") && !getenv("TPS_NO_PAIR16")) {
+        if (a.pat.so_mask == 0 && a.pat.dup_mask == 0 && k == 5 && P <= 15 && has_specialised_slide(prm.slide) && !(prm.flags & TPS_F_STORE_RAW) && !getenv("TPS_NO_PAIR") && !getenv("TPS_NO_PAIR16")) {
             a.pair16 = 1;
             a.lut16 = 1;
             a.pair_n = (1 << (2 * (k + 1))) / 2;       // dwords
