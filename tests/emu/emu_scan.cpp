@@ -125,7 +125,7 @@ extern "C" int emu_scan(const char* pats, int P, int k, const uint8_t* bases, co
         switch (a.variant) {
             EMU_CASE(5) EMU_CASE(6) EMU_CASE(7) EMU_CASE(8)
 #define EMU_CASE_X(S) case S: if (a.pair_n && !a.pair16) tps::scan_read<S, false, true, false>(a, r, lds.data(), lut1); else tps::scan_read<S, false, false, false>(a, r, lds.data(), lut1); break;
-            EMU_CASE_X(4) EMU_CASE_X(9) EMU_CASE_X(10) EMU_CASE_X(11) EMU_CASE_X(12)
+            EMU_CASE_X(3) EMU_CASE_X(4) EMU_CASE_X(9) EMU_CASE_X(10) EMU_CASE_X(11) EMU_CASE_X(12)
 #undef EMU_CASE_X
             default: tps::scan_read<0, false>(a, r, lds.data(), lut1); break;
         }

@@ -67,7 +67,7 @@ def test_emulation_synthetic_goldens(synth_cases, force_generic):
 
 def test_plan_picks_specialised_kernels_for_the_baseline_configs():
     for k, P, slide, nwin, variant in [(4, 12, 6, 2467, 6), (5, 14, 7, 2829, 7), (4, 12, 6, 3301, 6), (5, 12, 6, 3301, 6),
-                                       (6, 12, 6, 3301, 6), (3, 10, 5, 3000, 5), (6, 16, 8, 2400, 0), (4, 12, 11, 1000, 11), (4, 12, 13, 1000, 0), (4, 12, 3, 1000, 0)]:
+                                       (6, 12, 6, 3301, 6), (3, 10, 5, 3000, 5), (6, 16, 8, 2400, 0), (4, 12, 11, 1000, 11), (4, 12, 13, 1000, 0), (4, 12, 3, 1000, 3), (4, 12, 2, 1000, 0)]:
         pl = emu.plan(k, P, hiplib.make_params(slide=slide), nwin)
         assert pl["variant"] == variant, (k, P, slide, pl)
         assert pl["lds_bytes"] <= 160 * 1024
@@ -740,7 +740,7 @@ def test_emulation_self_overlap_sums_blocks_with_a_pattern_twice(k, slide):
         assert np.array_equal(out["sums"][lo:hi], counts.sum(axis=1)), (k, slide, i)
 
 
-@pytest.mark.parametrize("slide", [4, 9, 10, 11, 12])
+@pytest.mark.parametrize("slide", [3, 4, 9, 10, 11, 12])
 @pytest.mark.parametrize("force_pair", [False, True])
 def test_emulation_default_kernels_other_slides(slide, force_pair, monkeypatch):
     """Round 4: the default kernels (sums only, no self-overlapping k-mer) are instantiated for slides 4 and 9 .. 12 as well -- those

@@ -550,7 +550,7 @@ def test_planned_launch_shapes_of_the_benchmark_tables(sc, k, flags, kernel):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("slide,k,motif", [(4, 4, "CCCTAA"), (9, 4, "CCCTAA"), (10, 4, "CCCTAA"), (11, 4, "TTAGGG"), (12, 4, "CCCTAA"), (10, 5, "AAACCCT"), (12, 3, "TTAGG")])
+@pytest.mark.parametrize("slide,k,motif", [(3, 4, "CCCTAA"), (4, 4, "CCCTAA"), (9, 4, "CCCTAA"), (10, 4, "CCCTAA"), (11, 4, "TTAGGG"), (12, 4, "CCCTAA"), (10, 5, "AAACCCT"), (12, 3, "TTAGG")])
 def test_default_kernels_other_slides(sc, slide, k, motif):
     """Slides 4 and 9 .. 12 on the default kernels (sums only, no self-overlapping k-mer; `_s<slide>` / `_s<slide>p`): step 1, window
     sums and the boundary bit-exact against the oracle -- several tiles, both strands, N and lower case."""

@@ -457,19 +457,19 @@ int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm) {
                                     {(const void*)tps_scan_kernel_s7q, "tps_scan_kernel_s7q"}, {(const void*)tps_scan_kernel_s8q, "tps_scan_kernel_s8q"}};
         static const K solk[4] = {{(const void*)tps_scan_kernel_s5sol, "tps_scan_kernel_s5sol"}, {(const void*)tps_scan_kernel_s6sol, "tps_scan_kernel_s6sol"},
                                   {(const void*)tps_scan_kernel_s7sol, "tps_scan_kernel_s7sol"}, {(const void*)tps_scan_kernel_s8sol, "tps_scan_kernel_s8sol"}};
-        static const K plainx[5] = {{(const void*)tps_scan_kernel_s4, "tps_scan_kernel_s4"}, {(const void*)tps_scan_kernel_s9, "tps_scan_kernel_s9"},
+        static const K plainx[6] = {{(const void*)tps_scan_kernel_s3, "tps_scan_kernel_s3"}, {(const void*)tps_scan_kernel_s4, "tps_scan_kernel_s4"}, {(const void*)tps_scan_kernel_s9, "tps_scan_kernel_s9"},
                                     {(const void*)tps_scan_kernel_s10, "tps_scan_kernel_s10"}, {(const void*)tps_scan_kernel_s11, "tps_scan_kernel_s11"},
                                     {(const void*)tps_scan_kernel_s12, "tps_scan_kernel_s12"}};
-        static const K pairx[5] = {{(const void*)tps_scan_kernel_s4p, "tps_scan_kernel_s4p"}, {(const void*)tps_scan_kernel_s9p, "tps_scan_kernel_s9p"},
+        static const K pairx[6] = {{(const void*)tps_scan_kernel_s3p, "tps_scan_kernel_s3p"}, {(const void*)tps_scan_kernel_s4p, "tps_scan_kernel_s4p"}, {(const void*)tps_scan_kernel_s9p, "tps_scan_kernel_s9p"},
                                    {(const void*)tps_scan_kernel_s10p, "tps_scan_kernel_s10p"}, {(const void*)tps_scan_kernel_s11p, "tps_scan_kernel_s11p"},
                                    {(const void*)tps_scan_kernel_s12p, "tps_scan_kernel_s12p"}};
         if (tps::has_default_only_slide(a.variant)) {
             // the default kernels' other slides (sums only, no self-overlap: plan_geometry took the fused path for nothing else)
-            const int xi = a.variant == 4 ? 0 : a.variant - 8;
+            const int xi = a.variant <= 4 ? a.variant - 3 : a.variant - 7;
             const K& k = (pair && !a.pair16) ? pairx[xi] : plainx[xi];
             kfn = k.fn;
             sl.kernel_name = k.name;
-            kidx = 40 + ((pair && !a.pair16) ? 5 : 0) + xi;
+            kidx = 40 + ((pair && !a.pair16) ? 6 : 0) + xi;
         } else if (a.variant >= 5 && a.variant <= 8) {
             // sums only, self-overlap table: periods 2 .. 4 have their own kernels (96 registers, 5 waves per SIMD)
             const int fam = so ? (want_raw ? (a.lut16 ? 6 : 4) : (a.pp_d >= 2 && a.pp_d <= 4) ? 5 : 3) : want_raw ? 2 : (pair && a.pair16) ? 7 : pair ? 1 : 0;

@@ -1293,7 +1293,8 @@ struct TileGeo {
     static constexpr int BASES = LANES * Geo<S>::POS + 13 + 15;       // positions the lanes touch, look-ahead included
     static constexpr int NQ = (63 + BASES + 63) / 64;                 // quads of a tile whatever its sub-quad start offset
     static constexpr int PF = (NQ + NT - 1) / NT;
-    static constexpr int SEQ = SEQ_LEAD + 4 * NQ + 4;                 // dwords of seq2: lead, the tile, look-ahead reads of the last lane
+    static constexpr int SEQ_TILE = SEQ_LEAD + 4 * NQ + 4;            // dwords of seq2: lead, the tile, look-ahead reads of the last lane
+    static constexpr int SEQ = SEQ_TILE < 144 ? 144 : SEQ_TILE;       // ... and never less than step 1's two heads of 1000 bases need (slide 3: 112 for the tile)
 };
 constexpr bool tile_full_default(int s) { return s >= 1; }
 

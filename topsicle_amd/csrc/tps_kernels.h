@@ -112,6 +112,8 @@ TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s5sorh)
 TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s6sorh)
 TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s7sorh)
 TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s8sorh)
+TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s3)
+TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s3p)
 TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s4)
 TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s4p)
 TPS_SCAN_KERNEL_DECL(tps_scan_kernel_s9)
@@ -188,9 +190,10 @@ TPS_SCAN_KERNEL_D(tps_scan_kernel_s6q, 6, false, true, false, 5, 4)
 TPS_SCAN_KERNEL_D(tps_scan_kernel_s7q, 7, false, true, false, 5, 4)
 TPS_SCAN_KERNEL_D(tps_scan_kernel_s8q, 8, false, true, false, 5, 4)
 #endif
-// ... the default (sums only, no self-overlap) kernels for the other slides a window of 100 allows (round 4: slides outside 5 .. 8 took
+// ... the default (sums only, no self-overlap) kernels for the other slides a window of 100 allows (3, 4, 9 .. 12; round 4: slides outside 5 .. 8 took
 // the generic kernel, three to five times slower per window); the raw-row and self-overlap families keep slides 5 .. 8
 #if TPS_IN_GROUP(16)
+TPS_SCAN_KERNEL(tps_scan_kernel_s3, 3, false, false, false, 5)
 TPS_SCAN_KERNEL(tps_scan_kernel_s4, 4, false, false, false, 5)
 TPS_SCAN_KERNEL(tps_scan_kernel_s9, 9, false, false, false, 5)
 TPS_SCAN_KERNEL(tps_scan_kernel_s10, 10, false, false, false, 5)
@@ -198,6 +201,7 @@ TPS_SCAN_KERNEL(tps_scan_kernel_s11, 11, false, false, false, 5)
 TPS_SCAN_KERNEL(tps_scan_kernel_s12, 12, false, false, false, 5)
 #endif
 #if TPS_IN_GROUP(17)
+TPS_SCAN_KERNEL(tps_scan_kernel_s3p, 3, false, true, false, 5)
 TPS_SCAN_KERNEL(tps_scan_kernel_s4p, 4, false, true, false, 5)
 TPS_SCAN_KERNEL(tps_scan_kernel_s9p, 9, false, true, false, 5)
 TPS_SCAN_KERNEL(tps_scan_kernel_s10p, 10, false, true, false, 5)

@@ -112,7 +112,8 @@ inline std::string build_patterns(const char* pats, int P, int k, std::vector<ui
 inline int fused_seq_dw(int slide) {
     const int bases = NT * 8 * slide + 13 + 15;
     const int nq = (63 + bases + 63) / 64;
-    return SEQ_LEAD + 4 * nq + 4;
+    const int seq = SEQ_LEAD + 4 * nq + 4;
+    return seq < 144 ? 144 : seq;                  // (= TileGeo::SEQ)
 }
 
 // Waves per workgroup: 4, unless the table is big (k >= 6: 16 KB and more per workgroup) and sharing it among more waves
@@ -145,7 +146,7 @@ inline void plan_wpg(ScanArgs& a, int64_t budget_dw) {
 // Slides that have a specialised kernel instantiation (tps_scan_kernel_s<S>).
 inline bool has_specialised_slide(int s) { return s == 5 || s == 6 || s == 7 || s == 8; }
 // ... and the slides only the default kernels (sums only, no self-overlapping k-mer) are also instantiated for
-inline bool has_default_only_slide(int s) { return s == 4 || (s >= 9 && s <= 12); }
+inline bool has_default_only_slide(int s) { return s == 3 || s == 4 || (s >= 9 && s <= 12); }
 
 // Geometry of one scan: fills variant, lut_n, lw/q/r, span_dw, blk_log2, spans_per_tile, nblk_cap,
 // rec_rs, seq_dw, head_dw, tot_dw, blk_dw, lc_cap, jump_magic.  budget_dw = LDS dwords one workgroup (WPG waves +
