@@ -165,6 +165,9 @@ TPS_DEV uint32_t bitrev32(uint32_t x) { return __builtin_bitreverse32(x); }     
 // base both in SGPRs (the single table of the pair-table kernels: 8 lookups per tile at odd r, step 1's) it comes out as v_and +
 // v_or, a VOP3 instruction reading one scalar register only on gfx9.  The base pinned into a VGPR gives the one instruction, 6 VALU
 // per tile less -- and measures nothing at config 2 (55.0 / 54.8 against 54.8 / 55.0 us), +1 % on the kernels whose base is 0: not kept.
+// Nor does a compile-time table address help (tried: a fixed-size pair region, so that the single table starts at LDS byte 4096): the
+// base of the dynamic LDS array is resolved after instruction selection -- `| base` of the array's own start is folded late, any
+// other constant offset stays an instruction, and written as `+` even the start costs a `v_add_u32 0` per lookup.
 #ifdef TPS_EMU
 TPS_DEV uint32_t lut_at(const uint32_t* lut, uint32_t v4, uint32_t amask) { return *(const uint32_t*)((const char*)lut + (v4 & amask)); }
 #define lut_at_tile lut_at
