@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define TPS_ABI_VERSION 3
+#define TPS_ABI_VERSION 4
 
 /* error codes */
 #define TPS_OK            0
@@ -171,6 +171,17 @@ int  tps_batch_window_offsets(tps_ctx* ctx, int32_t slot, int64_t* win_off, int6
 /* Download S_w (needs TPS_F_STORE_SUMS) / c'_p (needs TPS_F_STORE_RAW) of the last scan. */
 int  tps_batch_window_sums(tps_ctx* ctx, int32_t slot, int32_t* sums, int64_t n_windows);
 int  tps_batch_window_raw(tps_ctx* ctx, int32_t slot, uint8_t* raw, int64_t n_windows_times_p);
+/* c'_p of SELECTED reads of the last scan (needs TPS_F_STORE_RAW) straight to a file (ABI 4): the rows of reads[0 .. n_sel)
+ * -- ascending indices into the batch -- back to back, u8[n_win x P] each, at byte `file_off` of `fd` (pwrite: the descriptor's
+ * own position is not used, several contexts may write into one file at once).  The rows never stop in the caller's memory:
+ * device -> two pinned pieces of the context -> pwritev, the next piece copied while the current one is written.  crc_fn (may be
+ * NULL; e.g. libtopsicle_io.so's tps_crc32) is run over the bytes in file order, starting from 0: *crc_out (may be NULL) is the
+ * CRC-32 of exactly what was written, *bytes_out its length -- a caller that lays the blocks of many batches into one zip / npy
+ * member joins the per-block values with crc32_combine.  Replaces, for the columnar raw-count output, the per-read
+ * DataFrame.to_csv of the reference (Topsicle/main.py:146-150; Topsicle/allsteps.py:398-411 builds the rows). */
+typedef uint32_t (*tps_crc32_fn)(uint32_t crc, const uint8_t* p, int64_t n);
+int  tps_batch_raw_to_fd(tps_ctx* ctx, int32_t slot, const int64_t* reads, int64_t n_sel, int fd, int64_t file_off,
+                         tps_crc32_fn crc_fn, uint32_t* crc_out, int64_t* bytes_out);
 /* S_w of ONE read of the last scan (any scan with TPS_F_WINDOWS; n_windows = the read's n_win). */
 int  tps_batch_read_sums(tps_ctx* ctx, int32_t slot, int64_t read, int32_t* sums, int64_t n_windows);
 /* Step-1 per-pattern counts of the last scan: c_start[n*P], c_end[n*P] (int32). */

@@ -12,6 +12,8 @@ Topsicle/allsteps.py unchanged through oracle/ref_import.py and records inputs +
   synth_cases.json/.npz  the same three calls on small seeded synthetic reads that exercise
                        lower case, non-ACGT letters, self-overlapping k-mers, short reads,
                        odd window/slide/trim values
+  cli_<seed>.json      whole runs of the reference's main() on seeded inputs (oracle/cli_cases.py): flags, input files, and the
+                       CSV rows / summary log lines / filtered files the run left behind   (main.py:52-154, 156-309)
   demo_col0.fastq.gz, demo_telolengths_all.csv, demo_run_log.json
                        data files of the reference's demo (inputs / its only result goldens)
 
@@ -275,6 +277,25 @@ def gen_overview():
     print("overview goldens:", [(h["motif"], h["k"], h["n_rows"]) for h in out["heatmaps"]])
 
 
+CLI_GOLDEN_SEEDS = (104, 108, 126, 134)      # oracle/cli_cases.py: three files / k = 4, 6 / cutoff list; three files / k = 4, 5, 6; --read_check; exit 1
+
+
+def gen_cli():
+    """Whole runs of the reference's own main() (Topsicle/main.py:312-343 -> analysis_run -> process_file) on seeded inputs:
+    the case (input files as text, flags) and what the run left behind (CSV row sequence, summary log lines, filtered files)."""
+    import cli_cases
+    for seed in CLI_GOLDEN_SEEDS:
+        case = cli_cases.make_case(seed)
+        with tempfile.TemporaryDirectory() as d:
+            inp, out = cli_cases.materialise(case, d)
+            code = ref_import.run_reference_main(["-i", inp, "-o", out] + case["argv"])
+            assert code == case["exit"], (seed, code)
+            expected = cli_cases.normalise(out)
+        with open(os.path.join(GOLD, f"cli_{seed}.json"), "w") as h:
+            json.dump({"case": case, "expected": expected}, h, indent=0, sort_keys=True)
+        print(f"cli_{seed}.json:", 0 if not expected["csv"] else len(expected["csv"]) - 1, "rows,", len(expected["filtered"]), "filtered files")
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     ref = ref_import.load_reference_allsteps()
@@ -282,6 +303,7 @@ def main():
     gen_demo(ref)
     gen_synth(ref)
     gen_overview()
+    gen_cli()
     print("fixture bytes:", sum(os.path.getsize(os.path.join(GOLD, f)) for f in os.listdir(GOLD)))
 
 

@@ -79,13 +79,33 @@ def _parse(handle, fmt):
         raise ValueError(fmt)
 
 
+def _write(records, handle, fmt):
+    """Bio.SeqIO.write's text for the two formats the reference writes (main.py:83-86): FASTA with the sequence wrapped at 60
+    columns, four-line FASTQ; the title is the description when it begins with the id (Biopython's FastaWriter / FastqPhredWriter
+    -- which is every record that came out of SeqIO.parse)."""
+    recs = [records] if isinstance(records, _Record) else list(records)
+    for r in recs:
+        title = r.description if (r.description and r.description.split(None, 1)[:1] == [r.id]) else \
+            (r.id + (" " + r.description if r.description and r.description != r.id else ""))
+        s = str(r.seq)
+        if fmt == "fasta":
+            handle.write(">" + title + "\n")
+            for i in range(0, len(s), 60):
+                handle.write(s[i:i + 60] + "\n")
+        elif fmt == "fastq":
+            handle.write("@" + title + "\n" + s + "\n+\n" + (r.qual or "") + "\n")
+        else:
+            raise ValueError(fmt)
+    return len(recs)
+
+
 def _install_standins():
     if "Topsicle.allsteps" in sys.modules:
         return
     bio = types.ModuleType("Bio")
     seqio = types.ModuleType("Bio.SeqIO")
     seqio.parse = _parse
-    seqio.write = lambda *a, **k: 0
+    seqio.write = _write
     qualio = types.ModuleType("Bio.SeqIO.QualityIO")
     qualio.FastqGeneralIterator = lambda handle: iter(())
     seqio.QualityIO = qualio
@@ -145,6 +165,35 @@ def load_reference_allsteps():
     # import the submodule directly: Topsicle/__init__.py star-imports descriptive_plot too,
     # which is harmless with the stand-ins in place.
     return importlib.import_module("Topsicle.allsteps")
+
+
+def load_reference_main():
+    """The reference's `Topsicle.main` module (its own code, unchanged): main() reads sys.argv, analysis_run(args) forks its
+    Pool over the input files (the stand-ins are inherited by the children)."""
+    load_reference_allsteps()
+    import importlib
+    return importlib.import_module("Topsicle.main")
+
+
+def run_reference_main(argv):
+    """Topsicle/main.py:main() on `argv` in this process: returns the SystemExit code (None when it returned)."""
+    import contextlib
+    import io
+    m = load_reference_main()
+    old = sys.argv
+    sys.argv = ["topsicle"] + list(argv)
+    if hasattr(m.tprint, "logfile"):
+        del m.tprint.logfile
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            m.main()
+    except SystemExit as e:
+        return e.code if e.code is not None else 0
+    finally:
+        sys.argv = old
+        import matplotlib.pyplot as plt
+        plt.close("all")
+    return None
 
 
 def load_reference_descriptive_plot():

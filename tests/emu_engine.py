@@ -102,6 +102,16 @@ class EmuEngine:
         o = self.slots[slot]["out"]
         return o["raw"], o["win_off"]
 
+    def raw_to_fd(self, slot, reads, fd, file_off):
+        """HipScanner.raw_to_fd for the emulated context: the same bytes at the same place, (bytes, crc32)."""
+        import os
+        import zlib
+        o = self.slots[slot]["out"]
+        wo, raw = o["win_off"], np.ascontiguousarray(o["raw"], np.uint8)
+        blob = b"".join(raw[int(wo[i]):int(wo[i + 1])].tobytes() for i in reads)
+        os.pwrite(fd, blob, file_off)
+        return len(blob), zlib.crc32(blob)
+
     def batch_trc_counts(self, slot):
         o = self.slots[slot]["out"]
         return o["c_start"], o["c_end"]

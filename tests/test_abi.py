@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     lib = C.CDLL(hiplib.LIB_PATH)
     for name in declared_symbols():
         assert hasattr(lib, name), name
-    assert hiplib.load_library().tps_abi_version() == 3
+    assert hiplib.load_library().tps_abi_version() == 4
 
 
 def test_struct_layouts_match_header():

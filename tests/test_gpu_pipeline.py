@@ -239,3 +239,109 @@ def test_compressed_inputs_scan_like_the_plain_file(tmp_path, monkeypatch):
     finally:
         for e in engines:
             e.close()
+
+
+def test_raw_rows_straight_to_a_file(sc, tmp_path):
+    """tps_batch_raw_to_fd (ABI 4): the rows of selected reads, device -> pinned pieces -> pwritev, equal to the rows
+    tps_batch_window_raw downloads -- all passing reads (runs that merge, > 32 MB: several pieces), every third read (runs with
+    gaps below and above the skip threshold), a sparse handful, nothing; the CRC equals zlib's over the same bytes; two contexts
+    write into one file at once (helper context sharing the batch)."""
+    import zlib
+    motif, k = "CCCTAA", 5
+    pats = orc.kmer_table(motif, k)
+    sc.set_patterns(pats)
+    bases, offsets = _ragged(3000, motif, 77)
+    seq2, inv, desc = seqio.pack_reads_host(bases, offsets)
+    sc.upload_packed(6, seq2, inv, desc)
+    prm = _params(motif, 6, flags=FULL | hiplib.F_STORE_RAW)
+    sc.scan(6, prm)
+    sc.sync()
+    res = sc.results(6)
+    raw, win_off = sc.window_raw(6)
+    passing = np.nonzero(res["pass"])[0]
+    assert 0 < len(passing) < len(res)
+    P = len(pats)
+    fd = os.open(tmp_path / "rows.bin", os.O_RDWR | os.O_CREAT | os.O_TRUNC)
+    try:
+        at = 4096
+        for sel in (passing, passing[::3], passing[[5, 400, 401, 2000 % len(passing)]] if len(passing) > 2001 else passing[:3], passing[:0],
+                    np.arange(len(res))):
+            sel = np.unique(sel)
+            want = b"".join(raw[win_off[i]:win_off[i + 1]].tobytes() for i in sel)
+            got_n, crc = sc.raw_to_fd(6, sel, fd, at)
+            assert got_n == len(want)
+            assert os.pread(fd, len(want), at) == want
+            assert crc == zlib.crc32(want)
+            at += len(want) + 17
+        assert len(b"".join(raw[win_off[i]:win_off[i + 1]].tobytes() for i in passing)) > (40 << 20)      # several 32 MB pieces were needed
+        # a second table on a helper context, same resident batch, both writing into the one file at the same time
+        import threading
+        h = sc.helper(0)
+        h.share(6, sc, 6)
+        pats6 = orc.kmer_table(motif, 6)
+        h.set_patterns(pats6)
+        h.scan(6, prm)
+        h.sync()
+        raw6, wo6 = h.window_raw(6)
+        a_off, b_off = at, at + int(sum(win_off[i + 1] - win_off[i] for i in passing)) * P + 4096
+        out = {}
+        t = threading.Thread(target=lambda: out.__setitem__("h", h.raw_to_fd(6, passing, fd, b_off)))
+        t.start()
+        out["s"] = sc.raw_to_fd(6, passing, fd, a_off)
+        t.join()
+        want_s = b"".join(raw[win_off[i]:win_off[i + 1]].tobytes() for i in passing)
+        want_h = b"".join(raw6[wo6[i]:wo6[i + 1]].tobytes() for i in passing)
+        assert os.pread(fd, len(want_s), a_off) == want_s and out["s"] == (len(want_s), zlib.crc32(want_s))
+        assert os.pread(fd, len(want_h), b_off) == want_h and out["h"] == (len(want_h), zlib.crc32(want_h))
+    finally:
+        os.close(fd)
+    with pytest.raises(hiplib.TopsicleHipError):
+        sc.raw_to_fd(6, np.array([3, 2]), 1, 0)                # not ascending
+
+
+def test_cli_npz_on_gpu_equals_the_per_read_csv_rows(tmp_path, gold_dir, monkeypatch):
+    """--rawcountformat npz through the real CLI: many batches on two contexts, three k -- the archive verifies (zip CRCs), its
+    rows equal the reference's rawCountPattern matrices (tests/golden/demo_windows.npz) and the oracle's on synthetic reads."""
+    import json
+    import shutil
+    import zipfile
+    from topsicle_amd import main as cli
+    d = tmp_path / "in"
+    d.mkdir()
+    fq = d / "demo.fastq.gz"
+    shutil.copyfile(os.path.join(gold_dir, "demo_col0.fastq.gz"), fq)
+    out = tmp_path / "out"
+    cli.main(["-i", str(fq), "-o", str(out), "--pattern", "CCCTAAA", "--slide", "6", "--rawcountpattern", "--rawcountformat", "npz"])
+    meta = json.load(open(os.path.join(gold_dir, "demo_windows.json")))
+    arrs = np.load(os.path.join(gold_dir, "demo_windows.npz"))
+    with zipfile.ZipFile(out / "rawcount_5_demo.fastq.npz") as zf:
+        assert zf.testzip() is None
+    z = np.load(out / "rawcount_5_demo.fastq.npz")
+    ids = z["read_id"].tolist()
+    assert len(ids) == 17
+    for j, r in enumerate(meta["reads"]):
+        if f"counts_{j}" in arrs:
+            i = ids.index(r["id"])
+            assert np.array_equal(z["counts"][z["win_off"][i]:z["win_off"][i + 1]], arrs[f"counts_{j}"])
+            assert str(z["tail"][i]) == r["tail"]
+    # synthetic, several batches, k = 4, 5, 6
+    monkeypatch.setattr(batch, "BATCH_BASES", 4 << 20)
+    bases, offsets, _truth = synth.make_reads(900, 12000, "CCCTAA", seed=5)
+    fq2 = tmp_path / "s.fastq"
+    _write_fastq(fq2, bases, offsets)
+    out2 = tmp_path / "out2"
+    cli.main(["-i", str(fq2), "-o", str(out2), "--pattern", "CCCTAA", "--telophrase", "4", "5", "6", "--rawcountpattern", "--rawcountformat", "npz"])
+    for k in (4, 5, 6):
+        with zipfile.ZipFile(out2 / f"rawcount_{k}_s.npz") as zf:
+            assert zf.testzip() is None
+        z = np.load(out2 / f"rawcount_{k}_s.npz")
+        pats = orc.kmer_table("CCCTAA", k)
+        ids = z["read_id"].tolist()
+        nums = [int("".join(ch for ch in r if ch.isdigit())) for r in ids]
+        assert len(ids) > 850 and nums == sorted(nums)                        # file order, although the batches finish out of order
+        for i in range(0, len(ids), 97):
+            rid = ids[i]
+            ridx = int("".join(ch for ch in rid if ch.isdigit()))
+            seq = bases[offsets[ridx]:offsets[ridx + 1]].tobytes().decode()
+            want = orc.window_count_matrix(seq, str(z["tail"][i]), pats, 100, 6, 100, 20000)[1]
+            assert np.array_equal(z["counts"][z["win_off"][i]:z["win_off"][i + 1]], want), (k, rid)

@@ -144,7 +144,10 @@ def bound_detect(filepath, read, pattern_telo, windowSize, slide, trimfirst, max
     for rec in seqio.read_records(filepath):
         if rec.id != read or windowSize is None:
             continue
-        m = min(maxlengthtelo, len(rec.seq))
+        # upstream OVERWRITES maxlengthtelo with a shorter record's length (allsteps.py:263-264) and has no `break`: with duplicate
+        # read ids a later record of the same id is clipped by the shortest one before it as well (the only place
+        # the per-read API and the reference could be made to disagree)
+        m = maxlengthtelo = min(maxlengthtelo, len(rec.seq))
         tails = [t for t in ("reverse", "forward") if tail in (None, t)]
         sums, win_off, _ = _window_scan(rec.seq, tails, patterns, windowSize, slide, trimfirst, m)
         eng = get_engine()

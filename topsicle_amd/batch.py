@@ -39,8 +39,32 @@ class Job:
     batch = `--telophrase 4 5 6`: the batch is parsed, packed and uploaded ONCE and scanned once per k (the reference
     re-parses the input for every k, main.py:206-235)."""
 
-    def __init__(self, patterns, prm: hiplib.Params, want_sums=False, want_raw=False):
+    def __init__(self, patterns, prm: hiplib.Params, want_sums=False, want_raw=False, raw_sink=None):
+        """raw_sink (with want_raw; rawnpz.RawNpzWriter): the raw rows of the reads the sink selects are written to its file by
+        the worker that scanned the batch, device -> file, and the caller gets a `RawKept` in place of the rows."""
         self.patterns, self.prm, self.want_sums, self.want_raw = list(patterns), prm, bool(want_sums), bool(want_raw)
+        self.raw_sink = raw_sink if want_raw else None
+
+
+class RawKept:
+    """What a job with a raw_sink returns in place of the raw rows: `keep` = the reads (indices into the batch) whose rows the
+    sink has written, in that order."""
+
+    def __init__(self, keep):
+        self.keep = keep
+
+
+def _sink_rows(job, seq, eng, slot, recs, res, slot_index=None):
+    """Hand the rows of one scanned batch to the job's sink.  `slot_index`: the batch indices of the reads resident in `slot`
+    when that is not the whole batch (second pass of the two-pass route: the passing reads only)."""
+    sink = job.raw_sink
+    keep = sink.select(recs, res)
+    if not len(keep):
+        sink.skip_batch(seq)
+        return RawKept(keep)
+    slot_reads = keep if slot_index is None else np.searchsorted(slot_index, keep)
+    sink.write_batch(seq, eng, slot, slot_reads, int(res["n_win"][keep].astype(np.int64).sum()))
+    return RawKept(keep)
 
 
 def upload_batch(engine, recs, slot: int = 0):
@@ -61,7 +85,7 @@ AUTO_MIN_FILE_BYTES = 1 << 30    # auto mode only probes files of at least this 
                                  # file, and what two passes save on a small file is less than that
 
 
-def scan_jobs_heads(engine, recs, jobs, slot: int = 0):
+def scan_jobs_heads(engine, recs, jobs, slot: int = 0, seq=None):
     """Two passes over a batch that came in HEADS mode (seqio.PackedBatch.full_len: only the first + last no_bp bases of every read
     were packed and uploaded -- all that step 1, allsteps.py:174-198, looks at):
       A  step 1 on the heads, one launch per job (table);
@@ -145,13 +169,18 @@ def scan_jobs_heads(engine, recs, jobs, slot: int = 0):
                 if job.want_sums:
                     sums, wo_b = eng.window_sums(slot_b)
                     assert int(wo_b[-1]) == int(win_off[-1])
-                if job.want_raw:
+                if job.want_raw and job.raw_sink is not None and seq is not None:
+                    raw = _sink_rows(job, seq, eng, slot_b, recs, res, slot_index=idx)
+                elif job.want_raw:
                     raw, wo_b = eng.window_raw(slot_b)
                     assert int(wo_b[-1]) == int(win_off[-1])
             else:
                 if job.want_sums:
                     sums = np.zeros(0, np.int32)
-                if job.want_raw:
+                if job.want_raw and job.raw_sink is not None and seq is not None:
+                    job.raw_sink.skip_batch(seq)
+                    raw = RawKept(np.zeros(0, np.int64))
+                elif job.want_raw:
                     raw = np.zeros((0, len(job.patterns)), np.uint8)
             out.append((res, sums, raw, win_off if (job.want_sums or job.want_raw) else None))
     except BaseException:
@@ -174,8 +203,9 @@ def _pack_passing(recs, idx, tails, maxlen):
     return seqio.pack_spans(recs, idx, tails, maxlen)
 
 
-def scan_jobs(engine, recs, jobs, slot: int = 0):
+def scan_jobs(engine, recs, jobs, slot: int = 0, seq=None):
     """Upload once, then one fused scan per job.  Returns [(results, sums, raw, win_off), ...] in job order.
+    `seq`: the batch's index in its file (EnginePool passes it): jobs with a raw_sink then write their rows through it.
     A batch in heads mode (PackedBatch.full_len) takes the two-pass route: scan_jobs_heads.
 
     Several jobs (pattern tables) on a HipScanner run AT THE SAME TIME: job j > 0 goes to the engine's j-th helper context,
@@ -183,7 +213,7 @@ def scan_jobs(engine, recs, jobs, slot: int = 0):
     of the k passes overlap on the GPU (measured: 603 vs 785 us per 10 000 x 25 kb batch for k = 4, 5, 6).
     TOPSICLE_SEQUENTIAL_TABLES=1 scans them back to back on the one context instead (the A/B switch)."""
     if getattr(recs, "full_len", None) is not None:
-        return scan_jobs_heads(engine, recs, jobs, slot)
+        return scan_jobs_heads(engine, recs, jobs, slot, seq)
     out = []
     concurrent = len(jobs) > 1 and hasattr(engine, "helper") and os.environ.get("TOPSICLE_SEQUENTIAL_TABLES", "0") != "1"
     engines = [engine] + ([engine.helper(j) for j in range(len(jobs) - 1)] if concurrent else [engine] * (len(jobs) - 1))
@@ -215,7 +245,10 @@ def scan_jobs(engine, recs, jobs, slot: int = 0):
             sums = raw = win_off = None
             if job.want_sums:
                 sums, win_off = eng.window_sums(slot)
-            if job.want_raw:
+            if job.want_raw and job.raw_sink is not None and seq is not None:
+                win_off = eng.window_offsets(slot)
+                raw = _sink_rows(job, seq, eng, slot, recs, res)
+            elif job.want_raw:
                 raw, win_off = eng.window_raw(slot)
             out.append((res, sums, raw, win_off))
     except BaseException:
@@ -240,11 +273,17 @@ class EnginePool:
     upload / launch ramp / result download of one batch with the scan of another).  Batches go to whichever context is
     free next; results come back in input order."""
 
-    def __init__(self, engines, patterns=None, two_pass="auto"):
-        """two_pass: "auto" (heads mode while few reads pass step 1: see _heads_mode), "on", "off"."""
+    def __init__(self, engines, patterns=None, two_pass=None):
+        """two_pass: "auto" (heads mode while few reads pass step 1: see _heads_mode), "on", "off"; None = $TOPSICLE_TWO_PASS or auto."""
         self.engines = list(engines)
-        self.two_pass = os.environ.get("TOPSICLE_TWO_PASS", two_pass)
+        # TOPSICLE_TWO_PASS is only the default of callers that say nothing (ADVICE r4: it used to override an explicit argument)
+        if two_pass is None:
+            two_pass = os.environ.get("TOPSICLE_TWO_PASS", "auto")
+        if two_pass not in ("auto", "on", "off"):
+            raise ValueError(f"two_pass must be auto, on or off, not {two_pass!r}")
+        self.two_pass = two_pass
         self.stats = {"batches": 0, "heads_batches": 0, "upload_bytes": 0, "input_bases": 0}
+        self._stats_lock = threading.Lock()           # (_heads_feedback runs on the worker threads)
         if not self.engines:
             raise ValueError("no engines")
         self.patterns = None if patterns is None else list(patterns)
@@ -262,9 +301,9 @@ class EnginePool:
         reads_cap = min(BATCH_READS, max(64, max_bases // 256))
         pool = self._staging_pool(words_cap, reads_cap)
         jobs = [Job(self.patterns, prm, want_sums, want_raw)]
-        hb = self._heads_mode(jobs, filepath)
+        hb, hm = self._heads_mode(jobs, filepath)
         return self._single(self._run(seqio.read_batches_packed(filepath, pool, max_records=reads_cap, heads_bp=hb,
-                                                                first_batch_records=self._probe_records()), jobs, pool))
+                                                                first_batch_records=self._probe_records(hm)), jobs, pool, hm))
 
     def scan_file_jobs(self, filepath, jobs, max_bases=None):
         """One pass over the file for several jobs (pattern tables): yields (PackedBatch, [(results, sums, raw, win_off) per job])."""
@@ -274,18 +313,20 @@ class EnginePool:
         reads_cap = min(BATCH_READS, max(64, max_bases // 256))
         pool = self._staging_pool(words_cap, reads_cap)
         jobs = list(jobs)
-        hb = self._heads_mode(jobs, filepath)
-        return self._run(seqio.read_batches_packed(filepath, pool, max_records=reads_cap, heads_bp=hb, first_batch_records=self._probe_records()),
-                         jobs, pool)
+        hb, hm = self._heads_mode(jobs, filepath)
+        return self._run(seqio.read_batches_packed(filepath, pool, max_records=reads_cap, heads_bp=hb, first_batch_records=self._probe_records(hm)),
+                         jobs, pool, hm)
 
-    def _probe_records(self):
+    @staticmethod
+    def _probe_records(hm):
         """auto mode: the file's first batch is a small probe (its verdict decides the mode of the rest; a whole 64-Mbase batch scanned
         in two passes for nothing cost a third of the 300 MB benchmark file's run)."""
-        hm = getattr(self, "_hm", None)
         return PROBE_READS if hm and hm["auto"] and hm["bp"] else 0
 
     def _heads_mode(self, jobs, filepath=None):
-        """The reader's heads_bp for the next batch of one file (a callable: seqio.read_batches_packed asks before every batch).
+        """(ask, hm): the reader's heads_bp for the next batch of one file (a callable: seqio.read_batches_packed asks before every
+        batch) and the state behind it, which belongs to ONE pass over one file (it used to live on the pool, where two
+        generators alive at once steered each other's mode).
         Heads mode needs step 1 in every job and the same no_bp; "auto" keeps it while the batches seen so far say that it pays:
         reads several times longer than the two heads, and few of them passing step 1 (real WGS input: < 1 % telomeric).  A
         telomere-enriched file (the demo, the synthetic benchmarks: every read passes) drops to the one-pass route after its
@@ -300,7 +341,7 @@ class EnginePool:
                 mode = "off"
         no_bp = {int(j.prm.no_bp) for j in jobs}
         ok = mode in ("auto", "on") and len(no_bp) == 1 and all(j.prm.flags & hiplib.F_STEP1 for j in jobs) and min(no_bp) > 0
-        hm = self._hm = {"bp": min(no_bp) if ok else 0, "auto": mode == "auto", "asked": 0, "first": threading.Event()}
+        hm = {"bp": min(no_bp) if ok else 0, "auto": mode == "auto", "asked": 0, "first": threading.Event()}
 
         def ask():
             # auto: the file opens with a small probe batch in heads mode (_probe_records); until the verdict on it is in, the reader
@@ -309,33 +350,32 @@ class EnginePool:
             if hm["auto"] and hm["bp"] and hm["asked"] > 1 and not hm["first"].is_set():
                 return 0
             return hm["bp"]
-        return ask
+        return ask, hm
 
-    def _heads_feedback(self, pb, outs):
+    def _heads_feedback(self, pb, outs, hm=None):
         """Called by the workers with every finished batch: the statistics, and auto mode's decision."""
-        hm = getattr(self, "_hm", None)
         st = self.stats
-        st["batches"] += 1
-        if not hasattr(pb, "n_bases"):              # (a list of records / an ASCII batch: scan_stream)
+        with self._stats_lock:
+            st["batches"] += 1
+            if not hasattr(pb, "n_bases"):              # (a list of records / an ASCII batch: scan_stream)
+                if hm:
+                    hm["first"].set()
+                return
+            st["input_bases"] += int(pb.n_bases)
+            if getattr(pb, "full_len", None) is None:
+                st["upload_bytes"] += int(getattr(pb, "uploaded_bytes", pb.n_bases * 3 // 8))
+                if hm:
+                    hm["first"].set()
+                return
+            st["heads_batches"] += 1
+            full = np.asarray(pb.full_len, np.int64)
+            frac = max((float(np.mean(o[0]["pass"] != 0)) if len(o[0]) else 0.0) for o in outs)
+            st["upload_bytes"] += int(getattr(pb, "uploaded_bytes", 0))
+            if hm and hm["auto"] and hm["bp"] and len(full) >= 8:
+                if frac > TWO_PASS_MAX_PASSING or float(full.mean()) < 4 * hm["bp"]:
+                    hm["bp"] = 0                            # the rest of the file goes up whole
             if hm:
                 hm["first"].set()
-            return
-        st["input_bases"] += int(pb.n_bases)
-        if getattr(pb, "full_len", None) is None:
-            st["upload_bytes"] += int(getattr(pb, "uploaded_bytes", pb.n_bases * 3 // 8))
-            if hm:
-                hm["first"].set()
-            return
-        st["heads_batches"] += 1
-        import numpy as np
-        full = np.asarray(pb.full_len, np.int64)
-        frac = max((float(np.mean(o[0]["pass"] != 0)) if len(o[0]) else 0.0) for o in outs)
-        st["upload_bytes"] += int(getattr(pb, "uploaded_bytes", 0))
-        if hm and hm["auto"] and hm["bp"] and len(full) >= 8:
-            if frac > TWO_PASS_MAX_PASSING or float(full.mean()) < 4 * hm["bp"]:
-                hm["bp"] = 0                            # the rest of the file goes up whole
-        if hm:
-            hm["first"].set()
 
     def _staging_pool(self, words_cap, reads_cap):
         """The pinned staging buffers of this engine set: allocated ONCE per (engine set, geometry) and kept on the first engine,
@@ -361,7 +401,7 @@ class EnginePool:
             yield (b,) + outs[0]
 
     # -- the pipeline
-    def _run(self, batches, jobs, pool=None):
+    def _run(self, batches, jobs, pool=None, hm=None):
         n = len(self.engines)
         if pool is not None:
             pool.abort.clear()
@@ -405,8 +445,8 @@ class EnginePool:
                     if item is None:
                         return
                     i, b = item
-                    outs = scan_jobs(eng, b, jobs, 0)
-                    self._heads_feedback(b, outs)
+                    outs = scan_jobs(eng, b, jobs, 0, seq=i)
+                    self._heads_feedback(b, outs, hm)
                     q_out.put(("batch", i, (b, outs)))
             except BaseException as e:
                 stop.set()
@@ -431,6 +471,9 @@ class EnginePool:
                     in_flight.release()                # (the consumer came back for more: it is done with that batch)
         finally:
             stop.set()
+            for job in jobs:
+                if getattr(job, "raw_sink", None) is not None:
+                    job.raw_sink.abort()               # a worker waiting for its turn in the raw-count file gives up (no-op after a clean run)
             if pool is not None:
                 pool.abort.set()                       # a reader waiting for a staging buffer gives up
             try:

@@ -4,7 +4,11 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <sys/uio.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <cerrno>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -212,6 +216,8 @@ struct tps_ctx {
     size_t lds_set_v[56] = {0};
     uint32_t* h_flag = nullptr;      // mapped host word the pack kernel raises when a read has a non-ACGT letter
     hipEvent_t share_ev = nullptr;   // tps_batch_share: orders this context's stream behind the lender's upload
+    void* raw_stage[2] = {nullptr, nullptr};    // tps_batch_raw_to_fd: two pinned pieces, one being written while the other is filled
+    hipEvent_t raw_ev[2] = {nullptr, nullptr};
 };
 
 namespace {
@@ -588,6 +594,10 @@ int tps_ctx_destroy(tps_ctx* c) {
     }
     if (c->h_flag) (void)hipHostFree(c->h_flag);
     if (c->share_ev) (void)hipEventDestroy(c->share_ev);
+    for (int i = 0; i < 2; ++i) {
+        if (c->raw_stage[i]) (void)hipHostFree(c->raw_stage[i]);
+        if (c->raw_ev[i]) (void)hipEventDestroy(c->raw_ev[i]);
+    }
     c->pinned.clear();
     for (auto& ep : c->ev_pool) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     (void)hipStreamDestroy(c->stream);
@@ -921,6 +931,110 @@ int tps_batch_window_raw(tps_ctx* c, int32_t slot, uint8_t* raw, int64_t nwp) {
     int64_t want = sl->h_win_off[(size_t)sl->n] * sl->plan_p;
     if (nwp != want || (nwp > 0 && !raw)) return fail(TPS_E_ARG, "raw must hold %lld bytes", (long long)want);
     if (nwp) HIP_TRY(hipMemcpy(raw, sl->raw.p, (size_t)nwp, hipMemcpyDeviceToHost));
+    return TPS_OK;
+}
+
+// Raw rows of selected reads -> a file, without a stop in the caller's memory (include/topsicle_hip.h).  The selected reads' rows
+// are runs of the slot's raw buffer; runs closer than RAW_GAP are fetched as one stretch (what lies between is copied and skipped:
+// cheaper than a copy call per read), stretches are cut into pieces of RAW_STAGE bytes, piece j + 1 is copied into one pinned
+// buffer while piece j is written from the other (pwritev of the wanted parts only) and checksummed.
+constexpr size_t RAW_STAGE = (size_t)32 << 20;
+constexpr int64_t RAW_GAP = 256 << 10;
+
+int tps_batch_raw_to_fd(tps_ctx* c, int32_t slot, const int64_t* reads, int64_t n_sel, int fd, int64_t file_off,
+                        tps_crc32_fn crc_fn, uint32_t* crc_out, int64_t* bytes_out) {
+    Slot* sl;
+    int rc;
+    if ((rc = need_scanned(c, slot, &sl))) return rc;
+    if (!(sl->last_flags & TPS_F_STORE_RAW)) return fail(TPS_E_STATE, "last scan did not store raw counts");
+    if (n_sel < 0 || (n_sel > 0 && !reads) || fd < 0 || file_off < 0) return fail(TPS_E_ARG, "bad arguments");
+    if (crc_out) *crc_out = 0;
+    if (bytes_out) *bytes_out = 0;
+    const int64_t P = sl->plan_p;
+    struct Run { int64_t lo, hi; };                    // bytes of the raw buffer
+    std::vector<Run> runs;
+    int64_t prev = -1;
+    for (int64_t j = 0; j < n_sel; ++j) {
+        const int64_t i = reads[j];
+        if (i <= prev || i >= sl->n) return fail(TPS_E_ARG, "reads[] must be ascending indices of the batch (entry %lld)", (long long)j);
+        prev = i;
+        const int64_t lo = sl->h_win_off[(size_t)i] * P, hi = sl->h_win_off[(size_t)i + 1] * P;
+        if (hi == lo) continue;
+        if (!runs.empty() && runs.back().hi == lo) runs.back().hi = hi;
+        else runs.push_back({lo, hi});
+    }
+    if (runs.empty()) return TPS_OK;
+    for (int i = 0; i < 2; ++i) {
+        if (!c->raw_stage[i]) HIP_TRY(hipHostMalloc(&c->raw_stage[i], RAW_STAGE, hipHostMallocPortable));
+        if (!c->raw_ev[i]) HIP_TRY(hipEventCreateWithFlags(&c->raw_ev[i], hipEventDisableTiming));
+    }
+    // pieces: [first run, last run) + the device span [lo, hi) that covers them (hi - lo <= RAW_STAGE); a run longer than what is
+    // left of a piece is split
+    struct Piece { size_t r0, r1; int64_t lo, hi; };
+    std::vector<Piece> pieces;
+    {
+        std::vector<Run> cut;                          // runs split at piece boundaries, in order
+        size_t i = 0;
+        int64_t pos = runs[0].lo;
+        while (i < runs.size()) {
+            Piece pc{cut.size(), cut.size(), pos, pos};
+            while (i < runs.size()) {
+                const int64_t start = std::max(pos, runs[i].lo);
+                if (pc.r1 > pc.r0 && (start - pc.hi > RAW_GAP || start >= pc.lo + (int64_t)RAW_STAGE)) break;
+                if (pc.r1 == pc.r0) pc.lo = start;
+                const int64_t end = std::min(runs[i].hi, pc.lo + (int64_t)RAW_STAGE);
+                if (end <= start) break;
+                cut.push_back({start, end});
+                pc.r1 = cut.size();
+                pc.hi = end;
+                pos = end;
+                if (end == runs[i].hi) { ++i; if (i < runs.size()) pos = runs[i].lo; }
+                else break;                            // the piece is full
+            }
+            pieces.push_back(pc);
+        }
+        runs.swap(cut);
+    }
+    auto enqueue = [&](size_t j) -> int {
+        const Piece& pc = pieces[j];
+        HIP_TRY(hipMemcpyAsync(c->raw_stage[j & 1], (const uint8_t*)sl->raw.p + pc.lo, (size_t)(pc.hi - pc.lo), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipEventRecord(c->raw_ev[j & 1], c->stream));
+        return TPS_OK;
+    };
+    if ((rc = enqueue(0))) return rc;
+    uint32_t crc = 0;
+    int64_t written = 0;
+    std::vector<struct iovec> iov;
+    for (size_t j = 0; j < pieces.size(); ++j) {
+        if (j + 1 < pieces.size() && (rc = enqueue(j + 1))) { (void)hipStreamSynchronize(c->stream); return rc; }
+        HIP_TRY(hipEventSynchronize(c->raw_ev[j & 1]));
+        const Piece& pc = pieces[j];
+        const uint8_t* base = (const uint8_t*)c->raw_stage[j & 1];
+        iov.clear();
+        for (size_t r = pc.r0; r < pc.r1; ++r) {
+            const uint8_t* p = base + (runs[r].lo - pc.lo);
+            const size_t len = (size_t)(runs[r].hi - runs[r].lo);
+            if (crc_fn) crc = crc_fn(crc, p, (int64_t)len);
+            iov.push_back({(void*)p, len});
+        }
+        size_t first = 0;
+        while (first < iov.size()) {
+            const int cnt = (int)std::min<size_t>(iov.size() - first, 1024);
+            const ssize_t w = pwritev(fd, iov.data() + first, cnt, (off_t)(file_off + written));
+            if (w < 0) {
+                if (errno == EINTR) continue;
+                const int e = errno;
+                (void)hipStreamSynchronize(c->stream);
+                return fail(TPS_E_ARG, "pwritev: %s", strerror(e));
+            }
+            written += w;
+            size_t left = (size_t)w;
+            while (first < iov.size() && left >= iov[first].iov_len) { left -= iov[first].iov_len; ++first; }
+            if (left) { iov[first].iov_base = (char*)iov[first].iov_base + left; iov[first].iov_len -= left; }
+        }
+    }
+    if (crc_out) *crc_out = crc;
+    if (bytes_out) *bytes_out = written;
     return TPS_OK;
 }
 

@@ -1301,8 +1301,11 @@ int64_t tps_gz_inflate(const char* path, uint8_t* out, int64_t cap, int32_t thre
     return total;
 }
 
-// Test hook: the carry-less-multiplication CRC-32 of tps_gzpar.h (tests compare it with zlib's).
+// zlib's crc32(crc, p, n) by carry-less multiplication (tps_gzpar.h; tests compare it with zlib's).  Also the checksum callback of
+// libtopsicle_hip.so's tps_batch_raw_to_fd: the raw-count archive's member CRC is computed block by block while the rows are
+// written, and the blocks' values are joined with tps_crc32_combine (= zlib's crc32_combine) instead of re-reading the file.
 uint32_t tps_crc32(uint32_t crc, const uint8_t* p, int64_t n) { return (uint32_t)gzpar::crc32_fast((uLong)crc, p, (size_t)(n > 0 ? n : 0)); }
+uint32_t tps_crc32_combine(uint32_t crc1, uint32_t crc2, int64_t len2) { return (uint32_t)crc32_combine((uLong)crc1, (uLong)crc2, (z_off_t)len2); }
 
 // Writes the records idx[0 .. n) of a packed batch that was read from the mmap'ed plain FASTQ `text` to `fd`, in the layout
 // Biopython's SeqIO.write gives (main.py:83-86): "@" header "\n" sequence "\n+\n" quality "\n".  Nothing is copied in user

@@ -23,7 +23,7 @@ EXPORTS = [
     "tps_set_patterns", "tps_batch_upload", "tps_batch_upload_packed", "tps_batch_share", "tps_host_alloc", "tps_host_free",
     "tps_batch_download_packed", "tps_batch_kmer_followers", "tps_batch_set_tails", "tps_batch_scan", "tps_sync",
     "tps_batch_results", "tps_batch_window_offsets", "tps_batch_window_sums", "tps_batch_window_raw",
-    "tps_batch_trc_counts", "tps_trc_counts", "tps_window_counts", "tps_binseg_l2", "tps_binseg_l2_ties", "tps_batch_read_sums", "tps_window_count",
+    "tps_batch_raw_to_fd", "tps_batch_trc_counts", "tps_trc_counts", "tps_window_counts", "tps_binseg_l2", "tps_binseg_l2_ties", "tps_batch_read_sums", "tps_window_count",
     "tps_kernel_time_ms", "tps_kernel_time_reset", "tps_device_info", "tps_batch_kernel_info",
 ]
 
@@ -94,6 +94,7 @@ def load_library(path: str | None = None) -> C.CDLL:
         "tps_batch_window_offsets": (C.c_int, [vp, i32, vp, i64]),
         "tps_batch_window_sums": (C.c_int, [vp, i32, vp, i64]),
         "tps_batch_window_raw": (C.c_int, [vp, i32, vp, i64]),
+        "tps_batch_raw_to_fd": (C.c_int, [vp, i32, vp, i64, C.c_int, i64, vp, C.POINTER(C.c_uint32), C.POINTER(i64)]),
         "tps_batch_trc_counts": (C.c_int, [vp, i32, vp, vp, i64]),
         "tps_trc_counts": (C.c_int, [vp, vp, vp, i64, i32, vp, vp]),
         "tps_window_counts": (C.c_int, [vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, vp, vp]),
@@ -119,6 +120,21 @@ def load_library(path: str | None = None) -> C.CDLL:
 
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+_crc_cb = None
+
+
+def _crc32_callback():
+    """Address of libtopsicle_io.so's tps_crc32 (the checksum tps_batch_raw_to_fd runs over what it writes)."""
+    global _crc_cb
+    if _crc_cb is None:
+        from . import seqio
+        lib = seqio._load_io()
+        if lib is None:
+            raise TopsicleHipError("libtopsicle_io.so is not built (its tps_crc32 checksums the raw-count archive)")
+        _crc_cb = C.cast(lib.tps_crc32, C.c_void_p)
+    return _crc_cb
 
 
 def pack_reads(seqs) -> tuple[np.ndarray, np.ndarray]:
@@ -354,6 +370,16 @@ class HipScanner:
         out = np.zeros(int(off[-1]) * p, dtype=np.uint8)
         self._check(self.lib.tps_batch_window_raw(self._h, slot, _ptr(out), len(out)))
         return out.reshape(-1, p), off
+
+    def raw_to_fd(self, slot: int, reads: np.ndarray, fd: int, file_off: int) -> tuple[int, int]:
+        """The raw rows of `reads` (ascending read indices of the slot's batch) of the last scan, back to back at byte `file_off`
+        of `fd`: device -> pinned pieces -> pwritev inside the library (tps_batch_raw_to_fd).  Returns (bytes written, their
+        CRC-32 -- libtopsicle_io.so's carry-less-multiplication CRC runs over the pieces as they are written)."""
+        reads = np.ascontiguousarray(reads, dtype=np.int64)
+        crc, nbytes = C.c_uint32(0), C.c_int64(0)
+        self._check(self.lib.tps_batch_raw_to_fd(self._h, slot, _ptr(reads), len(reads), int(fd), int(file_off), _crc32_callback(),
+                                                 C.byref(crc), C.byref(nbytes)))
+        return nbytes.value, crc.value
 
     def batch_trc_counts(self, slot: int) -> tuple[np.ndarray, np.ndarray]:
         n, p = self._n[slot], len(self.patterns)

@@ -20,7 +20,7 @@ from collections import defaultdict
 
 import numpy as np
 
-from . import allsteps, batch, hiplib, seqio
+from . import allsteps, batch, hiplib, rawnpz, seqio
 
 version_number = "1.0.0"
 Topsicle_output_prefix = "Topsicle"
@@ -132,10 +132,15 @@ def process_file_multi(args, seq_loc, phrases, engines):
     ratio = no_bp / len(args.pattern)
     want_sums = bool(args.plot)
     want_raw = bool(args.rawcountpattern)
+    # --rawcountformat npz: one archive per input file and k, its rows written device -> file by the batch workers (rawnpz.py)
+    npz = want_raw and getattr(args, "rawcountformat", "csv") == "npz"
+    raw_npz = [rawnpz.RawNpzWriter(f"{args.outputDir}/rawcount_{telo_phrase}_{file_name}.npz", pattern, sliding_val, args.read_check or None)
+               if npz else None for telo_phrase, pattern, sliding_val in phrases]
     jobs = [batch.Job(pattern, hiplib.make_params(
         no_bp=no_bp, min_len=args.minSeqLength, min_count=allsteps.min_count_for_cutoff(min_cutoff, ratio, no_bp),
         window=args.windowSize, slide=slide, trimfirst=args.trimfirst, maxlen=args.maxlengthtelo,
-        flags=hiplib.F_STEP1 | hiplib.F_WINDOWS | hiplib.F_BINSEG), want_sums, want_raw) for _k, pattern, slide in phrases]
+        flags=hiplib.F_STEP1 | hiplib.F_WINDOWS | hiplib.F_BINSEG), want_sums, want_raw, raw_sink=sink)
+        for (_k, pattern, slide), sink in zip(phrases, raw_npz)]
 
     fmt = _formats(seq_loc)
     fasta_temp = os.path.join(args.outputDir, f"{file_name}_trc_over_{min_cutoff}.fasta")
@@ -152,10 +157,8 @@ def process_file_multi(args, seq_loc, phrases, engines):
 
     rows = [[] for _ in phrases]
     image_num = [1] * len(phrases)
-    npz = getattr(args, "rawcountformat", "csv") == "npz"
-    raw_npz = [_RawNpz(args, file_name, telo_phrase, pattern, sliding_val) if npz else None for telo_phrase, pattern, sliding_val in phrases]
     csv_path = f"{args.outputDir}/telolengths_all.csv"
-    pool = batch.EnginePool(engines, two_pass=getattr(args, "twopass", "auto"))
+    pool = batch.EnginePool(engines, two_pass=getattr(args, "twopass", None))
     # the passing records are written by a helper thread, batch by batch in file order, while the next batches are scanned
     # (the native writer releases the GIL: writev straight from the mapped input)
     wq: "queue.Queue" = queue.Queue(maxsize=4)
@@ -174,6 +177,7 @@ def process_file_multi(args, seq_loc, phrases, engines):
     wthread = threading.Thread(target=writer, daemon=True) if out_handle is not None else None
     if wthread is not None:
         wthread.start()
+    ok = False
     try:
         for pb, outs in pool.scan_file_jobs(seq_loc, jobs):
             for n, ((telo_phrase, pattern, sliding_val), (res, sums, raw, win_off)) in enumerate(zip(phrases, outs)):
@@ -201,7 +205,12 @@ def process_file_multi(args, seq_loc, phrases, engines):
                     with _CSV_LOCK, open(csv_path, mode="a", newline="") as fh:
                         csv.writer(fh).writerows(zip([file_name] * len(ids), [telo_phrase] * len(ids), ["%.3f" % t for t in trc_l], ids, telo_l))
                 rows[n] += [(file_name, telo_phrase, [[rid, tl]], t) for rid, tl, t in zip(ids, telo_l, trc_l)]
-                if args.plot or args.rawcountpattern:                        # per-read artefacts (main.py:140-150)
+                if raw_npz[n] is not None:
+                    # the rows are in the archive already (written by the worker that scanned the batch); what is kept here is
+                    # one id, one tail and one window count per read -- no per-read loop over the rows
+                    assert np.array_equal(raw.keep, idx)
+                    raw_npz[n].add_reads(ids, np.where(fwd, "forward", "reverse").tolist(), r["n_win"])
+                if args.plot or (args.rawcountpattern and raw_npz[n] is None):   # per-read artefacts (main.py:140-150)
                     for j, i in enumerate(idx):
                         tail = "forward" if fwd[j] else "reverse"
                         if args.plot and r["n_win"][j] > 0:
@@ -210,23 +219,21 @@ def process_file_multi(args, seq_loc, phrases, engines):
                             allsteps._plot_changepoint(ids[j], y, sliding_val, args.trimfirst, int(point[j]), args.rangecp or int(m[j]))
                             plt.savefig(f"{args.outputDir}/plot_{telo_phrase}_{image_num[n] + j}.png", format="png", dpi=300)
                             plt.close()
-                        if args.rawcountpattern:
-                            block = raw[win_off[i]:win_off[i + 1]]
-                            if raw_npz[n] is not None:
-                                raw_npz[n].add(ids[j], tail, block)
-                            else:
-                                _write_rawcount(args, telo_phrase, image_num[n] + j, pattern, sliding_val, block, tail)
+                        if args.rawcountpattern and raw_npz[n] is None:
+                            _write_rawcount(args, telo_phrase, image_num[n] + j, pattern, sliding_val, raw[win_off[i]:win_off[i + 1]], tail)
                 image_num[n] += len(idx)
+        ok = True
     finally:
         if wthread is not None:
             wq.put(None)
             wthread.join()
         if out_handle is not None:
             out_handle.close()
+        if not ok or werr:                                  # no half-written archive is left behind, whatever went wrong
+            for w in raw_npz:
+                if w is not None:
+                    w.discard()
     if werr:
-        for w in raw_npz:
-            if w is not None:
-                w.discard()
         raise werr[0]
     for w in raw_npz:
         if w is not None:
@@ -251,61 +258,6 @@ def _write_rawcount(args, telo_phrase, image_num, pattern, slide, block, tail):
         "count": block.reshape(-1).astype(np.int64),
     })
     df.to_csv(f"{args.outputDir}/rawcount_{telo_phrase}_{image_num}.csv")
-
-
-class _RawNpz:
-    """--rawcountformat npz (an extension, not an upstream flag): ONE columnar file per input file and k instead of
-    one 1.2 MB CSV per read -- the same numbers: counts[win_off[i]:win_off[i+1], p] is read i's count of pattern p in
-    the window that starts at position (w - win_off[i]) * slide (the CSV volume is what bounds the
-    raw-count workload end to end).  The rows go to a spool file beside the output as the batches arrive and are copied into
-    the archive at the end (round 4: a file's rows used to stay in memory until then -- 14 GB resident for BASELINE configs[4]'s
-    per-GPU shard with three k); what stays in memory is one id, one tail and one length per passing read."""
-
-    def __init__(self, args, file_name, telo_phrase, pattern, slide):
-        self.path = f"{args.outputDir}/rawcount_{telo_phrase}_{file_name}.npz"
-        self.pattern, self.slide = list(pattern), int(slide)
-        self.read_id, self.tail, self.n_win = [], [], []
-        self.spool = None
-        self.rows = 0
-
-    def add(self, read_id, tail, block):
-        if self.spool is None:
-            self.spool = open(self.path + ".rows", "w+b")
-        b = np.ascontiguousarray(block, dtype=np.uint8)
-        self.spool.write(memoryview(b).cast("B"))
-        self.read_id.append(read_id)
-        self.tail.append(tail)
-        self.n_win.append(b.shape[0])
-        self.rows += b.shape[0]
-
-    def discard(self):
-        if self.spool is not None:
-            self.spool.close()
-            os.unlink(self.path + ".rows")
-            self.spool = None
-
-    def finish(self):
-        """The archive np.savez would write (stored, not deflated): small members through numpy, `counts` streamed from the spool."""
-        if not self.read_id:
-            self.discard()
-            return
-        import shutil
-        import zipfile
-        n_win = np.array(self.n_win, dtype=np.int64)
-        win_off = np.zeros(len(n_win) + 1, dtype=np.int64)
-        np.cumsum(n_win, out=win_off[1:])
-        small = dict(read_id=np.array(self.read_id), tail=np.array(self.tail), win_off=win_off, pattern=np.array(self.pattern),
-                     slide=np.int64(self.slide))
-        with zipfile.ZipFile(self.path, "w", zipfile.ZIP_STORED, allowZip64=True) as z:
-            for name, arr in small.items():
-                with z.open(name + ".npy", "w", force_zip64=True) as h:
-                    np.lib.format.write_array(h, np.asanyarray(arr), allow_pickle=False)
-            with z.open("counts.npy", "w", force_zip64=True) as h:
-                np.lib.format.write_array_header_1_0(h, {"descr": "|u1", "fortran_order": False, "shape": (int(self.rows), len(self.pattern))})
-                self.spool.flush()
-                self.spool.seek(0)
-                shutil.copyfileobj(self.spool, h, 16 << 20)
-        self.discard()
 
 
 def analysis_run(args, engines=None, engine_factory=None, wait_plots=True):
@@ -411,7 +363,10 @@ def _process_files(args, filenames, phrases, engines, engine_factory, num_cores)
     plots (pyplot is not thread-safe) -- up to min(num_cores, 8) files at a time, each on its own thread and contexts
     (parsing / gunzip is the bottleneck, the GPUs are shared).  Results keep file order: one list of per-k row lists per file."""
     workers = min(len(filenames), max(1, num_cores), 8)
-    if workers <= 1 or engine_factory is None or args.plot or args.rawcountpattern:
+    # (per-read plots and per-read CSVs go through pyplot / pandas on the calling thread; the npz archive is written natively by
+    # the batch workers, one archive per file: nothing is shared between files)
+    per_read_files = args.plot or (args.rawcountpattern and getattr(args, "rawcountformat", "csv") != "npz")
+    if workers <= 1 or engine_factory is None or per_read_files:
         return [process_file_multi(args, seq_loc, phrases, engines) for seq_loc in filenames]
     import threading
     from concurrent.futures import ThreadPoolExecutor
@@ -505,9 +460,10 @@ def build_parser():
     # MI355X build only
     parser.add_argument("--gpus", metavar="INT", type=int, default=1, help="GPUs of this node to shard reads over")
     parser.add_argument("--device", metavar="INT", type=int, default=0, help="index of the first GPU to use")
-    parser.add_argument("--twopass", choices=["auto", "on", "off"], default="auto",
+    parser.add_argument("--twopass", choices=["auto", "on", "off"], default=None,
                         help="MI355X build: upload only the two 1000-base ends of every read for the TRC filter and the scanned part of the "
-                             "reads that pass afterwards (auto: while few reads of a batch pass, as in whole-genome read sets)")
+                             "reads that pass afterwards (auto, the default unless $TOPSICLE_TWO_PASS says otherwise: while few reads of a batch pass, "
+                             "as in whole-genome read sets)")
     return parser
 
 

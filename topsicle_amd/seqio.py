@@ -214,6 +214,10 @@ def _load_io():
         lib.tps_text_release.argtypes = [C.c_void_p]
         lib.tps_write_fastq_spans.restype = C.c_int64
         lib.tps_write_fastq_spans.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+        lib.tps_crc32.restype = C.c_uint32
+        lib.tps_crc32.argtypes = [C.c_uint32, C.c_void_p, C.c_int64]
+        lib.tps_crc32_combine.restype = C.c_uint32
+        lib.tps_crc32_combine.argtypes = [C.c_uint32, C.c_uint32, C.c_int64]
         _io_lib = lib
     return _io_lib or None
 
