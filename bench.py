@@ -17,14 +17,23 @@ torch.distributed (gloo) is used only for the barrier and the max-over-ranks tim
 before this process has touched a GPU -- and relays rank 0's JSON line; it fails if fewer than N GPUs are visible
 (TPS_BENCH_SHARE_GPU=1 lets ranks share devices: the launcher test on a 1-GPU box).
 
-Two timed regions of K steps each, both bracketed by barrier + device sync (round 4):
-  1. strictly one launch after the other on one context -> the kernel's own duration (HIP events), `roofline`, `single_stream`;
+Two timed regions of K steps each, both bracketed by barrier + device sync (round 4), each REPEATED R times inside the run (round 5:
+R is chosen after the first repeat so that at least 50 ms of GPU work are timed whatever K is -- the driver's `--steps 20` is 0.9 ms of
+it -- and at least 3; `ms_per_step` is the MEDIAN over the repeats, p10 / p90 beside it):
+  1. strictly one launch after the other on one context -> the kernel's own duration (HIP events), `roofline`, `single_stream`,
+     `value_single_stream`;
   2. the same K steps with consecutive batches on `--streams` (default 2) contexts, each with its own stream, as the file pipeline
      issues them (batch.EnginePool keeps two contexts per GPU) -> `value`, `ms_per_step`, `pipelined`.  A 10 000-read launch is
      1.63 rounds of the chip's 6 144 wave slots: alone, its last third runs on a draining GPU (the roofline says what that costs:
-     frac 0.84 against steady_state_frac 0.99); with the next batch's launch already queued on the other stream its drain is the
-     neighbour's ramp.  `--streams 1` skips region 2 (`value` = `single_stream.value`): the command for a rocprofv3 --stats summary
-     whose average duration is that of an undisturbed launch (overlapping launches stretch each other: `pipelined.kernel_ms_mean_while_overlapping`).
+     frac 0.84 against steady_state_frac 0.97); with the next batch's launch already queued on the other stream its drain is the
+     neighbour's ramp -- so `ms_per_step` is a two-launch-overlap figure and can lie BELOW the kernel's own duration
+     (`roofline.kernel_ms_mean`); the line says so in `consistency`.  `--streams 1` skips region 2 (`value` = `value_single_stream`):
+     the command for a rocprofv3 --stats summary whose average duration is that of an undisturbed launch (scripts/profile.sh adds
+     `--no-steady`: the steady-state leg's 4x launches carry the same kernel name).
+`roofline.steady_state` is measured in the run (40 launches of a batch four times the size, ~8 ms) unless `--no-steady`.
+`roofline.traffic` and the `roofline.valu` object (instructions per read, lane-instructions per scanned base, VALU busy over one
+launch and over the two-stream region) use the PMC counters of the newest committed profile of the same workload -- counters cannot
+be collected inside a timed run -- and name their source file.
 
 Prints ONE JSON line (rank 0).
 """
@@ -102,31 +111,50 @@ def algorithmic_bytes(lens, passed, n_win, P, prm):
     return int(step1 + step2 + step3), int(step1), int(step2), int(step3)
 
 
-def profiled_traffic(workload):
-    """HBM bytes per launch of the scan kernel from the newest committed rocprofv3 PMC summary
-    (profiles/*/pmc_per_launch_mean.csv: FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes of
-    this same command; KB units; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
-    Only meaningful for the workload the profile was taken on (config2); None otherwise."""
-    import csv
+def _profile_dirs():
     import glob
-    if workload != "config2":
-        return None, None
     import re
 
     def version(d):                      # profiles/r<round>_v<version>_<name>
         m = re.match(r"r(\d+)_v(\d+)", os.path.basename(d))
         return (int(m.group(1)), int(m.group(2))) if m else (-1, -1)
-    for d in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*")), key=version, reverse=True):
-        f = os.path.join(d, "pmc_per_launch_mean.csv")
+    return sorted(glob.glob(os.path.join(ROOT, "profiles", "r*")), key=version, reverse=True)
+
+
+def profiled_traffic(workload, flags=0, ks=None):
+    """HBM bytes per launch (per step for a several-table workload) of the scan kernel(s) and their per-launch counter means from
+    the newest committed rocprofv3 PMC summary: config2 -> profiles/*/pmc_per_launch_mean.csv (FETCH_SIZE and WRITE_SIZE collected
+    in separate --pmc passes of this same command; KB units; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), the
+    other workloads -> profiles/*/workloads.csv (scripts/profile_workloads.sh; a several-table step = its table passes' rows
+    added up).  (None, None) when no committed profile covers the workload."""
+    import csv
+    PROFILED_COUNTERS.clear()
+    for d in _profile_dirs():
+        if workload == "config2" and not flags:
+            f = os.path.join(d, "pmc_per_launch_mean.csv")
+            if not os.path.exists(f):
+                continue
+            vals = {}
+            for r in csv.DictReader(open(f)):
+                if r["kernel"].startswith("tps_scan_kernel"):
+                    vals[r["counter"]] = float(r["mean_value"])
+            if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+                PROFILED_COUNTERS.update(vals)
+                return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), os.path.relpath(f, ROOT)
+            continue
+        f = os.path.join(d, "workloads.csv")
         if not os.path.exists(f):
             continue
-        vals = {}
-        for r in csv.DictReader(open(f)):
-            if r["kernel"].startswith("tps_scan_kernel"):
-                vals[r["counter"]] = float(r["mean_value"])
-        if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
-            PROFILED_COUNTERS.update(vals)
-            return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), os.path.relpath(f, ROOT)
+        rows = {r["workload"]: r for r in csv.DictReader(open(f))}
+        want = [f"{workload}_k{kk}_f31" for kk in ks] if (ks and len(ks) > 1) else [f"{workload}_f{flags}"]
+        if not all(w in rows and rows[w].get("hbm_traffic_MB") and rows[w].get("SQ_INSTS_VALU") for w in want):
+            continue
+        try:
+            for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES"):
+                PROFILED_COUNTERS[c] = sum(float(rows[w][c]) for w in want)
+            return int(sum(float(rows[w]["hbm_traffic_MB"]) for w in want) * 1e6), os.path.relpath(f, ROOT) + " (" + " + ".join(want) + ")"
+        except (KeyError, ValueError):
+            PROFILED_COUNTERS.clear()
     return None, None
 
 
@@ -276,9 +304,15 @@ def main():
     ap.add_argument("--no-store-sums", action="store_true", help="do not write S_w to HBM (boundary-only run)")
     ap.add_argument("--n-reads", type=int, default=0, help="diagnostic: override the batch size (NOT the metric's workload)")
     ap.add_argument("--flags", type=int, default=0, help="diagnostic: override the scan flags (partial pipelines are NOT the metric)")
-    ap.add_argument("--steady", action="store_true", help="also time the kernel on a batch four times the size (steady state: the launch ramp and the "
-                    "last round of wave slots weigh a quarter); NOT part of the default run -- its launches would sit in a rocprofv3 "
-                    "average of the same command -- the default line quotes the committed profiles/*/steady_state.json instead")
+    ap.add_argument("--no-steady", action="store_true", help="skip the steady-state leg (the kernel on a batch four times the size: the launch ramp "
+                    "and the last round of wave slots weigh a quarter; 46 launches, ~8 ms): the command whose rocprofv3 --stats average is "
+                    "compared with the live kernel duration leaves it out, its launches carry the same kernel name")
+    ap.add_argument("--steady", action="store_true", help=argparse.SUPPRESS)          # (round 4's opt-in switch: the leg is on by default now)
+    ap.add_argument("--min-timed-ms", type=float, default=50.0, help="each timed region is repeated until this much time has been measured (and >= 3 repeats); 0 = one repeat (profiling runs)")
+    ap.add_argument("--sequential-tables", action="store_true", help="several tables per step (config5): back to back on the one context instead of "
+                    "overlapping on one context per table (the A/B switch; batch.SEQUENTIAL_TABLES in the pipeline)")
+    ap.add_argument("--prime", type=int, default=256, help="launches before the warm-up (runtime growth steps, clocks)")
+    ap.add_argument("--no-wgs", action="store_true", help="skip the e2e leg of the step-1-dominated regime")
     ap.add_argument("--streams", type=int, default=2, help="contexts (streams) the batches of the `value` region alternate between: 2 = the pipeline's "
                     "own shape (batch.EnginePool: two contexts per GPU) -- the ramp of one launch fills the drain of the previous one; 1 = strictly one "
                     "launch after the other.  The kernel's own duration and the roofline are measured on serialised launches either way")
@@ -335,9 +369,6 @@ def main():
             ref_py = reference_python_baseline(bases, offsets, motif, k, prm)
         except Exception as e:
             ref_py = {"error": repr(e)}
-    # kernel durations come from HIP events stamped by the dispatch itself; every 4th launch is timed (timing a
-    # launch costs ~3.5 us of host/queue work, which would otherwise sit inside every timed step)
-    os.environ.setdefault("TPS_EVENT_STRIDE", "4")
     # one GPU per rank; TPS_BENCH_SHARE_GPU=1 (testing the launcher path on a box with fewer GPUs than ranks) wraps around
     import ctypes
     n_dev = ctypes.c_int(0)
@@ -352,6 +383,10 @@ def main():
     elif n_dev.value < world:
         raise SystemExit(f"--gpus {world} but only {n_dev.value} GPU(s) visible ({lib.tps_last_error().decode()})")
     sc = hiplib.HipScanner(dev)
+    # kernel durations come from HIP events stamped by the dispatch itself; every 4th launch is timed (timing a
+    # launch costs ~3.5 us of host/queue work, which would otherwise sit inside every timed step); helper contexts inherit it
+    if "event_stride" not in hiplib.debug_options_from_env():
+        sc.debug_option("event_stride", 4)
     # the GPU this rank really got: its PCI address from the runtime (independent of ROCR_VISIBLE_DEVICES), and -- when a launcher
     # other than this script started the rank (torch.distributed.run: no TPS_BENCH_CPUS) -- the CPUs of that GPU's NUMA node
     import re as _re
@@ -375,8 +410,8 @@ def main():
         sc.upload(s, bases, offsets)
     # several tables per batch (config 5: k = 4, 5, 6): one context per table, all scanning the SAME resident batch at the same
     # time (the helpers borrow it: tps_batch_share), as batch.scan_jobs runs `--telophrase 4 5 6`;
-    # TOPSICLE_SEQUENTIAL_TABLES=1: back to back on the one context (the A/B switch)
-    concurrent = len(tables) > 1 and os.environ.get("TOPSICLE_SEQUENTIAL_TABLES", "0") != "1"
+    # --sequential-tables: back to back on the one context (the A/B switch)
+    concurrent = len(tables) > 1 and not args.sequential_tables
     engines = [sc]
     if concurrent:
         engines += [sc.helper(j) for j in range(len(tables) - 1)]
@@ -387,7 +422,7 @@ def main():
                     eng.share(s, sc, s)
 
     # the longest table pass is launched first (the largest k: its launch ends last otherwise and the step with it)
-    launch_order = engines[::-1] if os.environ.get("TPS_BENCH_TABLE_ORDER", "desc") == "desc" else engines
+    launch_order = engines[::-1]
 
     def sync_all():
         for eng in engines:
@@ -413,21 +448,56 @@ def main():
                 sc.set_patterns(t)
                 sc.scan(slot, prm)
 
-    for s in range(max(int(os.environ.get("TPS_BENCH_PRIME", "256")) // len(tables), 4 * copies)):
+    for s in range(max(args.prime // len(tables), 4 * copies)):
         step(s % copies)
     sync_all()
     for i in range(args.warmup):
         step(i % copies)
+    import math
+
+    def timed_region(run_steps, sync):
+        """R repeats of EXACTLY args.steps steps, each bracketed by barrier + device sync on both sides and timed as the max over
+        ranks; R = enough for --min-timed-ms of measured time, at least 3 (decided from the first repeat's max-over-ranks time, so
+        every rank takes the same R).  Returns ([seconds of repeat r (max over ranks)], [this rank's seconds])."""
+        glob_t, own_t = [], []
+        repeats = 1
+        r = 0
+        while r < repeats:
+            sync()
+            grp.barrier()
+            t0 = time.perf_counter()
+            run_steps()
+            sync()                 # device idle: every step's kernel and result copy has finished
+            own = time.perf_counter() - t0
+            glob_t.append(grp.max(own))
+            own_t.append(own)
+            grp.barrier()
+            if r == 0:
+                repeats = 1 if args.min_timed_ms <= 0 else int(min(400, max(3, math.ceil(args.min_timed_ms * 1e-3 / max(glob_t[0], 1e-7)))))
+            r += 1
+        return glob_t, own_t
+
+    def spread(ts):
+        """median / p10 / p90 of the repeats, in ms per step"""
+        v = np.sort(np.asarray(ts)) / args.steps * 1e3
+        return float(np.median(v)), float(v[int(0.1 * (len(v) - 1))]), float(v[int(math.ceil(0.9 * (len(v) - 1)))])
+
+    def run_serial():
+        for i in range(args.steps):
+            step(i % copies)
+
     barrier()
     for eng in engines:
         eng.kernel_time_reset()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i % copies)
-    sync_all()                     # device idle: every step's kernel and result copy has finished
-    dt_rank = time.perf_counter() - t0
-    dt = grp.max(dt_rank)
-    grp.barrier()
+    serial_t, serial_own = timed_region(run_serial, sync_all)
+
+    def median_repeat(ts):
+        """index of the repeat whose max-over-ranks time is the median (the lower middle one of an even count): the headline is a
+        repeat that really ran, and every rank reports its own time of THAT repeat -- `ms_per_step` stays the max over `ranks`"""
+        return int(np.argsort(np.asarray(ts), kind="stable")[(len(ts) - 1) // 2])
+    mid = median_repeat(serial_t)
+    dt = float(serial_t[mid])
+    dt_rank = float(serial_own[mid])
     if concurrent:                 # per step: the sum of the overlapping launches' own durations (each stretched by its neighbours)
         kt = [eng.kernel_time_ms() for eng in engines]
         n_launch, k_mean_ms = sum(x[0] for x in kt), sum(x[2] for x in kt) / len(tables)
@@ -458,20 +528,23 @@ def main():
         def sync_pipe():
             for eng in pipe:
                 eng.sync()
+
+        def run_piped():
+            for i in range(args.steps):
+                pipe[i % len(pipe)].scan(i % copies, prm)
         grp.barrier()
         for eng in pipe:
             eng.kernel_time_reset()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            pipe[i % len(pipe)].scan(i % copies, prm)
-        sync_pipe()
-        dt_rank_p = time.perf_counter() - t0
-        dt = grp.max(dt_rank_p)
-        grp.barrier()
+        piped_t, piped_own = timed_region(run_piped, sync_pipe)
+        mid_p = median_repeat(piped_t)
+        dt = float(piped_t[mid_p])
         ktp = [eng.kernel_time_ms() for eng in pipe]
-        piped = dict(streams=len(pipe), ms_per_step=dt / args.steps * 1e3,
+        _med, p10, p90 = spread(piped_t)
+        med = dt / args.steps * 1e3
+        piped = dict(streams=len(pipe), ms_per_step=med, ms_per_step_p10=p10, ms_per_step_p90=p90, repeats=len(piped_t),
+                     timed_ms_total=float(np.sum(piped_t)) * 1e3,
                      kernel_ms_mean_while_overlapping=sum(x[1] for x in ktp) / max(1, sum(x[0] for x in ktp)))
-        dt_rank = dt_rank_p
+        dt_rank = float(piped_own[mid_p])
     per_rank = grp.gather_objects(dict(rank=rank, device=dev, device_info=sc.device_info(), pci=rank_pci,
                                        cpus=len(os.sched_getaffinity(0)), ms_per_step=dt_rank / args.steps * 1e3,
                                        ms_per_step_single_stream=dt_serial / args.steps * 1e3,
@@ -479,7 +552,7 @@ def main():
     # the same kernel on a batch four times the size (the reads repeated): the launch ramp and the partly filled last round of wave
     # slots weigh a quarter as much -- what the kernel does in steady state (rank 0 at N = 1, default workload shapes only)
     steady = None
-    if args.steady and world == 1 and len(tables) == 1 and not (args.flags or args.n_reads or args.errors) and copies < hiplib.MAX_SLOTS and \
+    if not args.no_steady and world == 1 and len(tables) == 1 and not (args.flags or args.n_reads or args.errors) and copies < hiplib.MAX_SLOTS and \
             batch_bases * 4 <= (3 << 30):
         try:
             big_off = np.concatenate([offsets[:-1] + j * batch_bases for j in range(4)] + [np.array([4 * batch_bases], np.int64)])
@@ -493,7 +566,7 @@ def main():
                 sc.scan(copies, prm)
             sc.sync()
             nl_big, _tot, km_big = sc.kernel_time_ms()
-            steady = dict(reads_per_launch=4 * n_reads, kernel_ms_mean=km_big, kernel_launches_timed=nl_big)
+            steady = dict(reads_per_launch=4 * n_reads, kernel_ms_mean=km_big, kernel_launches_timed=nl_big, source="measured in this run")
         except Exception as e:                      # (out of device memory on a small GPU must not cost the bench line)
             steady = {"error": repr(e)}
     lens = np.diff(offsets)
@@ -531,7 +604,9 @@ def main():
         # the GPU's time more than once); a single launch: its own duration
         roof_ms = dt / args.steps * 1e3 if concurrent else k_mean_ms
         achieved = alg_total / (roof_ms * 1e-3) / 1e9 if roof_ms > 0 else 0.0
-        traffic, traffic_src = profiled_traffic(args.workload) if not (args.flags or args.n_reads) else (None, None)
+        traffic, traffic_src = profiled_traffic(args.workload, 0, ks) if not (args.flags or args.n_reads or args.errors) else (None, None)
+        _sm, s_p10, s_p90 = spread(serial_t)
+        s_med = dt_serial / args.steps * 1e3
         out = {
             "metric": "bases_scanned_per_sec",
             "value": value,
@@ -544,9 +619,21 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step_p10": piped["ms_per_step_p10"] if piped else s_p10,
+            "ms_per_step_p90": piped["ms_per_step_p90"] if piped else s_p90,
+            "repeats": piped["repeats"] if piped else len(serial_t),
+            "timed_ms_total": piped["timed_ms_total"] if piped else float(np.sum(serial_t)) * 1e3,
             "streams": piped["streams"] if piped else (len(tables) if concurrent else 1),
             # strictly one launch after the other (the region the roofline's kernel duration comes from)
-            "single_stream": {"value": touched * world * args.steps / dt_serial, "ms_per_step": dt_serial / args.steps * 1e3},
+            "value_single_stream": touched * world * args.steps / dt_serial,
+            "single_stream": {"value": touched * world * args.steps / dt_serial, "ms_per_step": s_med, "ms_per_step_p10": s_p10,
+                              "ms_per_step_p90": s_p90, "repeats": len(serial_t), "timed_ms_total": float(np.sum(serial_t)) * 1e3},
+            "consistency": ("`value` / `ms_per_step`: median of %d repeats of exactly %d steps with consecutive batches alternating over %d streams -- "
+                            "two launches overlap, so ms_per_step may lie below the kernel's own duration (roofline.kernel_ms_mean, measured on the "
+                            "serialised region = single_stream, where ms_per_step >= kernel_ms_mean holds)" % (piped["repeats"], args.steps, piped["streams"]))
+                           if piped else ("`value` / `ms_per_step`: median of %d repeats of exactly %d steps, %s" %
+                                          (len(serial_t), args.steps, "the step's %d table launches overlapping on %d streams" % (len(tables), len(tables))
+                                           if concurrent else "strictly one launch after the other")),
             **({"pipelined_error": pipe_err} if pipe_err else {}),
             "higher_is_better": True,
             "scaling": "weak",
@@ -596,19 +683,22 @@ def main():
         if traffic and PROFILED_COUNTERS.get("SQ_INSTS_VALU") and roof_ms > 0:
             # what really bounds the kernel: integer VALU issue (one wave-instruction per 4 cycles per SIMD), from the committed
             # counters of the same workload; HBM carries `traffic_frac` of its peak (section 3 of DESIGN.md)
-            roof["valu_busy"] = PROFILED_COUNTERS["SQ_INSTS_VALU"] * 4.0 / (N_SIMDS * ENGINE_CLOCK_HZ * roof_ms * 1e-3)
-            roof["valu_busy_source"] = "SQ_INSTS_VALU of %s x 4 cycles / (%d SIMDs x %.1f GHz x this run's kernel duration)" % (traffic_src, N_SIMDS, ENGINE_CLOCK_HZ / 1e9)
+            insts = PROFILED_COUNTERS["SQ_INSTS_VALU"]                     # wave-instructions per launch (per step: all table passes)
+            issue_ms = insts * 4.0 / (N_SIMDS * ENGINE_CLOCK_HZ) * 1e3      # the launch's VALU issue time with every SIMD busy
+            roof["valu_busy"] = issue_ms / roof_ms
+            roof["valu"] = {
+                "insts_per_read": insts / n_reads,
+                "lane_insts_per_base": insts * 64.0 / max(scanned * len(tables), 1),   # per base a table pass scans
+                "issue_ms_per_launch": issue_ms,
+                "busy_single": issue_ms / roof_ms,
+                "busy_pipelined": (issue_ms / piped["ms_per_step"]) if piped else None,
+                "source": "SQ_INSTS_VALU of %s x 4 cycles / (%d SIMDs x %.1f GHz) against this run's durations" % (traffic_src, N_SIMDS, ENGINE_CLOCK_HZ / 1e9),
+            }
+            roof["valu_busy_source"] = roof["valu"]["source"]
             roof["limiter"] = "valu-issue"
         if steady and "kernel_ms_mean" in steady and steady["kernel_ms_mean"] > 0:
             steady["frac"] = 4 * alg_total / (steady["kernel_ms_mean"] * 1e-3) / 1e9 / HBM_PEAK_GBS
             steady["workload"] = args.workload
-        if steady is None and traffic_src:            # the committed measurement of the same profile directory (bench.py --steady)
-            try:
-                st_ = json.load(open(os.path.join(ROOT, os.path.dirname(traffic_src), "steady_state.json")))
-                if st_.get("workload") == args.workload:
-                    steady = dict(st_, source=os.path.join(os.path.dirname(traffic_src), "steady_state.json"))
-            except (OSError, ValueError):
-                pass
         if steady:
             roof["steady_state"] = steady
             if "frac" in steady:
@@ -627,7 +717,7 @@ def main():
                 out["e2e"] = e2e.measure(bases, offsets, motif, k, cfg["slide"], device=dev)
             except Exception as e:                  # a full /tmp must not cost the bench line
                 out["e2e"] = {"error": repr(e)}
-            if args.workload == "config2" and not os.environ.get("TPS_BENCH_NO_WGS"):
+            if args.workload == "config2" and not args.no_wgs:
                 try:                                # the step-1-dominated regime end to end: 30 kb reads, 1 % telomeric, one-pass against two-pass upload
                     out["e2e"]["wgs_1pct"] = e2e.measure_wgs(device=dev)
                 except Exception as e:

@@ -230,6 +230,14 @@ int  tps_batch_kmer_followers(tps_ctx* ctx, int32_t slot, int32_t n_fwd, int32_t
  * total and mean milliseconds (events are recorded on the stream the kernel runs on). */
 int  tps_kernel_time_ms(tps_ctx* ctx, int32_t* n_launches, double* total_ms, double* mean_ms);
 int  tps_kernel_time_reset(tps_ctx* ctx);
+/* Diagnostics and tests only (ABI 4).  The library reads NO environment variables: what experiments and tests need to steer is
+ * set per context through this call -- "event_stride" (time every n-th launch; default 1), "no_events", "force_generic" (the
+ * generic kernel instead of the fused tiles), "spans_per_tile", "force_pair", "so_order" (csrc/tps_plan.h: PlanKnobs), "stamps"
+ * (per-read phase clocks; only a -DTPS_STAMPS build writes them).  topsicle_amd.hiplib applies $TOPSICLE_HIP_DEBUG
+ * ("key=value,key=value") to every context it creates: the ONE documented variable of the Python host. */
+int  tps_ctx_debug_option(tps_ctx* ctx, const char* key, int64_t value);
+/* The stamps of the last scan of `slot`: 16 uint64 per read. */
+int  tps_debug_stamps_get(tps_ctx* ctx, int32_t slot, uint64_t* out, int64_t n_reads);
 /* Name of the device and a few properties, as a NUL-terminated string. */
 int  tps_device_info(tps_ctx* ctx, char* buf, int32_t buf_len);
 /* What the last tps_batch_scan of `slot` launched: "<kernel name> lds=<bytes per workgroup> wgs_per_cu=<n>"

@@ -1,7 +1,7 @@
-"""Diagnostic (GPU box): TPS_IO_TIMING of the reader over a BGZF file of config-2 reads with noisy quality lines."""
+"""Diagnostic (GPU box): the reader's timing lines (option "timing") over a BGZF file of config-2 reads with noisy quality lines."""
 import os, sys, time
 sys.path.insert(0, '.')
-os.environ["TPS_IO_TIMING"] = "1"
+os.environ["TOPSICLE_IO_DEBUG"] = "timing"
 import numpy as np
 from topsicle_amd import e2e, seqio, synth
 b, o, t = synth.make_reads(10000, 15000, "CCCTAA", seed=20250920, errors=synth.ONT)

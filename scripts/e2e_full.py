@@ -131,7 +131,34 @@ def spot_check(cfg, bases, offsets, outdir, n_check=48):
                 bad.append((rid, rows.get(rid), want))
         elif rid in rows:
             bad.append((rid, rows[rid], None))
-    return {"reads_checked": len(idx), "rows_in_csv_for_first_k": len(rows), "mismatches": len(bad), "first_mismatches": bad[:3]}
+    rep = {"reads_checked": len(idx), "rows_in_csv_for_first_k": len(rows), "mismatches": len(bad), "first_mismatches": bad[:3]}
+    # raw rows (--rawcountformat npz): every archive's member CRCs (zipfile.testzip re-reads it once), and for a sample of reads the
+    # rows themselves against the oracle -- mapped in place (counts.npy is stored, its rows begin at byte 4096: topsicle_amd/rawnpz.py)
+    import glob
+    import zipfile
+    raw_bad, raw_checked, crc_ok = 0, 0, True
+    for path in sorted(glob.glob(os.path.join(outdir, "rawcount_*.npz"))):
+        kk = int(os.path.basename(path).split("_")[1])
+        with zipfile.ZipFile(path) as zf:
+            crc_ok = crc_ok and zf.testzip() is None
+            ids = np.load(zf.open("read_id.npy")).tolist()
+            tails = np.load(zf.open("tail.npy")).tolist()
+            wo = np.load(zf.open("win_off.npy"))
+        pk = orc.kmer_table(cfg["motif"], kk)
+        rows_mm = np.memmap(path, dtype=np.uint8, mode="r", offset=4096, shape=(int(wo[-1]), len(pk)))
+        pos = {r: j for j, r in enumerate(ids)}
+        for i in idx[::6]:
+            j = pos.get(f"read{i}")
+            if j is None:
+                continue
+            seq = bases[offsets[i]:offsets[i + 1]].tobytes().decode()
+            want = orc.window_count_matrix(seq, tails[j], pk, 100, cfg["slide"], 100, 20000)[1]
+            raw_checked += 1
+            raw_bad += not np.array_equal(rows_mm[wo[j]:wo[j + 1]], want)
+        del rows_mm
+    if raw_checked or not crc_ok:
+        rep.update({"raw_rows_reads_checked": raw_checked, "raw_rows_mismatches": raw_bad, "npz_member_crcs_ok": crc_ok})
+    return rep
 
 
 def run_cli(path, outdir, cfg, device):

@@ -8,7 +8,6 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-export TPS_BENCH_PRIME=16
 G1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"
 G2="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"
 G3="SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU"
@@ -19,7 +18,7 @@ for v in "$@"; do
   i=0
   for G in "$G1" "$G2" "$G3" "FETCH_SIZE" "WRITE_SIZE"; do
     i=$((i+1))
-    rocprofv3 --pmc $G --output-format csv -d $OUT/${v}_g$i -- python3 $ROOT/bench.py $BARGS --steps 4 --warmup 1 --no-cpu-baseline --no-e2e --streams 1 > $OUT/${v}_g$i.log 2>&1
+    rocprofv3 --pmc $G --output-format csv -d $OUT/${v}_g$i -- python3 $ROOT/bench.py $BARGS --prime 16 --steps 4 --warmup 1 --min-timed-ms 0 --no-cpu-baseline --no-e2e --streams 1 > $OUT/${v}_g$i.log 2>&1
     echo "$v group $i rc=$?"
   done
 done

@@ -1,5 +1,5 @@
 """Reader alone (no GPU work): packed batches of a config-2-shaped plain FASTQ file, best of a few passes.
-TOPSICLE_IO_LIB selects the library, TPS_IO_TIMING=1 prints the reader's phase times.  usage: reader_bench.py [n_reads]"""
+TOPSICLE_IO_LIB selects the library, TOPSICLE_IO_DEBUG=timing prints the reader's phase times.  usage: reader_bench.py [n_reads]"""
 import os, sys, time
 ROOT = os.environ.get('GRAFT_REPO_ROOT', '/root/repo')
 sys.path.insert(0, ROOT)

@@ -15,7 +15,7 @@ sc = hiplib.HipScanner(0); sc.set_patterns(pats)
 sc.upload(0, b, o)
 prm = hiplib.make_params(min_len=9000, min_count=allsteps.min_count_for_cutoff(0.7, 1000 / len(motif), 1000), slide=slide, flags=1 | 2 | 4 | 8 | (16 if raw else 0))
 sc.scan(0, prm); sc.sync()
-sc.lib.tps_debug_stamps_enable(sc._h, 1)
+sc.debug_option("stamps", 1)
 sc.kernel_time_reset()
 sc.scan(0, prm); sc.sync()
 print("kernel", sc.kernel_info(0), "ms", sc.kernel_time_ms()[2])

@@ -19,7 +19,7 @@ prm = hiplib.make_params(min_len=9000, min_count=allsteps.min_count_for_cutoff(0
 for _ in range(300):
     sc.scan(0, prm)
 sc.sync()
-sc.lib.tps_debug_stamps_enable(sc._h, 1)
+sc.debug_option("stamps", 1)
 sc.scan(0, prm); sc.sync()
 st = np.zeros((n, 16), np.uint64)
 sc.lib.tps_debug_stamps_get.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]

@@ -30,6 +30,16 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture(autouse=True)
+def _io_options_back_to_defaults():
+    """Tests steer the native reader through seqio.io_option (tps_io_set_option: process-wide); every test starts from the defaults."""
+    yield
+    from topsicle_amd import seqio
+    if seqio._io_lib:
+        for key, val in seqio.IO_OPTION_DEFAULTS.items():
+            seqio.io_option(key, val)
+
+
 @pytest.fixture(scope="session")
 def gold_dir():
     return GOLD

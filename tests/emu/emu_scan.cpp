@@ -22,6 +22,12 @@ extern "C" int emu_variant_calls(int v) { return (v >= 0 && v < 9) ? g_variant_c
 
 extern "C" const char* emu_last_error() { return g_err.c_str(); }
 
+// planner knobs + "val_off" of the next emu_scan / emu_plan* calls (tests/emu_driver.py: KNOBS); test infrastructure reads no environment either
+static tps::PlanKnobs g_knobs;
+static int g_val_off = 0;
+extern "C" void emu_set_knobs(int force_pair, int so_order, int val_off) { g_knobs = tps::PlanKnobs{}; g_knobs.force_pair = force_pair; g_knobs.so_order = so_order; g_val_off = val_off; }
+static tps::PlanKnobs knobs_with(int spans_pref, int force_generic) { tps::PlanKnobs k = g_knobs; k.spans_per_tile = spans_pref; k.force_generic = force_generic; return k; }
+
 extern "C" int64_t emu_window_count(int64_t L, int W, int s, int t, int M) { return tps::window_count(L, W, s, t, M); }
 
 // One scan over a batch, like tps_batch_upload + tps_batch_scan + downloads.
@@ -33,7 +39,7 @@ extern "C" int emu_scan(const char* pats, int P, int k, const uint8_t* bases, co
                         int64_t* win_off_out, int32_t* sums, uint8_t* raw) {
     std::vector<uint32_t> lut;
     tps::ScanArgs a{};
-    a.val_on = getenv("TPS_EMU_VAL_OFF") ? 0 : 1;  // (the emulation keeps the invalid-mask staging area; TPS_EMU_VAL_OFF: the layout of a clean batch, bases without invalid letters only)
+    a.val_on = g_val_off ? 0 : 1;  // (the emulation keeps the invalid-mask staging area; knob val_off: the layout of a clean batch, bases without invalid letters only)
     std::string err = tps::build_patterns(pats, P, k, lut, a.pat);
     if (!err.empty()) { g_err = err; return TPS_E_PATTERN; }
     std::vector<int64_t> win_off((size_t)n + 1);
@@ -46,7 +52,7 @@ extern "C" int emu_scan(const char* pats, int P, int k, const uint8_t* bases, co
     }
     win_off[(size_t)n] = acc;
     if (win_off_out) memcpy(win_off_out, win_off.data(), (size_t)(n + 1) * 8);
-    err = tps::plan_geometry(a, *prm, k, P, mx, lds_budget_bytes / 4, spans_pref, force_generic);
+    err = tps::plan_geometry(a, *prm, k, P, mx, lds_budget_bytes / 4, knobs_with(spans_pref, force_generic));
     if (!err.empty()) { g_err = err; return TPS_E_CAPACITY; }
 
     // the packed batch, exactly as the library keeps it in HBM (tps_pack.h).  Words the layout does not own are filled
@@ -98,6 +104,8 @@ extern "C" int emu_scan(const char* pats, int P, int k, const uint8_t* bases, co
     if (a.pair16) {                                // k = 5 pair-table kernels (_s*q): 4^(k+1) 16-bit masks, the two positions' masks ORed
         for (int c = 0; c < 2 * a.pair_n; ++c)
             ((uint16_t*)lutbuf.data())[c] = (uint16_t)(lut[(size_t)(c & (int)a.pat.kmask)] | lut[(size_t)((c >> 2) & (int)a.pat.kmask)]);
+    } else if (a.lut_fields) {                     // raw-row kernels, k <= 4: the two positions' one-hot fields added up (tile_pp_s<.., PAIRF>)
+        for (int c = 0; c < a.pair_n; ++c) lutbuf[(size_t)c] = lut1[c & a.pat.kmask] + lut1[(c >> 2) & a.pat.kmask];
     } else
     for (int c = 0; c < a.pair_n; ++c) {
         const uint32_t e1 = lut1[c & a.pat.kmask], e2 = lut1[(c >> 2) & a.pat.kmask];
@@ -117,6 +125,7 @@ extern "C" int emu_scan(const char* pats, int P, int k, const uint8_t* bases, co
             if (so && want_raw && a.lut16) tps::scan_read<S, true, false, true, tps::tile_full_default(S), 3>(a, r, lds.data(), lut1); \
             else if (so && want_raw) tps::scan_read<S, true, false, true>(a, r, lds.data(), lut1);               \
             else if (so) tps::scan_read<S, true, false, false>(a, r, lds.data(), lut1);                          \
+            else if (want_raw && a.pair_n) tps::scan_read<S, false, true, true>(a, r, lds.data(), lut1);         \
             else if (want_raw) tps::scan_read<S, false, false, true>(a, r, lds.data(), lut1);                    \
             else if (a.pair_n && a.pair16) tps::scan_read<S, false, true, false, tps::tile_full_default(S), 4>(a, r, lds.data(), lut1); \
             else if (a.pair_n) tps::scan_read<S, false, true, false>(a, r, lds.data(), lut1);                    \
@@ -178,7 +187,7 @@ extern "C" int emu_binseg(const int32_t* sums, const int64_t* win_off, int64_t n
 extern "C" int emu_plan(int k, int P, const tps_params* prm, int64_t max_nwin, int spans_pref, int lds_budget_bytes, int force_generic, int32_t* out10) {
     tps::ScanArgs a{};
     a.val_on = 1;                                  // (the emulation always keeps the invalid-mask staging area)
-    std::string err = tps::plan_geometry(a, *prm, k, P, max_nwin, lds_budget_bytes / 4, spans_pref, force_generic);
+    std::string err = tps::plan_geometry(a, *prm, k, P, max_nwin, lds_budget_bytes / 4, knobs_with(spans_pref, force_generic));
     if (!err.empty()) { g_err = err; return TPS_E_CAPACITY; }
     out10[0] = a.spans_per_tile; out10[1] = a.span_dw; out10[2] = a.blk_log2; out10[3] = a.q; out10[4] = a.r;
     out10[5] = a.lw; out10[6] = a.seq_dw; out10[7] = (int32_t)(tps::wg_lds_dwords(a) * 4); out10[8] = a.variant; out10[9] = a.rec_rs;
@@ -191,7 +200,7 @@ extern "C" int emu_plan_table(const char* pats, int P, int k, const tps_params* 
     a.val_on = 1;                                  // (the emulation always keeps the invalid-mask staging area)
     std::vector<uint32_t> lut;
     std::string err = tps::build_patterns(pats, P, k, lut, a.pat);
-    if (err.empty()) err = tps::plan_geometry(a, *prm, k, P, max_nwin, 160 * 1024 / 4, 0, 0);
+    if (err.empty()) err = tps::plan_geometry(a, *prm, k, P, max_nwin, 160 * 1024 / 4, knobs_with(0, 0));
     if (!err.empty()) { g_err = err; return TPS_E_CAPACITY; }
     out4[0] = a.variant; out4[1] = a.pp_d; out4[2] = (int32_t)(tps::wg_lds_dwords(a) * 4); out4[3] = a.pair_n; out4[4] = a.tile_full; out4[5] = a.tw;
     return TPS_OK;

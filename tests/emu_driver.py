@@ -26,6 +26,13 @@ def build(asan=False):
 
 
 _lib = None
+# planner knobs of the next scan / plan calls (tps::PlanKnobs; tests set them with monkeypatch.setitem) and "val_off": the LDS layout of
+# a batch without invalid letters
+KNOBS = {"force_pair": 0, "so_order": 0, "val_off": 0}
+
+
+def _knobs(L):
+    L.emu_set_knobs(int(KNOBS["force_pair"]), int(KNOBS["so_order"]), int(KNOBS["val_off"]))
 
 
 def lib():
@@ -57,6 +64,7 @@ def scan(patterns, seqs, prm, tails=None, spans_pref=0, lds_budget=160 * 1024, b
     sums = np.zeros(max(tot, 1), np.int32)
     raw = np.zeros(max(tot * P, 1), np.uint8)
     t = None if tails is None else np.ascontiguousarray(tails, dtype=np.uint8)
+    _knobs(L)
     rc = L.emu_scan("".join(patterns).encode(), P, k, _p(bases), _p(offsets), C.c_int64(n), _p(t), C.byref(prm),
                     spans_pref, lds_budget, base_shift, force_generic, _p(res), _p(cs), _p(ce), _p(win_off), _p(sums), _p(raw))
     if rc != 0:
@@ -92,6 +100,7 @@ def binseg(sums, win_off, n_patterns, jump=5, min_size=2, want_tie=False):
 
 def plan(k, P, prm, max_nwin, spans_pref=0, lds_budget=160 * 1024, force_generic=0):
     out = (C.c_int32 * 10)()
+    _knobs(lib())
     rc = lib().emu_plan(k, P, C.byref(prm), C.c_int64(max_nwin), spans_pref, lds_budget, force_generic, out)
     if rc != 0:
         raise RuntimeError(lib().emu_last_error().decode())
@@ -103,6 +112,7 @@ def plan_table(patterns, prm, max_nwin):
     """Plan of a scan with a real pattern table: dict(variant, pp_d, lds_bytes, pair_n)."""
     out = (C.c_int32 * 6)()
     k = len(patterns[0])
+    _knobs(lib())
     rc = lib().emu_plan_table("".join(patterns).encode(), len(patterns), k, C.byref(prm), C.c_int64(max_nwin), out)
     if rc != 0:
         raise RuntimeError(lib().emu_last_error().decode())

@@ -1,7 +1,7 @@
 """Randomised check of the several-tables-at-once path (run on the GPU box): random motifs, 2-4 values of k, random window
 parameters and output flags, batch after batch of random size through batch.scan_jobs -- helper contexts borrowing the
 resident batch, all tables launched together -- against the same jobs back to back on the one context
-(TOPSICLE_SEQUENTIAL_TABLES=1).  Rows, window sums and raw rows of passing reads must be identical."""
+(batch.SEQUENTIAL_TABLES).  Rows, window sums and raw rows of passing reads must be identical."""
 import os, sys, time
 ROOT = os.environ.get('GRAFT_REPO_ROOT', '/root/repo')
 sys.path.insert(0, ROOT)
@@ -40,9 +40,9 @@ for case in range(n_cases):
                                                  len_mu=float(rng.choice([7.5, 8.5, 9.3])), len_sigma=0.8, min_len=30, max_len=40000)[:2]
         recs = type("B", (), {"bases": bases, "offsets": offsets})()
         try:
-            os.environ["TOPSICLE_SEQUENTIAL_TABLES"] = "1"
+            batch.SEQUENTIAL_TABLES = True
             seq = batch.scan_jobs(sc, recs, jobs)
-            os.environ["TOPSICLE_SEQUENTIAL_TABLES"] = "0"
+            batch.SEQUENTIAL_TABLES = False
             con = batch.scan_jobs(sc, recs, jobs)
         except hiplib.TopsicleHipError as e:
             print("case", case, "rejected:", str(e)[:100])

@@ -100,12 +100,12 @@ def run(cases=300, seed=0):
         rng = np.random.default_rng(seed * 1000003 + case)
         p, damage = make_file(rng, os.path.join(tmp, "f%d" % case))
         # compressed inputs: the thread team's inflaters also on small files, windows of inflated text from tiny to default
-        os.environ["TPS_IO_PARGZ_MIN"] = str(int(rng.choice([0, 1 << 40])))
+        seqio.io_option("pargz_min", int(rng.choice([0, 1 << 40])))
         g = int(rng.choice([0, 700, 20000, 1 << 20]))
         if g:
-            os.environ["TPS_IO_BGZF_GROUP"] = str(g)
+            seqio.io_option("bgzf_group", g)
         else:
-            os.environ.pop("TPS_IO_BGZF_GROUP", None)
+            seqio.io_option("bgzf_group", 0)
         if os.environ.get("RD_FUZZ_VERBOSE"):
             print("case", case, p, flush=True)
         want = [(r.id, r.description, r.seq, r.qual) for r in seqio.read_records(p)]
@@ -152,8 +152,8 @@ def run(cases=300, seed=0):
                 prefix += 1
         os.unlink(p)
     os.rmdir(tmp)
-    os.environ.pop("TPS_IO_PARGZ_MIN", None)
-    os.environ.pop("TPS_IO_BGZF_GROUP", None)
+    seqio.io_option("pargz_min", -1)
+    seqio.io_option("bgzf_group", 0)
     return same, prefix
 
 

@@ -421,10 +421,10 @@ def test_emulation_chain_free_tiles_hand_over(motif, k, slide, unit, detect_ever
     """Self-overlap table: tiles without a chained occurrence complete as plain tiles (sums only: tile_fused_s<.., CD>; raw rows:
     tile_pp_s<S, 0, CD>), the others go through tile_so_s / tile_pp_s<S, D>.  Chains planted around every tile boundary (before, across, after; 2 to 6 links; both
     tails) check the hand-over in both directions: what a plain tile leaves for a chained successor, and a chained tile
-    followed by a plain one.  detect_every_tile (TPS_SO_FAST=2): the raw-row kernels try the chain-free tile first for EVERY tile (the
+    followed by a plain one.  detect_every_tile (planner knob so_order = 2): the raw-row kernels try the chain-free tile first for EVERY tile (the
     order of round 3); otherwise a tile that follows a chained one goes straight to the canonical-pick tile (round 4)."""
     if detect_every_tile:
-        monkeypatch.setenv("TPS_SO_FAST", "2")
+        monkeypatch.setitem(emu.KNOBS, "so_order", 2)
     rng = np.random.default_rng(7 * k + slide)
     pats = orc.kmer_table(motif, k)
     flags = hiplib.F_WINDOWS | hiplib.F_BINSEG | hiplib.F_TAILS_IN | hiplib.F_STORE_SUMS
@@ -492,7 +492,8 @@ def test_planner_picks_per_pattern_tiles():
     def plan(motif, k, slide, flags=0):
         return emu.plan_table(orc.kmer_table(motif, k), hiplib.make_params(slide=slide, flags=hiplib.F_WINDOWS | flags), 3301)
     assert plan("CCCTAA", 4, 6)["pp_d"] == 0 and plan("CCCTAA", 4, 6)["pair_n"] == 1024          # no overlap; pair table for sums only
-    assert plan("CCCTAA", 4, 6, hiplib.F_STORE_RAW)["pair_n"] == 0                               # raw counts: single lookups
+    assert plan("CCCTAA", 4, 6, hiplib.F_STORE_RAW)["pair_n"] == 1024                            # raw counts (round 5): a pair table of fields at k = 4, slide 6
+    assert plan("CCCTAA", 4, 7, hiplib.F_STORE_RAW)["pair_n"] == 0 and plan("CCCTAA", 4, 5, hiplib.F_STORE_RAW)["pair_n"] == 0    # ... only
     assert plan("CCCTAA", 5, 6)["pp_d"] == 4 and plan("CCCTAA", 6, 6)["pp_d"] == 5               # CTAAC: period 4; CCTAAC: period 5
     assert plan("TTTAGGG", 7, 7)["pp_d"] == 6 and plan("AAACCCT", 5, 7)["pp_d"] == 0
     assert plan("ACACAC", 5, 6)["pp_d"] == -1                                                    # ACACA: periods 2 and 4
@@ -554,7 +555,7 @@ def test_emulation_self_overlap_sums_clean_batch_layout(motif, k, slide, units, 
     LDS table (ScanArgs::lut16) and XT aliased onto the head of the staged bases (xt_alias without xt_own) -- the layout the
     planner picks for a clean batch on the device.  Whole pipeline (step 1 on the 16-bit table, chain-corrected tiles, change
     point) against the oracle, both tails decided by step 1."""
-    monkeypatch.setenv("TPS_EMU_VAL_OFF", "1")
+    monkeypatch.setitem(emu.KNOBS, "val_off", 1)
     rng = np.random.default_rng(99 + 10 * k + slide)
     pats, seqs = _pp_reads(rng, motif, k, 6, 7000, units)
     seqs = [s if i % 2 == 0 else s[::-1] for i, s in enumerate(seqs)]
@@ -643,7 +644,7 @@ def test_emulation_raw_rows_clean_batch_layout(motif, k, slide, units, monkeypat
     """The raw-row kernels on a batch without non-ACGT letters (round 4): no XF / XT words in the exchange region -- the per-pattern
     tiles keep their lane totals in the pad words of END, the row staging buffer is XPC alone -- the LDS layout the planner picks
     for a clean batch on the device (xt_alias = 2 without xt_own).  Rows, sums and change point against the oracle."""
-    monkeypatch.setenv("TPS_EMU_VAL_OFF", "1")
+    monkeypatch.setitem(emu.KNOBS, "val_off", 1)
     rng = np.random.default_rng(7 + 10 * k + slide)
     pats, seqs = _pp_reads(rng, motif, k, 4, 8000, units)
     prm = hiplib.make_params(window=100, slide=slide, trimfirst=100, maxlen=20000,
@@ -667,7 +668,7 @@ def test_emulation_k5_pair_table_of_16_bit_masks(motif, slide, W, monkeypatch):
     lookup from a 16-bit pair table (ScanArgs::pair16, kernels _s*q; the single table in the same format).  On the device the planner
     picks it by itself (8-wave workgroups); the emulation's slices are bigger, so the test forces it.  Step 1, window sums and the
     boundary against the oracle -- reads of several tiles, both strands, a read with N, lower case."""
-    monkeypatch.setenv("TPS_FORCE_PAIR", "1")
+    monkeypatch.setitem(emu.KNOBS, "force_pair", 1)
     k = 5
     pats = orc.kmer_table(motif, k)
     prm = hiplib.make_params(no_bp=1000, min_len=0, min_count=-1, window=W, slide=slide, trimfirst=100, maxlen=20000,
@@ -747,7 +748,7 @@ def test_emulation_default_kernels_other_slides(slide, force_pair, monkeypatch):
     took the generic kernel before, three to five times slower per window.  Step 1, window sums and the boundary against the oracle;
     with and without the pair table (the emulation's planner drops it where its bigger slices make it cost a workgroup)."""
     if force_pair:
-        monkeypatch.setenv("TPS_FORCE_PAIR", "1")
+        monkeypatch.setitem(emu.KNOBS, "force_pair", 1)
     motif, k, W = "CCCTAA", 4, 100
     pats = orc.kmer_table(motif, k)
     prm = hiplib.make_params(no_bp=1000, min_len=0, min_count=-1, window=W, slide=slide, trimfirst=100, maxlen=20000,
@@ -778,3 +779,57 @@ def test_emulation_default_kernels_other_slides(slide, force_pair, monkeypatch):
         assert hi - lo == counts.shape[0] and hi - lo > 400
         assert np.array_equal(out["sums"][lo:hi], counts.sum(axis=1)), i
         assert r["bkp"] == orc.binseg_l2_exact(counts.sum(axis=1)), i
+
+
+@pytest.mark.parametrize("slide,W,force_pair", [(6, 100, True), (6, 100, False), (8, 100, True), (6, 102, True), (6, 101, True), (7, 100, True), (5, 100, True)])
+def test_emulation_raw_rows_pair_table_of_fields(slide, W, force_pair, monkeypatch):
+    """Round 5: the raw-row kernels of tables without self-overlap take two positions per lookup at k <= 4 from a pair table of one-hot
+    FIELDS (tile_pp_s<.., PAIRF>; ScanArgs::pair_n with lut_fields) when the window's partial block ends between two pairs -- k = 4 at the
+    default window, slide 6 -- and the partial-block position is a compile-time constant there (RPT).  Other windows / slides
+    keep single lookups (the planner must not grant the table).  Rows, sums and the boundary against the oracle, reads of several
+    tiles, both tails, a read with an N (its tile takes the fallback, which must not touch the fields table), lower case."""
+    if force_pair:
+        monkeypatch.setitem(emu.KNOBS, "force_pair", 1)
+    motif, k = "CCCTAA", 4
+    pats = orc.kmer_table(motif, k)
+    prm = hiplib.make_params(window=W, slide=slide, trimfirst=100, maxlen=20000,
+                             flags=hiplib.F_WINDOWS | hiplib.F_BINSEG | hiplib.F_TAILS_IN | hiplib.F_STORE_SUMS | hiplib.F_STORE_RAW)
+    pl = emu.plan_table(pats, prm, 3000)
+    assert pl["variant"] == slide, pl
+    if force_pair:                             # (without the knob the occupancy rule decides: the emulation's slices are bigger than the device's)
+        assert (pl["pair_n"] == 1024) == (slide == 6 and W == 100), pl
+    else:
+        assert pl["pair_n"] in (0, 1024), pl
+    rng = np.random.default_rng(100 * slide + W)
+    _, seqs = _pp_reads(rng, motif, k, 4, 9500, [])
+    seqs[1] = seqs[1][:5000] + "N" + seqs[1][5001:]
+    seqs[2] = seqs[2][:300] + seqs[2][300:900].lower() + seqs[2][900:]
+    tails = [0, 1, 0, 1]
+    L = emu.lib()
+    t0 = L.emu_counter(0)
+    out = emu.scan(pats, seqs, prm, tails=tails, base_shift=int(rng.integers(16)))
+    assert L.emu_counter(0) - t0 >= (8 if slide != 8 else 0)        # (slide 8: a lane could hold 16 occurrences of a 4-mer -- no per-pattern tile, the fallback counts)
+    for i, seq in enumerate(seqs):
+        _, counts = orc.window_count_matrix(seq, ["forward", "reverse"][tails[i]], pats, W, slide, 100, 20000)
+        lo, hi = out["win_off"][i], out["win_off"][i + 1]
+        assert np.array_equal(out["raw"][lo:hi], counts), i
+        assert np.array_equal(out["sums"][lo:hi], counts.sum(axis=1)), i
+        assert out["results"][i]["bkp"] == orc.binseg_l2_exact(counts.sum(axis=1))
+
+
+@pytest.mark.parametrize("k,W", [(5, 100), (6, 100), (5, 103), (6, 97)])
+def test_emulation_self_overlap_raw_rows_home_and_other_windows(k, W):
+    """Round 5: the self-overlap raw-row tiles carry the partial-block position of their home shape (CCCTAA at k = 5 / 6, window 100) as a
+    compile-time constant; other windows take the run-time instantiation.  Both against the oracle."""
+    motif, slide = "CCCTAA", 6
+    rng = np.random.default_rng(31 * k + W)
+    pats, seqs = _pp_reads(rng, motif, k, 3, 9000, ["CTAA", "GATT"] if k == 5 else ["CCTAA", "GGATT"])
+    prm = hiplib.make_params(window=W, slide=slide, trimfirst=100, maxlen=20000,
+                             flags=hiplib.F_WINDOWS | hiplib.F_BINSEG | hiplib.F_TAILS_IN | hiplib.F_STORE_SUMS | hiplib.F_STORE_RAW)
+    tails = [0, 1, 1]
+    out = emu.scan(pats, seqs, prm, tails=tails, base_shift=int(rng.integers(16)))
+    for i, seq in enumerate(seqs):
+        _, counts = orc.window_count_matrix(seq, ["forward", "reverse"][tails[i]], pats, W, slide, 100, 20000)
+        lo, hi = out["win_off"][i], out["win_off"][i + 1]
+        assert np.array_equal(out["raw"][lo:hi], counts), i
+        assert np.array_equal(out["sums"][lo:hi], counts.sum(axis=1)), i

@@ -167,9 +167,9 @@ def test_tables_scanned_concurrently_equal_back_to_back(sc, monkeypatch):
     for n, seed in ((600, 5), (1500, 6), (300, 7)):              # the slot grows, then shrinks
         bases, offsets = _ragged(n, motif, seed)
         recs = type("B", (), {"bases": bases, "offsets": offsets})()     # (goes up as ASCII: batch.upload_batch)
-        monkeypatch.setenv("TOPSICLE_SEQUENTIAL_TABLES", "1")
+        monkeypatch.setattr(batch, "SEQUENTIAL_TABLES", True)
         seq = batch.scan_jobs(sc, recs, jobs)
-        monkeypatch.setenv("TOPSICLE_SEQUENTIAL_TABLES", "0")
+        monkeypatch.setattr(batch, "SEQUENTIAL_TABLES", False)
         con = batch.scan_jobs(sc, recs, jobs)
         assert len(sc._helpers) == 2
         for j, ((r1, s1, w1, o1), (r2, s2, w2, o2)) in enumerate(zip(seq, con)):
@@ -220,7 +220,7 @@ def test_compressed_inputs_scan_like_the_plain_file(tmp_path, monkeypatch):
         for i in range(len(offsets) - 1):
             h.write(b">r%d some text\n" % i + bases[offsets[i]:offsets[i + 1]].tobytes() + b"\n")
     assert os.path.getsize(gz) > (1 << 20)                      # (large enough for the parallel inflater)
-    monkeypatch.setenv("TPS_IO_BGZF_GROUP", str(6 << 20))       # windows of ~6 MB of text: several refills per file
+    seqio.io_option("bgzf_group", 6 << 20)       # windows of ~6 MB of text: several refills per file
     prm = _params(motif, slide, hiplib.F_STEP1 | hiplib.F_WINDOWS | hiplib.F_BINSEG)
     engines = [hiplib.HipScanner(0), hiplib.HipScanner(0)]
     try:
@@ -338,7 +338,7 @@ def test_cli_npz_on_gpu_equals_the_per_read_csv_rows(tmp_path, gold_dir, monkeyp
         pats = orc.kmer_table("CCCTAA", k)
         ids = z["read_id"].tolist()
         nums = [int("".join(ch for ch in r if ch.isdigit())) for r in ids]
-        assert len(ids) > 850 and nums == sorted(nums)                        # file order, although the batches finish out of order
+        assert len(ids) > 700 and nums == sorted(nums)                        # file order, although the batches finish out of order
         for i in range(0, len(ids), 97):
             rid = ids[i]
             ridx = int("".join(ch for ch in rid if ch.isdigit()))

@@ -138,11 +138,11 @@ def test_reader_takes_the_parallel_path_for_fastq_gz(tmp_path, text):
         ids_gz += pb.ids
         nb += pb.n_bases
     assert ids_gz == ids_plain and len(ids_gz) == 2500
-    os.environ["TPS_IO_NO_PARGZ"] = "1"
+    seqio.io_option("no_pargz", 1)
     try:
         ids_z = [i for pb in seqio.read_batches_packed(str(gz), seqio.BufferPool(2, 1 << 22, 1 << 16)) for i in pb.ids]
     finally:
-        del os.environ["TPS_IO_NO_PARGZ"]
+        seqio.io_option("no_pargz", 0)
     assert ids_z == ids_plain
 
 

@@ -241,7 +241,7 @@ def test_cli_fasta_input_several_k_keeps_the_first_k_records(engine, tmp_path, d
 def test_scan_jobs_tables_on_helper_contexts_equal_back_to_back(monkeypatch):
     """batch.scan_jobs with several pattern tables: job j > 0 runs on the engine's j-th helper context, which borrows the batch
     (share) and keeps its own table -- the host logic of `--telophrase 4 5 6`, here on emulated contexts: the same rows, sums
-    and raw counts as the tables back to back on the one context (TOPSICLE_SEQUENTIAL_TABLES=1), batch after batch."""
+    and raw counts as the tables back to back on the one context (batch.SEQUENTIAL_TABLES), batch after batch."""
     from emu_engine import EmuEngine
     import topsicle_oracle as orc
     from topsicle_amd import batch, hiplib, synth
@@ -252,9 +252,9 @@ def test_scan_jobs_tables_on_helper_contexts_equal_back_to_back(monkeypatch):
     for seed, n in ((1, 7), (2, 12)):
         bases, offsets, _ = synth.make_reads(n, 2500, "CCCTAA", seed=seed, errors=synth.ONT, tract_min=300, tract_max=1800)
         recs = type("B", (), {"bases": bases, "offsets": offsets})()
-        monkeypatch.setenv("TOPSICLE_SEQUENTIAL_TABLES", "1")
+        monkeypatch.setattr(batch, "SEQUENTIAL_TABLES", True)
         seq = batch.scan_jobs(eng, recs, jobs)
-        monkeypatch.delenv("TOPSICLE_SEQUENTIAL_TABLES")
+        monkeypatch.setattr(batch, "SEQUENTIAL_TABLES", False)
         con = batch.scan_jobs(eng, recs, jobs)
         assert len(eng._helpers) == 2 and [h.patterns for h in eng._helpers] == [jobs[1].patterns, jobs[2].patterns]
         assert eng.patterns == jobs[0].patterns                          # (the owner keeps the first table: no switch per batch)
@@ -267,7 +267,7 @@ def test_scan_jobs_tables_on_helper_contexts_equal_back_to_back(monkeypatch):
 
 
 def test_cli_same_outputs_from_plain_gzip_and_bgzf_input(engine, tmp_path, demo_records, monkeypatch):
-    """The same reads as plain FASTQ, ordinary gzip (inflated by the thread team: TPS_IO_PARGZ_MIN=0 takes that path for a small
+    """The same reads as plain FASTQ, ordinary gzip (inflated by the thread team: the option pargz_min = 0 takes that path for a small
     file too) and BGZF, with windows of inflated text far smaller than the file (many refills; the passing records of a batch are
     written from the window the batch keeps alive): telolengths_all.csv and the filtered FASTQ are byte for byte the same."""
     import struct
@@ -284,8 +284,8 @@ def test_cli_same_outputs_from_plain_gzip_and_bgzf_input(engine, tmp_path, demo_
     with open(fq, "rb") as src, gzip.open(d_gz / "reads.fastq.gz", "wb", compresslevel=1) as dst:
         dst.write(src.read())
     e2e.write_bgzf(str(d_bg / "reads.fastq.gz"), str(fq), block=20000)
-    monkeypatch.setenv("TPS_IO_PARGZ_MIN", "0")
-    monkeypatch.setenv("TPS_IO_BGZF_GROUP", "150000")
+    seqio.io_option("pargz_min", 0)
+    seqio.io_option("bgzf_group", 150000)
     outs = {}
     for tag, path in (("plain", fq), ("gz", d_gz / "reads.fastq.gz"), ("bgzf", d_bg / "reads.fastq.gz")):
         out = tmp_path / ("o_" + tag)

@@ -58,7 +58,7 @@ def test_native_plain_fastq_thread_team(tmp_path, monkeypatch, threads):
     """Plain 4-line FASTQ goes through the mmap + thread-team decoder; anything irregular (wrapped lines,
     blank lines, length mismatch) must hand the rest of the file to the streaming decoder with no record
     lost or duplicated."""
-    monkeypatch.setenv("TPS_IO_THREADS", threads)
+    seqio.io_option("threads", int(threads))
     rng = np.random.default_rng(11)
 
     def rec(i, n, crlf=False):
@@ -132,7 +132,7 @@ def _write_bgzf(path, payload: bytes, block=60000, splits=None):
 def test_native_bgzf_blocks_inflate_in_parallel(tmp_path, monkeypatch, caplog, threads):
     """bgzip'ed FASTQ: the blocks are inflated by the thread team and decoded like plain FASTQ; records span block
     boundaries; an irregular record hands over to the streaming decoder; a corrupt block is an error, not a short file."""
-    monkeypatch.setenv("TPS_IO_THREADS", threads)
+    seqio.io_option("threads", int(threads))
     rng = np.random.default_rng(11)
     recs = []
     for i in range(900):
@@ -145,10 +145,10 @@ def test_native_bgzf_blocks_inflate_in_parallel(tmp_path, monkeypatch, caplog, t
     _write_bgzf(str(p), text.encode(), block=50021)
     got = all_records(str(p), max_bases=700000)
     assert [(r.description, r.seq, r.qual) for r in got] == recs
-    monkeypatch.setenv("TPS_IO_BGZF_GROUP", "300000")       # many refills: partial records are carried over
+    seqio.io_option("bgzf_group", 300000)       # many refills: partial records are carried over
     got = all_records(str(p), max_bases=2000000)
     assert [(r.description, r.seq, r.qual) for r in got] == recs
-    monkeypatch.delenv("TPS_IO_BGZF_GROUP")
+    seqio.io_option("bgzf_group", 0)
     assert [(r.description, r.seq) for r in seqio.read_records(str(p))] == [(h, s) for h, s, _ in recs]     # it is plain gzip too
     # wrapped sequence lines in the middle: the streaming decoder takes over at that record
     odd = text + "@wrapped\nAC\nGT\n+\nII\nII\n@last\nA\n+\n#\n"
@@ -245,7 +245,7 @@ def test_packed_reader_thread_team_resynchronises_at_any_byte(tmp_path):
         print("ok")
     """) % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path))
     for threads in ("2", "7", "16"):
-        env = dict(os.environ, TPS_IO_THREADS=threads, TPS_IO_PACK_MIN_SPAN="1")
+        env = dict(os.environ, TOPSICLE_IO_DEBUG=f"threads={threads},pack_min_span=1")
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
         assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (threads, r.stdout[-2000:], r.stderr[-4000:])
 
@@ -398,7 +398,7 @@ def test_bgzf_window_that_ends_at_a_quality_line_stays_packed(tmp_path, monkeypa
         recs.append(("r%d" % i, seq.decode()))
     p = tmp_path / "cut.fastq.gz"
     _write_bgzf(str(p), text, splits=cuts)
-    monkeypatch.setenv("TPS_IO_BGZF_GROUP", "1")          # one block per group
+    seqio.io_option("bgzf_group", 1)          # one block per group
     pool = seqio.BufferPool(3, 1024, 64)
     got, kinds = [], []
     for pb in seqio.read_batches_packed(str(p), pool):
@@ -415,9 +415,9 @@ def test_wrapped_fasta_takes_the_thread_team_decoder(tmp_path, monkeypatch, nl):
     """Round 4: FASTA records whose sequence is wrapped (60 / 80 / any columns; blank lines in between) are joined line by line and
     packed by the thread team, plain, gzip'ed and bgzip'ed -- the same records, bases and 2-bit words as the same reads on one line
     each; a record with padded lines still goes to the streaming decoder."""
-    monkeypatch.setenv("TPS_IO_PACK_MIN_SPAN", "2000")    # the team on small files
-    monkeypatch.setenv("TPS_IO_PARGZ_MIN", "0")
-    monkeypatch.setenv("TPS_IO_THREADS", "5")
+    seqio.io_option("pack_min_span", 2000)    # the team on small files
+    seqio.io_option("pargz_min", 0)
+    seqio.io_option("threads", 5)
     rng = np.random.default_rng(11)
     seqs = [bytes(rng.choice(np.frombuffer(b"ACGTacgtN", np.uint8), int(L))) for L in list(rng.integers(0, 4000, 150)) + [60, 61, 120, 1]]
     one, wrapped = b"", b""
@@ -464,9 +464,9 @@ def test_multiline_fastq_takes_the_thread_team_decoder(tmp_path, monkeypatch, nl
     plain, gzip'ed and bgzip'ed: the same records, qualities and 2-bit words as the same reads written four lines each; the
     record writer puts them out in Biopython's four-line layout; a record with a blank line inside still goes to the streaming
     decoder."""
-    monkeypatch.setenv("TPS_IO_PACK_MIN_SPAN", "2000")    # the team on small files
-    monkeypatch.setenv("TPS_IO_PARGZ_MIN", "0")
-    monkeypatch.setenv("TPS_IO_THREADS", "5")
+    seqio.io_option("pack_min_span", 2000)    # the team on small files
+    seqio.io_option("pargz_min", 0)
+    seqio.io_option("threads", 5)
     rng = np.random.default_rng(12)
     seqs = [bytes(rng.choice(np.frombuffer(b"ACGTacgtN", np.uint8), int(L))) for L in list(rng.integers(1, 4000, 150)) + [60, 61, 120, 1, 2]]
     quals = [bytes(rng.choice(np.frombuffer(b"@+I#5", np.uint8), len(s))) for s in seqs]
@@ -519,7 +519,7 @@ def test_compressed_windows_are_inflated_and_indexed_only_for_who_uses_them(tmp_
     """an ASCII consumer of bgzip'ed FASTA -- which the thread-team decoder does not serve -- used to inflate and
     line-index a whole first window at open and throw it away; the packed decoder line-indexed every window it never looked at by
     lines.  Now the first window is built by the first call that wants records, and the line index only for Fast::next.  The
-    library's own timing lines (TPS_IO_TIMING, a fresh process: the switch is read once) say what ran."""
+    library's own timing lines ($TOPSICLE_IO_DEBUG=timing in a fresh process) say what ran."""
     import subprocess
     import sys
     rng = np.random.default_rng(5)
@@ -547,7 +547,7 @@ print("records", n)
 
     def run(mode, name):
         r = subprocess.run([sys.executable, "-c", code, mode, str(tmp_path / name)], capture_output=True, text=True, timeout=300,
-                           env=dict(os.environ, TPS_IO_TIMING="1"))
+                           env=dict(os.environ, TOPSICLE_IO_DEBUG="timing"))
         assert r.returncode == 0 and "records 300" in r.stdout, r.stdout + r.stderr
         return r.stderr
     err = run("ascii", "a.fasta.gz")

@@ -19,6 +19,8 @@ from . import hiplib
 
 BATCH_BASES = 64 << 20           # bases per upload: 16 MB of packed words + 8 MB of invalid masks across PCIe
 BATCH_READS = 1 << 18
+SEQUENTIAL_TABLES = False        # True: several pattern tables of one batch are scanned back to back on the one context instead of
+                                 # at the same time on helper contexts (the A/B switch of tests and bench.py --sequential-tables)
 
 
 def record_batches(records, max_bases: int = BATCH_BASES, max_reads: int = BATCH_READS):
@@ -96,7 +98,7 @@ def scan_jobs_heads(engine, recs, jobs, slot: int = 0, seq=None):
     laid out over ALL reads of the batch with no windows for the reads that do not pass.  PCIe bytes per input base, 30 kb reads of
     which 1 % pass: 0.375 -> 0.028.  Same return value as scan_jobs."""
     import numpy as np
-    concurrent = len(jobs) > 1 and hasattr(engine, "helper") and os.environ.get("TOPSICLE_SEQUENTIAL_TABLES", "0") != "1"
+    concurrent = len(jobs) > 1 and hasattr(engine, "helper") and not SEQUENTIAL_TABLES
     engines = [engine] + ([engine.helper(j) for j in range(len(jobs) - 1)] if concurrent else [engine] * (len(jobs) - 1))
     slot_b = slot + 1
     full = np.asarray(recs.full_len, np.int64)
@@ -211,11 +213,11 @@ def scan_jobs(engine, recs, jobs, slot: int = 0, seq=None):
     Several jobs (pattern tables) on a HipScanner run AT THE SAME TIME: job j > 0 goes to the engine's j-th helper context,
     which borrows the resident batch (tps_batch_share) and keeps its own table -- no table switch per batch, and the launches
     of the k passes overlap on the GPU (measured: 603 vs 785 us per 10 000 x 25 kb batch for k = 4, 5, 6).
-    TOPSICLE_SEQUENTIAL_TABLES=1 scans them back to back on the one context instead (the A/B switch)."""
+    batch.SEQUENTIAL_TABLES scans them back to back on the one context instead (the A/B switch)."""
     if getattr(recs, "full_len", None) is not None:
         return scan_jobs_heads(engine, recs, jobs, slot, seq)
     out = []
-    concurrent = len(jobs) > 1 and hasattr(engine, "helper") and os.environ.get("TOPSICLE_SEQUENTIAL_TABLES", "0") != "1"
+    concurrent = len(jobs) > 1 and hasattr(engine, "helper") and not SEQUENTIAL_TABLES
     engines = [engine] + ([engine.helper(j) for j in range(len(jobs) - 1)] if concurrent else [engine] * (len(jobs) - 1))
     try:
         upload_batch(engine, recs, slot)

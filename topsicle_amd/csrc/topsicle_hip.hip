@@ -190,7 +190,7 @@ struct tps_ctx {
     hipDeviceProp_t prop{};
     // dev: [4^k masks][pair table, k <= 4][ready-made LDS images of the table for the fused kernels, each a multiple of 4 dwords:
     // mask << 16 | count, one-hot fields, 16-bit masks -- a workgroup copies its image in 16-byte pieces instead of converting it]
-    struct Table { DevBuf dev; int P = 0, k = 0; std::string key; tps::PatInfo pat{}; size_t off_e32 = 0, off_fld = 0, off_m16 = 0, off_f16 = 0, off_p16 = 0; };
+    struct Table { DevBuf dev; int P = 0, k = 0; std::string key; tps::PatInfo pat{}; size_t off_e32 = 0, off_fld = 0, off_m16 = 0, off_f16 = 0, off_p16 = 0, off_pfld = 0; };
     std::deque<Table> tables;         // resident pattern tables (deque: pointers to elements stay valid)
     Table* lut_cur = nullptr;
     size_t table_rr = 0;
@@ -204,15 +204,11 @@ struct tps_ctx {
     std::vector<EventPair> ev_pool;
     size_t ev_used = 0;      // next free event pair (never rewound: re-recording old events was measured slow)
     size_t ev_base = 0;      // first pair of the current measurement window
-    int spans_override = 0;
+    tps::PlanKnobs knobs{};           // tps_ctx_debug_option: tests / diagnostics only; the library reads no environment
     int want_stamps = 0;
     int no_events = 0;
-    int event_stride = 1;             // time every event_stride-th launch (TPS_EVENT_STRIDE): timing costs ~3.5 us per launch
+    int event_stride = 1;             // time every event_stride-th launch (tps_ctx_debug_option "event_stride"): timing costs ~3.5 us per launch
     uint64_t launch_seq = 0;
-    int no_copy = 0;
-    int zero_copy = 1;       // per-read results are written by the kernel straight into mapped pinned host memory
-    int force_generic = 0;
-    int64_t lds_target_dw = 32 * 256;
     size_t lds_set_v[56] = {0};
     uint32_t* h_flag = nullptr;      // mapped host word the pack kernel raises when a read has a non-ACGT letter
     hipEvent_t share_ev = nullptr;   // tps_batch_share: orders this context's stream behind the lender's upload
@@ -233,11 +229,9 @@ using tps::window_count;
 int plan_lds(tps_ctx* c, Slot& sl, const tps_params& prm, int64_t max_nwin) {
     const size_t lds_max = c->prop.sharedMemPerBlock > 0 ? std::min<size_t>(c->prop.sharedMemPerBlock, 160 * 1024) : 64 * 1024;
     sl.args.pat = c->pat;                          // the plan looks at dup_mask
-    std::string err = tps::plan_geometry(sl.args, prm, c->pat.k, c->pat.P, max_nwin, (int64_t)lds_max / 4, c->spans_override,
-                                         c->force_generic, c->lds_target_dw);
+    std::string err = tps::plan_geometry(sl.args, prm, c->pat.k, c->pat.P, max_nwin, (int64_t)lds_max / 4, c->knobs);
     if (!err.empty()) return fail(TPS_E_CAPACITY, "%s", err.c_str());
     sl.lds_bytes = (size_t)tps::wg_lds_dwords(sl.args) * 4;
-    if (const char* e = getenv("TPS_LDS_PAD_BYTES")) sl.lds_bytes += (size_t)atoi(e);   // diagnostic: occupancy experiments
     return TPS_OK;
 }
 
@@ -376,7 +370,6 @@ int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm) {
         sl.planned = true;
     }
     const int64_t total_win = sl.h_win_off[(size_t)n];
-    if ((rc = sl.results.ensure((size_t)std::max<int64_t>(n, 1) * sizeof(tps_read_result)))) return rc;
     if (sl.h_results_cap < (size_t)n) {
         if (sl.h_results) (void)hipHostFree(sl.h_results);
         sl.h_results = nullptr;
@@ -390,9 +383,9 @@ int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm) {
     a.desc = (const tps_read_desc*)sl.desc.p;
     a.tails_in = ((prm.flags & TPS_F_TAILS_IN) && !(prm.flags & TPS_F_STEP1)) ? (const uint8_t*)sl.tails.p : nullptr;
     a.lut = (const uint32_t*)c->lut_cur->dev.p;
-    a.pair_img = a.lut + (a.pair16 ? c->lut_cur->off_p16 : (size_t)a.lut_n);      // (the 32-bit pair table follows the 4^k masks)
+    a.pair_img = a.lut + (a.pair16 ? c->lut_cur->off_p16 : (a.lut_fields && a.pair_n) ? c->lut_cur->off_pfld : (size_t)a.lut_n);      // (the 32-bit pair table follows the 4^k masks)
     a.lut_img = a.lut + ((a.lut16 && a.lut_fields) ? c->lut_cur->off_f16 : a.lut16 ? c->lut_cur->off_m16 : a.lut_fields ? c->lut_cur->off_fld : c->lut_cur->off_e32);
-    a.results = c->zero_copy ? sl.h_results : (tps_read_result*)sl.results.p;
+    a.results = sl.h_results;                      // (written by the kernel straight into mapped pinned host memory)
     a.c_start = a.c_end = nullptr;
     if (prm.flags & TPS_F_STEP1) {
         if ((rc = sl.c_start.ensure((size_t)std::max<int64_t>(n * P, 1) * 4))) return rc;
@@ -519,7 +512,6 @@ int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm) {
         HIP_TRY(hipExtLaunchKernel(kfn, dim3((unsigned)grid), dim3(tps::NT * a.wpg), kargs, sl.lds_bytes, c->stream,
                                    timed ? ep.a : nullptr, timed ? ep.b : nullptr, 0));
     }
-    if (!c->no_copy && !c->zero_copy) HIP_TRY(hipMemcpyAsync(sl.h_results, sl.results.p, (size_t)n * sizeof(tps_read_result), hipMemcpyDeviceToHost, c->stream));
     sl.scanned = true;
     return TPS_OK;
 }
@@ -563,13 +555,6 @@ int tps_ctx_create(int device, tps_ctx** out) {
         delete c;
         return fail(TPS_E_HIP, "cannot initialise device %d", device);
     }
-    if (const char* s = getenv("TPS_SPANS_PER_TILE")) c->spans_override = atoi(s);
-    if (const char* s = getenv("TPS_FORCE_GENERIC")) c->force_generic = atoi(s);
-    if (const char* s = getenv("TPS_NO_EVENTS")) c->no_events = atoi(s);
-    if (const char* s = getenv("TPS_EVENT_STRIDE")) c->event_stride = std::max(1, atoi(s));
-    if (const char* s = getenv("TPS_NO_COPY")) c->no_copy = atoi(s);
-    if (const char* s = getenv("TPS_ZERO_COPY")) c->zero_copy = atoi(s);
-    if (const char* s = getenv("TPS_LDS_TARGET_KB")) c->lds_target_dw = (int64_t)atoi(s) * 256;
     *out = c;
     return TPS_OK;
 }
@@ -653,7 +638,7 @@ int tps_set_patterns(tps_ctx* c, const char* pats, int32_t P, int32_t k) {
             lut[n1 + cc] = ((m1 | m2) << 16) | (uint32_t)(__builtin_popcount(m1) + __builtin_popcount(m2));
         }
     }
-    size_t off_e32 = 0, off_fld = 0, off_m16 = 0, off_f16 = 0, off_p16 = 0;
+    size_t off_e32 = 0, off_fld = 0, off_m16 = 0, off_f16 = 0, off_p16 = 0, off_pfld = 0;
     if (!pi.hash_shift) {
         const size_t n1 = (size_t)1 << (2 * k), n4 = (n1 + 3) & ~(size_t)3, n16 = ((n1 + 1) / 2 + 3) & ~(size_t)3;
         off_e32 = (lut.size() + 3) & ~(size_t)3;       // (16-byte aligned: the kernels copy uint4)
@@ -668,6 +653,14 @@ int tps_set_patterns(tps_ctx* c, const char* pats, int32_t P, int32_t k) {
             ((uint16_t*)&lut[off_m16])[i] = (uint16_t)m;
             // (field index of THE pattern: tables with duplicate k-mers never take the kernels that read this image)
             ((uint16_t*)&lut[off_f16])[i] = m ? (uint16_t)(1u << tps::pp_field(__builtin_ctz(m))) : (uint16_t)0;
+        }
+        if (k <= 4) {
+            // pair table of one-hot FIELDS for the raw-row kernels' per-pattern tiles (tile_pp_s<.., PAIRF>): entry of the (k+1)-mer
+            // code c = field of the k-mer at p + field of the one at p + 1
+            const size_t n2 = n1 * 4;
+            off_pfld = lut.size();                      // (a multiple of 4 dwords)
+            lut.resize(off_pfld + n2, 0u);
+            for (size_t cc = 0; cc < n2; ++cc) lut[off_pfld + cc] = lut[off_fld + (cc & (n1 - 1))] + lut[off_fld + ((cc >> 2) & (n1 - 1))];
         }
         if (k == 5 && P <= 16) {
             // 16-bit pair table of the _s*q kernels (ScanArgs::pair16): entry of the (k+1)-mer code c = the masks of the k-mers at p
@@ -687,7 +680,7 @@ int tps_set_patterns(tps_ctx* c, const char* pats, int32_t P, int32_t k) {
     HIP_TRY(hipMemcpyAsync(slot->dev.p, lut.data(), lut.size() * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     slot->P = P; slot->k = k; slot->key = key; slot->pat = pi;
-    slot->off_e32 = off_e32; slot->off_fld = off_fld; slot->off_m16 = off_m16; slot->off_f16 = off_f16; slot->off_p16 = off_p16;
+    slot->off_e32 = off_e32; slot->off_fld = off_fld; slot->off_m16 = off_m16; slot->off_f16 = off_f16; slot->off_p16 = off_p16; slot->off_pfld = off_pfld;
     c->lut_cur = slot;
     c->pat = pi;
     c->have_pat = true;
@@ -1164,8 +1157,22 @@ int tps_kernel_time_ms(tps_ctx* c, int32_t* n_launches, double* total_ms, double
     return TPS_OK;
 }
 
-/* diagnostics (not part of the public header): per-read phase clock stamps of the next scans */
-int tps_debug_stamps_enable(tps_ctx* c, int on) { if (!c) return TPS_E_ARG; c->want_stamps = on; return TPS_OK; }
+int tps_ctx_debug_option(tps_ctx* c, const char* key, int64_t value) {
+    if (!c || !key) return fail(TPS_E_ARG, "null argument");
+    const std::string k(key);
+    if (k == "event_stride") c->event_stride = (int)std::max<int64_t>(1, value);
+    else if (k == "no_events") c->no_events = value != 0;
+    else if (k == "force_generic") c->knobs.force_generic = value != 0;
+    else if (k == "spans_per_tile") c->knobs.spans_per_tile = (int)std::max<int64_t>(0, value);
+    else if (k == "force_pair") c->knobs.force_pair = value != 0;
+    else if (k == "so_order") c->knobs.so_order = (int)value;
+    else if (k == "stamps") c->want_stamps = value != 0;
+    else return fail(TPS_E_ARG, "unknown debug option '%s' (event_stride, no_events, force_generic, spans_per_tile, force_pair, so_order, stamps)", key);
+    for (auto& sl : c->slots) sl.planned = false;
+    return TPS_OK;
+}
+
+/* per-read phase clock stamps of the last scan (only a -DTPS_STAMPS build of the kernels writes them; option "stamps") */
 int tps_debug_stamps_get(tps_ctx* c, int32_t slot, uint64_t* out, int64_t n) {
     Slot* sl;
     int rc;

@@ -298,7 +298,8 @@ struct ScanArgs {
     const uint8_t* tails_in;     // n, or nullptr
     const uint32_t* lut;         // 4^k masks over the pattern list (+ the pair table behind them)
     const uint32_t* lut_img;     // fused kernels: the table as it sits in LDS (mask << 16 | count, one-hot fields or 16-bit masks: lut_dw(a) dwords)
-    const uint32_t* pair_img;    // pair-table kernels: the pair table as it sits in LDS (pair_n dwords: mask << 16 | count per (k+1)-mer, or -- pair16 -- 16-bit masks)
+    const uint32_t* pair_img;    // pair-table kernels: the pair table as it sits in LDS (pair_n dwords: mask << 16 | count per (k+1)-mer; pair16: 16-bit masks;
+                                 // raw-row kernels with lut_fields: the two positions' one-hot fields added up)
     tps_read_result* results;    // n
     int32_t* c_start;            // n*P or nullptr
     int32_t* c_end;              // n*P or nullptr
@@ -1326,7 +1327,7 @@ TPS_DEV Lds carve_fused(uint32_t* base, uint32_t* lut, const ScanArgs& a) {
     Lds l;
     l.lut2 = lut - a.pair_n;
     l.lut = lut;
-    l.lshift = XTA ? LUT_M16 : (a.lut_fields && a.lut16) ? LUT_F16 : a.lut_fields ? LUT_FIELDS : 16;     // (the XTA kernels are the LUT_M16 kernels)
+    l.lshift = (a.lut16 && !a.lut_fields && !a.pair16) ? LUT_M16 : (a.lut_fields && a.lut16) ? LUT_F16 : a.lut_fields ? LUT_FIELDS : 16;     // (P16K kernels: scan_read sets LUT_M16 itself)
     l.blk = base;
     l.XPC = base;
     l.XF = base + 9 * NT;
@@ -1835,6 +1836,12 @@ TPS_DEV void tile_candidates(const TileConst& tc, const Lds& l, int w0, int tile
 // Against tile_fused_s per tile and lane: 17 LDS stores instead of 35 (no XS, no rewritten XF / XT, no second copy of
 // S_w for the scan), 13 + the table gathers LDS loads instead of 37 + the gathers, three wave barriers instead of six,
 // two 16-byte stores to HBM instead of eight dword stores.
+#ifndef TPS_PP_RPT
+#define TPS_PP_RPT 1        // (0: A/B builds -- the per-pattern tiles read the window's partial-block position at run time, as before round 5)
+#endif
+#ifndef TPS_PP_PAIRF
+#define TPS_PP_PAIRF 1      // (0: A/B builds -- _s6r looks every position up by itself although the pair table of fields is loaded)
+#endif
 #ifndef TPS_XPAD
 #define TPS_XPAD 1          // (0: the default kernels keep XF / XT arrays in the exchange region -- A/B builds, with TPS_NO_XPAD=1 in the environment)
 #endif
@@ -1915,7 +1922,10 @@ TPS_DEV void tile_lc_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
     constexpr int LS = M16 ? 1 : 2;               // log2(bytes per table entry)
     // XPAD (the default kernels, round 4): a lane's OR | matches (XF) and its exclusive prefix in the tile (XT) live in the pad words of
     // its XPC and row[] rows (9 words per lane, the ninth unused) -- no XF / XT arrays in the wave's slice (carve_fused<.., XM = 2>)
-    constexpr bool XPAD = CD == 0 && TPS_XPAD != 0;
+    // (round 5: the chain-corrected tiles too -- nothing of theirs touches the pad words: the window phase and the difference array
+    // index row[] / XPC by PADDED window, the zeroing of the difference array comes before xt_at is written -- which frees the 80
+    // dwords of XF per wave that stood between the k = 6 sums kernel and three 8-wave workgroups per CU: 6 waves per SIMD)
+    constexpr bool XPAD = TPS_XPAD != 0;
     typedef Geo<S> g_;
     auto xf_at = [&](int lane_) -> uint32_t& { return XPAD ? l.XPC[lane_ * (g_::B + 1) + g_::B] : l.XF[lane_]; };
     auto xt_at = [&](int lane_) -> uint32_t& { return XPAD ? l.row[lane_ * (g_::B + 1) + g_::B] : l.XT[lane_]; };
@@ -2478,10 +2488,18 @@ TPS_DEV void pp_expand(uint32_t ne, uint32_t no, uint32_t* b) {   // nibble word
 // lane saw a pattern occur at p and again at p + CD inside the tile it returns true right after phase 1 (nothing but its own
 // exchange words written) and the caller runs tile_pp_s<S, CD> on the tile; otherwise every window's per-pattern count is
 // the plain prefix difference and the tile completes here (see tile_fused_s<.., CD> for the argument and the hand-over).
-template <int S, int D, int CD = 0, bool F16 = false>
+// RPT >= 0: the window's partial-block position r as a compile-time constant (the capture of the far-end block's prefix is one
+// select per position otherwise: 8 S of a tile-lane's ~800 instructions); scan_read instantiates the r of the kernel's home k at the
+// default window (k = 4 / 5 / 6 at W = 100) beside the run-time variant.
+// PAIRF (D = 0, even RPT: k = 4 at the default window): two positions per lookup from a pair table of FIELDS -- the entry of the
+// (k+1)-mer at p is field(p) + field(p + 1) (ScanArgs::pair_n with lut_fields; a table without self-overlap never matches one
+// pattern at two adjacent positions, so the 2-bit fields still hold a block's counts): half the gathers and adds of phase 1.
+template <int S, int D, int CD = 0, bool F16 = false, int RPT = -1, bool PAIRF = false>
 TPS_DEV bool tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int delta, int w0, int tile, int nw_tile,
                        int64_t out_base, uint64_t& s_total) {
     static_assert(CD == 0 || (D == 0 && CD <= 6), "chain detection runs on the tile without self-overlap logic");
+    static_assert(RPT < S, "r is a position inside a block");
+    static_assert(!PAIRF || (D == 0 && CD == 0 && !F16 && RPT >= 0 && (RPT & 1) == 0), "pair lookups: plain tiles, the partial block ends between two pairs");
     // look-back over the previous lane's last LBK positions (tables with a self-overlap period only): enough for a chain that
     // starts inside it; a chain through the whole look-back takes the walk below
     constexpr int B = 8, POS = B * S, LBK = D > 0 ? 2 * D + 2 : 0;
@@ -2490,8 +2508,9 @@ TPS_DEV bool tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
     constexpr int AHEAD = (D > 0 && 2 * D > S) ? 2 * D - S : 0;   // positions past the lane whose occurrences close a start-skip chain
     constexpr uint32_t M3 = 0x33333333u;
     const PatInfo& pat = a.pat;
-    int rp = tc.r, q = tc.q;
-    TPS_PIN_S(rp); TPS_PIN_S(q);                  // opaque per tile: what derives from them is recomputed (scalar) per tile, not kept in SGPRs across the read
+    int rp = RPT >= 0 ? RPT : tc.r, q = tc.q;
+    if constexpr (RPT < 0) TPS_PIN_S(rp);
+    TPS_PIN_S(q);                                 // opaque per tile: what derives from them is recomputed (scalar) per tile, not kept in SGPRs across the read
     constexpr int LS = F16 ? 1 : 2;               // log2(bytes per table entry): F16 = the 16-bit field-index table (LUT_F16)
     const uint32_t amask = pat.kmask << LS;
     uint32_t* ende = l.XPC;                       // END, even patterns (padded block index)
@@ -2602,6 +2621,17 @@ TPS_DEV bool tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
                 }
             }
             uint32_t acc = 0, pb = 0, sfw = 0;
+            if constexpr (PAIRF) {
+                const uint32_t amask2 = (pat.kmask << 4) | 0xCu;          // the (k+1)-mer's code << 2
+                TPS_UNROLL
+                for (int i = 0; i + 1 < S; i += 2) {
+                    const int idx = blk * S + i, dw = idx >> 4, bit = idx & 15;          // (LBK = 0)
+                    const uint32_t v4 = bit ? alignbit(dw + 1 < WDW ? w[dw + 1] : 0u, w[dw], 2u * bit) : w[dw];
+                    acc += lut_at(l.lut2, v4, amask2);
+                    if (i + 2 == RPT) pb = acc;
+                }
+                if (S & 1) acc += look(blk * S + S - 1);
+            } else {
             TPS_UNROLL
             for (int i = 0; i < S; ++i) {
                 const int p = blk * S + i;
@@ -2620,7 +2650,9 @@ TPS_DEV bool tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
                     if (p >= CD) chain_any |= h & pk[p - CD];
                 }
                 acc += pick;
-                pb = (i + 1 == rp) ? acc : pb;
+                if constexpr (RPT >= 0) { if (i + 1 == RPT) pb = acc; }
+                else pb = (i + 1 == rp) ? acc : pb;
+            }
             }
             const uint32_t ee = pe + (pb & M3), eo = po + ((pb >> 2) & M3);
             ende[span * (B + 1) + blk] = ee;
@@ -3405,7 +3437,7 @@ template <int SV, bool SO, bool PAIR = false, bool RAW = true, bool FULL = tile_
 TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_t* lut) {
     constexpr bool M16K = SV != 0 && SO && !RAW;       // sums-only kernels of self-overlap tables: 16-bit table, XT aliased (lut16 / xt_alias)
     // (XM = 2 also for the default kernels: every tile of theirs is a tile_lc_s<.., CD = 0>, which keeps XF / XT in the pad words too)
-    constexpr int XM = M16K ? 1 : (SV != 0 && (RAW || (!SO && TPS_LC_TILE != 0 && TPS_XPAD != 0))) ? 2 : 0;
+    constexpr int XM = (SV != 0 && (RAW || ((M16K || !SO) && TPS_LC_TILE != 0 && TPS_XPAD != 0))) ? 2 : 0;
     constexpr bool F16K = SV != 0 && SO && RAW && DCLASS == 3;     // raw rows of a big self-overlap table: 16-bit field-index table (_s*sorh)
     constexpr bool P16K = SV != 0 && !SO && !RAW && PAIR && DCLASS == 4;      // pair-table kernels of k = 5 tables: 16-bit pair + single table (_s*q)
     Lds l_ = SV ? carve_fused<SV ? SV : 5, FULL, XM>(lds_base, lut, a) : carve(lds_base, lut, a);
@@ -3676,9 +3708,15 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
                             // follows a chained one skips that attempt (round 4: the telomere is a run of tiles at the start of the
                             // scanned tail, and at ONT error rates every telomeric tile at k = 6 holds a chain -- the detecting
                             // pass was phase 1 run twice for them)
+                            // (the HOME shape of the kernel -- the period and partial-block position of the reference's human motif at the
+                            // default window: CCCTAA at k = 5 (period 4, r = 95 % S; _s*sor) and k = 6 (period 5, r = 94 % S; _s*sorh) -- takes
+                            // instantiations with r as a compile-time constant; every other period / window the run-time ones)
+                            constexpr int HD = F16K ? 5 : 4, HR = (F16K ? 94 : 95) % SP;
+                            const bool home = TPS_PP_RPT != 0 && a.pp_d == HD && tc.r == HR;
                             bool chained = true;
                             if (a.so_fast && !pp_expect) {
-                                switch (a.pp_d) {
+                                if (home) chained = tile_pp_s<SP, 0, HD, F16K, HR>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total);
+                                else switch (a.pp_d) {
                                     case 2: chained = tile_pp_s<SP, 0, 2, F16K>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
                                     case 3: chained = tile_pp_s<SP, 0, 3, F16K>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
                                     case 4: chained = tile_pp_s<SP, 0, 4, F16K>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
@@ -3688,7 +3726,8 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
                             }
                             if (!chained) { pp_expect = false; continue; }
                             const uint64_t s_before = s_total;
-                            switch (a.pp_d) {
+                            if (home) tile_pp_s<SP, HD, 0, F16K, HR>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total);
+                            else switch (a.pp_d) {
                                 case 2: tile_pp_s<SP, 2, 0, F16K>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
                                 case 3: tile_pp_s<SP, 3, 0, F16K>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
                                 case 4: tile_pp_s<SP, 4, 0, F16K>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); break;
@@ -3699,7 +3738,12 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
                             // without matches; a guess that only decides which exact tile code runs first)
                             pp_expect = a.so_fast != 2 && (s_total - s_before) > (uint64_t)nw_tile * (uint64_t)(pat.P + 4);
                         } else {
-                            tile_pp_s<SP, 0>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total);
+                            constexpr int HR4 = 96 % SP;       // k = 4 at the default window
+                            if constexpr (PAIR && (HR4 & 1) == 0 && TPS_PP_PAIRF != 0) {
+                                if (tc.r == HR4 && a.pair_n != 0) { tile_pp_s<SP, 0, 0, false, HR4, true>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total); continue; }
+                            }
+                            if (TPS_PP_RPT != 0 && tc.r == HR4) tile_pp_s<SP, 0, 0, false, HR4>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total);
+                            else tile_pp_s<SP, 0>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total);
                         }
                         continue;
                     }
@@ -3734,8 +3778,9 @@ TPS_DEV void scan_read(const ScanArgs& a, int64_t r, uint32_t* lds_base, uint32_
                     else tile_fused_s<SF, SO, true, -1, false, RAW>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r);
                 } else if constexpr (SO || RAW) {
                     // (these kernels reach the plain tile only as a fallback: one instantiation with r read at run time)
-                    if (tc.r == 0) tile_fused_s<SF, SO, false, 0, PAIR, RAW>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r);
-                    else tile_fused_s<SF, SO, false, -1, PAIR, RAW>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r);
+                    // (the raw-row kernels' pair table holds FIELDS, for tile_pp_s only: their fallback tile looks positions up one by one)
+                    if (tc.r == 0) tile_fused_s<SF, SO, false, 0, PAIR && !RAW, RAW>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r);
+                    else tile_fused_s<SF, SO, false, -1, PAIR && !RAW, RAW>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r);
                 } else {
 #define TPS_TILE_RP(N) case N: if constexpr (N < SF) { if constexpr (LC) { if ((tc.q & 7) == 0) tile_lc_s<SF, false, (N < SF ? N : 0), PAIR, true, 0, P16K>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r); \
                                                                           else tile_lc_s<SF, false, (N < SF ? N : 0), PAIR, false, 0, P16K>(a, tc, l, fdelta, w0, tile, nw_tile, out_base, s_total, r); } \

@@ -621,7 +621,7 @@ struct ParGz {
     size_t next_member = 0;
     // statistics (tests, diagnostics)
     uint64_t n_chunks = 0, n_spec_ok = 0, n_serial = 0, n_gap = 0;
-    bool timing = getenv("TPS_IO_TIMING") != nullptr;
+    bool timing = false;                         // phase times on stderr (tps_io_set_option "timing")
     static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 
     bool eof() const { return done; }

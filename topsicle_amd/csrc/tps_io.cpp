@@ -171,8 +171,20 @@ struct Reader {
 
 
 // ---------------------------------------------------------------- mmap + thread-team decoder
+// Options of the reader (tps_io_set_option: tests and diagnostics; include/topsicle_io.h).  The library reads NO environment
+// variables (round 5): topsicle_amd.seqio applies $TOPSICLE_IO_DEBUG = "key=value,..." when it loads the library.
+struct IoOptions {
+    std::atomic<int> threads{0};               // 0 = by the host's CPUs and the cgroup quota
+    std::atomic<int> timing{0};                // phase times of the fast reader on stderr
+    std::atomic<long long> bgzf_group{0};      // bytes of inflated text per refill of a compressed input's window (0 = 128 MiB)
+    std::atomic<long long> pack_min_span{-1};  // text below this many bytes is decoded by one thread (-1 = 4 MiB)
+    std::atomic<int> no_pargz{0};              // ordinary gzip through zlib's one stream instead of the thread team's inflater
+    std::atomic<long long> pargz_min{-1};      // smallest .gz file the team inflates (-1 = 1 MiB)
+};
+IoOptions g_opt;
+
 int io_threads() {
-    if (const char* e = getenv("TPS_IO_THREADS")) { int t = atoi(e); if (t > 0) return std::min(t, 64); }
+    if (const int t = g_opt.threads.load()) return std::min(t, 64);
     unsigned hc = std::thread::hardware_concurrency();
     unsigned n = std::min(hc ? hc : 1u, 32u);
     // containers: the cgroup CPU quota, not the number of logical CPUs, is what the team can use
@@ -187,8 +199,8 @@ int io_threads() {
     }
     return (int)std::max(1u, n);
 }
-// TPS_IO_TIMING=1: phase times of the fast reader on stderr (diagnostics)
-inline bool io_timing() { static const bool on = getenv("TPS_IO_TIMING") != nullptr; return on; }
+// option "timing": phase times of the fast reader on stderr (diagnostics)
+inline bool io_timing() { return g_opt.timing.load() != 0; }
 inline double now_s() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 // The thread team: f(thread index, thread count) on `nthreads` threads, the caller being thread 0.  The workers are
 // created once and parked on a condition variable between calls (a team call per batch used to create and join its
@@ -314,44 +326,24 @@ struct Bgzf : TextSource {
         struct Rep { double t0; size_t n, bytes; int T; ~Rep() { if (io_timing()) fprintf(stderr, "[tps_io] bgzf group: %zu blocks, %zu MB of text, %d threads, %.2f ms\n", n, bytes >> 20, T, 1e3 * (now_s() - t0)); } } rep{t_bg0, blks.size(), total, T};
         // every block is a raw deflate stream of its own: the in-tree inflater (tps_gzpar.h: one-word table entries, 8-byte refills,
         // word copies -- 1.7 x zlib's rate per thread) into a per-thread scratch block, checked against the block's ISIZE and its
-        // CRC-32 (carry-less multiplication), then copied to its place.  TPS_IO_BGZF_ZLIB=1: zlib's inflate as before (A/B)
-        static const bool use_zlib = getenv("TPS_IO_BGZF_ZLIB") != nullptr;
+        // CRC-32 (carry-less multiplication), then copied to its place (zlib's inflate, the A/B partner of round 3, is gone)
         team(T, [&](int t, int nt) {
             const size_t a = blks.size() * (size_t)t / (size_t)nt, b = blks.size() * (size_t)(t + 1) / (size_t)nt;
-            if (!use_zlib) {
-                gzpar::ByteBuf scratch;
-                scratch.reserve((size_t)80 << 10);
-                for (size_t i = a; i < b; ++i) {
-                    const Blk& k = blks[i];
-                    if (k.isize == 0) continue;                  // the empty end-of-file block
-                    scratch.clear();
-                    uint64_t end_bit = 0;
-                    // (the input ends where the block's deflate data ends: the inflater cannot read into the trailer or beyond)
-                    const int rc = gzpar::inflate_blocks<false>(data, k.in + k.in_len, (uint64_t)k.in * 8u, ~0ull >> 1, nullptr, 0, scratch, end_bit,
-                                                                k.isize + 1024);
-                    if (rc != 1 || scratch.size() != k.isize) { bad[(size_t)t] = 1; break; }
-                    char* dst = out.data() + base + k.ooff;
-                    memcpy(dst, scratch.data(), k.isize);
-                    if ((uint32_t)gzpar::crc32_fast(crc32(0L, Z_NULL, 0), (const uint8_t*)dst, k.isize) != k.crc) { bad[(size_t)t] = 1; break; }
-                }
-                return;
-            }
-            z_stream zs;
-            memset(&zs, 0, sizeof zs);
-            if (inflateInit2(&zs, -15) != Z_OK) { bad[(size_t)t] = 1; return; }
+            gzpar::ByteBuf scratch;
+            scratch.reserve((size_t)80 << 10);
             for (size_t i = a; i < b; ++i) {
                 const Blk& k = blks[i];
-                if (k.isize == 0) continue;                      // the empty end-of-file block
-                inflateReset(&zs);
-                zs.next_in = (Bytef*)(data + k.in);
-                zs.avail_in = (uInt)k.in_len;
-                zs.next_out = (Bytef*)(out.data() + base + k.ooff);
-                zs.avail_out = (uInt)k.isize;
-                const int rc = inflate(&zs, Z_FINISH);
-                if (rc != Z_STREAM_END || zs.total_out != k.isize ||
-                    (uint32_t)crc32(0L, (const Bytef*)(out.data() + base + k.ooff), (uInt)k.isize) != k.crc) { bad[(size_t)t] = 1; break; }
+                if (k.isize == 0) continue;                  // the empty end-of-file block
+                scratch.clear();
+                uint64_t end_bit = 0;
+                // (the input ends where the block's deflate data ends: the inflater cannot read into the trailer or beyond)
+                const int rc = gzpar::inflate_blocks<false>(data, k.in + k.in_len, (uint64_t)k.in * 8u, ~0ull >> 1, nullptr, 0, scratch, end_bit,
+                                                            k.isize + 1024);
+                if (rc != 1 || scratch.size() != k.isize) { bad[(size_t)t] = 1; break; }
+                char* dst = out.data() + base + k.ooff;
+                memcpy(dst, scratch.data(), k.isize);
+                if ((uint32_t)gzpar::crc32_fast(crc32(0L, Z_NULL, 0), (const uint8_t*)dst, k.isize) != k.crc) { bad[(size_t)t] = 1; break; }
             }
-            inflateEnd(&zs);
         });
         for (int x : bad)
             if (x) { g_err = "BGZF block failed to inflate (corrupt file)"; failed = true; return false; }
@@ -446,7 +438,7 @@ struct Fast {
     void top_up(size_t target) {
         if (!src || !hold || hold->refs.load() != 1) return;
         size_t group = (size_t)128 << 20;
-        if (const char* e = getenv("TPS_IO_BGZF_GROUP")) { const long long g = atoll(e); if (g > 0) group = (size_t)g; }
+        if (const long long g = g_opt.bgzf_group.load()) group = (size_t)g;
         while (!src->eof() && !src->failed && size - pos < target) {
             src->read_group(hold->buf, group);
             data = hold->buf.data();
@@ -483,7 +475,7 @@ struct Fast {
             base_off += pos;
             pos = 0;
             size_t group = (size_t)128 << 20;          // text per refill (tests shrink it to exercise the carry-over)
-            if (const char* e = getenv("TPS_IO_BGZF_GROUP")) { const long long g = atoll(e); if (g > 0) group = (size_t)g; }
+            if (const long long g = g_opt.bgzf_group.load()) group = (size_t)g;
             if (!src->eof()) src->read_group(hold->buf, group);
             // (packed batches: a window should hold a whole batch's worth of text -- nobody else points into this new buffer
             // yet, so further groups are simply appended to it)
@@ -765,7 +757,7 @@ struct Fast {
         if (p >= size || only_blank(p)) return 0;
         // text that yields at most words_cap words if it were nothing but sequence + quality lines
         size_t span = std::min<size_t>(size - p, (size_t)std::max<int64_t>(words_cap, 1024) * (fasta ? 17 : 32));      // (FASTA: no quality lines)
-        static const size_t min_span = getenv("TPS_IO_PACK_MIN_SPAN") ? (size_t)atoll(getenv("TPS_IO_PACK_MIN_SPAN")) : (size_t)4 << 20;   // (tests: team on small files)
+        const size_t min_span = g_opt.pack_min_span.load() >= 0 ? (size_t)g_opt.pack_min_span.load() : (size_t)4 << 20;   // (tests: team on small files)
         const int T = span < min_span ? 1 : threads;
         if (chunks.empty()) take_spare();
         if ((int)chunks.size() < T) chunks.resize((size_t)T);
@@ -910,6 +902,21 @@ extern "C" {
 
 const char* tps_io_last_error(void) { return g_err.c_str(); }
 
+// Tests and diagnostics (process-wide; readers opened afterwards see the new value): "threads" (0 = by the host's CPUs and cgroup
+// quota), "timing", "bgzf_group" (bytes; 0 = 128 MiB), "pack_min_span" (bytes; -1 = 4 MiB), "no_pargz", "pargz_min" (bytes; -1 = 1 MiB).
+int tps_io_set_option(const char* key, int64_t value) {
+    if (!key) { g_err = "null argument"; return -1; }
+    const std::string k(key);
+    if (k == "threads") g_opt.threads = (int)std::max<int64_t>(0, std::min<int64_t>(value, 64));
+    else if (k == "timing") g_opt.timing = value != 0;
+    else if (k == "bgzf_group") g_opt.bgzf_group = std::max<int64_t>(0, value);
+    else if (k == "pack_min_span") g_opt.pack_min_span = value;
+    else if (k == "no_pargz") g_opt.no_pargz = value != 0;
+    else if (k == "pargz_min") g_opt.pargz_min = value;
+    else { g_err = "unknown option '" + k + "' (threads, timing, bgzf_group, pack_min_span, no_pargz, pargz_min)"; return -1; }
+    return 0;
+}
+
 // Opens a FASTA/FASTQ file (plain or .gz).  The format comes from the first byte, like check_file_type
 // (allsteps.py:36-50).  Plain FASTQ files are mmap'ed for the thread-team decoder.  Returns 0 or -1.
 static Reader* open_stream(const char* path, int64_t seek_to, int format, size_t buf_bytes = (size_t)4 << 20) {
@@ -969,7 +976,7 @@ int tps_reader_open(const char* path, void** out) {
         }
     }
     const bool cr_lines = r->cr_lines;
-    if (!plain && !cr_lines && !getenv("TPS_IO_NO_MMAP") && !getenv("TPS_IO_NO_BGZF")) {
+    if (!plain && !cr_lines) {
         // bgzip'ed FASTQ: blocks inflate in parallel, then the same thread-team record decoder runs over the text
         Bgzf* z = new Bgzf();
         z->fd = open(path, O_RDONLY);
@@ -996,14 +1003,14 @@ int tps_reader_open(const char* path, void** out) {
         }
         delete z;
     }
-    if (!plain && !cr_lines && !h->fast && !getenv("TPS_IO_NO_MMAP") && !getenv("TPS_IO_NO_PARGZ")) {
+    if (!plain && !cr_lines && !h->fast && !g_opt.no_pargz.load()) {
         // ordinary gzip'ed FASTQ: the deflate stream is inflated by the thread team (speculative block starts, tps_gzpar.h),
         // then the same thread-team record decoder runs over the text.  Small files stay with zlib's stream.
         GzSource* z = new GzSource();
         z->fd = open(path, O_RDONLY);
         struct stat st;
-        const char* pm = getenv("TPS_IO_PARGZ_MIN");               // (tests: the team's inflater on small files too)
-        if (z->fd >= 0 && fstat(z->fd, &st) == 0 && st.st_size >= (pm ? (off_t)atoll(pm) : ((off_t)1 << 20)) && st.st_size >= 64) {
+        const long long pm = g_opt.pargz_min.load();                // (tests: the team's inflater on small files too)
+        if (z->fd >= 0 && fstat(z->fd, &st) == 0 && st.st_size >= (pm >= 0 ? (off_t)pm : ((off_t)1 << 20)) && st.st_size >= 64) {
             void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, z->fd, 0);
             if (m != MAP_FAILED) {
                 z->data = (const uint8_t*)m;
@@ -1012,6 +1019,7 @@ int tps_reader_open(const char* path, void** out) {
                 z->z.data = z->data;
                 z->z.size = z->size;
                 z->z.threads = io_threads();
+                z->z.timing = io_timing();
                 z->z.team = [](int n, const std::function<void(int, int)>& f) { team(n, f); };
                 Fast* f = new Fast();
                     f->fasta = h->format == 1;
@@ -1025,7 +1033,7 @@ int tps_reader_open(const char* path, void** out) {
         }
         delete z;
     }
-    if (plain && !cr_lines && !getenv("TPS_IO_NO_MMAP")) {
+    if (plain && !cr_lines) {
         Fast* f = new Fast();
                     f->fasta = h->format == 1;
         f->fd = open(path, O_RDONLY);
@@ -1282,6 +1290,7 @@ int64_t tps_gz_inflate(const char* path, uint8_t* out, int64_t cap, int32_t thre
     z.data = (const uint8_t*)m;
     z.size = (size_t)st.st_size;
     z.threads = threads > 0 ? threads : io_threads();
+    z.timing = io_timing();
     z.team = [](int n, const std::function<void(int, int)>& f) { team(n, f); };
     gzpar::TextBuf buf;
     int64_t total = 0;

@@ -70,7 +70,8 @@
 #define TPS_SOL_MINW 6     // waves per SIMD the sums kernels of self-overlap periods 2 .. 4 (k = 5) are compiled for: 80 VGPRs without a spill, and their LDS (25 472 B per workgroup) allows the sixth: k = 5 sums 106.0 -> 102.0 us, 97 -> 90 per batch on two streams
 #endif
 #ifndef TPS_SO_MINW
-#define TPS_SO_MINW 5     // waves per SIMD the sums-only self-overlap kernels are compiled for
+#define TPS_SO_MINW 6     // waves per SIMD the sums-only self-overlap kernels are compiled for (round 5: 80 VGPRs, no VGPR spill; with the lane totals in the
+                          // pad words a k = 6 wave slice is 5 536 B: 8 192 + 8 x 5 536 = 52 480 B -> three 8-wave workgroups = 24 waves per CU instead of 20)
 #endif
 #define TPS_SCAN_KERNEL(NAME, SV, SO, PAIR, RAW, MINW) TPS_SCAN_KERNEL_F(NAME, SV, SO, PAIR, RAW, MINW, tps::tile_full_default(SV), 0)
 #define TPS_SCAN_KERNEL_D(NAME, SV, SO, PAIR, RAW, MINW, DCLASS) TPS_SCAN_KERNEL_F(NAME, SV, SO, PAIR, RAW, MINW, tps::tile_full_default(SV), DCLASS)
@@ -143,8 +144,10 @@ TPS_SCAN_KERNEL(tps_scan_kernel_s8p, 8, false, true, false, 5)
 #endif
 #if TPS_IN_GROUP(2)
 TPS_SCAN_KERNEL(tps_scan_kernel, 0, false, false, true, 4)          // generic: any slide, up to 31 patterns
+// (_s6r: PAIR = a pair table of FIELDS for k <= 4 when the planner grants it, ScanArgs::pair_n -- tile_pp_s<.., PAIRF>; at slides 5 and 7 the window's partial block
+// ends inside a pair (r = 96 % S is odd), at slide 8 a lane can hold 16 occurrences of a 4-mer: no per-pattern tile there at all)
 TPS_SCAN_KERNEL(tps_scan_kernel_s5r, 5, false, false, true, TPS_R_MINW)       // ... with the per-pattern raw counts (TPS_F_STORE_RAW)
-TPS_SCAN_KERNEL(tps_scan_kernel_s6r, 6, false, false, true, TPS_R_MINW)
+TPS_SCAN_KERNEL(tps_scan_kernel_s6r, 6, false, true, true, TPS_R_MINW)
 TPS_SCAN_KERNEL(tps_scan_kernel_s7r, 7, false, false, true, TPS_R_MINW)
 TPS_SCAN_KERNEL(tps_scan_kernel_s8r, 8, false, false, true, 3)
 #endif

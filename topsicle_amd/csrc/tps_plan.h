@@ -116,24 +116,23 @@ inline int fused_seq_dw(int slide) {
     return seq < 144 ? 144 : seq;                  // (= TileGeo::SEQ)
 }
 
-// Waves per workgroup: 4, unless the table is big (k >= 6: 16 KB and more per workgroup) and sharing it among more waves
-// puts more waves on a CU.  LDS is handed out in 1280-byte granules, 128 per CU; at most 8 workgroups per CU.
-inline void plan_wpg(ScanArgs& a, int64_t budget_dw) {
+// Waves per workgroup: 4, unless the table is big (8 KB and more per workgroup) and sharing it among 8 waves puts more waves on a
+// CU.  LDS is handed out in 1280-byte granules, 128 per CU; at most 8 workgroups per CU; and no more waves per SIMD than the
+// kernel family's registers allow (`max_waves_simd`: what tps_kernels.h compiles the family for -- the raw-row kernels 5, the
+// sums kernels of self-overlap tables 6 since round 5, the others are LDS-bound before their registers matter).
+inline void plan_wpg(ScanArgs& a, int64_t budget_dw, int max_waves_simd = 8) {
     auto waves_per_cu = [&](int w) {
         a.wpg = w;
         const int64_t dw = wg_lds_dwords(a);
         if (dw > budget_dw) return 0;
         const int64_t gran = std::max<int64_t>(1, (dw * 4 + 1279) / 1280);
-        return (int)std::min<int64_t>(32, std::min<int64_t>(8, 128 / gran) * w);
+        const int64_t wgs = std::min<int64_t>(std::min<int64_t>(8, 128 / gran), (4 * max_waves_simd) / w);
+        return (int)std::min<int64_t>(32, wgs * w);
     };
     int best = WPG, best_w = waves_per_cu(WPG);
-    if (const char* e = getenv("TPS_WPG")) {
-        const int w = atoi(e);
-        if (w >= 1 && w <= WPG_MAX && waves_per_cu(w) > 0) { a.wpg = w; return; }
-    }
     // only multiples of four: a workgroup's waves go round the four SIMDs, and five waves would put two on one of them
     // (measured at k = 6, 10 000 x 25 kb reads: 4 waves per workgroup 0.256 ms, 5: 0.306, 7: 0.251, 8: 0.222)
-    if (lut_dw(a) * 4 >= 16384 || (a.pair16 && (a.pair_n + lut_dw(a)) * 4 >= 8192)) {      // (the 8 KB tables of the k = 6 self-overlap kernels run better in five 4-wave workgroups)
+    if (lut_dw(a) * 4 >= 8192 || (a.pair16 && (a.pair_n + lut_dw(a)) * 4 >= 8192)) {
         // (ten waves per workgroup -- two workgroups of ten with a 16 KB table each fill the CU's LDS, 5 waves per SIMD -- was
         // measured in round 3: 248 us against 207 us with eight at k = 6: ten waves sit 3 / 3 / 2 / 2 on the four SIMDs)
         const int v = waves_per_cu(WPG_MAX);
@@ -148,21 +147,32 @@ inline bool has_specialised_slide(int s) { return s == 5 || s == 6 || s == 7 || 
 // ... and the slides only the default kernels (sums only, no self-overlapping k-mer) are also instantiated for
 inline bool has_default_only_slide(int s) { return s == 3 || s == 4 || (s >= 9 && s <= 12); }
 
+// The planner reads NO environment (round 5; it used to consult thirteen A/B switches of four rounds of experiments on every plan).
+// What tests and diagnostics still need to steer is explicit: the library sets these through tps_ctx_debug_option
+// (include/topsicle_hip.h), the emulation through emu_set_knobs; all zero in normal use.
+struct PlanKnobs {
+    int spans_per_tile = 0;   // > 0: the generic kernel with this many spans per tile (small tiles in tests)
+    int force_generic = 0;    // the generic kernel whatever the parameters (A/B against the fused tiles)
+    int force_pair = 0;       // keep the pair table where it costs a resident workgroup (the emulation's slices are bigger than the device's)
+    int so_order = 0;         // 2: the raw-row kernels of self-overlap tables try the chain-free tile first for EVERY tile (round 3's order)
+};
+
 // Geometry of one scan: fills variant, lut_n, lw/q/r, span_dw, blk_log2, spans_per_tile, nblk_cap,
 // rec_rs, seq_dw, head_dw, tot_dw, blk_dw, lc_cap, jump_magic.  budget_dw = LDS dwords one workgroup (WPG waves +
-// the shared table) may use; target_dw = preferred workgroup LDS size (occupancy); spans_pref > 0
-// forces the spans per tile.
-inline std::string plan_geometry_core(ScanArgs& a, const tps_params& prm, int k, int P, int64_t max_nwin, int64_t budget_dw,
-                                      int spans_pref, int force_generic, int64_t target_dw);
+// the shared table) may use.
+inline std::string plan_geometry_core(ScanArgs& a, const tps_params& prm, int k, int P, int64_t max_nwin, int64_t budget_dw, const PlanKnobs& kn);
 inline std::string plan_geometry(ScanArgs& a, const tps_params& prm, int k, int P, int64_t max_nwin, int64_t budget_dw,
-                                 int spans_pref, int force_generic = 0, int64_t target_dw = 32 * 256) {
+                                 const PlanKnobs& kn = PlanKnobs()) {
     a.wpg = WPG;
-    std::string err = plan_geometry_core(a, prm, k, P, max_nwin, budget_dw, spans_pref, force_generic, target_dw);
-    if (err.empty()) plan_wpg(a, budget_dw);
+    std::string err = plan_geometry_core(a, prm, k, P, max_nwin, budget_dw, kn);
+    if (err.empty()) {
+        const bool raw = (prm.flags & TPS_F_STORE_RAW) != 0;
+        plan_wpg(a, budget_dw, !a.variant ? 8 : raw ? 5 : a.pat.so_mask != 0 ? 6 : 8);
+    }
     return err;
 }
-inline std::string plan_geometry_core(ScanArgs& a, const tps_params& prm, int k, int P, int64_t max_nwin, int64_t budget_dw,
-                                      int spans_pref, int force_generic, int64_t target_dw) {
+inline std::string plan_geometry_core(ScanArgs& a, const tps_params& prm, int k, int P, int64_t max_nwin, int64_t budget_dw, const PlanKnobs& kn) {
+    const int spans_pref = kn.spans_per_tile, force_generic = kn.force_generic;
     a.lut_n = a.pat.hash_shift ? 2 * 256 : 1 << (2 * k);     // hashed table: 256 (key, mask) pairs
     a.lw = std::max(0, prm.window - k);            // k-mer start positions in a (W-1)-char window
     a.q = a.lw / prm.slide;
@@ -190,13 +200,12 @@ inline std::string plan_geometry_core(ScanArgs& a, const tps_params& prm, int k,
     a.lc_cap = (int)(max_nwin / jump + 2);
     a.jump_magic = jump == 1 ? 0u : (uint32_t)(((1ull << 32) + (uint64_t)jump - 1) / (uint64_t)jump);   // 0: divide by 1
     a.head_dw = 4 * ((prm.no_bp + 63 + 63) / 64) + 4;      // whole quads of a step-1 head whatever its start offset, + look-ahead words
-    (void)target_dw;
     // fused kernels: compile-time slide, 16-bit masks (<= 15 patterns), a window spans at least one
     // 8-block chunk and its far end lies within the exchange halo (XLANES - NT lanes)
     int max_period = 0;                            // self-overlap periods of the table (0 = none)
     for (int i = 0; i < a.pat.n_periods; ++i) max_period = std::max(max_period, a.pat.period[i]);
     const bool sw16_ok = (int64_t)P * ((a.lw + k - 1) / k + 1) < 65536;        // the fused kernels keep S_w in 16 bits
-    const bool fused = !force_generic && spans_pref <= 0 && k <= TPS_DIRECT_K && (has_specialised_slide(prm.slide) || (has_default_only_slide(prm.slide) && a.pat.so_mask == 0 && !(prm.flags & TPS_F_STORE_RAW) && !getenv("TPS_NO_EXT_SLIDES"))) && P <= 15 && a.q >= 8 && sw16_ok &&
+    const bool fused = !force_generic && spans_pref <= 0 && k <= TPS_DIRECT_K && (has_specialised_slide(prm.slide) || (has_default_only_slide(prm.slide) && a.pat.so_mask == 0 && !(prm.flags & TPS_F_STORE_RAW))) && P <= 15 && a.q >= 8 && sw16_ok &&
                        a.q / 8 + 2 < (XLANES - NT) && max_period <= std::min(prm.slide, 6) &&
                        2 * a.head_dw <= fused_seq_dw(prm.slide);   // the two step-1 heads fit the tile buffer (TileGeo::SEQ)
     a.lc16 = 0; a.tile_cap = 0; a.tw = 0; a.tw_magic = 0; a.pair_n = 0; a.lc_global = 0; a.lc_stride = 0; a.pp_d = -1; a.so_fast = 0; a.seq_alias = 0; a.lut_fields = 0; a.tile_full = 0;
@@ -207,31 +216,31 @@ inline std::string plan_geometry_core(ScanArgs& a, const tps_params& prm, int k,
         // most 14 non-overlapping occurrences of a pattern (nibbles), a block at most 2, a window at most 127 (bytes);
         // self-overlap only with ONE period d (then 2 d >= k: picks alternate along a chain)
         const bool pp_counts = a.pat.dup_mask == 0 && k >= 4 && P <= 14 && (8 * prm.slide + k - 1) / k <= 14 && (prm.slide + k - 1) / k <= 2 &&
-                               a.lw / k + 2 <= 127 && !getenv("TPS_NO_PP");
+                               a.lw / k + 2 <= 127;
         if (pp_counts && a.pat.n_periods == 0) a.pp_d = 0;
         if (pp_counts && a.pat.n_periods == 1 && a.pat.period[0] >= 2 && 2 * a.pat.period[0] >= k) a.pp_d = a.pat.period[0];
         a.lut_fields = (a.pp_d >= 0 && (prm.flags & TPS_F_STORE_RAW)) ? 1 : 0;   // the per-pattern tiles will run: table of one-hot fields
-        a.so_fast = getenv("TPS_NO_SO_FAST") ? 0 : (getenv("TPS_SO_FAST") && atoi(getenv("TPS_SO_FAST")) == 2) ? 2 : 1;
+        a.so_fast = kn.so_order == 2 ? 2 : 1;
         // the chain-corrected sums tiles (tile_lc_s<.., CD>) carry a window's matches and pairs as two 8-bit fields of one 16-bit
         // count (at most one of either per start position): windows of more than 255 start positions take the flag-and-recount tile
         if (!(prm.flags & TPS_F_STORE_RAW) && a.pp_d > 0 && a.lw > 255) a.so_fast = 0;   // sums only, pp_d > 0: chain-free tiles complete as plain tiles (tile_fused_s<.., CD>)
         // the sums-only kernels of self-overlap tables (_s*so, _s*sol): 16-bit table, XT aliased onto the staged bases unless the
-        // fallback tile can run (a batch with non-ACGT letters, a table the chain corrections do not take, TPS_NO_SO_FAST)
+        // fallback tile can run (a batch with non-ACGT letters, a table the chain corrections do not take, windows of more than 255 start positions)
         if (a.pat.so_mask != 0 && !(prm.flags & TPS_F_STORE_RAW)) {
             a.lut16 = 1;
-            a.xt_alias = 1;
-            a.xt_own = (a.val_on || !a.so_fast || a.pp_d <= 0 || getenv("TPS_XT_OWN")) ? 1 : 0;
+            a.xt_alias = 2;                        // (round 5: lane totals in the pad words, like the default kernels -- no XF / XT in the slice)
+            a.xt_own = (a.val_on || !a.so_fast || a.pp_d <= 0) ? 1 : 0;
         }
         // the raw-row kernels (_s*r, _s*sor): no XF / XT in the exchange region (tile_pp_s keeps its lane totals in END's pad words);
         // the fallback tile -- a batch with non-ACGT letters, a table the per-pattern tiles do not take -- gets them back
         if (prm.flags & TPS_F_STORE_RAW) {
             // ... and a self-overlap table of 4^6 k-mers or more goes into LDS as 16-bit field indices (LUT_F16, kernels _s*sorh)
-            if (a.lut_fields && a.pat.so_mask != 0 && a.pp_d > 0 && a.lut_n >= 4096 && !getenv("TPS_NO_F16")) a.lut16 = 1;
+            if (a.lut_fields && a.pat.so_mask != 0 && a.pp_d > 0 && a.lut_n >= 4096) a.lut16 = 1;
             a.xt_alias = 2;
-            a.xt_own = (a.val_on || (a.pat.so_mask != 0 ? a.pp_d <= 0 : a.pp_d != 0) || getenv("TPS_XT_OWN")) ? 1 : 0;
+            a.xt_own = (a.val_on || (a.pat.so_mask != 0 ? a.pp_d <= 0 : a.pp_d != 0)) ? 1 : 0;
         }
         // ... and so do the default kernels (no self-overlap, sums only: every tile is a tile_lc_s<.., CD = 0>, lane totals in the pad words)
-        if (a.pat.so_mask == 0 && !(prm.flags & TPS_F_STORE_RAW) && !getenv("TPS_NO_XPAD")) { a.xt_alias = 2; a.xt_own = 0; }
+        if (a.pat.so_mask == 0 && !(prm.flags & TPS_F_STORE_RAW)) { a.xt_alias = 2; a.xt_own = 0; }
         a.variant = prm.slide;
         a.blk_log2 = 3;                            // 8 blocks per lane for every slide
         a.span_dw = 0;                             // lanes start at arbitrary bit offsets (per-lane shift)
@@ -247,7 +256,7 @@ inline std::string plan_geometry_core(ScanArgs& a, const tps_params& prm, int k,
         // them in the tail of row[] (carve_fused): with no invalid letters in the batch that is the sixth workgroup per CU
         a.seq_alias = 0;
 #ifndef TPS_EMU
-        if (a.pat.so_mask == 0 && !(prm.flags & TPS_F_STORE_RAW) && !getenv("TPS_NO_SEQ_ALIAS")) a.seq_alias = 1;
+        if (a.pat.so_mask == 0 && !(prm.flags & TPS_F_STORE_RAW)) a.seq_alias = 1;
 #endif
         // windows per tile: every lane's 8 blocks hold window starts, a window spans q + 1 blocks; EVEN, because the fused
         // kernels store S_w as 16-bit values in whole dwords (g_store_sw8): no tile but a read's last ends inside a dword
@@ -257,7 +266,7 @@ inline std::string plan_geometry_core(ScanArgs& a, const tps_params& prm, int k,
         // The candidates' left sums live off-chip (L2-resident scratch, written once and read once by the same wave) as
         // absolute 32-bit sums: 4 bytes per candidate instead of the 2 of the tile-relative 16-bit form, but the
         // change-point step then needs no per-candidate tile lookup (mul, mulhi, LDS read, add) and no Tc array in LDS.
-        // TPS_LC16 / TPS_LC_IN_LDS select the older layouts (experiments).
+        // (The tile-relative 16-bit and the in-LDS layouts of rounds 1 - 2 are gone with their switches.)
         // Round 4, the 40 MB this round trip adds to a config-2 launch's 128 MB at the memory side -- three ways around it, measured
         // (A/B on one box each, us per launch) and dropped:  (i) the block indexed by the HARDWARE WAVE SLOT (s_getreg HW_ID / XCC_ID:
         // 12 MB rewritten in place launch after launch instead of 20 MB per batch): 55.3 -> 54.4, config 4's sample 67.7 -> 66.7 -- but
@@ -269,22 +278,25 @@ inline std::string plan_geometry_core(ScanArgs& a, const tps_params& prm, int k,
         // a scalar branch to one v_mov per pass; 57 -> 73 VGPRs, still six waves per SIMD; emulation and all GPU tests green --
         // 58.2 against 54.8 (and 56.6 with the registers compiled in but switched off): the longer live ranges and the 16-way uniform
         // dispatch in the tile loop and the change-point step cost more than the round trip, which rides the Infinity Cache.
-        a.lc16 = (getenv("TPS_LC16") || getenv("TPS_LC_IN_LDS")) && a.pat.dup_mask == 0 && (int64_t)a.tw * (a.lw + P) < 65536 ? 1 : 0;
-        a.lc_global = getenv("TPS_LC_IN_LDS") ? 0 : 1;
-        a.lc_stride = a.lc16 ? ((a.lc_cap + 1) & ~1) : 2 * ((a.lc_cap + 1) & ~1);        // in 16-bit units
+        a.lc16 = 0;
+        a.lc_global = 1;
+        a.lc_stride = 2 * ((a.lc_cap + 1) & ~1);        // in 16-bit units
         // pair table (two positions per lookup) while it is small: k <= 4 -> at most 4 KB per workgroup
-        a.pair_n = (a.pat.so_mask == 0 && k <= 4 && !(prm.flags & TPS_F_STORE_RAW) && !getenv("TPS_NO_PAIR")) ? (1 << (2 * (k + 1))) : 0;   // (the raw-count kernels use single lookups)
+        a.pair_n = (a.pat.so_mask == 0 && k <= 4 && !(prm.flags & TPS_F_STORE_RAW)) ? (1 << (2 * (k + 1))) : 0;
+        // the raw-row kernel of slide 6 (round 5): a pair table of one-hot FIELDS for the per-pattern tiles (tile_pp_s<.., PAIRF>) when
+        // the window's partial block ends between two pairs (k = 4 at the default window: r = 0)
+        if (a.pat.so_mask == 0 && k <= 4 && (prm.flags & TPS_F_STORE_RAW) && a.lut_fields && a.pp_d == 0 && prm.slide == 6 && a.r == 0) a.pair_n = 1 << (2 * (k + 1));
         // ... and at k = 5 as 16-bit pattern masks (round 4; the single table likewise: kernels _s*q): 4^6 entries = 8 KB per workgroup,
         // which plan_wpg then shares among 8 waves -- the plant-type 7-mer motifs (CCCTAAA at the reference's default k = 5) get two
         // positions per lookup like the 6-mer motifs at k = 4
         a.pair16 = 0;
-        if (a.pat.so_mask == 0 && a.pat.dup_mask == 0 && k == 5 && P <= 15 && has_specialised_slide(prm.slide) && !(prm.flags & TPS_F_STORE_RAW) && !getenv("TPS_NO_PAIR") && !getenv("TPS_NO_PAIR16")) {
+        if (a.pat.so_mask == 0 && a.pat.dup_mask == 0 && k == 5 && P <= 15 && has_specialised_slide(prm.slide) && !(prm.flags & TPS_F_STORE_RAW)) {
             a.pair16 = 1;
             a.lut16 = 1;
             a.pair_n = (1 << (2 * (k + 1))) / 2;       // dwords
         }
         a.blk_dw = (int32_t)blk_region_dw(a);
-        if (a.pair_n && !getenv("TPS_FORCE_PAIR")) {
+        if (a.pair_n && !kn.force_pair) {
             // ... unless it costs a resident workgroup where one is scarce: LDS is handed out in 1280-byte granules,
             // 128 per CU.  Measured at config 2 (ms per batch): 4 workgroups + pair 0.096 vs 5 + single lookups 0.092;
             // 5 + pair 0.089 vs 6 + single lookups 0.091 -- so the pair table stays if 5 workgroups still fit.
@@ -312,7 +324,7 @@ inline std::string plan_geometry_core(ScanArgs& a, const tps_params& prm, int k,
     }
     a.variant = 0;
     // the generic kernel's 32-bit candidate sums go off-chip too (stride counted in 16-bit units)
-    a.lc_global = getenv("TPS_LC_IN_LDS") ? 0 : 1;
+    a.lc_global = 1;
     a.lc_stride = 2 * ((a.lc_cap + 1) & ~1);
     const int g = gcd_i(prm.slide, 16);
     a.span_dw = prm.slide / g;

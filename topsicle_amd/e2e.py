@@ -205,7 +205,7 @@ def measure(bases, offsets, motif: str, k: int, slide: int, device: int = 0, con
                 legs = {}
                 for name, env in (("parallel", None), ("zlib_stream", "1")):
                     if env:
-                        os.environ["TPS_IO_NO_PARGZ"] = env
+                        seqio.io_option("no_pargz", int(env))
                     try:
                         times = []
                         for _ in range(repeats if env is None else 1):
@@ -217,7 +217,7 @@ def measure(bases, offsets, motif: str, k: int, slide: int, device: int = 0, con
                             assert nr == n_reads
                         legs[name] = times
                     finally:
-                        os.environ.pop("TPS_IO_NO_PARGZ", None)
+                        seqio.io_option("no_pargz", 0)
                 leg = _leg(legs["parallel"], n_bases, zlib_stream_value=n_bases / legs["zlib_stream"][0],
                            zlib_stream_seconds=round(legs["zlib_stream"][0], 4), text_bytes=os.path.getsize(src_path),
                            gz_bytes=os.path.getsize(gz), gz_write_s=round(t_gz, 2), note=note)
@@ -225,7 +225,7 @@ def measure(bases, offsets, motif: str, k: int, slide: int, device: int = 0, con
                 return leg
 
             out["gz_file_to_results"] = gz_leg(fq, "ordinary single-stream gzip (level 1) of the same FASTQ file -> results; zlib_stream_* = "
-                                                   "the same with the reader's one-stream zlib path (TPS_IO_NO_PARGZ=1)")
+                                                   "the same with the reader's one-stream zlib path (reader option no_pargz)")
             fq_noisy = os.path.join(tmp, "reads_noisy_quality.fastq")
             write_fastq(fq_noisy, bases, offsets, random_quality_seed=1)
             out["gz_noisy_quality_file_to_results"] = gz_leg(fq_noisy, "the same reads with ONT-like noisy quality lines (Phred 3-40): gzip -1 leaves "

@@ -24,7 +24,7 @@ EXPORTS = [
     "tps_batch_download_packed", "tps_batch_kmer_followers", "tps_batch_set_tails", "tps_batch_scan", "tps_sync",
     "tps_batch_results", "tps_batch_window_offsets", "tps_batch_window_sums", "tps_batch_window_raw",
     "tps_batch_raw_to_fd", "tps_batch_trc_counts", "tps_trc_counts", "tps_window_counts", "tps_binseg_l2", "tps_binseg_l2_ties", "tps_batch_read_sums", "tps_window_count",
-    "tps_kernel_time_ms", "tps_kernel_time_reset", "tps_device_info", "tps_batch_kernel_info",
+    "tps_kernel_time_ms", "tps_kernel_time_reset", "tps_device_info", "tps_batch_kernel_info", "tps_ctx_debug_option", "tps_debug_stamps_get",
 ]
 
 
@@ -106,6 +106,8 @@ def load_library(path: str | None = None) -> C.CDLL:
         "tps_kernel_time_reset": (C.c_int, [vp]),
         "tps_device_info": (C.c_int, [vp, C.c_char_p, i32]),
         "tps_batch_kernel_info": (C.c_int, [vp, i32, C.c_char_p, i32]),
+        "tps_ctx_debug_option": (C.c_int, [vp, C.c_char_p, i64]),
+        "tps_debug_stamps_get": (C.c_int, [vp, i32, vp, i64]),
     }
     for name, (res, args) in proto.items():
         try:
@@ -120,6 +122,18 @@ def load_library(path: str | None = None) -> C.CDLL:
 
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def debug_options_from_env() -> dict:
+    """$TOPSICLE_HIP_DEBUG = "key=value,key" -> {key: int}: the one environment variable through which diagnostics reach the
+    library (tps_ctx_debug_option; the library itself reads no environment).  Unset in normal use."""
+    out = {}
+    for item in os.environ.get("TOPSICLE_HIP_DEBUG", "").split(","):
+        item = item.strip()
+        if item:
+            key, _, val = item.partition("=")
+            out[key.strip()] = int(val) if val.strip() else 1
+    return out
 
 
 _crc_cb = None
@@ -209,13 +223,34 @@ class HipScanner:
         self._n = {}
         self._lib_path = lib_path
         self._helpers: list["HipScanner"] = []
+        for key, value in debug_options_from_env().items():
+            self.debug_option(key, value)
+
+    def debug_option(self, key: str, value: int = 1):
+        """tps_ctx_debug_option: diagnostics / tests (event_stride, no_events, force_generic, spans_per_tile, force_pair, so_order,
+        stamps).  Applies to this context and to the helper contexts it makes afterwards."""
+        self._check(self.lib.tps_ctx_debug_option(self._h, key.encode(), int(value)))
+        self._debug = getattr(self, "_debug", {})
+        self._debug[key] = int(value)
+        for h in self._helpers:
+            h.debug_option(key, value)
+
+    def stamps(self, slot: int) -> np.ndarray:
+        """uint64[n, 16] phase clocks of the slot's last scan (a -DTPS_STAMPS build with the option "stamps" on)."""
+        n = self._n[slot]
+        out = np.zeros((n, 16), dtype=np.uint64)
+        self._check(self.lib.tps_debug_stamps_get(self._h, slot, _ptr(out), n))
+        return out
 
     def helper(self, j: int) -> "HipScanner":
         """The j-th helper context on this context's device (made on first use, closed with this one): with several pattern
         tables per batch (`--telophrase 4 5 6`) every table beyond the first is scanned by a helper that BORROWS this context's
         resident batch (share) and keeps its own table, outputs and stream -- the k passes overlap on the GPU."""
         while len(self._helpers) <= j:
-            self._helpers.append(HipScanner(self.device, self._lib_path))
+            h = HipScanner(self.device, self._lib_path)
+            for key, value in getattr(self, "_debug", {}).items():
+                h.debug_option(key, value)
+            self._helpers.append(h)
         return self._helpers[j]
 
     # -- plumbing

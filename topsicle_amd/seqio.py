@@ -175,6 +175,30 @@ class RecordBatch:
 
 _io_lib = None
 
+# libtopsicle_io.so's exports (include/topsicle_io.h), bound from this one table: name -> (restype, argtypes) as ctypes type names
+IO_EXPORTS = {
+    "tps_io_last_error": ("c_char_p", []),
+    "tps_reader_open": ("c_int", ["c_char_p", "POINTER(c_void_p)"]),
+    "tps_reader_format": ("c_int", ["c_void_p"]),
+    "tps_reader_close": (None, ["c_void_p"]),
+    "tps_reader_next": ("c_int64", ["c_void_p", "c_void_p", "c_int64", "c_void_p", "c_int64", "c_void_p", "c_int64", "c_void_p", "c_void_p"]),
+    "tps_reader_next_packed": ("c_int64", ["c_void_p", "c_void_p", "c_void_p", "c_int64", "c_void_p", "c_int64", "c_void_p", "c_int64", "c_void_p",
+                                           "c_void_p", "POINTER(c_int64)"]),
+    "tps_reader_next_heads": ("c_int64", ["c_void_p", "c_int32", "c_void_p", "c_void_p", "c_int64", "c_void_p", "c_int64", "c_void_p", "c_int64",
+                                          "c_void_p", "c_void_p", "c_void_p", "POINTER(c_int64)"]),
+    "tps_reader_text_hold": ("c_int", ["c_void_p", "POINTER(c_void_p)", "POINTER(c_int64)", "POINTER(c_void_p)"]),
+    "tps_text_release": (None, ["c_void_p"]),
+    "tps_pack_spans": ("c_int64", ["c_void_p", "c_int64", "c_int32", "c_void_p", "c_void_p", "c_void_p", "c_void_p", "c_int64", "c_int32", "c_void_p",
+                                   "c_void_p", "c_void_p", "c_int64"]),
+    "tps_packed_words_total": ("c_int64", ["c_void_p", "c_int64"]),
+    "tps_pack_reads": ("c_int64", ["c_void_p", "c_void_p", "c_int64", "c_void_p", "c_void_p", "c_void_p", "c_int32"]),
+    "tps_write_fastq_spans": ("c_int64", ["c_int", "c_void_p", "c_int64", "c_void_p", "c_void_p", "c_void_p", "c_int64"]),
+    "tps_crc32": ("c_uint32", ["c_uint32", "c_void_p", "c_int64"]),
+    "tps_crc32_combine": ("c_uint32", ["c_uint32", "c_uint32", "c_int64"]),
+    "tps_io_set_option": ("c_int", ["c_char_p", "c_int64"]),
+    "tps_gz_inflate": ("c_int64", ["c_char_p", "c_void_p", "c_int64", "c_int32", "c_int64", "c_void_p"]),
+}
+
 
 def _load_io():
     """libtopsicle_io.so (csrc/tps_io.cpp): C++ FASTA/FASTQ(.gz) decoder; None if not built."""
@@ -188,38 +212,33 @@ def _load_io():
             _io_lib = False
             return None
         lib = C.CDLL(path)
-        lib.tps_io_last_error.restype = C.c_char_p
-        lib.tps_reader_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
-        lib.tps_reader_format.argtypes = [C.c_void_p]
-        lib.tps_reader_close.argtypes = [C.c_void_p]
-        lib.tps_reader_next.restype = C.c_int64
-        lib.tps_reader_next.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
-                                        C.c_void_p, C.c_void_p]
-        lib.tps_reader_next_packed.restype = C.c_int64
-        lib.tps_reader_next_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
-                                               C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
-        lib.tps_reader_next_heads.restype = C.c_int64
-        lib.tps_reader_next_heads.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
-                                              C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]
-        lib.tps_pack_spans.restype = C.c_int64
-        lib.tps_pack_spans.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
-                                       C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
-        lib.tps_pack_reads.restype = C.c_int64
-        lib.tps_pack_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
-        lib.tps_packed_words_total.restype = C.c_int64
-        lib.tps_packed_words_total.argtypes = [C.c_void_p, C.c_int64]
-        lib.tps_reader_text_hold.restype = C.c_int
-        lib.tps_reader_text_hold.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_void_p)]
-        lib.tps_text_release.restype = None
-        lib.tps_text_release.argtypes = [C.c_void_p]
-        lib.tps_write_fastq_spans.restype = C.c_int64
-        lib.tps_write_fastq_spans.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
-        lib.tps_crc32.restype = C.c_uint32
-        lib.tps_crc32.argtypes = [C.c_uint32, C.c_void_p, C.c_int64]
-        lib.tps_crc32_combine.restype = C.c_uint32
-        lib.tps_crc32_combine.argtypes = [C.c_uint32, C.c_uint32, C.c_int64]
+        ns = {"POINTER": C.POINTER, **{n: getattr(C, n) for n in ("c_char_p", "c_void_p", "c_int", "c_int32", "c_int64", "c_uint32")}}
+        for name, (res, args) in IO_EXPORTS.items():
+            fn = getattr(lib, name)
+            fn.restype = None if res is None else eval(res, ns)
+            fn.argtypes = [eval(a, ns) for a in args]
+        # $TOPSICLE_IO_DEBUG = "key=value,key": the one environment variable through which diagnostics reach the reader (the library
+        # itself reads no environment: tps_io_set_option); unset in normal use
+        for item in os.environ.get("TOPSICLE_IO_DEBUG", "").split(","):
+            item = item.strip()
+            if item:
+                key, _, val = item.partition("=")
+                if lib.tps_io_set_option(key.strip().encode(), int(val) if val.strip() else 1) != 0:
+                    raise ValueError("TOPSICLE_IO_DEBUG: " + lib.tps_io_last_error().decode())
         _io_lib = lib
     return _io_lib or None
+
+
+IO_OPTION_DEFAULTS = {"threads": 0, "timing": 0, "bgzf_group": 0, "pack_min_span": -1, "no_pargz": 0, "pargz_min": -1}
+
+
+def io_option(key: str, value: int):
+    """tps_io_set_option: tests and diagnostics (process-wide; IO_OPTION_DEFAULTS restores)."""
+    lib = _load_io()
+    if lib is None:
+        raise RuntimeError("libtopsicle_io.so is not built")
+    if lib.tps_io_set_option(key.encode(), int(value)) != 0:
+        raise ValueError(lib.tps_io_last_error().decode())
 
 
 def read_batches(filepath: str, max_bases: int = 256 << 20, max_records: int = 1 << 20, want_quals: bool = True):
