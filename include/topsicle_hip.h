@@ -232,7 +232,7 @@ int  tps_kernel_time_ms(tps_ctx* ctx, int32_t* n_launches, double* total_ms, dou
 int  tps_kernel_time_reset(tps_ctx* ctx);
 /* Diagnostics and tests only (ABI 4).  The library reads NO environment variables: what experiments and tests need to steer is
  * set per context through this call -- "event_stride" (time every n-th launch; default 1), "no_events", "force_generic" (the
- * generic kernel instead of the fused tiles), "spans_per_tile", "force_pair", "so_order" (csrc/tps_plan.h: PlanKnobs), "stamps"
+ * generic kernel instead of the fused tiles), "spans_per_tile", "force_pair", "so_order", "wpg" (csrc/tps_plan.h: PlanKnobs), "stamps"
  * (per-read phase clocks; only a -DTPS_STAMPS build writes them).  topsicle_amd.hiplib applies $TOPSICLE_HIP_DEBUG
  * ("key=value,key=value") to every context it creates: the ONE documented variable of the Python host. */
 int  tps_ctx_debug_option(tps_ctx* ctx, const char* key, int64_t value);

@@ -28,6 +28,14 @@ const char* tps_io_last_error(void);
 /* Opens a FASTA / FASTQ file, plain or gzip'ed (ordinary gzip and BGZF are told apart by their headers).  The format comes from
  * the first character of the first line, like check_file_type (allsteps.py:36-50).  0, or -1 (unreadable, unknown format). */
 int  tps_reader_open(const char* path, void** out);
+/* One reader per BYTE RANGE of a plain (uncompressed) file: the records that START in [lo, hi) -- the first one found like a team
+ * thread finds the first record of its stretch, the last one decoded to its end beyond hi.  Readers over adjacent ranges partition
+ * the file's records; each runs a team of `threads` threads (0 = default) at the same time as the others: ONE big file feeds every
+ * GPU of the node (the reference's answer to "> 20 GB and / or > 1 million reads" is splitting the file by hand, README.md:267-268).
+ * tps_reader_range_info: where this reader's first record began and where it stopped -- reader i must have stopped where reader
+ * i + 1 began (the caller's seam check; FASTQ framing is a heuristic only at a range's first record).  Compressed input: -1. */
+int  tps_reader_open_range(const char* path, int64_t lo, int64_t hi, int32_t threads, void** out);
+int  tps_reader_range_info(void* reader, int64_t* first_record, int64_t* stopped_at);
 /* 0 = empty file, 1 = FASTA, 2 = FASTQ. */
 int  tps_reader_format(void* reader);
 void tps_reader_close(void* reader);

@@ -197,7 +197,7 @@ extern "C" int emu_plan(int k, int P, const tps_params* prm, int64_t max_nwin, i
 // plan for a real pattern table: out = {variant, pp_d, workgroup LDS bytes, pair_n, tile_full, tw}
 extern "C" int emu_plan_table(const char* pats, int P, int k, const tps_params* prm, int64_t max_nwin, int32_t* out4) {
     tps::ScanArgs a{};
-    a.val_on = 1;                                  // (the emulation always keeps the invalid-mask staging area)
+    a.val_on = g_val_off ? 0 : 1;                  // (the emulation keeps the invalid-mask staging area unless the knob says "clean batch")
     std::vector<uint32_t> lut;
     std::string err = tps::build_patterns(pats, P, k, lut, a.pat);
     if (err.empty()) err = tps::plan_geometry(a, *prm, k, P, max_nwin, 160 * 1024 / 4, knobs_with(0, 0));

@@ -67,7 +67,7 @@ def test_emulation_synthetic_goldens(synth_cases, force_generic):
 
 def test_plan_picks_specialised_kernels_for_the_baseline_configs():
     for k, P, slide, nwin, variant in [(4, 12, 6, 2467, 6), (5, 14, 7, 2829, 7), (4, 12, 6, 3301, 6), (5, 12, 6, 3301, 6),
-                                       (6, 12, 6, 3301, 6), (3, 10, 5, 3000, 5), (6, 16, 8, 2400, 0), (4, 12, 11, 1000, 11), (4, 12, 13, 1000, 0), (4, 12, 3, 1000, 3), (4, 12, 2, 1000, 0)]:
+                                       (6, 12, 6, 3301, 6), (3, 10, 5, 3000, 5), (6, 16, 8, 2400, 8), (6, 17, 8, 2400, 0), (4, 12, 11, 1000, 11), (4, 12, 13, 1000, 0), (4, 12, 3, 1000, 3), (4, 12, 2, 1000, 0)]:
         pl = emu.plan(k, P, hiplib.make_params(slide=slide), nwin)
         assert pl["variant"] == variant, (k, P, slide, pl)
         assert pl["lds_bytes"] <= 160 * 1024
@@ -833,3 +833,53 @@ def test_emulation_self_overlap_raw_rows_home_and_other_windows(k, W):
         lo, hi = out["win_off"][i], out["win_off"][i + 1]
         assert np.array_equal(out["raw"][lo:hi], counts), i
         assert np.array_equal(out["sums"][lo:hi], counts.sum(axis=1)), i
+
+
+@pytest.mark.parametrize("motif,k,slide", [("TTTTAGGG", 6, 8), ("TTTTAGGG", 6, 6), ("CCCTAAAA", 6, 8), ("TTTTAGGG", 5, 8), ("AACCGGTT", 6, 8)])
+def test_emulation_sixteen_patterns_take_the_fused_tiles(motif, k, slide, monkeypatch):
+    """Round 5: an 8-letter motif has P = 16 k-mers (+ complements) at the reference's default k = len - 2 -- one more than the fused
+    kernels' 16-bit masks held while bit 15 was reserved for the fallback tile's self-overlap flag.  A table WITHOUT self-overlapping
+    k-mers has no use for the flag: it takes the default tiles (sums only); step 1 counts through the histogram path (the packed
+    counter's squaring trick needs bit 15 free).  Step 1, sums, boundary against the oracle; reads of several tiles, both strands, N."""
+    pats = orc.kmer_table(motif, k)
+    assert len(pats) == 16
+    so = any(p[:d] == p[-d:] for p in pats for d in range(1, k))           # TTTTAGGG at k = 6: TAGGGT / ATCCCA have period 5
+    prm = hiplib.make_params(no_bp=1000, min_len=0, min_count=-1, window=100, slide=slide, trimfirst=100, maxlen=20000,
+                             flags=hiplib.F_STEP1 | hiplib.F_WINDOWS | hiplib.F_BINSEG | hiplib.F_STORE_SUMS)
+    if so:
+        # a self-overlap table of sixteen: the chain-corrected tiles on a batch without non-ACGT letters (the fallback tile's flag bit
+        # is the sixteenth pattern); a batch WITH such letters keeps the generic kernel
+        assert emu.plan_table(pats, prm, 3000)["variant"] == 0
+        monkeypatch.setitem(emu.KNOBS, "val_off", 1)
+    pl = emu.plan_table(pats, prm, 3000)
+    assert pl["variant"] == slide, pl
+    rng = np.random.default_rng(slide + 17 * k)
+    comp = str.maketrans("ACGTacgt", "TGCAtgca")
+    seqs = []
+    for i in range(4):
+        tract = (motif * 500)[int(rng.integers(0, 8)):][: int(rng.integers(800, 3000))]
+        body = list(tract) + ["ACGT"[x] for x in rng.integers(0, 4, 9000 - len(tract))]
+        for _ in range(60):
+            p = int(rng.integers(0, len(tract)))
+            body[p] = "ACGT"[int(rng.integers(4))]
+        s = "".join(body)
+        if i == 2 and not so:
+            s = s[:2500] + "N" + s[2501:]
+        if i & 1:
+            s = s.translate(comp)[::-1]
+        seqs.append(s)
+    if so:                                       # overlapping occurrences of TAGGGT: (TAGGG)n runs and deletion-made pairs
+        seqs[0] = seqs[0][:3000] + "TAGGG" * 9 + "T" + seqs[0][3046:]
+        seqs[3] = seqs[3][:1500] + "TTTTAGGGTAGGGTTTTAGGG" + seqs[3][1521:]
+    out = emu.scan(pats, seqs, prm)
+    for i, seq in enumerate(seqs):
+        cs, ce = orc.trc_counts(seq, pats)
+        assert np.array_equal(out["c_start"][i], cs) and np.array_equal(out["c_end"][i], ce), i
+        tail = ["forward", "reverse"][int(out["results"][i]["tail"])]
+        _, counts = orc.window_count_matrix(seq, tail, pats, 100, slide, 100, 20000)
+        lo, hi = out["win_off"][i], out["win_off"][i + 1]
+        assert np.array_equal(out["sums"][lo:hi], counts.sum(axis=1)), i
+        assert out["results"][i]["bkp"] == orc.binseg_l2_exact(counts.sum(axis=1))
+    # raw rows of 16 patterns keep the generic kernel (rows of at most 14 bytes in the per-pattern tiles)
+    prm_raw = hiplib.make_params(window=100, slide=slide, trimfirst=100, maxlen=20000, flags=hiplib.F_WINDOWS | hiplib.F_TAILS_IN | hiplib.F_STORE_SUMS | hiplib.F_STORE_RAW)
+    assert emu.plan_table(pats, prm_raw, 3000)["variant"] == 0

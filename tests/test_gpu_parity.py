@@ -7,7 +7,8 @@ import numpy as np
 import pytest
 
 import topsicle_oracle as orc
-from topsicle_amd import hiplib, synth
+import oracle_c
+from topsicle_amd import allsteps, hiplib, synth
 
 pytestmark = pytest.mark.gpu
 TAILV = {"forward": 0, "reverse": 1}
@@ -529,11 +530,13 @@ def test_k5_pair_table_kernels(sc, motif, slide, W):
 
 
 @pytest.mark.gpu
+# (round 5: _s6r carries the 4 KB pair table of fields -- 5 waves per SIMD by registers either way; _s6sol / _s6so keep their lane totals in the pad
+# words (no XF array); _s6so: 80 VGPRs + the slimmer slice = three 8-wave workgroups, 6 waves per SIMD)
 @pytest.mark.parametrize("k,flags,kernel", [(4, 0, "tps_scan_kernel_s6p lds=23936 wgs_per_cu=6 waves_per_wg=4"),
-                                           (4, hiplib.F_STORE_RAW, "tps_scan_kernel_s6r lds=23168 wgs_per_cu=6 waves_per_wg=4"),
-                                           (5, 0, "tps_scan_kernel_s6sol lds=25472 wgs_per_cu=6 waves_per_wg=4"),
+                                           (4, hiplib.F_STORE_RAW, "tps_scan_kernel_s6r lds=27264 wgs_per_cu=5 waves_per_wg=4"),
+                                           (5, 0, "tps_scan_kernel_s6sol lds=24192 wgs_per_cu=6 waves_per_wg=4"),
                                            (5, hiplib.F_STORE_RAW, "tps_scan_kernel_s6sor lds=26240 wgs_per_cu=6 waves_per_wg=4"),
-                                           (6, 0, "tps_scan_kernel_s6so lds=31616 wgs_per_cu=5 waves_per_wg=4"),
+                                           (6, 0, "tps_scan_kernel_s6so lds=52480 wgs_per_cu=3 waves_per_wg=8"),
                                            (6, hiplib.F_STORE_RAW, "tps_scan_kernel_s6sorh lds=30336 wgs_per_cu=5 waves_per_wg=4")])
 def test_planned_launch_shapes_of_the_benchmark_tables(sc, k, flags, kernel):
     """The kernel, LDS bytes and workgroup shape the planner picks for CCCTAA at k = 4, 5, 6 on a clean batch (BASELINE configs[1] and
@@ -590,3 +593,37 @@ def test_default_kernels_other_slides(sc, slide, k, motif):
         assert np.array_equal(sums[win_off[i]:win_off[i + 1]], counts.sum(axis=1)), i
         want = orc.binseg_l2_exact(counts.sum(axis=1)) if counts.shape[0] >= 7 else None
         assert res["bkp"][i] == (-1 if want is None else want), i
+
+
+@pytest.mark.gpu
+def test_sixteen_patterns_take_the_fused_kernels_on_gpu(sc):
+    """Round 5: an 8-letter motif at the reference's default k = len - 2 has sixteen patterns -- TTTTAGGG at k = 6,
+    default slide 8, where TAGGGT / ATCCCA overlap themselves (period 5).  A clean batch takes the chain-corrected fused tiles
+    (tps_scan_kernel_s8so; the generic kernel before: 398 -> 283 us per 10 000 x 15 kb reads), a batch with a non-ACGT letter keeps the
+    generic kernel (the fallback tile's flag bit is the sixteenth pattern); a table of sixteen without self-overlap (CCCTAAAA) takes
+    the default kernels.  Every window sum (per-read checksums), tails and change points against oracle.c."""
+    for motif, k, slide, clean_kernel in (("TTTTAGGG", 6, 8, "tps_scan_kernel_s8so"), ("CCCTAAAA", 6, 8, "tps_scan_kernel_s8so"), ("AACCGGTT", 6, 8, "tps_scan_kernel_s8")):
+        pats = orc.kmer_table(motif, k)
+        assert len(pats) == 16
+        sc.set_patterns(pats)
+        bases, offsets, _ = synth.make_reads(500, 12000, motif, seed=16 + k, errors=synth.ONT)
+        prm = hiplib.make_params(min_len=9000, min_count=allsteps.min_count_for_cutoff(0.7, 1000 / len(motif), 1000), slide=slide,
+                                 flags=hiplib.F_STEP1 | hiplib.F_WINDOWS | hiplib.F_BINSEG | hiplib.F_STORE_SUMS)
+        for dirty in (False, True):
+            b = bases.copy()
+            if dirty:
+                b[offsets[7] + 3000] = ord("N")
+            sc.upload(5, b, offsets)
+            sc.scan(5, prm)
+            sc.sync()
+            name = sc.kernel_info(5).split()[0]
+            assert name == (clean_kernel if (not dirty or clean_kernel == "tps_scan_kernel_s8") else "tps_scan_kernel"), (motif, dirty, name)
+            res = sc.results(5)
+            sums, win_off = sc.window_sums(5)
+            out, ck = oracle_c.batch_ck(b, offsets, pats, len(motif), 1000, 9000, 0.7, 100, slide, 100, 20000, threads=8)
+            got = oracle_c.checksums(sums, win_off)
+            assert int(res["pass"].sum()) > 300
+            for i in range(len(res)):
+                assert bool(out[i, 0]) == bool(res["pass"][i]), (motif, dirty, i)
+                if out[i, 0]:
+                    assert int(out[i, 1]) == int(res["tail"][i]) and int(out[i, 5]) == int(res["bkp"][i]) and int(ck[i, 0]) == int(got[i]), (motif, dirty, i)

@@ -345,3 +345,35 @@ def test_cli_npz_on_gpu_equals_the_per_read_csv_rows(tmp_path, gold_dir, monkeyp
             seq = bases[offsets[ridx]:offsets[ridx + 1]].tobytes().decode()
             want = orc.window_count_matrix(seq, str(z["tail"][i]), pats, 100, 6, 100, 20000)[1]
             assert np.array_equal(z["counts"][z["win_off"][i]:z["win_off"][i + 1]], want), (k, rid)
+
+
+def test_one_file_cut_into_shards_on_four_contexts(tmp_path):
+    """One plain FASTQ file, 3 byte ranges with a reader team each, four contexts ("2 GPUs x 2 contexts") on this box's GPU: rows
+    equal the one-reader run's, in file order, every seam closed; the heads-mode (two-pass) route through the shards too."""
+    bases, offsets = _ragged(2600, "CCCTAA", 41)
+    fq = tmp_path / "big.fastq"
+    _write_fastq(fq, bases, offsets)
+    motif = "CCCTAA"
+    pats = orc.kmer_table(motif, 4)
+    prm = _params(motif, 6, flags=hiplib.F_STEP1 | hiplib.F_WINDOWS | hiplib.F_BINSEG)
+    engines = [hiplib.HipScanner(0) for _ in range(4)]
+    try:
+        def rows(shards, two_pass):
+            ep = batch.EnginePool(engines, pats, two_pass=two_pass)
+            out = []
+            for pb, outs in ep.scan_file_jobs(str(fq), [batch.Job(pats, prm)], max_bases=4 << 20, shards=shards, shard_min_bytes=1 << 20):
+                res = outs[0][0]
+                for i in range(len(res)):
+                    out.append((pb.read_id(i), int(res["pass"][i]), int(res["tail"][i]), int(res["best_start"][i]), int(res["best_end"][i]),
+                                int(res["n_win"][i]), int(res["bkp"][i])))
+            return out, ep.stats
+        one, _ = rows(1, "off")
+        cut, st = rows(3, "off")
+        assert st.get("shards") == 3 and len(one) == 2600
+        assert cut == one
+        cut2, st2 = rows(3, "on")
+        assert st2.get("shards") == 3 and st2["heads_batches"] > 0
+        assert cut2 == one
+    finally:
+        for e in engines:
+            e.close()

@@ -1,0 +1,117 @@
+"""One big file on several GPUs: a plain FASTA / FASTQ file cut into byte ranges, one reader team per range
+(tps_reader_open_range), all feeding one set of contexts; rows, filtered file and log summary byte-identical to the one-reader run.
+The cuts of these small files land inside headers, sequence and quality lines, multi-line records and blank lines; quality lines
+that begin with '@' sit right behind cuts.  Emulated engines here; `-m gpu`: tests/test_gpu_pipeline.py."""
+import os
+
+import numpy as np
+import pytest
+
+import cli_cases
+from topsicle_amd import batch, main as cli, seqio
+
+
+def run_cli(engines, argv):
+    args = cli.build_parser().parse_args(argv)
+    cli.tprint.logfile = cli.get_log_path(args)
+    cli.analysis_run(args, engines=engines)
+
+
+def make_file(path, fmt, seed, n=60, layout="plain"):
+    rng = np.random.default_rng(seed)
+    with open(path, "w") as h:
+        for i in range(n):
+            L = int(rng.choice([1300, 2100, 2600, 3400, 900]))
+            s = cli_cases.make_read(rng, "CCCTAA", L, rng.random() < 0.7, rng.random() < 0.5)
+            head = f"r{i}" + (" some text" if i % 3 == 0 else "")
+            if fmt == "fastq":
+                q = "".join(chr(33 + int(c)) for c in rng.integers(2, 40, len(s)))
+                if i % 4 == 1:
+                    q = "@" + q[1:]                                         # a quality line that looks like a header
+                if layout == "multiline":
+                    w = int(rng.choice([61, 80, 200]))
+                    h.write(f"@{head}\n" + "".join(s[j:j + w] + "\n" for j in range(0, len(s), w)) + "+\n" +
+                            "".join(q[j:j + w + 7] + "\n" for j in range(0, len(q), w + 7)))
+                else:
+                    h.write(f"@{head}\n{s}\n+\n{q}\n")
+            else:
+                w = {"plain": 0, "wrapped": 70}.get(layout, 0)
+                h.write(f">{head}\n" + (s + "\n" if not w else "".join(s[j:j + w] + "\n" for j in range(0, len(s), w))))
+            if layout == "blanklines" and i % 5 == 0:
+                h.write("\n")
+
+
+def outputs(out):
+    res = cli_cases.normalise(str(out))
+    return res["csv"], res["summary"], res["filtered"]
+
+
+@pytest.mark.parametrize("fmt,layout", [("fastq", "plain"), ("fastq", "multiline"), ("fasta", "plain"), ("fasta", "wrapped"), ("fastq", "blanklines")])
+@pytest.mark.parametrize("shards", [2, 3, 7])
+def test_sharded_file_equals_the_one_reader_run(fmt, layout, shards, tmp_path, emu_engine_factory, monkeypatch):
+    monkeypatch.setattr(batch, "BATCH_BASES", 24000)               # several batches per shard
+    path = tmp_path / f"big.{fmt}"
+    make_file(path, fmt, seed=shards * 10 + len(layout))
+    base = ["-i", str(path), "--pattern", "CCCTAA", "--minSeqLength", "1000", "--cutoff", "0.4", "--telophrase", "4", "5"]
+    run_cli(emu_engine_factory(), base + ["-o", str(tmp_path / "one"), "--shards", "1"])
+    run_cli(emu_engine_factory(), base + ["-o", str(tmp_path / "cut"), "--shards", str(shards)])
+    one, cut = outputs(tmp_path / "one"), outputs(tmp_path / "cut")
+    assert len(one[0]) > 10
+    assert one == cut
+    assert f"read as {shards} byte ranges" in open(tmp_path / "cut" / "topsicle_run.log").read()
+
+
+def test_shard_ranges_and_seams(tmp_path):
+    """The readers of adjacent ranges partition the records exactly: ids in order, none twice, every seam closed -- at every cut
+    position of a stretch of the file (a cut per byte: inside '@' lines, quality lines that begin with '@', the '+' line, line ends)."""
+    path = tmp_path / "f.fastq"
+    make_file(path, "fastq", seed=5, n=8)
+    size = os.path.getsize(path)
+    ids = [r.id for r in seqio.read_records(str(path))]
+    pool = seqio.BufferPool(3, 1 << 16, 1 << 10)
+    text = open(path, "rb").read()
+    first_end = text.index(b"\n@r2")                              # cuts from inside record 0 to the start of record 2
+    for cut in list(range(1, first_end + 3)) + [size - 1, size]:
+        got, infos = [], [dict(), dict()]
+        for i, rg in enumerate([(0, cut), (cut, size)]):
+            for pb in seqio.read_batches_packed(str(path), pool, byte_range=rg, threads=1, range_info=infos[i]):
+                got += pb.ids
+                pb.release()
+        assert got == ids, cut
+        assert infos[0]["stopped"] == infos[1]["first"], (cut, infos)
+    assert seqio.shard_ranges(str(path), 4, min_bytes=1 << 40) is None and len(seqio.shard_ranges(str(path), 4, min_bytes=100)) == 4
+    import gzip
+    gz = tmp_path / "f.fastq.gz"
+    gz.write_bytes(gzip.compress(text))
+    assert seqio.shard_ranges(str(gz), 4, min_bytes=10) is None      # one inflating reader
+
+
+def test_odd_records_inside_a_shard_go_to_the_streaming_decoder_and_stop_at_the_range(tmp_path):
+    """A shard whose records the thread-team decoder declines (padded lines) hands over to the one-thread streaming decoder, which
+    must stop at the range's end too (it tracks where every record begins)."""
+    path = tmp_path / "odd.fastq"
+    rng = np.random.default_rng(3)
+    recs = []
+    with open(path, "w") as h:
+        for i in range(12):
+            s = "".join("ACGT"[c] for c in rng.integers(0, 4, 400))
+            recs.append(f"r{i}")
+            pad = "  " if i in (2, 3, 7) else ""
+            h.write(f"@r{i}\n{pad}{s}\n+\n{'I' * len(s)}\n")
+    size = os.path.getsize(path)
+    pool = seqio.BufferPool(3, 1 << 16, 1 << 10)
+    for n in (2, 3, 4):
+        cuts = [size * i // n for i in range(n + 1)]
+        got, infos = [], [dict() for _ in range(n)]
+        for i in range(n):
+            for pb in seqio.read_batches_packed(str(path), pool, byte_range=(cuts[i], cuts[i + 1]), threads=1, range_info=infos[i]):
+                got += pb.ids
+                pb.release()
+        seams_closed = all(infos[i]["stopped"] == infos[i + 1]["first"] for i in range(n - 1))
+        if n == 4:
+            # the cut at a quarter of the file falls right in front of r3, a padded record: a range's FIRST record is found by its
+            # framing, which a record of unusual layout does not pass -- the seam check sees the gap (the CLI then refuses the file:
+            # batch._scan_sharded) instead of losing the record silently
+            assert not seams_closed and got == [r for r in recs if r != "r3"], (got, infos)
+        else:
+            assert got == recs and seams_closed, (n, got, infos)

@@ -307,17 +307,50 @@ class EnginePool:
         return self._single(self._run(seqio.read_batches_packed(filepath, pool, max_records=reads_cap, heads_bp=hb,
                                                                 first_batch_records=self._probe_records(hm)), jobs, pool, hm))
 
-    def scan_file_jobs(self, filepath, jobs, max_bases=None):
-        """One pass over the file for several jobs (pattern tables): yields (PackedBatch, [(results, sums, raw, win_off) per job])."""
+    def scan_file_jobs(self, filepath, jobs, max_bases=None, shards=1, shard_min_bytes=64 << 20):
+        """One pass over the file for several jobs (pattern tables): yields (PackedBatch, [(results, sums, raw, win_off) per job]).
+        shards > 1 (round 5): ONE plain file is cut into that many byte ranges, each decoded by a reader thread team of its own at the
+        same time (seqio.shard_ranges / tps_reader_open_range), all of them feeding this pool's contexts; batches come back in FILE
+        order.  The reference tells users to split a file of "> 20 GB and / or > 1 million reads" by hand and run the pieces
+        (README.md:267-268; its unit of parallelism is the file: main.py:232-235).  Only jobs whose results are per-read records
+        (no window sums / raw rows handed back, no raw sink: those are laid out in batch order); compressed files keep one reader."""
         from . import seqio
         max_bases = max_bases or BATCH_BASES
         words_cap = max(max_bases // 16, 1024)
         reads_cap = min(BATCH_READS, max(64, max_bases // 256))
-        pool = self._staging_pool(words_cap, reads_cap)
         jobs = list(jobs)
+        ranges = None
+        if shards and shards > 1 and not any(j.want_sums or j.want_raw for j in jobs):
+            ranges = seqio.shard_ranges(filepath, shards, shard_min_bytes)
+        if not ranges:
+            pool = self._staging_pool(words_cap, reads_cap)
+            hb, hm = self._heads_mode(jobs, filepath)
+            return self._run(seqio.read_batches_packed(filepath, pool, max_records=reads_cap, heads_bp=hb, first_batch_records=self._probe_records(hm)),
+                             jobs, pool, hm)
+        return self._scan_sharded(filepath, jobs, ranges, words_cap, reads_cap)
+
+    def _scan_sharded(self, filepath, jobs, ranges, words_cap, reads_cap):
+        from . import seqio
+        n = len(ranges)
+        # every shard's reader gets its share of the host's cores (the teams run at the same time) and staging buffers of its own
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        threads = max(1, min(32, cores) // n) if cores >= 2 * n else 1
+        pool = self._staging_pool(words_cap, reads_cap, sets=len(self.engines) + 2 * n)
         hb, hm = self._heads_mode(jobs, filepath)
-        return self._run(seqio.read_batches_packed(filepath, pool, max_records=reads_cap, heads_bp=hb, first_batch_records=self._probe_records(hm)),
-                         jobs, pool, hm)
+        if hm["auto"]:
+            hm["first"].set()                          # (no probe batch per shard: auto mode starts from whole reads and switches on the first verdict)
+        infos = [dict() for _ in ranges]
+        sources = [seqio.read_batches_packed(filepath, pool, max_records=reads_cap, heads_bp=hb, byte_range=rg, threads=threads, range_info=infos[i])
+                   for i, rg in enumerate(ranges)]
+        self.stats["shards"] = n
+        yield from self._run(sources, jobs, pool, hm)
+        # the seams: reader i must have stopped exactly where reader i + 1 found its first record (a FASTQ record start inside a
+        # range is recognised by its framing -- a heuristic only there; a mismatch means records were lost or read twice)
+        for i in range(n - 1):
+            a, b = infos[i].get("stopped"), infos[i + 1].get("first")
+            if a is None or b is None or a != b:
+                raise RuntimeError(f"{filepath}: shard {i} stopped at byte {a}, shard {i + 1} began at byte {b}: the file cannot be read by byte "
+                                   f"ranges (records with unusual line layout around the cut); rerun with one reader (--shards 1)")
 
     @staticmethod
     def _probe_records(hm):
@@ -379,7 +412,7 @@ class EnginePool:
             if hm:
                 hm["first"].set()
 
-    def _staging_pool(self, words_cap, reads_cap):
+    def _staging_pool(self, words_cap, reads_cap, sets=None):
         """The pinned staging buffers of this engine set: allocated ONCE per (engine set, geometry) and kept on the first engine,
         so that a new EnginePool per input file (main.process_file_multi) reuses them -- they are only freed with the context
         (a pool per file leaked ~28 MB of pinned memory per buffer set and file: ADVICE r2).  Every context uploads from them
@@ -389,9 +422,10 @@ class EnginePool:
         pools = getattr(owner, "_staging_pools", None)
         if pools is None:
             pools = owner._staging_pools = {}
-        key = (words_cap, reads_cap, len(self.engines) + 2)
+        sets = sets or len(self.engines) + 2
+        key = (words_cap, reads_cap, sets)
         if key not in pools:
-            pools[key] = seqio.BufferPool(len(self.engines) + 2, words_cap, reads_cap, getattr(owner, "host_alloc", None))
+            pools[key] = seqio.BufferPool(sets, words_cap, reads_cap, getattr(owner, "host_alloc", None))
         return pools[key]
 
     def scan_stream(self, records, prm, want_sums=False, want_raw=False, max_bases=None):
@@ -404,6 +438,12 @@ class EnginePool:
 
     # -- the pipeline
     def _run(self, batches, jobs, pool=None, hm=None):
+        """`batches`: an iterator of batches, or a LIST of them (the shards of one file, in file order): one reader thread per source,
+        one shared queue, results yielded source after source, batch after batch."""
+        sources = list(batches) if isinstance(batches, (list, tuple)) else [batches]
+        multi = len(sources) > 1
+        if multi and any(getattr(j, "raw_sink", None) is not None or j.want_sums or j.want_raw for j in jobs):
+            raise ValueError("several sources: per-read records only")
         n = len(self.engines)
         if pool is not None:
             pool.abort.clear()
@@ -413,18 +453,21 @@ class EnginePool:
         # At most n + 3 batches between the reader and the consumer: a batch's results (raw rows: hundreds of MB per batch and k) wait
         # in `pending` until the consumer has dealt with the batches before it, and a consumer slower than the GPUs -- the CLI writing
         # raw rows -- let them pile up (configs[4]'s shard: 9.9 GB resident one second into the run).  The reader takes the tokens, in
-        # batch order, so the batch the consumer waits for always has one.
-        in_flight = threading.Semaphore(n + 3)
+        # batch order, so the batch the consumer waits for always has one.  (Several sources: per-read records only, a few MB per
+        # batch -- the later shards' results simply wait for their turn.)
+        in_flight = None if multi else threading.Semaphore(n + 3)
+        readers_left = [len(sources)]
+        rl_lock = threading.Lock()
 
-        def reader():
+        def reader(si, it):
             count = 0
             try:
-                for b in batches:
-                    while not stop.is_set() and not in_flight.acquire(timeout=0.2):
+                for b in it:
+                    while in_flight is not None and not stop.is_set() and not in_flight.acquire(timeout=0.2):
                         pass
                     while not stop.is_set():
                         try:
-                            q_in.put((count, b), timeout=0.2)
+                            q_in.put(((si, count), b), timeout=0.2)
                             break
                         except queue.Full:
                             continue
@@ -433,12 +476,16 @@ class EnginePool:
                             b.release()
                         break
                     count += 1
-                q_out.put(("eof", count, None))
+                q_out.put(("eof", si, count))
             except BaseException as e:          # parse errors surface in the consumer
                 q_out.put(("error", None, e))
             finally:
-                for _ in range(n):
-                    q_in.put(None)
+                with rl_lock:
+                    readers_left[0] -= 1
+                    last = readers_left[0] == 0
+                if last:
+                    for _ in range(n):
+                        q_in.put(None)
 
         def worker(eng):
             try:
@@ -446,31 +493,37 @@ class EnginePool:
                     item = q_in.get()
                     if item is None:
                         return
-                    i, b = item
-                    outs = scan_jobs(eng, b, jobs, 0, seq=i)
+                    key, b = item
+                    outs = scan_jobs(eng, b, jobs, 0, seq=None if multi else key[1])
                     self._heads_feedback(b, outs, hm)
-                    q_out.put(("batch", i, (b, outs)))
+                    q_out.put(("batch", key, (b, outs)))
             except BaseException as e:
                 stop.set()
                 q_out.put(("error", None, e))
 
-        threads = [threading.Thread(target=reader, daemon=True)] + [threading.Thread(target=worker, args=(e,), daemon=True) for e in self.engines]
+        threads = [threading.Thread(target=reader, args=(si, it), daemon=True) for si, it in enumerate(sources)] + \
+                  [threading.Thread(target=worker, args=(e,), daemon=True) for e in self.engines]
         for t in threads:
             t.start()
-        pending, nxt, total = {}, 0, None
+        pending, totals, cur, nxt = {}, {}, 0, 0
         try:
-            while total is None or nxt < total:
-                kind, i, payload = q_out.get()
+            while cur < len(sources):
+                if cur in totals and nxt >= totals[cur]:
+                    cur, nxt = cur + 1, 0
+                    continue
+                if (cur, nxt) in pending:
+                    yield pending.pop((cur, nxt))
+                    nxt += 1
+                    if in_flight is not None:
+                        in_flight.release()            # (the consumer came back for more: it is done with that batch)
+                    continue
+                kind, key, payload = q_out.get()
                 if kind == "error":
                     raise payload
                 if kind == "eof":
-                    total = i
+                    totals[key] = payload
                     continue
-                pending[i] = payload
-                while nxt in pending:
-                    yield pending.pop(nxt)
-                    nxt += 1
-                    in_flight.release()                # (the consumer came back for more: it is done with that batch)
+                pending[key] = payload
         finally:
             stop.set()
             for job in jobs:

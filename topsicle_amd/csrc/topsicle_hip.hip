@@ -1166,8 +1166,9 @@ int tps_ctx_debug_option(tps_ctx* c, const char* key, int64_t value) {
     else if (k == "spans_per_tile") c->knobs.spans_per_tile = (int)std::max<int64_t>(0, value);
     else if (k == "force_pair") c->knobs.force_pair = value != 0;
     else if (k == "so_order") c->knobs.so_order = (int)value;
+    else if (k == "wpg") c->knobs.wpg = (int)value;
     else if (k == "stamps") c->want_stamps = value != 0;
-    else return fail(TPS_E_ARG, "unknown debug option '%s' (event_stride, no_events, force_generic, spans_per_tile, force_pair, so_order, stamps)", key);
+    else return fail(TPS_E_ARG, "unknown debug option '%s' (event_stride, no_events, force_generic, spans_per_tile, force_pair, so_order, wpg, stamps)", key);
     for (auto& sl : c->slots) sl.planned = false;
     return TPS_OK;
 }

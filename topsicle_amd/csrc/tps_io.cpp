@@ -39,6 +39,7 @@
 #include <condition_variable>
 #include <functional>
 #include <mutex>
+#include <new>
 #include <pthread.h>
 #include <ctime>
 #include <string>
@@ -61,11 +62,15 @@ struct Reader {
     std::string p_head, p_seq, p_qual;
     std::string next_head;              // FASTA: header line already consumed while reading the previous record
     bool have_next_head = false;
+    // byte ranges (tps_reader_open_range): offset of buf[0] in the (plain) file, where the last parsed record began, and where the
+    // FASTA header consumed ahead began
+    uint64_t base = 0, rec_start = 0, next_head_start = 0;
 
     bool fill() {
         if (eof) return false;
         if (pos < len) memmove(buf.data(), buf.data() + pos, len - pos);
         len -= pos;
+        base += pos;
         pos = 0;
         int got = gzread(gz, buf.data() + len, (unsigned)(buf.size() - len));
         if (got < 0) { g_err = "gzread failed"; eof = true; return false; }
@@ -122,6 +127,7 @@ struct Reader {
         std::string line;
         if (format == 2) {
             do {
+                rec_start = base + pos;
                 if (!getline(line)) return false;
             } while (line.empty());
             if (line[0] != '@') { g_err = "FASTQ record does not start with '@'"; return false; }
@@ -147,18 +153,23 @@ struct Reader {
         // FASTA
         if (!have_next_head) {
             for (;;) {
+                next_head_start = base + pos;
                 if (!getline(line)) return false;
                 if (!line.empty() && line[0] == '>') break;
             }
             next_head.assign(line, 1, std::string::npos);
         }
         p_head = next_head;
+        rec_start = next_head_start;
         have_next_head = false;
         p_seq.clear();
         p_qual.clear();
-        while (getline(line)) {
+        for (;;) {
+            const uint64_t line_start = base + pos;
+            if (!getline(line)) break;
             if (!line.empty() && line[0] == '>') {
                 next_head.assign(line, 1, std::string::npos);
+                next_head_start = line_start;
                 have_next_head = true;
                 break;
             }
@@ -204,10 +215,9 @@ inline bool io_timing() { return g_opt.timing.load() != 0; }
 inline double now_s() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 // The thread team: f(thread index, thread count) on `nthreads` threads, the caller being thread 0.  The workers are
 // created once and parked on a condition variable between calls (a team call per batch used to create and join its
-// threads: on a busy or quota-limited host that cost more than the decoding).  One team runs at a time; readers of
-// several files take turns.  A forked child starts with a fresh pool (threads do not survive fork).
+// threads: on a busy or quota-limited host that cost more than the decoding).  A forked child starts with fresh pools.
 struct Pool {
-    std::mutex run_mu;                         // one team at a time
+    std::mutex run_mu;                         // (one call at a time per pool: a leased pool has one user)
     std::mutex mu;
     std::condition_variable cv_work, cv_done;
     std::function<void(int, int)> job;
@@ -252,19 +262,30 @@ struct Pool {
         cv_done.wait(lk, [&] { return remaining == 0; });
     }
 };
-Pool* g_pool = nullptr;
+// Pools are LEASED per team call (round 5): readers of different shards of one file -- or of different files -- run their teams at the
+// same time, each on a pool of its own; a pool goes back to the idle list when its call is over, so there are never more pools than
+// calls that overlapped (round 4 had ONE pool behind a mutex: the teams of several readers took turns).
+std::mutex g_pools_mu;
+std::vector<Pool*>* g_idle_pools = nullptr;    // never destroyed: the pools' threads are detached and end with the process
 std::once_flag g_pool_once;
-inline Pool& pool() {
-    std::call_once(g_pool_once, [] {
-        g_pool = new Pool();                   // never destroyed: its threads are detached and end with the process
-        pthread_atfork(nullptr, nullptr, [] { g_pool = new Pool(); });
-    });
-    return *g_pool;
-}
+struct PoolLease {
+    Pool* p;
+    PoolLease() {
+        std::call_once(g_pool_once, [] {
+            g_idle_pools = new std::vector<Pool*>();
+            pthread_atfork(nullptr, nullptr, [] { g_idle_pools = new std::vector<Pool*>(); new (&g_pools_mu) std::mutex(); });   // (threads do not survive fork)
+        });
+        std::lock_guard<std::mutex> lk(g_pools_mu);
+        if (g_idle_pools->empty()) p = new Pool();
+        else { p = g_idle_pools->back(); g_idle_pools->pop_back(); }
+    }
+    ~PoolLease() { std::lock_guard<std::mutex> lk(g_pools_mu); g_idle_pools->push_back(p); }
+};
 template <typename F>
 void team(int nthreads, F f) {                 // f(thread index, thread count); runs inline for one thread
     if (nthreads <= 1) { f(0, 1); return; }
-    pool().run(nthreads, std::function<void(int, int)>(f));
+    PoolLease lease;
+    lease.p->run(nthreads, std::function<void(int, int)>(f));
 }
 
 // A compressed input whose text arrives group by group: read_group() appends the next stretch of text to `out` (about `want`
@@ -405,6 +426,7 @@ struct Fast {
     const char* data = nullptr;
     size_t size = 0;
     size_t pos = 0;                            // start of the first unconsumed record
+    size_t limit = (size_t)-1;                 // byte ranges (tps_reader_open_range): records that START at or behind this offset are not this reader's
     std::vector<uint64_t> nl;                  // newline offsets of the indexed window, ascending
     size_t nl_i = 0;                           // first unconsumed entry of nl
     size_t win_hi = 0;                         // end of the indexed window
@@ -754,9 +776,9 @@ struct Fast {
         nl.clear(); nl_i = 0; whole = false;       // (the line index of next() is not used here and is stale afterwards)
         const double t_a = io_timing() ? now_s() : 0.0;
         const size_t p = pos;
-        if (p >= size || only_blank(p)) return 0;
+        if (p >= size || p >= limit || only_blank(p)) return 0;
         // text that yields at most words_cap words if it were nothing but sequence + quality lines
-        size_t span = std::min<size_t>(size - p, (size_t)std::max<int64_t>(words_cap, 1024) * (fasta ? 17 : 32));      // (FASTA: no quality lines)
+        size_t span = std::min<size_t>(std::min(size, limit) - p, (size_t)std::max<int64_t>(words_cap, 1024) * (fasta ? 17 : 32));      // (FASTA: no quality lines; a record that starts before `limit` is decoded to its end)
         const size_t min_span = g_opt.pack_min_span.load() >= 0 ? (size_t)g_opt.pack_min_span.load() : (size_t)4 << 20;   // (tests: team on small files)
         const int T = span < min_span ? 1 : threads;
         if (chunks.empty()) take_spare();
@@ -861,7 +883,36 @@ struct Fast {
         if (io_timing()) fprintf(stderr, "[tps_io] batch of %lld records: decode+pack %.2f ms, join+copy %.2f ms (%lld words, %d threads, %zu bytes of text)\n",
                                  (long long)n, 1e3 * (t_b - t_a), 1e3 * (now_s() - t_b), (long long)nw, T, cur - p);
         pos = cur;
+        release_behind();
         return n;
+    }
+    // Plain files: the pages of the mapping well behind the read position leave the process's resident set (MADV_DONTNEED on a
+    // read-only file mapping only drops the page-table entries -- the page cache keeps the data, a late reader faults it back in):
+    // a 3 GB input used to sit in RSS for the whole run (round 4's configs[4] shard: 4.8 GB resident with the plain file).
+    size_t released = 0;
+    void release_behind() {
+        if (src || !data) return;
+        const size_t lag = (size_t)256 << 20, step = (size_t)64 << 20;
+        if (pos < lag + step || pos - lag < released + step) return;
+        const size_t hi = (pos - lag) & ~(size_t)4095;
+        if (hi > released) { madvise((void*)(data + released), hi - released, MADV_DONTNEED); released = hi; }
+    }
+    // Byte ranges: the first line start >= lo that opens a record -- '>' for FASTA; for FASTQ an '@' line that parse_at accepts (a
+    // quality line may begin with '@': the four-line / multi-line framing test rejects it) -- or `hi` if no record starts in [lo, hi).
+    size_t first_record_from(size_t lo, size_t hi) const {
+        if (lo == 0) return 0;
+        if (hi > size) hi = size;
+        if (lo >= hi) return hi;
+        Rec r;
+        size_t nx = 0;
+        const char* q = (const char*)memchr(data + lo - 1, '\n', hi - (lo - 1));
+        while (q) {
+            const size_t cand = (size_t)(q - data) + 1;
+            if (cand >= hi) break;
+            if (fasta ? data[cand] == '>' : (data[cand] == '@' && parse_at(cand, r, nx) == 0)) return cand;
+            q = (const char*)memchr(data + cand, '\n', hi - cand);
+        }
+        return hi;
     }
     bool only_blank(size_t from) const {
         for (size_t i = from; i < size; ++i)
@@ -890,6 +941,9 @@ struct Handle {
     Fast* fast = nullptr;
     std::string path;
     int format = 0;
+    // byte ranges (tps_reader_open_range): the reader owns the records that start in [first, limit); first = the first record start
+    // at or behind the range's lower bound
+    int64_t limit = -1, first = 0, stream_stopped = -1;
     ~Handle() {
         if (slow) { if (slow->gz) gzclose(slow->gz); delete slow; }
         delete fast;
@@ -1056,6 +1110,45 @@ int tps_reader_open(const char* path, void** out) {
     return 0;
 }
 
+// One reader per BYTE RANGE of a plain (uncompressed) FASTA / FASTQ file: it yields the records that START in [lo, hi) -- the first
+// one is found like a thread of the team finds the first record of its stretch, the last one is decoded to its end beyond hi -- so
+// readers over adjacent ranges partition the file's records, each with a team of its own (`threads`; 0 = the default), and one big
+// file feeds several GPUs (the reference's advice for "> 20 GB and / or > 1 million reads" is to split the file by hand:
+// README.md:267-268).  tps_reader_range_info tells where the reader's first record began and where it stopped, for the caller's
+// seam check (reader i must have stopped where reader i + 1 began).  Compressed input: -1 (BGZF and gzip go through one reader).
+int tps_reader_open_range(const char* path, int64_t lo, int64_t hi, int32_t threads, void** out) {
+    if (lo < 0 || hi < lo) { g_err = "bad byte range"; return -1; }
+    if (tps_reader_open(path, out) != 0) return -1;
+    Handle* h = (Handle*)*out;
+    if (!h->format) return 0;                                                // an empty file
+    if (!h->fast || h->fast->src) { g_err = "byte ranges need a plain (uncompressed) FASTA / FASTQ file"; delete h; *out = nullptr; return -1; }
+    Fast* f = h->fast;
+    if (threads > 0) f->threads = std::min(threads, 64);
+    const size_t hi_c = std::min<size_t>((size_t)hi, f->size);
+    if (lo > 0) f->pos = f->first_record_from(std::min<size_t>((size_t)lo, f->size), hi_c);
+    f->limit = hi_c;
+    h->limit = (int64_t)hi_c;
+    h->first = (int64_t)std::min(f->pos, hi_c);
+    return 0;
+}
+int tps_reader_range_info(void* hv, int64_t* first, int64_t* stopped) {
+    Handle* h = (Handle*)hv;
+    if (!h || !first || !stopped) { g_err = "null argument"; return -1; }
+    *first = h->first;
+    int64_t at = 0;
+    if (h->fast) {
+        size_t p = h->fast->pos;
+        while (p < h->fast->size && (h->fast->data[p] == '\n' || h->fast->data[p] == '\r' || h->fast->data[p] == ' ')) ++p;     // (blank lines between records are nobody's)
+        at = (int64_t)p;
+    } else if (h->stream_stopped >= 0) {
+        at = h->stream_stopped;
+    } else if (h->slow) {
+        at = (int64_t)(h->slow->have_pending ? h->slow->rec_start : h->slow->base + h->slow->pos);
+    }
+    *stopped = at;
+    return 0;
+}
+
 int tps_reader_format(void* h) { return h ? ((Handle*)h)->format : 0; }
 
 void tps_reader_close(void* h) { delete (Handle*)h; }
@@ -1074,7 +1167,8 @@ int64_t tps_reader_next(void* hv, uint8_t* bases, int64_t bases_cap, int64_t* of
     head_off[0] = 0;
     if (!h->format) return 0;
     if (h->fast) {
-        const int64_t n = h->fast->next(bases, bases_cap, offsets, max_records, heads, heads_cap, head_off, quals);
+        // (a byte-range reader's ASCII batches come from the streaming decoder, which knows where every record begins)
+        const int64_t n = h->limit >= 0 ? -3 : h->fast->next(bases, bases_cap, offsets, max_records, heads, heads_cap, head_off, quals);
         if (n != -3) return n;
         // not plain 4-line FASTQ from here on: the streaming decoder takes over at the same byte
         const int64_t at = (int64_t)(h->fast->base_off + h->fast->pos);
@@ -1083,6 +1177,7 @@ int64_t tps_reader_next(void* hv, uint8_t* bases, int64_t bases_cap, int64_t* of
         if (h->slow) { if (h->slow->gz) gzclose(h->slow->gz); delete h->slow; }
         h->slow = open_stream(h->path.c_str(), at, h->format);
         if (!h->slow) return -1;
+        h->slow->base = (uint64_t)at;
     }
     Reader* r = h->slow;
     if (r->buf.size() < ((size_t)4 << 20)) r->buf.resize((size_t)4 << 20);      // (opened with the small sniffing buffer)
@@ -1092,6 +1187,11 @@ int64_t tps_reader_next(void* hv, uint8_t* bases, int64_t bases_cap, int64_t* of
         if (!r->have_pending) {
             if (!r->parse_one()) {
                 if (!g_err.empty()) return -1;
+                break;
+            }
+            if (h->limit >= 0 && r->rec_start >= (uint64_t)h->limit) {               // the next shard's record
+                h->stream_stopped = (int64_t)r->rec_start;
+                r->eof = true; r->len = r->pos = 0; r->have_next_head = false;
                 break;
             }
             r->have_pending = true;

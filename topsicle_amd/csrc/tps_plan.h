@@ -155,6 +155,7 @@ struct PlanKnobs {
     int force_generic = 0;    // the generic kernel whatever the parameters (A/B against the fused tiles)
     int force_pair = 0;       // keep the pair table where it costs a resident workgroup (the emulation's slices are bigger than the device's)
     int so_order = 0;         // 2: the raw-row kernels of self-overlap tables try the chain-free tile first for EVERY tile (round 3's order)
+    int wpg = 0;              // 4 or 8: waves per workgroup whatever plan_wpg would pick (A/B of the workgroup shapes)
 };
 
 // Geometry of one scan: fills variant, lut_n, lw/q/r, span_dw, blk_log2, spans_per_tile, nblk_cap,
@@ -165,9 +166,22 @@ inline std::string plan_geometry(ScanArgs& a, const tps_params& prm, int k, int 
                                  const PlanKnobs& kn = PlanKnobs()) {
     a.wpg = WPG;
     std::string err = plan_geometry_core(a, prm, k, P, max_nwin, budget_dw, kn);
+    if (err.empty() && a.variant && !a.pat.hash_shift) {
+        // the table gathers address LDS as (offset & mask) | base (tps_device.h: lut_at / lut16_at): the single table, which sits behind
+        // the pair table, must start at a multiple of its own (power-of-two) byte size (nothing checked this when pair_n or
+        // the table formats changed)
+        const int64_t single_bytes = (int64_t)a.lut_n * (a.lut16 ? 2 : 4);
+        if ((single_bytes & (single_bytes - 1)) != 0 || ((int64_t)a.pair_n * 4) % single_bytes != 0)
+            err = "LDS plan: the single table (" + std::to_string(single_bytes) + " B) would not be aligned behind a pair table of " + std::to_string((int64_t)a.pair_n * 4) + " B";
+    }
     if (err.empty()) {
         const bool raw = (prm.flags & TPS_F_STORE_RAW) != 0;
         plan_wpg(a, budget_dw, !a.variant ? 8 : raw ? 5 : a.pat.so_mask != 0 ? 6 : 8);
+        if ((kn.wpg == WPG || kn.wpg == WPG_MAX) && a.variant) {
+            const int32_t keep = a.wpg;
+            a.wpg = kn.wpg;
+            if (wg_lds_dwords(a) > budget_dw) a.wpg = keep;
+        }
     }
     return err;
 }
@@ -200,12 +214,22 @@ inline std::string plan_geometry_core(ScanArgs& a, const tps_params& prm, int k,
     a.lc_cap = (int)(max_nwin / jump + 2);
     a.jump_magic = jump == 1 ? 0u : (uint32_t)(((1ull << 32) + (uint64_t)jump - 1) / (uint64_t)jump);   // 0: divide by 1
     a.head_dw = 4 * ((prm.no_bp + 63 + 63) / 64) + 4;      // whole quads of a step-1 head whatever its start offset, + look-ahead words
-    // fused kernels: compile-time slide, 16-bit masks (<= 15 patterns), a window spans at least one
+    // fused kernels: compile-time slide, 16-bit masks (<= 15 patterns: bit 15 is the self-overlap flag of the fallback tile, FLAG16 -- a table
+    // WITHOUT self-overlapping k-mers may use it as a sixteenth pattern, sums only: the 8-letter motifs at the reference's default
+    // k = len - 2, e.g. TTTTAGGG at k = 6; round 5), a window spans at least one
     // 8-block chunk and its far end lies within the exchange halo (XLANES - NT lanes)
     int max_period = 0;                            // self-overlap periods of the table (0 = none)
     for (int i = 0; i < a.pat.n_periods; ++i) max_period = std::max(max_period, a.pat.period[i]);
     const bool sw16_ok = (int64_t)P * ((a.lw + k - 1) / k + 1) < 65536;        // the fused kernels keep S_w in 16 bits
-    const bool fused = !force_generic && spans_pref <= 0 && k <= TPS_DIRECT_K && (has_specialised_slide(prm.slide) || (has_default_only_slide(prm.slide) && a.pat.so_mask == 0 && !(prm.flags & TPS_F_STORE_RAW))) && P <= 15 && a.q >= 8 && sw16_ok &&
+    // the table's ONE self-overlap period, if the chain-corrected sums tiles (tile_lc_s<.., CD>) take it: distinct k-mers, k >= 4, 2 d >= k
+    const int one_period = (a.pat.dup_mask == 0 && k >= 4 && a.pat.n_periods == 1 && a.pat.period[0] >= 2 && 2 * a.pat.period[0] >= k) ? a.pat.period[0] : 0;
+    // sixteen patterns (sums only, distinct k-mers): bit 15 of the 16-bit masks is the self-overlap FLAG of the fallback tile (FLAG16), so
+    // a sixteenth pattern fits where that tile cannot run -- a table without self-overlapping k-mers, or one the chain-corrected tiles take
+    // on a batch without non-ACGT letters (TTTTAGGG at k = 6: TAGGGT has period 5)
+    const bool p16_ok = P == 16 && a.pat.dup_mask == 0 && !(prm.flags & TPS_F_STORE_RAW) &&
+                        (a.pat.so_mask == 0 || (!a.val_on && one_period > 0 && one_period <= prm.slide && a.lw <= 255));
+    const bool fused = !force_generic && spans_pref <= 0 && k <= TPS_DIRECT_K && (has_specialised_slide(prm.slide) || (has_default_only_slide(prm.slide) && a.pat.so_mask == 0 && !(prm.flags & TPS_F_STORE_RAW))) &&
+                       (P <= 15 || p16_ok) && a.q >= 8 && sw16_ok &&
                        a.q / 8 + 2 < (XLANES - NT) && max_period <= std::min(prm.slide, 6) &&
                        2 * a.head_dw <= fused_seq_dw(prm.slide);   // the two step-1 heads fit the tile buffer (TileGeo::SEQ)
     a.lc16 = 0; a.tile_cap = 0; a.tw = 0; a.tw_magic = 0; a.pair_n = 0; a.lc_global = 0; a.lc_stride = 0; a.pp_d = -1; a.so_fast = 0; a.seq_alias = 0; a.lut_fields = 0; a.tile_full = 0;
@@ -219,6 +243,8 @@ inline std::string plan_geometry_core(ScanArgs& a, const tps_params& prm, int k,
                                a.lw / k + 2 <= 127;
         if (pp_counts && a.pat.n_periods == 0) a.pp_d = 0;
         if (pp_counts && a.pat.n_periods == 1 && a.pat.period[0] >= 2 && 2 * a.pat.period[0] >= k) a.pp_d = a.pat.period[0];
+        // (sums only: the chain-corrected tiles need the one period, not the per-pattern tiles' nibble and row-length limits)
+        if (!(prm.flags & TPS_F_STORE_RAW) && P > 14 && one_period > 0) a.pp_d = one_period;
         a.lut_fields = (a.pp_d >= 0 && (prm.flags & TPS_F_STORE_RAW)) ? 1 : 0;   // the per-pattern tiles will run: table of one-hot fields
         a.so_fast = kn.so_order == 2 ? 2 : 1;
         // the chain-corrected sums tiles (tile_lc_s<.., CD>) carry a window's matches and pairs as two 8-bit fields of one 16-bit

@@ -178,8 +178,14 @@ def process_file_multi(args, seq_loc, phrases, engines):
     if wthread is not None:
         wthread.start()
     ok = False
+    # one big plain file on several GPUs: cut into byte ranges, a reader team per range (batch.EnginePool.scan_file_jobs; per-read
+    # records only -- plots and raw rows keep one reader).  --shards N forces it (tests); the default cuts files of at least 256 MiB per GPU
+    n_shards = int(getattr(args, "shards", 0) or 0)
+    shard_min = 4096
+    if n_shards <= 0:
+        n_shards, shard_min = max(1, len({getattr(e, "device", 0) for e in engines})), 256 << 20
     try:
-        for pb, outs in pool.scan_file_jobs(seq_loc, jobs):
+        for pb, outs in pool.scan_file_jobs(seq_loc, jobs, shards=n_shards, shard_min_bytes=shard_min):
             for n, ((telo_phrase, pattern, sliding_val), (res, sums, raw, win_off)) in enumerate(zip(phrases, outs)):
                 idx = np.nonzero(res["pass"])[0]
                 if wthread is not None and len(idx) and n == writer_k:
@@ -241,6 +247,8 @@ def process_file_multi(args, seq_loc, phrases, engines):
     if out_handle is not None:
         tprint(f"Temporary fasta file with TRC more than {min_cutoff}:", fasta_temp)
     st = pool.stats
+    if st.get("shards", 0) > 1:
+        tprint(f"{base_name}: read as {st['shards']} byte ranges, one reader team each")
     if st["heads_batches"]:
         tprint(f"{base_name}: {st['heads_batches']} of {st['batches']} batches scanned in two passes (read ends first, then the reads that pass): "
                f"{st['upload_bytes']} bytes uploaded for {st['input_bases']} bases")
@@ -460,6 +468,9 @@ def build_parser():
     # MI355X build only
     parser.add_argument("--gpus", metavar="INT", type=int, default=1, help="GPUs of this node to shard reads over")
     parser.add_argument("--device", metavar="INT", type=int, default=0, help="index of the first GPU to use")
+    parser.add_argument("--shards", metavar="INT", type=int, default=0,
+                        help="MI355X build: cut ONE plain input file into this many byte ranges, each decoded by a reader thread team of its own "
+                             "(0 = one per GPU when the file has at least 256 MiB per GPU; compressed files keep one reader)")
     parser.add_argument("--twopass", choices=["auto", "on", "off"], default=None,
                         help="MI355X build: upload only the two 1000-base ends of every read for the TRC filter and the scanned part of the "
                              "reads that pass afterwards (auto, the default unless $TOPSICLE_TWO_PASS says otherwise: while few reads of a batch pass, "

@@ -179,6 +179,8 @@ _io_lib = None
 IO_EXPORTS = {
     "tps_io_last_error": ("c_char_p", []),
     "tps_reader_open": ("c_int", ["c_char_p", "POINTER(c_void_p)"]),
+    "tps_reader_open_range": ("c_int", ["c_char_p", "c_int64", "c_int64", "c_int32", "POINTER(c_void_p)"]),
+    "tps_reader_range_info": ("c_int", ["c_void_p", "POINTER(c_int64)", "POINTER(c_int64)"]),
     "tps_reader_format": ("c_int", ["c_void_p"]),
     "tps_reader_close": (None, ["c_void_p"]),
     "tps_reader_next": ("c_int64", ["c_void_p", "c_void_p", "c_int64", "c_void_p", "c_int64", "c_void_p", "c_int64", "c_void_p", "c_void_p"]),
@@ -463,6 +465,20 @@ class PackedBatch:
         q = self.qual_bytes(i)
         return Record(_first_token(d), d, self.seq_bytes(i).decode("ascii", "replace"), None if q is None else q.decode("ascii", "replace"))
 
+    def _drop_text_pages(self, text_arr):
+        """After this batch's records have been written from the MAPPED input file: its stretch of the mapping leaves the resident
+        set (the page cache keeps the data; nothing reads this batch's text again) -- a 3 GB plain input no longer sits in RSS."""
+        import mmap
+        if not isinstance(self.text, mmap.mmap) or self.spans is None or not len(self.spans) or not hasattr(mmap, "MADV_DONTNEED"):
+            return
+        lo = int(self.spans[0][0]) & ~(mmap.PAGESIZE - 1)
+        hi = int(self.spans[-1][0]) & ~(mmap.PAGESIZE - 1)              # (up to the last record's header: the next batch may share that page)
+        if hi > lo:
+            try:
+                self.text.madvise(mmap.MADV_DONTNEED, lo, hi - lo)
+            except (OSError, ValueError):
+                pass
+
     def write_records(self, handle, indices, fmt: str):
         """Write the given records to a BINARY handle in the layout Biopython's SeqIO.write produces (main.py:84-86).  Records
         of a batch that was packed straight from a mmap'ed plain FASTQ file leave through the native writer: writev from the
@@ -483,6 +499,7 @@ class PackedBatch:
                 got = lib.tps_write_fastq_spans(fd, text.ctypes.data, len(text), spans.ctypes.data, lens.ctypes.data, idx.ctypes.data, len(idx))
                 if got < 0:
                     raise OSError(lib.tps_io_last_error().decode())
+                self._drop_text_pages(text)
                 return
         out = []
         for i in indices:
@@ -562,12 +579,36 @@ def pack_spans(pb: "PackedBatch", idx, tails, maxlen: int):
     return seq2[:got], inv[:got], desc
 
 
-def read_batches_packed(filepath: str, pool: BufferPool, max_records: int = 1 << 20, heads_bp=0, first_batch_records: int = 0):
+def shard_ranges(filepath: str, n_shards: int, min_bytes: int = 64 << 20):
+    """Byte ranges [(lo, hi), ...] that cut a PLAIN (uncompressed) FASTA / FASTQ file into at most n_shards readers of at least
+    min_bytes each (read_batches_packed(byte_range=...): a record belongs to the range its first byte lies in), or None when the file
+    cannot be cut: compressed (gzip / BGZF: one inflating reader), too small, unreadable."""
+    import os
+    try:
+        size = os.path.getsize(filepath)
+        with open(filepath, "rb") as fh:
+            magic = fh.read(2)
+    except OSError:
+        return None
+    if magic == b"\x1f\x8b" or n_shards < 2:
+        return None
+    n = min(int(n_shards), max(1, size // max(int(min_bytes), 1)))
+    if n < 2:
+        return None
+    cuts = [size * i // n for i in range(n + 1)]
+    return list(zip(cuts[:-1], cuts[1:]))
+
+
+def read_batches_packed(filepath: str, pool: BufferPool, max_records: int = 1 << 20, heads_bp=0, first_batch_records: int = 0,
+                        byte_range=None, threads: int = 0, range_info=None):
     """Generator of PackedBatch over a FASTA/FASTQ(.gz) file.  Plain FASTQ is packed straight from the mmap'ed file by
     the native thread team (no ASCII copy, qualities untouched); other inputs are decoded to ASCII batches first
     (read_batches) and packed by the same team.  Every batch owns one BufferSet of `pool` until `release()`.
     heads_bp (an int, or a callable asked before every batch): > 0 = heads mode, see PackedBatch.full_len.
-    first_batch_records > 0: the first batch holds at most that many records (a small probe: batch.EnginePool's auto mode)."""
+    first_batch_records > 0: the first batch holds at most that many records (a small probe: batch.EnginePool's auto mode).
+    byte_range = (lo, hi): only the records that START in that byte range of a plain file, decoded by a team of `threads` threads
+    (tps_reader_open_range: one reader per shard of one big file); range_info (a dict) receives "first" / "stopped" when the range is
+    exhausted -- the caller checks the seams (shard i stopped where shard i + 1 began)."""
     import ctypes as C
     import mmap
     import numpy as np
@@ -575,7 +616,10 @@ def read_batches_packed(filepath: str, pool: BufferPool, max_records: int = 1 <<
     if lib is None:
         raise RuntimeError("libtopsicle_io.so is not built (python -c 'import __graft_entry__ as g; g.build()')")
     h = C.c_void_p()
-    if lib.tps_reader_open(filepath.encode(), C.byref(h)) != 0:
+    if byte_range is not None:
+        if lib.tps_reader_open_range(filepath.encode(), int(byte_range[0]), int(byte_range[1]), int(threads), C.byref(h)) != 0:
+            raise RuntimeError("cannot read %s by byte ranges: %s" % (filepath, lib.tps_io_last_error().decode()))
+    elif lib.tps_reader_open(filepath.encode(), C.byref(h)) != 0:
         logging.error("Error parsing file: %s", lib.tps_io_last_error().decode())
         return
     fh = mm = None
@@ -652,5 +696,9 @@ def read_batches_packed(filepath: str, pool: BufferPool, max_records: int = 1 <<
             seq2, inv, desc = pack_reads_host(rb.bases, rb.offsets, out=(bs.seq2, bs.inv, bs.desc))
             yield PackedBatch(seq2, inv, desc, np.frombuffer(rb.heads, np.uint8), rb.head_off, fmt, ascii_batch=rb, bufset=bs, pool=pool)
     finally:
+        if range_info is not None and byte_range is not None:
+            a, b = C.c_int64(0), C.c_int64(0)
+            if lib.tps_reader_range_info(h, C.byref(a), C.byref(b)) == 0:
+                range_info["first"], range_info["stopped"] = a.value, b.value
         lib.tps_reader_close(h)
         # (the mapping stays alive as long as a yielded batch references it)
