@@ -164,6 +164,8 @@ def process_file_multi(args, seq_loc, phrases, engines):
     wq: "queue.Queue" = queue.Queue(maxsize=4)
     werr = []
 
+    wstat = {"write_s": 0.0, "blocked_s": 0.0, "records": 0}             # where the filtered file's time goes (logged below)
+
     def writer():
         while True:
             item = wq.get()
@@ -171,7 +173,10 @@ def process_file_multi(args, seq_loc, phrases, engines):
                 return
             try:
                 if not werr:
+                    t0 = time.perf_counter()
                     item[0].write_records(out_handle, item[1], fmt)
+                    wstat["write_s"] += time.perf_counter() - t0
+                    wstat["records"] += len(item[1])
             except BaseException as e:                                     # surfaces in the main thread below
                 werr.append(e)
     wthread = threading.Thread(target=writer, daemon=True) if out_handle is not None else None
@@ -189,7 +194,9 @@ def process_file_multi(args, seq_loc, phrases, engines):
             for n, ((telo_phrase, pattern, sliding_val), (res, sums, raw, win_off)) in enumerate(zip(phrases, outs)):
                 idx = np.nonzero(res["pass"])[0]
                 if wthread is not None and len(idx) and n == writer_k:
+                    t0 = time.perf_counter()
                     wq.put((pb, idx))                                        # every passing record (main.py:83-86)
+                    wstat["blocked_s"] += time.perf_counter() - t0
                 ids = [pb.read_id(int(i)) for i in idx]
                 if args.read_check:
                     keep = [j for j, rid in enumerate(ids) if rid == args.read_check]
@@ -246,6 +253,10 @@ def process_file_multi(args, seq_loc, phrases, engines):
             w.finish()
     if out_handle is not None:
         tprint(f"Temporary fasta file with TRC more than {min_cutoff}:", fasta_temp)
+        if wstat["write_s"] > 0.05:                 # (big outputs only: what bounds a run that rewrites most of its input)
+            nbytes = os.path.getsize(fasta_temp)
+            tprint(f"{base_name}: {wstat['records']} passing records, {nbytes} bytes written in {wstat['write_s']:.2f} s on the writer thread "
+                   f"({nbytes / wstat['write_s'] / 1e9:.2f} GB/s); the scan loop waited {wstat['blocked_s']:.2f} s for it")
     st = pool.stats
     if st.get("shards", 0) > 1:
         tprint(f"{base_name}: read as {st['shards']} byte ranges, one reader team each")
