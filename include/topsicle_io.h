@@ -80,6 +80,11 @@ int64_t tps_pack_reads(const uint8_t* bases, const int64_t* offsets, int64_t n, 
 /* The records idx[0 .. n) of a packed FASTQ batch to `fd` in SeqIO.write's layout (main.py:83-86): writev straight from the
  * text the spans point into.  Returns the bytes written or -1. */
 int64_t tps_write_fastq_spans(int fd, const char* text, int64_t text_len, const int64_t* spans, const int32_t* lens, const int64_t* idx, int64_t n);
+/* The same at an explicit file offset (pwritev; several threads write different batches of one file at once) and the bytes a set
+ * of records takes there: header + 2 x bases + 6 each, whatever the input's line layout. */
+int64_t tps_write_fastq_spans_at(int fd, int64_t file_off, const char* text, int64_t text_len, const int64_t* spans, const int32_t* lens,
+                                 const int64_t* idx, int64_t n);
+int64_t tps_fastq_spans_bytes(const int64_t* spans, const int32_t* lens, const int64_t* idx, int64_t n);
 /* zlib's crc32(crc, p, n) by carry-less multiplication (the checksum callback of tps_batch_raw_to_fd) and crc32_combine. */
 uint32_t tps_crc32(uint32_t crc, const uint8_t* p, int64_t n);
 uint32_t tps_crc32_combine(uint32_t crc1, uint32_t crc2, int64_t len2);

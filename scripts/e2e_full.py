@@ -198,7 +198,7 @@ def run_cli(path, outdir, cfg, device):
     log = os.path.join(outdir, "topsicle_run.log")
     if os.path.exists(log):
         d["two_pass_line"] = [ln.strip() for ln in open(log) if "two passes" in ln][:1]
-        d["writer_line"] = [ln.strip().split("] ", 1)[-1] for ln in open(log) if "on the writer thread" in ln][:3]     # where the filtered file's time went
+        d["writer_line"] = [ln.strip().split("] ", 1)[-1] for ln in open(log) if "writer thread" in ln][:3]     # where the filtered file's time went
         d["shards_line"] = [ln.strip().split("] ", 1)[-1] for ln in open(log) if "byte ranges" in ln][:1]
     return d
 

@@ -50,6 +50,10 @@ def test_reader_and_packer_under_asan_ubsan():
     lib = _build_io_asan()
     out = _run_under_sanitizers(["tests/test_seqio_native.py"], {"TOPSICLE_IO_LIB": lib})
     assert " passed" in out and "skipped" not in out.split("passed")[-1]
+    # round 5: byte-range readers (plain and BGZF), concurrent thread-team pools, the offset-based record writer
+    # (the reader-level tests: the CLI-level ones import matplotlib, whose C++ exceptions a preloaded libasan cannot intercept)
+    out = _run_under_sanitizers(["tests/test_shards.py", "-k", "seams or odd_records or bgzf_readers"], {"TOPSICLE_IO_LIB": lib})
+    assert " passed" in out
 
 
 def test_parallel_gzip_inflater_under_asan_ubsan():

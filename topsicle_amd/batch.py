@@ -313,7 +313,8 @@ class EnginePool:
         same time (seqio.shard_ranges / tps_reader_open_range), all of them feeding this pool's contexts; batches come back in FILE
         order.  The reference tells users to split a file of "> 20 GB and / or > 1 million reads" by hand and run the pieces
         (README.md:267-268; its unit of parallelism is the file: main.py:232-235).  Only jobs whose results are per-read records
-        (no window sums / raw rows handed back, no raw sink: those are laid out in batch order); compressed files keep one reader."""
+        (no window sums / raw rows handed back, no raw sink: those are laid out in batch order); a BGZF file is cut at block boundaries,
+        an ordinary .gz (one deflate stream) keeps one reader."""
         from . import seqio
         max_bases = max_bases or BATCH_BASES
         words_cap = max(max_bases // 16, 1024)
@@ -346,11 +347,14 @@ class EnginePool:
         yield from self._run(sources, jobs, pool, hm)
         # the seams: reader i must have stopped exactly where reader i + 1 found its first record (a FASTQ record start inside a
         # range is recognised by its framing -- a heuristic only there; a mismatch means records were lost or read twice)
-        for i in range(n - 1):
-            a, b = infos[i].get("stopped"), infos[i + 1].get("first")
-            if a is None or b is None or a != b:
-                raise RuntimeError(f"{filepath}: shard {i} stopped at byte {a}, shard {i + 1} began at byte {b}: the file cannot be read by byte "
-                                   f"ranges (records with unusual line layout around the cut); rerun with one reader (--shards 1)")
+        # (a range in which no record / no block starts reports -2 and drops out of the chain: its neighbours are adjacent)
+        live = [(i, d) for i, d in enumerate(infos) if d.get("first", -2) != -2]
+        if any("first" not in d for d in infos):
+            raise RuntimeError(f"{filepath}: a shard's reader did not finish; rerun with one reader (--shards 1)")
+        for (i, da), (j, db) in zip(live, live[1:]):
+            if da.get("stopped") != db.get("first"):
+                raise RuntimeError(f"{filepath}: shard {i} stopped at {da.get('stopped')}, shard {j} began at {db.get('first')}: the file cannot be read by "
+                                   f"byte ranges (records with unusual line layout around the cut); rerun with one reader (--shards 1)")
 
     @staticmethod
     def _probe_records(hm):

@@ -290,9 +290,11 @@ void team(int nthreads, F f) {                 // f(thread index, thread count);
 
 // A compressed input whose text arrives group by group: read_group() appends the next stretch of text to `out` (about `want`
 // bytes), inflated with the thread team.
+struct Bgzf;
 struct TextSource {
     bool failed = false;
     virtual ~TextSource() {}
+    virtual Bgzf* as_bgzf() { return nullptr; }
     virtual bool read_group(gzpar::TextBuf& out, size_t want) = 0;
     virtual bool eof() const = 0;
 };
@@ -304,6 +306,24 @@ struct Bgzf : TextSource {
     const uint8_t* data = nullptr;
     size_t size = 0, cpos = 0;
     int threads = 1;
+    // byte ranges (tps_reader_open_range on a BGZF file): the blocks that start in [cpos at open, own_end) are this reader's; the text
+    // behind them (the next reader's blocks) is only inflated to complete the last record.  own_text = bytes of text the own blocks
+    // hold, known once the reader has come to own_end (a group of blocks never straddles it).
+    size_t own_end = (size_t)-1;
+    uint64_t text_total = 0, own_text = ~0ull;
+    Bgzf* as_bgzf() override { return this; }
+    // first offset >= from where a BGZF block starts that is followed by another block (or the end of the file): compressed data can
+    // hold the magic bytes by chance, two chained headers with consistent sizes it does not
+    static size_t find_block(const uint8_t* d, size_t n, size_t from) {
+        for (size_t p = from; p + 18 <= n; ++p) {
+            if (d[p] != 0x1f || d[p + 1] != 0x8b) continue;
+            size_t bs = 0, hd = 0;
+            if (!block_at(d + p, n - p, bs, hd)) continue;
+            size_t bs2 = 0, hd2 = 0;
+            if (p + bs == n || block_at(d + p + bs, n - p - bs, bs2, hd2)) return p;
+        }
+        return n;
+    }
     ~Bgzf() override {
         if (data) munmap((void*)data, size);
         if (fd >= 0) close(fd);
@@ -330,6 +350,10 @@ struct Bgzf : TextSource {
         std::vector<Blk> blks;
         size_t total = 0;
         while (cpos < size && total < want) {
+            if (cpos >= own_end && own_text == ~0ull) {         // the next reader's first block: the own text ends here, and so does this group
+                own_text = text_total + total;
+                if (total) break;
+            }
             size_t bsize = 0, hdr = 0;
             if (!block_at(data + cpos, size - cpos, bsize, hdr)) { g_err = "not a BGZF block (file truncated or mixed gzip members)"; failed = true; return false; }
             const uint8_t* tail = data + cpos + bsize - 8;
@@ -368,6 +392,7 @@ struct Bgzf : TextSource {
         });
         for (int x : bad)
             if (x) { g_err = "BGZF block failed to inflate (corrupt file)"; failed = true; return false; }
+        text_total += total;
         return true;
     }
 };
@@ -427,6 +452,17 @@ struct Fast {
     size_t size = 0;
     size_t pos = 0;                            // start of the first unconsumed record
     size_t limit = (size_t)-1;                 // byte ranges (tps_reader_open_range): records that START at or behind this offset are not this reader's
+    // ... of a BGZF file: a record belongs to the reader whose text holds the line end in front of it, i.e. it starts at a text
+    // offset in [1, own_text] of the reader's own blocks (the first reader also owns offset 0); first_abs = where the first one began
+    bool bgzf_range = false, bgzf_first = false;
+    int64_t first_abs = -2;
+    size_t eff_limit() const {
+        if (!bgzf_range) return limit;
+        if (limit == 0) return 0;                                           // (an empty range)
+        Bgzf* z = src ? src->as_bgzf() : nullptr;
+        if (!z || z->own_text == ~0ull) return (size_t)-1;
+        return z->own_text + 1 > base_off ? (size_t)(z->own_text + 1 - base_off) : 0;
+    }
     std::vector<uint64_t> nl;                  // newline offsets of the indexed window, ascending
     size_t nl_i = 0;                           // first unconsumed entry of nl
     size_t win_hi = 0;                         // end of the indexed window
@@ -476,6 +512,13 @@ struct Fast {
         if (!lazy) return;
         lazy = false;
         index_window();                                  // first group of blocks; leading blank lines skipped like the streaming decoder does
+        if (bgzf_range && !bgzf_first) {
+            // a later range of a BGZF file: its text begins somewhere inside a record -- the first line start that opens one
+            pos = limit == 0 ? size : first_record_from(1, size);
+            first_abs = pos < size ? (int64_t)(base_off + pos) : -2;
+        } else if (bgzf_range) {
+            first_abs = 0;
+        }
         while (pos < size && (data[pos] == '\n' || data[pos] == '\r' || data[pos] == ' ')) ++pos;
         if (pos && want_lines) index_lines();
     }
@@ -776,9 +819,10 @@ struct Fast {
         nl.clear(); nl_i = 0; whole = false;       // (the line index of next() is not used here and is stale afterwards)
         const double t_a = io_timing() ? now_s() : 0.0;
         const size_t p = pos;
-        if (p >= size || p >= limit || only_blank(p)) return 0;
+        const size_t lim = eff_limit();
+        if (p >= size || p >= lim || only_blank(p)) return 0;
         // text that yields at most words_cap words if it were nothing but sequence + quality lines
-        size_t span = std::min<size_t>(std::min(size, limit) - p, (size_t)std::max<int64_t>(words_cap, 1024) * (fasta ? 17 : 32));      // (FASTA: no quality lines; a record that starts before `limit` is decoded to its end)
+        size_t span = std::min<size_t>(std::min(size, lim) - p, (size_t)std::max<int64_t>(words_cap, 1024) * (fasta ? 17 : 32));      // (FASTA: no quality lines; a record that starts before `limit` is decoded to its end)
         const size_t min_span = g_opt.pack_min_span.load() >= 0 ? (size_t)g_opt.pack_min_span.load() : (size_t)4 << 20;   // (tests: team on small files)
         const int T = span < min_span ? 1 : threads;
         if (chunks.empty()) take_spare();
@@ -1121,14 +1165,29 @@ int tps_reader_open_range(const char* path, int64_t lo, int64_t hi, int32_t thre
     if (tps_reader_open(path, out) != 0) return -1;
     Handle* h = (Handle*)*out;
     if (!h->format) return 0;                                                // an empty file
-    if (!h->fast || h->fast->src) { g_err = "byte ranges need a plain (uncompressed) FASTA / FASTQ file"; delete h; *out = nullptr; return -1; }
+    if (h->fast && h->fast->src && h->fast->src->as_bgzf()) {
+        // BGZF: the range is one of COMPRESSED bytes; the reader owns the blocks that start in it
+        Fast* f = h->fast;
+        Bgzf* z = f->src->as_bgzf();
+        if (threads > 0) { f->threads = std::min(threads, 64); z->threads = f->threads; }
+        const size_t lo_c = std::min<size_t>((size_t)lo, z->size), hi_c2 = std::min<size_t>((size_t)hi, z->size);
+        z->cpos = lo_c == 0 ? 0 : Bgzf::find_block(z->data, z->size, lo_c);
+        z->own_end = hi_c2 >= z->size ? z->size : Bgzf::find_block(z->data, z->size, hi_c2);
+        f->bgzf_range = true;
+        f->bgzf_first = lo_c == 0;
+        if (z->cpos >= z->own_end) f->limit = 0;                             // no block starts in this range
+        h->limit = (int64_t)hi_c2;
+        h->first = -2;
+        return 0;
+    }
+    if (!h->fast || h->fast->src) { g_err = "byte ranges need a plain or BGZF-compressed FASTA / FASTQ file (an ordinary .gz is one stream)"; delete h; *out = nullptr; return -1; }
     Fast* f = h->fast;
     if (threads > 0) f->threads = std::min(threads, 64);
     const size_t hi_c = std::min<size_t>((size_t)hi, f->size);
     if (lo > 0) f->pos = f->first_record_from(std::min<size_t>((size_t)lo, f->size), hi_c);
     f->limit = hi_c;
     h->limit = (int64_t)hi_c;
-    h->first = (int64_t)std::min(f->pos, hi_c);
+    h->first = f->pos < hi_c ? (int64_t)f->pos : -2;                        // -2: no record starts in this range
     return 0;
 }
 int tps_reader_range_info(void* hv, int64_t* first, int64_t* stopped) {
@@ -1136,6 +1195,17 @@ int tps_reader_range_info(void* hv, int64_t* first, int64_t* stopped) {
     if (!h || !first || !stopped) { g_err = "null argument"; return -1; }
     *first = h->first;
     int64_t at = 0;
+    if (h->fast && h->fast->bgzf_range) {
+        // BGZF: `first` counts from the start of the reader's own text, `stopped` from its END (= the start of the next reader's text)
+        Fast* f = h->fast;
+        if (f->lazy && f->limit != 0) f->first_window();
+        *first = f->first_abs;
+        Bgzf* z = f->src->as_bgzf();
+        size_t p = f->pos;
+        while (p < f->size && (f->data[p] == '\n' || f->data[p] == '\r' || f->data[p] == ' ')) ++p;
+        *stopped = (f->limit == 0 || z->own_text == ~0ull) ? -2 : (int64_t)(f->base_off + p) - (int64_t)z->own_text;
+        return 0;
+    }
     if (h->fast) {
         size_t p = h->fast->pos;
         while (p < h->fast->size && (h->fast->data[p] == '\n' || h->fast->data[p] == '\r' || h->fast->data[p] == ' ')) ++p;     // (blank lines between records are nobody's)
@@ -1166,6 +1236,10 @@ int64_t tps_reader_next(void* hv, uint8_t* bases, int64_t bases_cap, int64_t* of
     offsets[0] = 0;
     head_off[0] = 0;
     if (!h->format) return 0;
+    if (h->fast && h->fast->bgzf_range) {
+        g_err = "records the thread-team decoder does not take inside a BGZF byte range: read this file with one reader";
+        return -1;
+    }
     if (h->fast) {
         // (a byte-range reader's ASCII batches come from the streaming decoder, which knows where every record begins)
         const int64_t n = h->limit >= 0 ? -3 : h->fast->next(bases, bases_cap, offsets, max_records, heads, heads_cap, head_off, quals);
@@ -1243,7 +1317,7 @@ static int64_t reader_next_packed(void* hv, uint32_t* seq2, uint16_t* inv, int64
     // compressed input: the window ends in an incomplete record (or is used up) while the source has more -- the next group
     // of blocks is inflated into a new window behind the unconsumed tail.  (An unconsumed stretch longer than any record that
     // yields nothing is not an incomplete record: the streaming decoder judges it.)
-    while (f->src && (n == 0 || n == -3) && !f->src->eof() && !f->src->failed && f->size - f->pos < ((size_t)64 << 20)) {
+    while (f->src && (n == 0 || n == -3) && !f->src->eof() && !f->src->failed && f->size - f->pos < ((size_t)64 << 20) && f->pos < f->eff_limit()) {
         f->fill_target = (size_t)std::max<int64_t>(words_cap, 1024) * 32 + (f->size - f->pos);
         f->index_window();
         if (f->src->failed) return -1;
@@ -1422,7 +1496,26 @@ uint32_t tps_crc32_combine(uint32_t crc1, uint32_t crc2, int64_t len2) { return 
 // quality offset; lens: bases per record), a record whose text already has that layout is one iovec, and neighbouring
 // records that are neighbours in the file merge into one.  Replaces the per-record Python loop of the round-2 writer
 // (0.1 s per 300 MB, the largest part of the CLI's per-read time).  Returns the bytes written or -1.
+static int64_t write_fastq_spans(int fd, int64_t file_off, const char* text, int64_t text_len, const int64_t* spans, const int32_t* lens, const int64_t* idx, int64_t n);
 int64_t tps_write_fastq_spans(int fd, const char* text, int64_t text_len, const int64_t* spans, const int32_t* lens, const int64_t* idx, int64_t n) {
+    return write_fastq_spans(fd, -1, text, text_len, spans, lens, idx, n);
+}
+// The same at an explicit file offset (pwritev: the descriptor's position is not used), so that several threads write different
+// batches of one filtered file at the same time; a record always takes header + 2 x bases + 6 bytes there (tps_fastq_spans_bytes),
+// whatever the input's line layout was.  BASELINE configs[3]'s shard rewrites 7.5 GB of passing records: one writev thread at
+// 4.9 - 6.5 GB/s was what the run waited for (round 5).
+int64_t tps_write_fastq_spans_at(int fd, int64_t file_off, const char* text, int64_t text_len, const int64_t* spans, const int32_t* lens,
+                                 const int64_t* idx, int64_t n) {
+    if (file_off < 0) { g_err = "negative file offset"; return -1; }
+    return write_fastq_spans(fd, file_off, text, text_len, spans, lens, idx, n);
+}
+int64_t tps_fastq_spans_bytes(const int64_t* spans, const int32_t* lens, const int64_t* idx, int64_t n) {
+    if (!spans || !lens || (n > 0 && !idx)) { g_err = "null argument"; return -1; }
+    int64_t total = 0;
+    for (int64_t j = 0; j < n; ++j) total += spans[4 * idx[j] + 1] + 2 * (int64_t)lens[idx[j]] + 6;     // "@" head "\n" seq "\n+\n" qual "\n"
+    return total;
+}
+static int64_t write_fastq_spans(int fd, int64_t file_off, const char* text, int64_t text_len, const int64_t* spans, const int32_t* lens, const int64_t* idx, int64_t n) {
     if (fd < 0 || !text || !spans || !lens || (n > 0 && !idx)) { g_err = "null argument"; return -1; }
     static const char at = '@', nl = '\n', plus[3] = {'\n', '+', '\n'};
     std::vector<struct iovec> iov;
@@ -1432,7 +1525,7 @@ int64_t tps_write_fastq_spans(int fd, const char* text, int64_t text_len, const 
         size_t first = 0;
         while (first < iov.size()) {
             const int cnt = (int)std::min<size_t>(iov.size() - first, 1024);
-            ssize_t w = writev(fd, iov.data() + first, cnt);
+            ssize_t w = file_off < 0 ? writev(fd, iov.data() + first, cnt) : pwritev(fd, iov.data() + first, cnt, (off_t)(file_off + total));
             if (w < 0) { if (errno == EINTR) continue; g_err = std::string("writev: ") + strerror(errno); return false; }
             total += w;
             size_t left = (size_t)w;                               // partial writes: advance inside the vector

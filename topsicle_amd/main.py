@@ -25,6 +25,9 @@ from . import allsteps, batch, hiplib, rawnpz, seqio
 version_number = "1.0.0"
 Topsicle_output_prefix = "Topsicle"
 CONTEXTS_PER_GPU = 2
+WRITER_THREADS = 1                # threads that write the passing records (native FASTQ writer, pwritev at offsets known up front).  Three were measured
+                                  # (round 5, configs[3]'s shard: 7.5 GB of records): buffered writes into ONE file serialise on the inode, three threads
+                                  # reach 1.4 - 2.0 GB/s each where one reaches 4.9 - 6.5 -- 1.68 -> 2.30 s (.gz), 1.50 -> 2.07 s (BGZF); one it is
 LAST_TIMINGS = {}                 # seconds of the last analysis_run: reads (step 1 + 2 + outputs) / summary (fit + PNG); bench.py's e2e leg reads it
 PLOT_THREADS = []                 # quadratic-fit PNGs being rendered off the critical path (summarize); wait_for_plots() joins them
 
@@ -159,44 +162,67 @@ def process_file_multi(args, seq_loc, phrases, engines):
     image_num = [1] * len(phrases)
     csv_path = f"{args.outputDir}/telolengths_all.csv"
     pool = batch.EnginePool(engines, two_pass=getattr(args, "twopass", None))
-    # the passing records are written by a helper thread, batch by batch in file order, while the next batches are scanned
-    # (the native writer releases the GIL: writev straight from the mapped input)
-    wq: "queue.Queue" = queue.Queue(maxsize=4)
+    # the passing records are written by a helper thread while the next batches are scanned (the native writer releases the GIL:
+    # pwritev straight from the mapped input).  Round 5: every batch whose records leave through the native writer gets its place in
+    # the file up front (a record takes header + 2 x bases + 6 bytes), so the writes need no order -- several threads could write
+    # different batches at once; measured, they do not pay (WRITER_THREADS above).  BASELINE configs[3]'s shard rewrites 7.5 GB: that
+    # one thread at 5 - 6 GB/s is what the run waits for.  Batches of other kinds (FASTA, ASCII batches) are written in order, after
+    # everything before them has landed.
+    wq: "queue.Queue" = queue.Queue(maxsize=2 * WRITER_THREADS + 2)
     werr = []
-
     wstat = {"write_s": 0.0, "blocked_s": 0.0, "records": 0}             # where the filtered file's time goes (logged below)
+    wlock = threading.Lock()
+    out_off = [0]                                                         # bytes of the filtered file given out so far
 
     def writer():
         while True:
             item = wq.get()
-            if item is None:
-                return
             try:
+                if item is None:
+                    return
                 if not werr:
                     t0 = time.perf_counter()
-                    item[0].write_records(out_handle, item[1], fmt)
-                    wstat["write_s"] += time.perf_counter() - t0
-                    wstat["records"] += len(item[1])
+                    item[0].write_records(out_handle, item[1], fmt, offset=item[2])
+                    with wlock:
+                        wstat["write_s"] += time.perf_counter() - t0
+                        wstat["records"] += len(item[1])
             except BaseException as e:                                     # surfaces in the main thread below
                 werr.append(e)
-    wthread = threading.Thread(target=writer, daemon=True) if out_handle is not None else None
-    if wthread is not None:
-        wthread.start()
-    ok = False
+            finally:
+                wq.task_done()
+    wthreads = [threading.Thread(target=writer, daemon=True) for _ in range(WRITER_THREADS)] if out_handle is not None else []
+    for t in wthreads:
+        t.start()
+    wthread = wthreads[0] if wthreads else None
+
+    def write_passing(pb, idx):
+        nbytes = pb.native_fastq_bytes(idx, fmt)
+        t0 = time.perf_counter()
+        if nbytes is not None:
+            wq.put((pb, idx, out_off[0]))
+            out_off[0] += nbytes
+        else:
+            wq.join()                                  # an ordered write: everything before it has landed
+            out_handle.seek(out_off[0])
+            pb.write_records(out_handle, idx, fmt)
+            out_handle.flush()
+            out_off[0] = out_handle.tell()
+            wstat["records"] += len(idx)
+        wstat["blocked_s"] += time.perf_counter() - t0
+
     # one big plain file on several GPUs: cut into byte ranges, a reader team per range (batch.EnginePool.scan_file_jobs; per-read
     # records only -- plots and raw rows keep one reader).  --shards N forces it (tests); the default cuts files of at least 256 MiB per GPU
     n_shards = int(getattr(args, "shards", 0) or 0)
     shard_min = 4096
     if n_shards <= 0:
         n_shards, shard_min = max(1, len({getattr(e, "device", 0) for e in engines})), 256 << 20
+    ok = False
     try:
         for pb, outs in pool.scan_file_jobs(seq_loc, jobs, shards=n_shards, shard_min_bytes=shard_min):
             for n, ((telo_phrase, pattern, sliding_val), (res, sums, raw, win_off)) in enumerate(zip(phrases, outs)):
                 idx = np.nonzero(res["pass"])[0]
                 if wthread is not None and len(idx) and n == writer_k:
-                    t0 = time.perf_counter()
-                    wq.put((pb, idx))                                        # every passing record (main.py:83-86)
-                    wstat["blocked_s"] += time.perf_counter() - t0
+                    write_passing(pb, idx)                                   # every passing record (main.py:83-86)
                 ids = [pb.read_id(int(i)) for i in idx]
                 if args.read_check:
                     keep = [j for j, rid in enumerate(ids) if rid == args.read_check]
@@ -237,9 +263,10 @@ def process_file_multi(args, seq_loc, phrases, engines):
                 image_num[n] += len(idx)
         ok = True
     finally:
-        if wthread is not None:
+        for _ in wthreads:
             wq.put(None)
-            wthread.join()
+        for t in wthreads:
+            t.join()
         if out_handle is not None:
             out_handle.close()
         if not ok or werr:                                  # no half-written archive is left behind, whatever went wrong
@@ -255,8 +282,8 @@ def process_file_multi(args, seq_loc, phrases, engines):
         tprint(f"Temporary fasta file with TRC more than {min_cutoff}:", fasta_temp)
         if wstat["write_s"] > 0.05:                 # (big outputs only: what bounds a run that rewrites most of its input)
             nbytes = os.path.getsize(fasta_temp)
-            tprint(f"{base_name}: {wstat['records']} passing records, {nbytes} bytes written in {wstat['write_s']:.2f} s on the writer thread "
-                   f"({nbytes / wstat['write_s'] / 1e9:.2f} GB/s); the scan loop waited {wstat['blocked_s']:.2f} s for it")
+            tprint(f"{base_name}: {wstat['records']} passing records, {nbytes} bytes written in {wstat['write_s']:.2f} thread-seconds on {len(wthreads)} writer threads "
+                   f"({nbytes / wstat['write_s'] / 1e9:.2f} GB/s per thread); the scan loop waited {wstat['blocked_s']:.2f} s for them")
     st = pool.stats
     if st.get("shards", 0) > 1:
         tprint(f"{base_name}: read as {st['shards']} byte ranges, one reader team each")

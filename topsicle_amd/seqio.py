@@ -195,6 +195,8 @@ IO_EXPORTS = {
     "tps_packed_words_total": ("c_int64", ["c_void_p", "c_int64"]),
     "tps_pack_reads": ("c_int64", ["c_void_p", "c_void_p", "c_int64", "c_void_p", "c_void_p", "c_void_p", "c_int32"]),
     "tps_write_fastq_spans": ("c_int64", ["c_int", "c_void_p", "c_int64", "c_void_p", "c_void_p", "c_void_p", "c_int64"]),
+    "tps_write_fastq_spans_at": ("c_int64", ["c_int", "c_int64", "c_void_p", "c_int64", "c_void_p", "c_void_p", "c_void_p", "c_int64"]),
+    "tps_fastq_spans_bytes": ("c_int64", ["c_void_p", "c_void_p", "c_void_p", "c_int64"]),
     "tps_crc32": ("c_uint32", ["c_uint32", "c_void_p", "c_int64"]),
     "tps_crc32_combine": ("c_uint32", ["c_uint32", "c_uint32", "c_int64"]),
     "tps_io_set_option": ("c_int", ["c_char_p", "c_int64"]),
@@ -479,10 +481,22 @@ class PackedBatch:
             except (OSError, ValueError):
                 pass
 
-    def write_records(self, handle, indices, fmt: str):
+    def native_fastq_bytes(self, indices, fmt: str):
+        """Bytes the native writer puts out for these records (header + 2 x bases + 6 each), or None when this batch does not leave
+        through it (FASTA, ASCII batches): the caller can then give every batch its place in the file up front and let several
+        threads write at once (write_records(..., offset))."""
+        import numpy as np
+        if not (fmt == "fastq" and self.fmt == "fastq" and self.spans is not None and self.text is not None) or _load_io() is None:
+            return None
+        idx = np.ascontiguousarray(indices, dtype=np.int64)
+        lens = (self.desc["len"] if self.full_len is None else self.full_len).astype(np.int64)
+        return int((np.asarray(self.spans)[idx, 1] + 2 * lens[idx] + 6).sum())
+
+    def write_records(self, handle, indices, fmt: str, offset=None):
         """Write the given records to a BINARY handle in the layout Biopython's SeqIO.write produces (main.py:84-86).  Records
         of a batch that was packed straight from a mmap'ed plain FASTQ file leave through the native writer: writev from the
-        mapping, no copy in user space (tps_write_fastq_spans)."""
+        mapping, no copy in user space (tps_write_fastq_spans).  offset (native path only: native_fastq_bytes is not None): write
+        at that byte of the file whatever the handle's position (pwritev) -- several threads, one file."""
         import numpy as np
         if fmt == "fastq" and self.fmt == "fastq" and self.spans is not None and self.text is not None and len(indices):
             lib = _load_io()
@@ -496,11 +510,16 @@ class PackedBatch:
                 idx = np.ascontiguousarray(indices, dtype=np.int64)
                 lens = np.ascontiguousarray(self.desc["len"] if self.full_len is None else self.full_len, dtype=np.int32)
                 spans = np.ascontiguousarray(self.spans, dtype=np.int64)
-                got = lib.tps_write_fastq_spans(fd, text.ctypes.data, len(text), spans.ctypes.data, lens.ctypes.data, idx.ctypes.data, len(idx))
+                if offset is None:
+                    got = lib.tps_write_fastq_spans(fd, text.ctypes.data, len(text), spans.ctypes.data, lens.ctypes.data, idx.ctypes.data, len(idx))
+                else:
+                    got = lib.tps_write_fastq_spans_at(fd, int(offset), text.ctypes.data, len(text), spans.ctypes.data, lens.ctypes.data, idx.ctypes.data, len(idx))
                 if got < 0:
                     raise OSError(lib.tps_io_last_error().decode())
                 self._drop_text_pages(text)
                 return
+        if offset is not None:
+            raise ValueError("offset: only for batches the native writer takes (native_fastq_bytes)")
         out = []
         for i in indices:
             i = int(i)
@@ -580,9 +599,10 @@ def pack_spans(pb: "PackedBatch", idx, tails, maxlen: int):
 
 
 def shard_ranges(filepath: str, n_shards: int, min_bytes: int = 64 << 20):
-    """Byte ranges [(lo, hi), ...] that cut a PLAIN (uncompressed) FASTA / FASTQ file into at most n_shards readers of at least
-    min_bytes each (read_batches_packed(byte_range=...): a record belongs to the range its first byte lies in), or None when the file
-    cannot be cut: compressed (gzip / BGZF: one inflating reader), too small, unreadable."""
+    """Byte ranges [(lo, hi), ...] that cut a plain FASTA / FASTQ file -- or a BGZF-compressed one, at block boundaries -- into at most
+    n_shards readers of at least min_bytes each (read_batches_packed(byte_range=...): a record belongs to the range its first byte
+    lies in; BGZF: to the reader whose blocks hold the line end in front of it), or None when the file cannot be cut: ordinary gzip
+    (one deflate stream), too small, unreadable."""
     import os
     try:
         size = os.path.getsize(filepath)
@@ -590,8 +610,18 @@ def shard_ranges(filepath: str, n_shards: int, min_bytes: int = 64 << 20):
             magic = fh.read(2)
     except OSError:
         return None
-    if magic == b"\x1f\x8b" or n_shards < 2:
+    if n_shards < 2:
         return None
+    if magic == b"\x1f\x8b":
+        # BGZF (bgzip): independent blocks -- the ranges are ranges of COMPRESSED bytes, a reader owns the blocks that start in its
+        # range; an ordinary gzip file is one deflate stream: one reader
+        try:
+            with open(filepath, "rb") as fh:
+                head = fh.read(18)
+        except OSError:
+            return None
+        if len(head) < 18 or head[2] != 8 or not (head[3] & 4) or head[12:14] != b"BC":
+            return None
     n = min(int(n_shards), max(1, size // max(int(min_bytes), 1)))
     if n < 2:
         return None
