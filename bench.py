@@ -81,6 +81,10 @@ CONFIGS = {
     "config5": dict(n_reads=10000, read_len=25000, motif="CCCTAA", k=4, ks=[4, 5, 6], raw=True, window=100, slide=6, errors=synth.ONT, seed=20250919 + 4,
                     desc="BASELINE configs[4] sample: 10k synthetic ONT reads x 25 kb, --pattern CCCTAA --telophrase 4 5 6 --rawcountpattern "
                          "(one step = the three k passes over one resident batch)"),
+    # not a BASELINE config: read lengths as a real ONT file has them (log-normal, median 11 kb, 60 b .. 60 kb; the reference's demo data span
+    # 1.6 - 48 kb) -- the shape on which the order of the reads in a launch matters (tps::plan_dispatch_order; TOPSICLE_HIP_DEBUG=file_order=1 for the A/B)
+    "ragged_ont": dict(n_reads=20000, read_len=0, ragged=True, motif="CCCTAA", k=4, window=100, slide=6, errors=synth.ONT, seed=20250919 + 7,
+                       desc="diagnostic: 20k synthetic ONT reads of log-normal length (median 11 kb, up to 60 kb), --pattern CCCTAA"),
     "config3_per_gpu": dict(n_reads=25000, read_len=20000, motif="AAACCCT", k=5, window=100, slide=7,
                             errors=synth.HIFI, seed=20250919 + 2,
                             desc="BASELINE configs[2] shard: 25k synthetic HiFi reads x 20 kb per GPU, --pattern AAACCCT"),
@@ -303,6 +307,7 @@ def main():
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end legs (FASTQ file on disk -> results / -> CLI outputs)")
     ap.add_argument("--no-store-sums", action="store_true", help="do not write S_w to HBM (boundary-only run)")
     ap.add_argument("--n-reads", type=int, default=0, help="diagnostic: override the batch size (NOT the metric's workload)")
+    ap.add_argument("--k", type=int, default=0, help="diagnostic: override the k of the workload's pattern table (NOT the metric's workload)")
     ap.add_argument("--flags", type=int, default=0, help="diagnostic: override the scan flags (partial pipelines are NOT the metric)")
     ap.add_argument("--no-steady", action="store_true", help="skip the steady-state leg (the kernel on a batch four times the size: the launch ramp "
                     "and the last round of wave slots weigh a quarter; 46 launches, ~8 ms): the command whose rocprofv3 --stats average is "
@@ -344,14 +349,21 @@ def main():
     if args.errors:
         cfg["errors"] = {"ont": synth.ONT, "hifi": synth.HIFI, "none": None}[args.errors]
         cfg["desc"] += f" [diagnostic error profile: {args.errors}]"
+    if args.k:
+        cfg["k"] = args.k
+        cfg.pop("ks", None)
+        cfg["desc"] += f" [diagnostic: k = {args.k}]"
     motif, k = cfg["motif"], cfg["k"]
     ks = cfg.get("ks", [k])
     tables = [kmer_table(motif, kk) for kk in ks]
     pats = tables[0]
     P = len(pats)
     # every rank scans its own, differently seeded batch of the same shape (weak scaling)
-    bases, offsets, truth = synth.make_reads(cfg["n_reads"], cfg["read_len"], motif, seed=cfg["seed"] + 1000 * rank,
-                                             errors=cfg["errors"], telomeric_fraction=cfg.get("telomeric_fraction", 1.0))
+    if cfg.get("ragged"):
+        bases, offsets, truth = synth.make_ragged_reads(cfg["n_reads"], motif, seed=cfg["seed"] + 1000 * rank, errors=cfg["errors"])
+    else:
+        bases, offsets, truth = synth.make_reads(cfg["n_reads"], cfg["read_len"], motif, seed=cfg["seed"] + 1000 * rank,
+                                                 errors=cfg["errors"], telomeric_fraction=cfg.get("telomeric_fraction", 1.0))
     n_reads = cfg["n_reads"]
     batch_bases = int(offsets[-1])
     prm = hiplib.make_params(no_bp=1000, min_len=9000, min_count=min_count_for_cutoff(0.7, 1000, len(motif)),
@@ -364,7 +376,7 @@ def main():
     if args.flags:
         prm.flags = args.flags
     ref_py = None
-    if not args.no_cpu_baseline and world == 1 and not (args.flags or args.n_reads or args.errors):
+    if not args.no_cpu_baseline and world == 1 and not (args.flags or args.n_reads or args.errors or args.k):
         try:                                      # forks a Pool: before anything touches the GPU
             ref_py = reference_python_baseline(bases, offsets, motif, k, prm)
         except Exception as e:
@@ -552,7 +564,7 @@ def main():
     # the same kernel on a batch four times the size (the reads repeated): the launch ramp and the partly filled last round of wave
     # slots weigh a quarter as much -- what the kernel does in steady state (rank 0 at N = 1, default workload shapes only)
     steady = None
-    if not args.no_steady and world == 1 and len(tables) == 1 and not (args.flags or args.n_reads or args.errors) and copies < hiplib.MAX_SLOTS and \
+    if not args.no_steady and world == 1 and len(tables) == 1 and not (args.flags or args.n_reads or args.errors or args.k) and copies < hiplib.MAX_SLOTS and \
             batch_bases * 4 <= (3 << 30):
         try:
             big_off = np.concatenate([offsets[:-1] + j * batch_bases for j in range(4)] + [np.array([4 * batch_bases], np.int64)])
@@ -604,7 +616,7 @@ def main():
         # the GPU's time more than once); a single launch: its own duration
         roof_ms = dt / args.steps * 1e3 if concurrent else k_mean_ms
         achieved = alg_total / (roof_ms * 1e-3) / 1e9 if roof_ms > 0 else 0.0
-        traffic, traffic_src = profiled_traffic(args.workload, 0, ks) if not (args.flags or args.n_reads or args.errors) else (None, None)
+        traffic, traffic_src = profiled_traffic(args.workload, 0, ks) if not (args.flags or args.n_reads or args.errors or args.k) else (None, None)
         _sm, s_p10, s_p90 = spread(serial_t)
         s_med = dt_serial / args.steps * 1e3
         out = {

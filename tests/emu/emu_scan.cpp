@@ -28,6 +28,14 @@ static int g_val_off = 0;
 extern "C" void emu_set_knobs(int force_pair, int so_order, int val_off) { g_knobs = tps::PlanKnobs{}; g_knobs.force_pair = force_pair; g_knobs.so_order = so_order; g_val_off = val_off; }
 static tps::PlanKnobs knobs_with(int spans_pref, int force_generic) { tps::PlanKnobs k = g_knobs; k.spans_per_tile = spans_pref; k.force_generic = force_generic; return k; }
 
+// tps::plan_dispatch_order as the library calls it; returns the number of entries written (0 = file order)
+extern "C" int64_t emu_dispatch_order(const int64_t* n_win, const uint8_t* passes, int64_t n, int32_t* out) {
+    std::vector<int32_t> order;
+    tps::plan_dispatch_order(n_win, passes, n, order);
+    for (size_t i = 0; i < order.size(); ++i) out[i] = order[i];
+    return (int64_t)order.size();
+}
+
 extern "C" int64_t emu_window_count(int64_t L, int W, int s, int t, int M) { return tps::window_count(L, W, s, t, M); }
 
 // One scan over a batch, like tps_batch_upload + tps_batch_scan + downloads.
@@ -115,7 +123,19 @@ extern "C" int emu_scan(const char* pats, int P, int k, const uint8_t* bases, co
     uint32_t* lds_al = (uint32_t*)(((uintptr_t)ldsbuf.data() + 15) & ~(uintptr_t)15);
     struct { uint32_t* p; size_t n; uint32_t* data() { return p; } uint32_t* begin() { return p; } uint32_t* end() { return p + n; } } lds{lds_al, (size_t)tps::lds_dwords(a)};
     g_variant_calls[a.variant] += (int)n;
-    for (int64_t r = 0; r < n; ++r) {
+    // the reads in the library's dispatch order (tps::plan_dispatch_order; results do not depend on it)
+    std::vector<int32_t> order;
+    {
+        std::vector<int64_t> nwv((size_t)n);
+        std::vector<uint8_t> longer((size_t)n);
+        for (int64_t i = 0; i < n; ++i) {
+            nwv[(size_t)i] = (prm->flags & TPS_F_WINDOWS) ? win_off[(size_t)i + 1] - win_off[(size_t)i] : 0;
+            longer[(size_t)i] = !(prm->flags & TPS_F_STEP1) || offsets[i + 1] - offsets[i] > prm->min_len;
+        }
+        tps::plan_dispatch_order(nwv.data(), longer.data(), n, order);
+    }
+    for (int64_t slot = 0; slot < n; ++slot) {
+        const int64_t r = order.empty() ? slot : order[(size_t)slot];
         for (auto& w : lds) w = 0xDEADBEEFu;          // LDS content is undefined at workgroup start
         const bool so = a.pat.so_mask != 0;
         const bool want_raw = a.raw != nullptr;

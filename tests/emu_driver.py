@@ -117,3 +117,15 @@ def plan_table(patterns, prm, max_nwin):
     if rc != 0:
         raise RuntimeError(lib().emu_last_error().decode())
     return dict(zip(["variant", "pp_d", "lds_bytes", "pair_n", "tile_full", "tw"], list(out)))
+
+
+def dispatch_order(n_win, passes):
+    """tps::plan_dispatch_order (csrc/tps_plan.h) as the library calls it: the read each wave slot of a launch takes, or an empty
+    array when the batch keeps file order."""
+    n_win = np.ascontiguousarray(n_win, dtype=np.int64)
+    passes = np.ascontiguousarray(passes, dtype=np.uint8)
+    out = np.zeros(max(len(n_win), 1), dtype=np.int32)
+    L = lib()
+    L.emu_dispatch_order.restype = C.c_int64
+    m = L.emu_dispatch_order(_p(n_win), _p(passes), C.c_int64(len(n_win)), _p(out))
+    return out[:m].copy()

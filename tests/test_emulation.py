@@ -6,7 +6,7 @@ import pytest
 
 import emu_driver as emu
 import topsicle_oracle as orc
-from topsicle_amd import hiplib
+from topsicle_amd import hiplib, synth
 
 TAILV = {"forward": 0, "reverse": 1}
 
@@ -501,6 +501,45 @@ def test_planner_picks_per_pattern_tiles():
     assert plan("CCCTAA", 6, 4)["variant"] == 0                                                  # no fused kernel for this slide
     for motif, k, s in [("CCCTAA", 4, 6), ("CCCTAA", 5, 6), ("AAACCCT", 5, 7)]:
         assert plan(motif, k, s)["lds_bytes"] <= 32000                                           # five workgroups per CU
+
+
+def test_dispatch_order_longest_reads_first_and_file_order_for_equal_reads():
+    """tps::plan_dispatch_order (round 5): the read each wave slot of a launch takes -- classes of equal work, the longest first, reads the
+    length filter drops last, file order inside a class; a batch of one class keeps file order (no indirection in the kernel)."""
+    rng = np.random.default_rng(5)
+    assert len(emu.dispatch_order(np.full(1000, 2484), np.ones(1000))) == 0                       # config 2: equal reads
+    assert len(emu.dispatch_order(np.zeros(50), np.zeros(50))) == 0 and len(emu.dispatch_order([7], [1])) == 0
+    assert len(emu.dispatch_order(2484 - rng.integers(0, 20, 1000), np.ones(1000))) == 0          # lengths within one class of 64
+    lens = np.clip(np.exp(rng.normal(9.3, 0.8, 5000)), 60, 60000).astype(np.int64)                # an ONT file's lengths
+    n_win = np.array([hiplib.window_count(int(x), 100, 6, 100, 20000) for x in lens])
+    passes = lens > 9000
+    order = emu.dispatch_order(n_win, passes)
+    assert sorted(order.tolist()) == list(range(5000))                                            # a permutation
+    work = np.where(passes, n_win, -1)[order]
+    mx = n_win[passes].max()
+    cls = np.where(work < 0, 0, 1 + (work * 62 + mx - 1) // mx)
+    assert np.all(np.diff(cls) <= 0)                                                              # classes in descending order
+    for c in np.unique(cls):
+        assert np.all(np.diff(order[cls == c]) > 0)                                               # file order inside a class
+    assert not passes[order[-(~passes).sum():]].any() and passes[order[:passes.sum()]].all()      # the dropped reads leave last
+
+
+def test_emulation_results_do_not_depend_on_the_dispatch_order():
+    """The emulation runs the reads in the library's dispatch order: a ragged batch (reordered) against the same reads one by one."""
+    motif, k = "CCCTAA", 4
+    pats = orc.kmer_table(motif, k)
+    b, o, _ = synth.make_ragged_reads(40, motif, 77, len_mu=8.6, len_sigma=0.9, max_len=14000)
+    seqs = synth.split_reads(b, o)
+    prm = hiplib.make_params(min_len=3000, min_count=20, slide=6, flags=hiplib.F_STEP1 | hiplib.F_WINDOWS | hiplib.F_BINSEG | hiplib.F_STORE_SUMS)
+    lens = np.diff(o)
+    order = emu.dispatch_order([hiplib.window_count(int(x), 100, 6, 100, 20000) for x in lens], lens > 3000)
+    assert len(order) == 40 and not np.array_equal(order, np.arange(40))
+    out = emu.scan(pats, seqs, prm)
+    for i in (int(order[0]), int(order[-1]), 7, 23):
+        one = emu.scan(pats, [seqs[i]], prm)
+        for f in ("pass", "tail", "n_win", "bkp", "best_start", "best_end"):
+            assert out["results"][f][i] == one["results"][f][0], (i, f)
+        assert np.array_equal(out["sums"][out["win_off"][i]:out["win_off"][i + 1]], one["sums"])
 
 
 def test_planner_full_tiles_everywhere():

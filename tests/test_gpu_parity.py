@@ -627,3 +627,41 @@ def test_sixteen_patterns_take_the_fused_kernels_on_gpu(sc):
                 assert bool(out[i, 0]) == bool(res["pass"][i]), (motif, dirty, i)
                 if out[i, 0]:
                     assert int(out[i, 1]) == int(res["tail"][i]) and int(out[i, 5]) == int(res["bkp"][i]) and int(ck[i, 0]) == int(got[i]), (motif, dirty, i)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,raw", [(4, False), (4, True), (6, False), (5, True)])
+def test_dispatch_order_changes_no_result(sc, k, raw):
+    """Round 5: wave slots take the reads of a ragged batch longest first (tps::plan_dispatch_order; ScanArgs::order).  Every output
+    array of such a scan equals the scan in file order (debug option "file_order"), and a sample of reads the oracle."""
+    motif = "CCCTAA"
+    pats = orc.kmer_table(motif, k)
+    bases, offsets, _ = synth.make_ragged_reads(3000, motif, 505 + k, n_frac=0.0002)
+    prm = hiplib.make_params(min_len=9000, min_count=allsteps.min_count_for_cutoff(0.7, 1000 / len(motif), 1000), slide=6,
+                             flags=hiplib.F_STEP1 | hiplib.F_WINDOWS | hiplib.F_BINSEG | hiplib.F_STORE_SUMS | (hiplib.F_STORE_RAW if raw else 0))
+    got = {}
+    for file_order in (1, 0):
+        s = hiplib.HipScanner(0)
+        try:
+            s.debug_option("file_order", file_order)
+            s.set_patterns(pats)
+            s.upload(0, bases, offsets)
+            s.scan(0, prm)
+            s.sync()
+            got[file_order] = dict(res=s.results(0).copy(), sums=s.window_sums(0), trc=s.batch_trc_counts(0), raw=s.window_raw(0) if raw else None)
+        finally:
+            s.close()
+    a, b = got[1], got[0]
+    assert a["res"].tobytes() == b["res"].tobytes()
+    assert np.array_equal(a["sums"][0], b["sums"][0]) and np.array_equal(a["sums"][1], b["sums"][1])
+    assert np.array_equal(a["trc"][0], b["trc"][0]) and np.array_equal(a["trc"][1], b["trc"][1])
+    if raw:
+        assert np.array_equal(a["raw"][0], b["raw"][0])
+    res, (sums, win_off) = b["res"], b["sums"]
+    assert 500 < int(res["pass"].sum()) < 2900
+    out, ck = oracle_c.batch_ck(bases, offsets, pats, len(motif), 1000, 9000, 0.7, 100, 6, 100, 20000, threads=8)
+    chk = oracle_c.checksums(sums, win_off)
+    for i in range(len(res)):
+        assert bool(out[i, 0]) == bool(res["pass"][i]), i
+        if out[i, 0]:
+            assert int(out[i, 1]) == int(res["tail"][i]) and int(out[i, 5]) == int(res["bkp"][i]) and int(ck[i, 0]) == int(chk[i]), i

@@ -156,7 +156,7 @@ struct DevBuf {
 };
 
 struct Slot {
-    DevBuf seq2, inv, desc, tails, results, c_start, c_end, win_off, win_off16, sums, raw, stamps, lc;
+    DevBuf seq2, inv, desc, tails, results, c_start, c_end, win_off, win_off16, sums, raw, stamps, lc, order;
     int64_t n_words = 0;                 // words of seq2 / inv in use
     bool inv_valid = true;               // false: the batch came packed without an inv array (no read is flagged)
     bool any_invalid = true;             // some read of the batch is flagged TPS_RD_HAS_INVALID (the kernels then stage the invalid masks)
@@ -164,6 +164,7 @@ struct Slot {
     std::vector<int64_t> h_win_off;      // window layout of the last plan
     std::vector<int64_t> h_win_off16;    // ... of the fused kernels' 16-bit sums on the device (every read padded to a multiple of 8 windows)
     std::vector<uint16_t> h_sums16;      // download scratch
+    std::vector<int32_t> h_order;        // dispatch order of the last plan (tps::plan_dispatch_order; empty = file order)
     tps_read_result* h_results = nullptr;   // pinned
     size_t h_results_cap = 0;
     int64_t n = -1;
@@ -207,6 +208,7 @@ struct tps_ctx {
     tps::PlanKnobs knobs{};           // tps_ctx_debug_option: tests / diagnostics only; the library reads no environment
     int want_stamps = 0;
     int no_events = 0;
+    int file_order = 0;               // tps_ctx_debug_option "file_order": wave slot i takes read i whatever the reads' lengths (A/B of tps::plan_dispatch_order)
     int event_stride = 1;             // time every event_stride-th launch (tps_ctx_debug_option "event_stride"): timing costs ~3.5 us per launch
     uint64_t launch_seq = 0;
     size_t lds_set_v[56] = {0};
@@ -342,16 +344,27 @@ int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm) {
         sl.h_win_off.resize((size_t)n + 1);
         sl.h_win_off16.resize((size_t)n + 1);
         int64_t acc = 0, acc16 = 0, mx = 0;
+        std::vector<int64_t> nwv((size_t)n);
+        std::vector<uint8_t> longer((size_t)n);
         for (int64_t i = 0; i < n; ++i) {
             sl.h_win_off[(size_t)i] = acc;
             sl.h_win_off16[(size_t)i] = acc16;
-            int64_t nw = window_count(sl.h_offsets[i + 1] - sl.h_offsets[i], prm.window, prm.slide, prm.trimfirst, prm.maxlen);
+            const int64_t len = sl.h_offsets[i + 1] - sl.h_offsets[i];
+            int64_t nw = window_count(len, prm.window, prm.slide, prm.trimfirst, prm.maxlen);
             mx = std::max(mx, nw);
             acc += nw;
             acc16 += tps::sums16_slots(nw);
+            nwv[(size_t)i] = (prm.flags & TPS_F_WINDOWS) ? nw : 0;
+            longer[(size_t)i] = !(prm.flags & TPS_F_STEP1) || len > prm.min_len;      // (scan_read: pass = L > min_len && ...)
         }
         sl.h_win_off[(size_t)n] = acc;
         sl.h_win_off16[(size_t)n] = acc16;
+        sl.h_order.clear();
+        if (!c->file_order) tps::plan_dispatch_order(nwv.data(), longer.data(), n, sl.h_order);
+        if (!sl.h_order.empty()) {
+            if ((rc = sl.order.ensure((size_t)n * 4))) return rc;
+            HIP_TRY(hipMemcpyAsync(sl.order.p, sl.h_order.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+        }
         sl.args = tps::ScanArgs{};
         sl.args.val_on = sl.any_invalid ? 1 : 0;
         if ((rc = plan_lds(c, sl, prm, mx))) return rc;
@@ -394,6 +407,7 @@ int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm) {
         a.c_end = (int32_t*)sl.c_end.p;
     }
     a.win_off = (const int64_t*)sl.win_off.p;
+    a.order = sl.h_order.empty() ? nullptr : (const int32_t*)sl.order.p;
     a.sums = nullptr;
     a.sums16 = nullptr;
     a.win_off16 = nullptr;
@@ -565,7 +579,7 @@ int tps_ctx_destroy(tps_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     for (auto& sl : c->slots) {
         sl.seq2.release(); sl.inv.release(); sl.desc.release(); sl.tails.release(); sl.results.release(); sl.win_off16.release();
-        sl.c_start.release(); sl.c_end.release(); sl.win_off.release(); sl.sums.release(); sl.raw.release(); sl.stamps.release(); sl.lc.release();
+        sl.c_start.release(); sl.c_end.release(); sl.win_off.release(); sl.sums.release(); sl.raw.release(); sl.stamps.release(); sl.lc.release(); sl.order.release();
         if (sl.h_results) (void)hipHostFree(sl.h_results);
     }
     for (auto& t : c->tables) t.dev.release();
@@ -1168,7 +1182,8 @@ int tps_ctx_debug_option(tps_ctx* c, const char* key, int64_t value) {
     else if (k == "so_order") c->knobs.so_order = (int)value;
     else if (k == "wpg") c->knobs.wpg = (int)value;
     else if (k == "stamps") c->want_stamps = value != 0;
-    else return fail(TPS_E_ARG, "unknown debug option '%s' (event_stride, no_events, force_generic, spans_per_tile, force_pair, so_order, wpg, stamps)", key);
+    else if (k == "file_order") c->file_order = value != 0;
+    else return fail(TPS_E_ARG, "unknown debug option '%s' (event_stride, no_events, force_generic, spans_per_tile, force_pair, so_order, wpg, stamps, file_order)", key);
     for (auto& sl : c->slots) sl.planned = false;
     return TPS_OK;
 }

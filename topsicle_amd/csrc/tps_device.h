@@ -312,6 +312,8 @@ struct ScanArgs {
     const int64_t* win_off16;    // n+1
     uint8_t* raw;                // or nullptr
     uint64_t* stamps;            // diagnostics: 16 clock stamps per read, or nullptr
+    const int32_t* order;        // n, or nullptr: the read wave slot i of the launch takes (plan_dispatch_order: reads in classes of equal work, longest first;
+                                 // nullptr = file order, also whenever every read of the batch is in one class)
     int64_t n_reads;
     PatInfo pat;
     tps_params prm;

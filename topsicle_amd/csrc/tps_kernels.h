@@ -14,7 +14,8 @@
 // diagnostics build: clock stamps at kernel entry (13: shader clock, 15: the 100 MHz device-wide real-time counter) and
 // behind the table barrier (14), per read like the stamps inside scan_read
 #ifdef TPS_STAMPS
-#define TPS_KSTAMP(i) do { const int64_t r_ = (int64_t)blockIdx.x * a.wpg + (int)(threadIdx.x >> 6);                          \
+#define TPS_KSTAMP(i) do { int64_t r_ = (int64_t)blockIdx.x * a.wpg + (int)(threadIdx.x >> 6);                                \
+        if (a.order && r_ < a.n_reads) r_ = a.order[r_];                                                                      \
         if (a.stamps && (threadIdx.x & 63u) == 0 && r_ < a.n_reads) { a.stamps[r_ * 16 + (i)] = __builtin_readcyclecounter(); \
             if ((i) == 13) a.stamps[r_ * 16 + 15] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
@@ -53,8 +54,14 @@
            the loop and keeps it live: _s6so 88 -> 96 VGPRs + scratch, 146 -> 227 spilled SGPRs.  So was requesting the read's      \
            descriptor and its step-1 heads BEFORE the table load: config 2 57.1 against 57.0 us, k = 6 146.9 against 144.9 --    \
            with 20 - 24 waves per CU in flight a read's own latency is hidden already) */                                         \
-        const int64_t r = (int64_t)blockIdx.x * a.wpg + wave;                                              \
-        if (r < a.n_reads) tps::scan_read<SV, SO, PAIR, RAW, FULL, DCLASS>(a, r, slice, lut);                           \
+        /* round 5: which read a wave slot takes is the host's choice (ScanArgs::order): a workgroup's LDS and wave slots come   \
+           free when its LAST read ends, so reads of similar length share a workgroup and the longest go first -- a batch of     \
+           log-normal read lengths (what an ONT file holds) takes a fifth less time; batches of equal reads keep file order */   \
+        const int64_t slot = (int64_t)blockIdx.x * a.wpg + wave;                                           \
+        if (slot < a.n_reads) {                                                                            \
+            const int64_t r = a.order ? (int64_t)__builtin_amdgcn_readfirstlane(a.order[slot]) : slot;     \
+            tps::scan_read<SV, SO, PAIR, RAW, FULL, DCLASS>(a, r, slice, lut);                             \
+        }                                                                                                  \
     }
 #ifndef TPS_R_MINW
 #define TPS_R_MINW 5      // waves per SIMD the raw-row kernels of tables without self-overlap are compiled for: 96 VGPRs with 7 spilled and 32 B
