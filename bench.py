@@ -149,7 +149,7 @@ def profiled_traffic(workload, flags=0, ks=None):
         f = os.path.join(d, "workloads.csv")
         if not os.path.exists(f):
             continue
-        rows = {r["workload"]: r for r in csv.DictReader(open(f))}
+        rows = {r.get("workload", ""): r for r in csv.DictReader(open(f))}      # (older profile directories keep other columns)
         want = [f"{workload}_k{kk}_f31" for kk in ks] if (ks and len(ks) > 1) else [f"{workload}_f{flags}"]
         if not all(w in rows and rows[w].get("hbm_traffic_MB") and rows[w].get("SQ_INSTS_VALU") for w in want):
             continue
