@@ -125,6 +125,11 @@ def make_case(seed):
     single = n_files == 1
     if single and all_ids and rng.random() < 0.6:
         argv += ["--read_check", all_ids[int(rng.integers(0, len(all_ids)))]]
+    # --rawcountpattern (BASELINE configs[4]'s flag; Topsicle/main.py:146-150 -> rawcount_{k}_{i}.csv per read).  Drawn from a generator of
+    # its own so that the cases of the seeds recorded earlier keep their inputs; never with --read_check (upstream's branch names an
+    # undefined variable there: main.py:118)
+    if "--read_check" not in argv and np.random.default_rng(seed ^ 0x7A3C).random() < 0.35:
+        argv += ["--rawcountpattern"]
     return {"name": f"case{seed}", "files": files, "pre": pre, "argv": argv, "input": next(iter(files)) if single else "in", "exit": exit_code}
 
 
@@ -154,7 +159,7 @@ SUMMARY_STARTS = ("k-mer:", "asymptotic TRC", "Median telomere length", "Asympto
 def normalise(out_dir):
     """What a run left behind, in comparable form."""
     import csv
-    res = {"csv": None, "summary": [], "filtered": {}}
+    res = {"csv": None, "summary": [], "filtered": {}, "rawcount": {}}
     p = os.path.join(out_dir, "telolengths_all.csv")
     if os.path.exists(p):
         res["csv"] = [r for r in csv.reader(open(p, newline=""))]
@@ -166,4 +171,6 @@ def normalise(out_dir):
     for f in sorted(os.listdir(out_dir)):
         if "_trc_over_" in f:
             res["filtered"][f] = open(os.path.join(out_dir, f)).read()
+        if f.startswith("rawcount_") and f.endswith(".csv"):
+            res["rawcount"][f] = open(os.path.join(out_dir, f)).read()
     return res

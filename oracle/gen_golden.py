@@ -23,6 +23,7 @@ Boundaries come from the reference's bound_detect driven by the Binseg restateme
     python oracle/gen_golden.py            # rewrites tests/golden/
 """
 import csv
+import hashlib
 import json
 import os
 import shutil
@@ -277,7 +278,7 @@ def gen_overview():
     print("overview goldens:", [(h["motif"], h["k"], h["n_rows"]) for h in out["heatmaps"]])
 
 
-CLI_GOLDEN_SEEDS = (104, 108, 126, 134)      # oracle/cli_cases.py: three files / k = 4, 6 / cutoff list; three files / k = 4, 5, 6; --read_check; exit 1
+CLI_GOLDEN_SEEDS = (104, 108, 126, 132, 134)      # oracle/cli_cases.py: three files / k = 4, 6 / cutoff list; three files / k = 4, 5, 6; --read_check; one file, k = 4 and 6, --rawcountpattern (the raw-count CSVs as digests); three files + raw counts
 
 
 def gen_cli():
@@ -291,9 +292,11 @@ def gen_cli():
             code = ref_import.run_reference_main(["-i", inp, "-o", out] + case["argv"])
             assert code == case["exit"], (seed, code)
             expected = cli_cases.normalise(out)
+            # the per-read raw-count CSVs (~ 100 kB each) are recorded as digests
+            expected["rawcount"] = {f: {"sha256": hashlib.sha256(t.encode()).hexdigest(), "bytes": len(t)} for f, t in expected["rawcount"].items()}
         with open(os.path.join(GOLD, f"cli_{seed}.json"), "w") as h:
             json.dump({"case": case, "expected": expected}, h, indent=0, sort_keys=True)
-        print(f"cli_{seed}.json:", 0 if not expected["csv"] else len(expected["csv"]) - 1, "rows,", len(expected["filtered"]), "filtered files")
+        print(f"cli_{seed}.json:", 0 if not expected["csv"] else len(expected["csv"]) - 1, "rows,", len(expected["filtered"]), "filtered files,", len(expected["rawcount"]), "raw-count files")
 
 
 def main():

@@ -5,6 +5,7 @@ inputs and flag sets (oracle/cli_cases.py: 1 - 3 files, fasta / fastq / gz, read
 topsicle_amd.main runs the same command on the emulated engines.  Compared: the CSV as a row SEQUENCE, the summary lines of the
 log, the filtered files by name and content, the exit code.  Skips without /root/reference (the GPU box): there the same runs
 are replayed from tests/golden/cli_*.json (test_cli_golden_cases here on the emulation, tests/test_gpu_parity.py on the GPU)."""
+import hashlib
 import json
 import os
 
@@ -33,6 +34,9 @@ def compare(a, b, what):
     assert sorted(a["filtered"]) == sorted(b["filtered"]), (what, "filtered file names")
     for f in a["filtered"]:
         assert a["filtered"][f] == b["filtered"][f], (what, f)
+    assert sorted(a.get("rawcount", {})) == sorted(b.get("rawcount", {})), (what, "raw-count file names")
+    for f in a.get("rawcount", {}):
+        assert a["rawcount"][f] == b["rawcount"][f], (what, f)
 
 
 @pytest.mark.skipif(not HAVE_REF, reason="needs /root/reference (build container only)")
@@ -114,6 +118,13 @@ def compare_replayed(a, b, what):
     assert sorted(a["filtered"]) == sorted(b["filtered"]), (what, "filtered file names")
     for f in a["filtered"]:
         assert a["filtered"][f] == b["filtered"][f], (what, f)
+    # rawcount_{k}_{i}.csv is numbered per input file (main.py:90, 150): runs over several files leave, under each name, the LAST file's
+    # read -- walk order again -- so their contents are compared for one-file runs only (recorded as digests)
+    assert sorted(a.get("rawcount", {})) == sorted(b.get("rawcount", {})), (what, "raw-count file names")
+    if len({r[0] for r in (a["csv"] or [])[1:]}) <= 1:
+        for f, d in a.get("rawcount", {}).items():
+            t = b["rawcount"][f]
+            assert d == {"sha256": hashlib.sha256(t.encode()).hexdigest(), "bytes": len(t)}, (what, f)
 
 
 def golden_cases(gold_dir):
@@ -123,7 +134,7 @@ def golden_cases(gold_dir):
 def test_cli_golden_cases(gold_dir, tmp_path, emu_engine_factory):
     """The runs oracle/gen_golden.py recorded from the reference's main(): replayed on the emulated engines."""
     names = golden_cases(gold_dir)
-    assert len(names) >= 3
+    assert len(names) >= 5
     for n in names:
         g = json.load(open(os.path.join(gold_dir, n)))
         inp, out = cli_cases.materialise(g["case"], str(tmp_path / n))
@@ -136,7 +147,7 @@ def test_cli_golden_cases(gold_dir, tmp_path, emu_engine_factory):
 def test_cli_golden_cases_on_gpu(gold_dir, tmp_path):
     """The same recorded runs of the reference's main() through the real CLI on the MI355X (fresh contexts, the native reader)."""
     names = golden_cases(gold_dir)
-    assert len(names) >= 3
+    assert len(names) >= 5
     for n in names:
         g = json.load(open(os.path.join(gold_dir, n)))
         inp, out = cli_cases.materialise(g["case"], str(tmp_path / n))
