@@ -36,6 +36,17 @@ extern "C" int64_t emu_dispatch_order(const int64_t* n_win, const uint8_t* passe
     return (int64_t)order.size();
 }
 
+// tps::stride_base as the library calls it: the base slide a scan at prm->slide runs at (0 = the planned kernel itself)
+extern "C" int emu_stride_base(const char* pats, int P, int k, const tps_params* prm, int64_t max_len) {
+    std::vector<uint32_t> lut;
+    tps::ScanArgs a{};
+    a.val_on = 0;
+    if (!tps::build_patterns(pats, P, k, lut, a.pat).empty()) return -1;
+    const int64_t budget = 160 * 1024 / 4;
+    if (!tps::plan_geometry(a, *prm, k, P, tps::window_count(max_len, prm->window, prm->slide, prm->trimfirst, prm->maxlen), budget, g_knobs).empty()) return -1;
+    return tps::stride_base(a, *prm, k, P, [&](int s0) { return tps::window_count(max_len, prm->window, s0, prm->trimfirst, prm->maxlen); }, budget, g_knobs);
+}
+
 extern "C" int64_t emu_window_count(int64_t L, int W, int s, int t, int M) { return tps::window_count(L, W, s, t, M); }
 
 // One scan over a batch, like tps_batch_upload + tps_batch_scan + downloads.

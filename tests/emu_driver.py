@@ -129,3 +129,9 @@ def dispatch_order(n_win, passes):
     L.emu_dispatch_order.restype = C.c_int64
     m = L.emu_dispatch_order(_p(n_win), _p(passes), C.c_int64(len(n_win)), _p(out))
     return out[:m].copy()
+
+
+def stride_base(patterns, prm, max_len=20000):
+    """tps::stride_base (csrc/tps_plan.h): the base slide whose fused kernel a scan at prm.slide runs on, keeping every m-th window; 0 = none."""
+    k = len(patterns[0])
+    return int(lib().emu_stride_base("".join(patterns).encode(), len(patterns), k, C.byref(prm), C.c_int64(max_len)))

@@ -542,6 +542,21 @@ def test_emulation_results_do_not_depend_on_the_dispatch_order():
         assert np.array_equal(out["sums"][out["win_off"][i]:out["win_off"][i + 1]], one["sums"])
 
 
+def test_planner_strided_scans_for_multiples_of_a_fused_slide():
+    """Round 5 (second half): a slide without a fused kernel that is a multiple of one with -- raw rows or a self-overlap
+    table at slide 10, 12, 14 ...; any table at 14, 15, 16, 18, 20 ... -- runs the base slide's fused kernel and keeps every m-th window."""
+    def base(motif, k, slide, flags=0, window=100):
+        return emu.stride_base(orc.kmer_table(motif, k), hiplib.make_params(slide=slide, window=window, flags=hiplib.F_STEP1 | hiplib.F_WINDOWS | hiplib.F_BINSEG | flags))
+    raw = hiplib.F_STORE_RAW
+    assert base("CCCTAA", 4, 10, raw) == 5 and base("CCCTAA", 4, 12, raw) == 6 and base("CCCTAA", 4, 14, raw) == 7 and base("CCCTAA", 4, 16, raw) == 8
+    assert base("CCCTAA", 4, 15, raw) == 5 and base("CCCTAA", 4, 18, raw) == 6 and base("CCCTAA", 4, 9, raw) == 0 and base("CCCTAA", 4, 11, raw) == 0
+    assert base("CCCTAA", 6, 10) == 5 and base("CCCTAA", 6, 12, raw) == 6 and base("CCCTAA", 5, 21) == 7       # self-overlap tables
+    assert base("CCCTAA", 4, 10) == 0 and base("CCCTAA", 4, 6) == 0 and base("CCCTAA", 4, 6, raw) == 0        # a fused kernel of their own
+    assert base("CCCTAA", 4, 20) == 10 and base("CCCTAA", 4, 24) == 12 and base("CCCTAA", 4, 22) == 11 and base("CCCTAA", 4, 13) == 0   # default tables: the largest base
+    assert base("CCCTAA", 4, 49) == 0                                                                           # 7 x 7: more than 6 windows dropped per window kept
+    assert base("CCCTAACCTA", 8, 10) == 0                                                                       # hashed table: generic at any slide
+
+
 def test_planner_full_tiles_everywhere():
     """With the packed batch a tile is staged as whole 64-base quads whatever the slide, so every fused tile uses all 64
     lanes: 512 - q - 1 windows rounded down to an even number (494 at slide 6, window 100: tiles start at even windows because

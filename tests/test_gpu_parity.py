@@ -665,3 +665,61 @@ def test_dispatch_order_changes_no_result(sc, k, raw):
         assert bool(out[i, 0]) == bool(res["pass"][i]), i
         if out[i, 0]:
             assert int(out[i, 1]) == int(res["tail"][i]) and int(out[i, 5]) == int(res["bkp"][i]) and int(ck[i, 0]) == int(chk[i]), i
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("motif,k,slide,raw,kernel", [
+    ("CCCTAA", 4, 10, True, "tps_scan_kernel_s5r every 2nd window"), ("CCCTAA", 4, 12, True, "tps_scan_kernel_s6r every 2nd window"),
+    ("CCCTAA", 4, 15, True, "tps_scan_kernel_s5r every 3rd window"), ("CCCTAA", 6, 10, False, "tps_scan_kernel_s5so every 2nd window"),
+    ("CCCTAA", 6, 12, True, "tps_scan_kernel_s6sorh every 2nd window"), ("CCCTAA", 5, 14, True, "tps_scan_kernel_s7sor every 2nd window"),
+    ("CCCTAA", 4, 20, False, "tps_scan_kernel_s10p every 2nd window"), ("AAACCCT", 5, 28, False, "tps_scan_kernel_s7q every 4th window"),
+    ("TTTTAGGG", 6, 16, False, "tps_scan_kernel_s8so every 2nd window")])
+def test_strided_scans_keep_every_mth_window_of_a_fused_kernel(sc, motif, k, slide, raw, kernel):
+    """Round 5: `--slide 10 --rawcountpattern`, `--slide 10 --telophrase 6` and the like have no fused kernel of their
+    own; their windows are every m-th window of a slide that has (tps::stride_base): the launch shape is asserted, every window sum
+    (per-read checksums), tails, change points against oracle.c, raw rows against the Python oracle on a sample, and the whole scan
+    against the generic kernel (debug option "no_stride") byte for byte -- ragged reads with a few N."""
+    pats = orc.kmer_table(motif, k)
+    P = len(pats)
+    # (sixteen patterns with a self-overlap take the fused tiles on clean batches only: no N for that table)
+    bases, offsets, _ = synth.make_ragged_reads(600, motif, 700 + slide + k, n_frac=0.0 if P == 16 else 0.0002, len_mu=9.5, len_sigma=0.5, max_len=26000)
+    prm = hiplib.make_params(min_len=9000, min_count=allsteps.min_count_for_cutoff(0.7, 1000 / len(motif), 1000), slide=slide,
+                             flags=hiplib.F_STEP1 | hiplib.F_WINDOWS | hiplib.F_BINSEG | hiplib.F_STORE_SUMS | (hiplib.F_STORE_RAW if raw else 0))
+    got = {}
+    for no_stride in (0, 1):
+        s = hiplib.HipScanner(0)
+        try:
+            s.debug_option("no_stride", no_stride)
+            s.set_patterns(pats)
+            s.upload(0, bases, offsets)
+            for _ in range(2):                                        # (the second scan reuses the cached plan and the borrowed batch)
+                s.scan(0, prm)
+            s.sync()
+            name = s.kernel_info(0).split(" lds=")[0]
+            assert name == (kernel if not no_stride else "tps_scan_kernel"), name
+            got[no_stride] = dict(res=s.results(0).copy(), sums=s.window_sums(0), trc=s.batch_trc_counts(0), raw=s.window_raw(0) if raw else None)
+        finally:
+            s.close()
+    a, b = got[0], got[1]
+    for f in ("pass", "tail", "n_win", "bkp", "best_start", "best_end", "best_start_idx", "best_end_idx", "flags"):
+        assert np.array_equal(a["res"][f], b["res"][f]), f
+    assert np.array_equal(a["sums"][0], b["sums"][0]) and np.array_equal(a["sums"][1], b["sums"][1])
+    assert np.array_equal(a["trc"][0], b["trc"][0]) and np.array_equal(a["trc"][1], b["trc"][1])
+    res, (sums, win_off) = a["res"], a["sums"]
+    if raw:
+        assert np.array_equal(a["raw"][0], b["raw"][0])
+        rows = a["raw"][0].reshape(-1, P)
+        seqs = synth.split_reads(bases, offsets)
+        done = 0
+        for i in np.nonzero(res["pass"])[0][:5]:
+            _, want = orc.window_count_matrix(seqs[i], ["forward", "reverse"][int(res["tail"][i])], pats, 100, slide, 100, 20000)
+            assert np.array_equal(rows[win_off[i]:win_off[i + 1]], want), i
+            done += 1
+        assert done >= 3
+    assert 200 < int(res["pass"].sum())
+    out, ck = oracle_c.batch_ck(bases, offsets, pats, len(motif), 1000, 9000, 0.7, 100, slide, 100, 20000, threads=8)
+    chk = oracle_c.checksums(sums, win_off)
+    for i in range(len(res)):
+        assert bool(out[i, 0]) == bool(res["pass"][i]), i
+        if out[i, 0]:
+            assert int(out[i, 1]) == int(res["tail"][i]) and int(out[i, 5]) == int(res["bkp"][i]) and int(ck[i, 0]) == int(chk[i]), i

@@ -38,6 +38,16 @@ extern "C" __global__ void __launch_bounds__(tps::NT * tps::WPG) tps_binseg_kern
     tps::binseg_read(a, r, smem + wave * tps::BINSEG_SMEM_DW);
 }
 
+// every m-th window of a base-slide scan, and the change point of the compacted series (tps_plan.h: stride_base)
+extern "C" __global__ void __launch_bounds__(tps::NT * tps::WPG) tps_stride_kernel(tps::StrideArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];      // per wave: the change point's scratch, then the series as 16-bit values
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t r = (int64_t)blockIdx.x * tps::WPG + wave;
+    if (r >= a.n_reads) return;
+    uint32_t* mine = smem + wave * (tps::BINSEG_SMEM_DW + a.s16_dw);
+    tps::stride_read(a, r, mine, a.s16_dw ? (uint16_t*)(mine + tps::BINSEG_SMEM_DW) : nullptr);
+}
+
 extern "C" __global__ void __launch_bounds__(tps::NT * tps::WPG) tps_followers_kernel(tps::FollowArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t smem[tps::WPG * tps::FOLLOW_LDS_DW];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -179,6 +189,12 @@ struct Slot {
     const char* kernel_name = "";       // what the last scan of this slot launched
     bool scanned = false;
     uint32_t last_flags = 0;
+    // scans at a multiple of a fused kernel's slide (tps::stride_base): the base-slide scan runs in a slot of its own that borrows this
+    // slot's batch; `sub_stale` = the batch has changed since it was borrowed
+    Slot* sub = nullptr;
+    bool sub_stale = true;
+    int stride_base = 0;                 // of the cached plan: 0 = the planned kernel runs itself
+    std::string info_name;               // kernel_name of a strided scan ("<base kernel> every <m>th window")
 };
 
 struct EventPair { hipEvent_t a, b; };
@@ -208,6 +224,7 @@ struct tps_ctx {
     tps::PlanKnobs knobs{};           // tps_ctx_debug_option: tests / diagnostics only; the library reads no environment
     int want_stamps = 0;
     int no_events = 0;
+    int no_stride = 0;                // tps_ctx_debug_option "no_stride": slides that are a multiple of a fused kernel's keep the generic kernel (A/B of tps::stride_base)
     int file_order = 0;               // tps_ctx_debug_option "file_order": wave slot i takes read i whatever the reads' lengths (A/B of tps::plan_dispatch_order)
     int event_stride = 1;             // time every event_stride-th launch (tps_ctx_debug_option "event_stride"): timing costs ~3.5 us per launch
     uint64_t launch_seq = 0;
@@ -248,6 +265,7 @@ int check_params(const tps_params& p) {
 }
 
 void reset_slot(Slot& sl, int64_t n, int64_t n_words) {
+    sl.sub_stale = true;
     sl.n = n;
     sl.n_words = n_words;
     sl.has_tails = false;
@@ -330,7 +348,68 @@ int do_upload_packed(tps_ctx* c, Slot& sl, const uint32_t* seq2, const uint16_t*
 
 bool same_params(const tps_params& x, const tps_params& y) { return memcmp(&x, &y, sizeof x) == 0; }
 
-int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm) {
+int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm, bool inner = false, hipEvent_t ev_start = nullptr);
+
+// The scan of `sl` at prm.slide = m x base: the fused kernel of the base slide in sl.sub (which borrows the batch), then
+// tps_stride_kernel.  Outputs land in sl's buffers in the generic kernel's layout (int32 sums, rows at win_off).
+int do_scan_strided(tps_ctx* c, Slot& sl, const tps_params& prm, int base, hipEvent_t ev_a, hipEvent_t ev_b) {
+    int rc;
+    if (!sl.sub) sl.sub = new Slot();
+    Slot& sb = *sl.sub;
+    if (sl.sub_stale) {
+        sb.seq2.borrow(sl.seq2);
+        sb.inv.borrow(sl.inv);
+        sb.desc.borrow(sl.desc);
+        sb.h_offsets = sl.h_offsets;
+        sb.inv_valid = sl.inv_valid;
+        sb.any_invalid = sl.any_invalid;
+        reset_slot(sb, sl.n, sl.n_words);
+        sl.sub_stale = false;
+    }
+    sb.tails.borrow(sl.tails);
+    sb.has_tails = sl.has_tails;
+    tps_params pb = prm;
+    pb.slide = base;
+    pb.flags = (prm.flags | TPS_F_STORE_SUMS) & ~(uint32_t)TPS_F_BINSEG;
+    if ((rc = do_scan(c, sb, pb, true, ev_a))) return rc;
+    if (!sb.args.variant) return fail(TPS_E_STATE, "strided scan: the base slide %d did not plan a fused kernel", base);
+    const int64_t n = sl.n;
+    tps::StrideArgs a{};
+    a.base_results = sb.h_results;
+    a.base_sums16 = (const uint16_t*)sb.sums.p;
+    a.base_win_off16 = (const int64_t*)sb.win_off16.p;
+    a.base_raw = (prm.flags & TPS_F_STORE_RAW) ? (const uint8_t*)sb.raw.p : nullptr;
+    a.base_win_off = (const int64_t*)sb.win_off.p;
+    a.win_off = (const int64_t*)sl.win_off.p;
+    a.sums = sl.args.sums;
+    a.raw = sl.args.raw;
+    a.results = sl.h_results;
+    a.n_reads = n;
+    a.m = prm.slide / base;
+    a.P = c->pat.P;
+    a.n_patterns = c->pat.P;
+    a.jump = prm.jump;
+    a.min_size = prm.min_size;
+    a.binseg = (prm.flags & TPS_F_BINSEG) ? 1 : 0;
+    int64_t mx = 0;
+    for (int64_t i = 0; i < n; ++i) mx = std::max(mx, sl.h_win_off[(size_t)i + 1] - sl.h_win_off[(size_t)i]);
+    a.s16_dw = (int32_t)((((mx + 1) / 2) + 3) & ~3ll);
+    if (a.s16_dw > 3072) a.s16_dw = 0;                 // (12 KB per wave: five workgroups per CU; longer series are read back from HBM)
+    const size_t lds = (size_t)tps::WPG * (size_t)(tps::BINSEG_SMEM_DW + a.s16_dw) * 4;
+    void* kargs[] = {(void*)&a};
+    HIP_TRY(hipExtLaunchKernel((const void*)tps_stride_kernel, dim3((unsigned)((n + tps::WPG - 1) / tps::WPG)), dim3(tps::NT * tps::WPG), kargs, lds, c->stream,
+                               nullptr, ev_b, 0));
+    // the step-1 counts are the base scan's
+    sl.c_start.borrow(sb.c_start);
+    sl.c_end.borrow(sb.c_end);
+    sl.info_name = std::string(sb.kernel_name) + (a.m == 2 ? " every 2nd window" : a.m == 3 ? " every 3rd window" : " every " + std::to_string(a.m) + "th window");
+    sl.kernel_name = sl.info_name.c_str();
+    sl.lds_bytes = sb.lds_bytes;
+    sl.args.wpg = sb.args.wpg;
+    return TPS_OK;
+}
+
+int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm, bool inner, hipEvent_t ev_start) {
     int rc;
     if (!c->have_pat) return fail(TPS_E_PATTERN, "tps_set_patterns has not been called");
     if (sl.n < 0) return fail(TPS_E_STATE, "no batch uploaded in this slot");
@@ -368,6 +447,14 @@ int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm) {
         sl.args = tps::ScanArgs{};
         sl.args.val_on = sl.any_invalid ? 1 : 0;
         if ((rc = plan_lds(c, sl, prm, mx))) return rc;
+        sl.stride_base = 0;
+        if (!inner && !c->no_stride) {
+            const size_t lds_max = c->prop.sharedMemPerBlock > 0 ? std::min<size_t>(c->prop.sharedMemPerBlock, 160 * 1024) : 64 * 1024;
+            int64_t max_len = 0;
+            for (int64_t i = 0; i < n; ++i) max_len = std::max(max_len, sl.h_offsets[i + 1] - sl.h_offsets[i]);
+            sl.stride_base = tps::stride_base(sl.args, prm, c->pat.k, P, [&](int s0) { return window_count(max_len, prm.window, s0, prm.trimfirst, prm.maxlen); },
+                                              (int64_t)lds_max / 4, c->knobs);
+        }
         if ((rc = sl.win_off.ensure((size_t)(n + 1) * 8))) return rc;
         HIP_TRY(hipMemcpyAsync(sl.win_off.p, sl.h_win_off.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, c->stream));
         if (sl.args.variant) {                          // fused kernels: the padded layout of their 16-bit sums
@@ -400,7 +487,7 @@ int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm) {
     a.lut_img = a.lut + ((a.lut16 && a.lut_fields) ? c->lut_cur->off_f16 : a.lut16 ? c->lut_cur->off_m16 : a.lut_fields ? c->lut_cur->off_fld : c->lut_cur->off_e32);
     a.results = sl.h_results;                      // (written by the kernel straight into mapped pinned host memory)
     a.c_start = a.c_end = nullptr;
-    if (prm.flags & TPS_F_STEP1) {
+    if ((prm.flags & TPS_F_STEP1) && !sl.stride_base) {       // (a strided scan borrows the base scan's counts)
         if ((rc = sl.c_start.ensure((size_t)std::max<int64_t>(n * P, 1) * 4))) return rc;
         if ((rc = sl.c_end.ensure((size_t)std::max<int64_t>(n * P, 1) * 4))) return rc;
         a.c_start = (int32_t*)sl.c_start.p;
@@ -515,8 +602,14 @@ int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm) {
             }
         }
     }
-    const bool timed = !c->no_events && (c->launch_seq++ % (uint64_t)c->event_stride) == 0;
+    const bool timed = !inner && !c->no_events && (c->launch_seq++ % (uint64_t)c->event_stride) == 0;
     EventPair& ep = c->ev_pool[timed ? c->ev_used++ : 0];
+    if (sl.stride_base) {
+        // (timed from the base kernel's start to the end of the compaction + change-point kernel)
+        if ((rc = do_scan_strided(c, sl, prm, sl.stride_base, timed ? ep.a : nullptr, timed ? ep.b : nullptr))) return rc;
+        sl.scanned = true;
+        return TPS_OK;
+    }
     {
         // hipExtLaunchKernel stamps the pair of events from the dispatch packet's own start / end timestamps:
         // no separate barrier packets around the kernel (two hipEventRecord calls cost ~6 us per launch and
@@ -524,7 +617,7 @@ int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm) {
         const int64_t grid = (n + a.wpg - 1) / a.wpg;
         void* kargs[] = {(void*)&a};
         HIP_TRY(hipExtLaunchKernel(kfn, dim3((unsigned)grid), dim3(tps::NT * a.wpg), kargs, sl.lds_bytes, c->stream,
-                                   timed ? ep.a : nullptr, timed ? ep.b : nullptr, 0));
+                                   inner ? ev_start : (timed ? ep.a : nullptr), timed ? ep.b : nullptr, 0));
     }
     sl.scanned = true;
     return TPS_OK;
@@ -578,6 +671,14 @@ int tps_ctx_destroy(tps_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (auto& sl : c->slots) {
+        if (sl.sub) {
+            Slot& sb = *sl.sub;
+            sb.seq2.release(); sb.inv.release(); sb.desc.release(); sb.tails.release(); sb.results.release(); sb.win_off16.release();
+            sb.c_start.release(); sb.c_end.release(); sb.win_off.release(); sb.sums.release(); sb.raw.release(); sb.stamps.release(); sb.lc.release(); sb.order.release();
+            if (sb.h_results) (void)hipHostFree(sb.h_results);
+            delete sl.sub;
+            sl.sub = nullptr;
+        }
         sl.seq2.release(); sl.inv.release(); sl.desc.release(); sl.tails.release(); sl.results.release(); sl.win_off16.release();
         sl.c_start.release(); sl.c_end.release(); sl.win_off.release(); sl.sums.release(); sl.raw.release(); sl.stamps.release(); sl.lc.release(); sl.order.release();
         if (sl.h_results) (void)hipHostFree(sl.h_results);
@@ -1183,7 +1284,8 @@ int tps_ctx_debug_option(tps_ctx* c, const char* key, int64_t value) {
     else if (k == "wpg") c->knobs.wpg = (int)value;
     else if (k == "stamps") c->want_stamps = value != 0;
     else if (k == "file_order") c->file_order = value != 0;
-    else return fail(TPS_E_ARG, "unknown debug option '%s' (event_stride, no_events, force_generic, spans_per_tile, force_pair, so_order, wpg, stamps, file_order)", key);
+    else if (k == "no_stride") c->no_stride = value != 0;
+    else return fail(TPS_E_ARG, "unknown debug option '%s' (event_stride, no_events, force_generic, spans_per_tile, force_pair, so_order, wpg, stamps, file_order, no_stride)", key);
     for (auto& sl : c->slots) sl.planned = false;
     return TPS_OK;
 }

@@ -3861,6 +3861,85 @@ TPS_DEV void binseg_read(const BinsegArgs& a, int64_t r, uint32_t* smem) {
 //            replace the occurrence bits and go to HBM (one bit per position: the host builds the reference's rows)
 //   phase 3  every pick adds one to hist[strand][pattern][code of the f following bases] (bin 4^f: a non-ACGT letter
 //            among them; on the reverse complement the codes are complemented: code ^ 2 per base)
+// ------------------------------------------------------------------ every m-th window of a scan at a base slide (tps_plan.h: stride_base)
+struct StrideArgs {
+    const tps_read_result* base_results;   // what the base-slide scan left (tail, pass, step-1 counts; n_win of the base slide)
+    const uint16_t* base_sums16;           // its S_w, 16-bit, win_off16 layout
+    const int64_t* base_win_off16;
+    const uint8_t* base_raw;               // its raw rows (win_off layout of the base slide), or nullptr
+    const int64_t* base_win_off;
+    const int64_t* win_off;                // n + 1: the layout of the requested slide
+    int32_t* sums;                         // S_w of the requested slide (int32, like the generic kernel's)
+    uint8_t* raw;                          // raw rows of the requested slide, or nullptr
+    tps_read_result* results;
+    int64_t n_reads;
+    int32_t m, P, n_patterns, jump, min_size, binseg;
+    int32_t s16_dw;                        // LDS words per wave for the compacted S_w as 16-bit values (0 = none)
+};
+// `s16`: this wave's LDS copy of the compacted series (host: StrideArgs::s16_dw words per wave, 0 = the series is too long for LDS and
+// the change point reads it back from HBM -- the lane-contiguous chunks of binseg_wg are 20 dependent-latency loads per pass there)
+TPS_DEV void stride_read(const StrideArgs& a, int64_t r, uint32_t* smem, uint16_t* s16) {
+    tps_read_result res = a.base_results[r];
+    const int64_t lo = a.win_off[r];
+    const int n = res.n_win > 0 ? (int)(a.win_off[r + 1] - lo) : 0;      // (the base scan had windows <=> this one has: window w is base window w m)
+    const int64_t lo16 = a.base_win_off16[r], lob = a.base_win_off[r];
+    const int m = a.m, P = a.P;
+    TPS_PHASE {
+        for (int w = tid; w < n; w += NT) {
+            const uint32_t v = a.base_sums16[lo16 + (int64_t)w * m];
+            a.sums[lo + w] = (int32_t)v;
+            if (s16) s16[w] = (uint16_t)v;
+        }
+        if (a.raw) {
+            if ((P & 3) == 0) {                    // rows of whole dwords (both layouts start dword-aligned then)
+                const int pd = P >> 2;
+                const uint32_t* src = (const uint32_t*)a.base_raw + lob * pd;
+                uint32_t* dst = (uint32_t*)a.raw + lo * pd;
+                for (int w = tid; w < n; w += NT) {
+                    const uint32_t* sr = src + (int64_t)w * m * pd;
+                    uint32_t* dr = dst + (int64_t)w * pd;
+                    TPS_NOVEC
+                    for (int d = 0; d < pd; ++d) dr[d] = sr[d];
+                }
+            } else {
+                const uint8_t* src = a.base_raw + lob * P;
+                uint8_t* dst = a.raw + lo * P;
+                for (int w = tid; w < n; w += NT) {
+                    const uint8_t* sr = src + (int64_t)w * m * P;
+                    uint8_t* dr = dst + (int64_t)w * P;
+                    TPS_NOVEC
+                    for (int d = 0; d < P; ++d) dr[d] = sr[d];
+                }
+            }
+        }
+    }
+    TPS_SYNC();
+    res.n_win = n;
+    res.bkp = -1;
+    res.gain = 0.0;
+    res.flags = 0;
+    if (a.binseg && n > 0 && binseg_admissible(n, a.jump, a.min_size)) {
+        uint32_t* xs = smem;
+        uint32_t* misc = smem + ((XS_DW + 1) / 2) * 2;
+        uint32_t* bs = misc + MISC_DW;
+        int bkp = -1;
+        double gain = 0.0;
+        bool tie = false;
+        if (s16) {
+            binseg_wg((const uint16_t*)s16, n, a.jump, a.min_size, a.n_patterns, bs, misc, xs, bkp, gain, tie);
+        } else {
+#ifndef TPS_EMU
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");      // this wave's own stores above, read back below
+#endif
+            binseg_wg(a.sums + lo, n, a.jump, a.min_size, a.n_patterns, bs, misc, xs, bkp, gain, tie);
+        }
+        res.bkp = bkp;
+        res.gain = gain;
+        res.flags = tie ? TPS_RES_TIE : 0u;
+    }
+    TPS_PHASE { if (tid == 0) a.results[r] = res; }
+}
+
 struct FollowArgs {
     const uint32_t* seq2;
     const uint16_t* inv;

@@ -415,4 +415,27 @@ inline std::string plan_geometry_core(ScanArgs& a, const tps_params& prm, int k,
     return "";
 }
 
+// A slide that no fused kernel is compiled for (13 and up for the default tables, 9 and up for raw rows and self-overlap tables) takes
+// the generic kernel, 12 - 24 x slower per launch (measured, round 5: 10 000 x 15 kb, slide 10: raw rows 1 870 us against 155 us at
+// slide 5; k = 6 sums 2 839 against 122).  But the windows of slide m s0 ARE every m-th window of slide s0 (same start grid, same
+// length): such a scan runs the fused kernel of the base slide s0 and keeps every m-th window (tps_stride_kernel: S_w and raw rows
+// compacted into the layout of the requested slide, the change point searched on the compacted series).  Returns the base slide
+// (the largest one whose plan is fused: fewest windows to drop) or 0; `max_nwin_of(s)` = the longest read's windows at slide s.
+template <typename F>
+inline int stride_base(const ScanArgs& planned, const tps_params& prm, int k, int P, F max_nwin_of, int64_t budget_dw, const PlanKnobs& kn) {
+    if (planned.variant != 0 || kn.force_generic || kn.spans_per_tile > 0 || !(prm.flags & TPS_F_WINDOWS)) return 0;
+    for (int s0 = 12; s0 >= 3; --s0) {
+        if (prm.slide <= s0 || prm.slide % s0 != 0 || prm.slide / s0 > 6) continue;
+        if (!has_specialised_slide(s0) && !has_default_only_slide(s0)) continue;
+        ScanArgs t{};
+        t.val_on = planned.val_on;
+        t.pat = planned.pat;
+        tps_params pb = prm;
+        pb.slide = s0;
+        pb.flags = (prm.flags | TPS_F_STORE_SUMS) & ~(uint32_t)TPS_F_BINSEG;
+        if (plan_geometry(t, pb, k, P, max_nwin_of(s0), budget_dw, kn).empty() && t.variant != 0) return s0;
+    }
+    return 0;
+}
+
 }  // namespace tps
