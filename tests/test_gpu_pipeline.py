@@ -377,3 +377,39 @@ def test_one_file_cut_into_shards_on_four_contexts(tmp_path):
     finally:
         for e in engines:
             e.close()
+
+
+def test_cli_slide_10_with_raw_rows_and_two_pass_equals_the_generic_kernel(tmp_path, monkeypatch):
+    """`--slide 10 --telophrase 4 6 --rawcountpattern` through the real CLI (several batches, two contexts, the two-pass reader, rows
+    device -> file): the strided scans (tps::stride_base: the slide-5 kernels, every second window) against the same run on the generic
+    kernel (TOPSICLE_HIP_DEBUG=no_stride=1) -- CSV rows, archives' rows and filtered files equal."""
+    import zipfile
+    from topsicle_amd import main as cli
+    monkeypatch.setattr(batch, "BATCH_BASES", 3 << 20)
+    bases, offsets, _truth = synth.make_ragged_reads(700, "CCCTAA", 91, len_mu=9.4, len_sigma=0.5, max_len=24000, telomeric_fraction=0.6)
+    fq = tmp_path / "s.fastq"
+    _write_fastq(fq, bases, offsets)
+    outs = {}
+    for mode in ("strided", "generic"):
+        if mode == "generic":
+            monkeypatch.setenv("TOPSICLE_HIP_DEBUG", "no_stride=1")
+        else:
+            monkeypatch.delenv("TOPSICLE_HIP_DEBUG", raising=False)
+        out = tmp_path / mode
+        cli.main(["-i", str(fq), "-o", str(out), "--pattern", "CCCTAA", "--telophrase", "4", "6", "--slide", "10", "--rawcountpattern", "--rawcountformat", "npz",
+                  "--twopass", "on"])
+        outs[mode] = out
+    a, b = outs["strided"], outs["generic"]
+    rows_a = open(a / "telolengths_all.csv").read()
+    assert rows_a == open(b / "telolengths_all.csv").read() and rows_a.count("\n") > 300
+    for k in (4, 6):
+        for o in (a, b):
+            with zipfile.ZipFile(o / f"rawcount_{k}_s.npz") as zf:
+                assert zf.testzip() is None
+        za, zb = np.load(a / f"rawcount_{k}_s.npz"), np.load(b / f"rawcount_{k}_s.npz")
+        for f in ("read_id", "tail", "win_off", "counts"):
+            assert np.array_equal(za[f], zb[f]), (k, f)
+        assert len(za["read_id"]) > 100
+    for f in sorted(os.listdir(a)):
+        if "_trc_over_" in f:
+            assert open(a / f).read() == open(b / f).read(), f
