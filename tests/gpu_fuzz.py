@@ -21,7 +21,7 @@ for case in range(n_cases):
     if len(pats) > hiplib.MAX_PATTERNS:
         continue
     W = int(rng.choice([100, 100, 100, 60, 150, 260, 37]))
-    s = int(rng.choice([6, 7, 5, 8, len(motif), 3, 10, 13]))
+    s = int(rng.choice([6, 7, 5, 8, len(motif), 3, 10, 13, 12, 14, 15, 16, 20, 21]))      # (10, 12, 14 ...: strided scans of a fused base slide for raw rows and self-overlap tables, for every table above 12)
     t = int(rng.choice([100, 0, 50]))
     M = int(rng.choice([20000, 4000, 12000]))
     jump = int(rng.choice([5, 5, 1, 3, 8]))

@@ -20,7 +20,7 @@ for case in range(n_cases):
     ks = sorted(set(int(x) for x in rng.integers(3, len(motif) + 1, int(rng.integers(2, 5)))))
     if len(ks) < 2:
         continue
-    slide = int(rng.choice([6, 7, 5, 8, len(motif), 3]))
+    slide = int(rng.choice([6, 7, 5, 8, len(motif), 3, 10, 12, 14, 15, 16, 20]))      # (10 and up: no fused kernel of their own -- strided scans, tps::stride_base)
     W = int(rng.choice([100, 100, 60, 150]))
     prm = hiplib.make_params(no_bp=int(rng.choice([1000, 500])), min_len=int(rng.choice([0, 1000, 3000])),
                              min_count=int(rng.integers(0, 40)), window=W, slide=slide, trimfirst=int(rng.choice([100, 0])),
