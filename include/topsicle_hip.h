@@ -235,7 +235,8 @@ int  tps_kernel_time_reset(tps_ctx* ctx);
  * generic kernel instead of the fused tiles), "spans_per_tile", "force_pair", "so_order", "wpg" (csrc/tps_plan.h: PlanKnobs), "stamps"
  * (per-read phase clocks; only a -DTPS_STAMPS build writes them), "file_order" (wave slot i takes read i: switches
  * tps::plan_dispatch_order off, which otherwise starts the longest reads of a batch first), "no_stride" (a slide that is a multiple of a
- * fused kernel's slide keeps the generic kernel instead of running that kernel and keeping every m-th window: tps::stride_base).  topsicle_amd.hiplib applies $TOPSICLE_HIP_DEBUG
+ * fused kernel's slide keeps the generic kernel instead of running that kernel and keeping every m-th window: tps::stride_base), "no_inline_rows" (such a scan at twice the base
+ * slide copies its raw rows like the other multiples instead of letting the tiles store every second row: ScanArgs::raw_m).  topsicle_amd.hiplib applies $TOPSICLE_HIP_DEBUG
  * ("key=value,key=value") to every context it creates: the ONE documented variable of the Python host. */
 int  tps_ctx_debug_option(tps_ctx* ctx, const char* key, int64_t value);
 /* The stamps of the last scan of `slot`: 16 uint64 per read. */

@@ -25,6 +25,8 @@ extern "C" const char* emu_last_error() { return g_err.c_str(); }
 // planner knobs + "val_off" of the next emu_scan / emu_plan* calls (tests/emu_driver.py: KNOBS); test infrastructure reads no environment either
 static tps::PlanKnobs g_knobs;
 static int g_val_off = 0;
+static int g_raw_m = 0;        // ScanArgs::raw_m of the next emu_scan (2: the per-pattern tiles store every 2nd window's row, packed per read)
+extern "C" void emu_set_raw_m(int m) { g_raw_m = m; }
 extern "C" void emu_set_knobs(int force_pair, int so_order, int val_off) { g_knobs = tps::PlanKnobs{}; g_knobs.force_pair = force_pair; g_knobs.so_order = so_order; g_val_off = val_off; }
 static tps::PlanKnobs knobs_with(int spans_pref, int force_generic) { tps::PlanKnobs k = g_knobs; k.spans_per_tile = spans_pref; k.force_generic = force_generic; return k; }
 
@@ -105,6 +107,13 @@ extern "C" int emu_scan(const char* pats, int P, int k, const uint8_t* bases, co
     a.sums16 = sums16.data();
     a.win_off16 = win_off16.data();
     a.raw = (prm->flags & TPS_F_STORE_RAW) ? raw : nullptr;
+    // knob raw_m = 2: the rows of the even windows only, in the layout of twice the slide (read i's rows start at sum of ceil(n_win / 2))
+    std::vector<int64_t> rwo((size_t)n + 1, 0);
+    if (g_raw_m == 2 && a.raw) {
+        for (int64_t i = 0; i < n; ++i) rwo[(size_t)i + 1] = rwo[(size_t)i] + (win_off[(size_t)i + 1] - win_off[(size_t)i] + 1) / 2;
+        a.raw_m = 2;
+        a.raw_win_off = rwo.data();
+    }
     a.n_reads = n;
     a.prm = *prm;
     std::vector<uint16_t> lc_scratch(a.lc_global ? (size_t)n * (size_t)a.lc_stride + 8 : 8, (uint16_t)0xBEEF);

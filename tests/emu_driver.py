@@ -28,11 +28,12 @@ def build(asan=False):
 _lib = None
 # planner knobs of the next scan / plan calls (tps::PlanKnobs; tests set them with monkeypatch.setitem) and "val_off": the LDS layout of
 # a batch without invalid letters
-KNOBS = {"force_pair": 0, "so_order": 0, "val_off": 0}
+KNOBS = {"force_pair": 0, "so_order": 0, "val_off": 0, "raw_m": 0}
 
 
 def _knobs(L):
     L.emu_set_knobs(int(KNOBS["force_pair"]), int(KNOBS["so_order"]), int(KNOBS["val_off"]))
+    L.emu_set_raw_m(int(KNOBS.get("raw_m", 0)))
 
 
 def lib():

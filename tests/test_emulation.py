@@ -542,6 +542,41 @@ def test_emulation_results_do_not_depend_on_the_dispatch_order():
         assert np.array_equal(out["sums"][out["win_off"][i]:out["win_off"][i + 1]], one["sums"])
 
 
+@pytest.mark.parametrize("motif,k,slide", [("CCCTAA", 4, 6), ("CCCTAA", 4, 5), ("TTAGGG", 4, 7), ("TTAGGC", 4, 6)])
+def test_emulation_per_pattern_tiles_store_every_second_row(motif, k, slide):
+    """Strided scans at twice a base slide (round 5): the per-pattern tiles of a table without self-overlap store the even windows' raw
+    rows themselves, packed per read in the layout of slide 2 s (ScanArgs::raw_m = 2) -- against the oracle AT slide 2 s, reads of one,
+    several and partly filled tiles; the sums stay those of the base slide."""
+    pats = orc.kmer_table(motif, k)
+    P = len(pats)
+    if P % 4:
+        pytest.skip("rows of whole dwords only")
+    rng = np.random.default_rng(slide)
+    seqs = []
+    for L in (1500, 3300, 7000, 100 + 100 + 494 * slide, 100 + 100 + 495 * slide, 12000):
+        b, o, _ = synth.make_reads(1, L + int(rng.integers(0, 6)), motif, seed=int(rng.integers(1 << 30)), tract_min=500, tract_max=min(L, 4000))
+        seqs.append(synth.split_reads(b, o)[0])
+    prm = hiplib.make_params(min_len=0, min_count=0, slide=slide, maxlen=1 << 20, flags=hiplib.F_STEP1 | hiplib.F_WINDOWS | hiplib.F_STORE_SUMS | hiplib.F_STORE_RAW)
+    emu.KNOBS.update(raw_m=2, val_off=1)
+    try:
+        L = emu.lib()
+        t0 = L.emu_counter(0)
+        out = emu.scan(pats, seqs, prm)
+        assert L.emu_counter(0) > t0
+    finally:
+        emu.KNOBS.update(raw_m=0, val_off=0)
+    rows = out["raw"]
+    at = 0
+    for i, seq in enumerate(seqs):
+        tail = ["forward", "reverse"][int(out["results"]["tail"][i])]
+        _, want = orc.window_count_matrix(seq, tail, pats, 100, 2 * slide, 100, 1 << 20)
+        _, base = orc.window_count_matrix(seq, tail, pats, 100, slide, 100, 1 << 20)
+        assert len(want) == (len(base) + 1) // 2
+        assert np.array_equal(rows[at:at + len(want)], want), i
+        assert np.array_equal(out["sums"][out["win_off"][i]:out["win_off"][i + 1]], base.sum(axis=1)), i
+        at += len(want)
+
+
 def test_planner_strided_scans_for_multiples_of_a_fused_slide():
     """Round 5 (second half): a slide without a fused kernel that is a multiple of one with -- raw rows or a self-overlap
     table at slide 10, 12, 14 ...; any table at 14, 15, 16, 18, 20 ... -- runs the base slide's fused kernel and keeps every m-th window."""

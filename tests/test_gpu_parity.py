@@ -653,11 +653,17 @@ def test_dispatch_order_changes_no_result(sc, k, raw):
             s.close()
     a, b = got[1], got[0]
     assert a["res"].tobytes() == b["res"].tobytes()
-    assert np.array_equal(a["sums"][0], b["sums"][0]) and np.array_equal(a["sums"][1], b["sums"][1])
+    assert np.array_equal(a["sums"][1], b["sums"][1])
     assert np.array_equal(a["trc"][0], b["trc"][0]) and np.array_equal(a["trc"][1], b["trc"][1])
-    if raw:
-        assert np.array_equal(a["raw"][0], b["raw"][0])
     res, (sums, win_off) = b["res"], b["sums"]
+    # (the window regions of reads that do not pass are never written: only the passing reads' are compared)
+    keep = np.zeros(int(win_off[-1]), bool)
+    for i in np.nonzero(res["pass"])[0]:
+        keep[win_off[i]:win_off[i + 1]] = True
+    assert np.array_equal(a["sums"][0][keep], b["sums"][0][keep])
+    if raw:
+        P = len(pats)
+        assert np.array_equal(a["raw"][0].reshape(-1, P)[keep], b["raw"][0].reshape(-1, P)[keep])
     assert 500 < int(res["pass"].sum()) < 2900
     out, ck = oracle_c.batch_ck(bases, offsets, pats, len(motif), 1000, 9000, 0.7, 100, 6, 100, 20000, threads=8)
     chk = oracle_c.checksums(sums, win_off)
@@ -703,11 +709,16 @@ def test_strided_scans_keep_every_mth_window_of_a_fused_kernel(sc, motif, k, sli
     a, b = got[0], got[1]
     for f in ("pass", "tail", "n_win", "bkp", "best_start", "best_end", "best_start_idx", "best_end_idx", "flags"):
         assert np.array_equal(a["res"][f], b["res"][f]), f
-    assert np.array_equal(a["sums"][0], b["sums"][0]) and np.array_equal(a["sums"][1], b["sums"][1])
+    assert np.array_equal(a["sums"][1], b["sums"][1])
     assert np.array_equal(a["trc"][0], b["trc"][0]) and np.array_equal(a["trc"][1], b["trc"][1])
     res, (sums, win_off) = a["res"], a["sums"]
+    # (the window regions of reads that do not pass are never written by either route: only the passing reads' are compared)
+    keep = np.zeros(int(win_off[-1]), bool)
+    for i in np.nonzero(res["pass"])[0]:
+        keep[win_off[i]:win_off[i + 1]] = True
+    assert np.array_equal(a["sums"][0][keep], b["sums"][0][keep])
     if raw:
-        assert np.array_equal(a["raw"][0], b["raw"][0])
+        assert np.array_equal(a["raw"][0].reshape(-1, P)[keep], b["raw"][0].reshape(-1, P)[keep])
         rows = a["raw"][0].reshape(-1, P)
         seqs = synth.split_reads(bases, offsets)
         done = 0

@@ -193,6 +193,10 @@ struct Slot {
     // slot's batch; `sub_stale` = the batch has changed since it was borrowed
     Slot* sub = nullptr;
     bool sub_stale = true;
+    // (a base-slide slot) where the scan may store every 2nd raw row itself: the requesting scan's buffer and window layout
+    void* ext_raw = nullptr;
+    const int64_t* ext_raw_win_off = nullptr;
+    bool rows_inline = false;            // ... and it did (last scan)
     int stride_base = 0;                 // of the cached plan: 0 = the planned kernel runs itself
     std::string info_name;               // kernel_name of a strided scan ("<base kernel> every <m>th window")
 };
@@ -224,6 +228,7 @@ struct tps_ctx {
     tps::PlanKnobs knobs{};           // tps_ctx_debug_option: tests / diagnostics only; the library reads no environment
     int want_stamps = 0;
     int no_events = 0;
+    int no_inline_rows = 0;           // tps_ctx_debug_option "no_inline_rows": strided scans at twice the base slide copy their raw rows like the others (A/B of ScanArgs::raw_m)
     int no_stride = 0;                // tps_ctx_debug_option "no_stride": slides that are a multiple of a fused kernel's keep the generic kernel (A/B of tps::stride_base)
     int file_order = 0;               // tps_ctx_debug_option "file_order": wave slot i takes read i whatever the reads' lengths (A/B of tps::plan_dispatch_order)
     int event_stride = 1;             // time every event_stride-th launch (tps_ctx_debug_option "event_stride"): timing costs ~3.5 us per launch
@@ -371,6 +376,8 @@ int do_scan_strided(tps_ctx* c, Slot& sl, const tps_params& prm, int base, hipEv
     tps_params pb = prm;
     pb.slide = base;
     pb.flags = (prm.flags | TPS_F_STORE_SUMS) & ~(uint32_t)TPS_F_BINSEG;
+    sb.ext_raw = (prm.slide == 2 * base && !c->no_inline_rows) ? sl.args.raw : nullptr;
+    sb.ext_raw_win_off = (const int64_t*)sl.win_off.p;
     if ((rc = do_scan(c, sb, pb, true, ev_a))) return rc;
     if (!sb.args.variant) return fail(TPS_E_STATE, "strided scan: the base slide %d did not plan a fused kernel", base);
     const int64_t n = sl.n;
@@ -378,11 +385,11 @@ int do_scan_strided(tps_ctx* c, Slot& sl, const tps_params& prm, int base, hipEv
     a.base_results = sb.h_results;
     a.base_sums16 = (const uint16_t*)sb.sums.p;
     a.base_win_off16 = (const int64_t*)sb.win_off16.p;
-    a.base_raw = (prm.flags & TPS_F_STORE_RAW) ? (const uint8_t*)sb.raw.p : nullptr;
+    a.base_raw = ((prm.flags & TPS_F_STORE_RAW) && !sb.rows_inline) ? (const uint8_t*)sb.raw.p : nullptr;
     a.base_win_off = (const int64_t*)sb.win_off.p;
     a.win_off = (const int64_t*)sl.win_off.p;
     a.sums = sl.args.sums;
-    a.raw = sl.args.raw;
+    a.raw = sb.rows_inline ? nullptr : sl.args.raw;
     a.results = sl.h_results;
     a.n_reads = n;
     a.m = prm.slide / base;
@@ -512,9 +519,22 @@ int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm, bool inner, hipEvent_t 
             a.sums = (int32_t*)sl.sums.p;
         }
     }
+    a.raw_m = 0;
+    a.raw_win_off = nullptr;
+    sl.rows_inline = false;
     if (prm.flags & TPS_F_STORE_RAW) {
-        if ((rc = sl.raw.ensure((size_t)std::max<int64_t>(total_win * P, 1)))) return rc;
-        a.raw = (uint8_t*)sl.raw.p;
+        // a base-slide scan at half the requested slide: the per-pattern tiles of a table without self-overlap store the even windows' rows
+        // straight into the requesting scan's layout (rows of whole dwords; a clean batch -- the fallback tile of a batch with
+        // non-ACGT letters writes whole rows by address)
+        if (inner && sl.ext_raw && a.variant && a.pp_d == 0 && c->pat.so_mask == 0 && (P & 3) == 0 && !sl.any_invalid) {
+            a.raw = (uint8_t*)sl.ext_raw;
+            a.raw_m = 2;
+            a.raw_win_off = sl.ext_raw_win_off;
+            sl.rows_inline = true;
+        } else {
+            if ((rc = sl.raw.ensure((size_t)std::max<int64_t>(total_win * P, 1)))) return rc;
+            a.raw = (uint8_t*)sl.raw.p;
+        }
     }
     a.lc_scratch = nullptr;
     if (a.lc_global) {
@@ -1285,7 +1305,8 @@ int tps_ctx_debug_option(tps_ctx* c, const char* key, int64_t value) {
     else if (k == "stamps") c->want_stamps = value != 0;
     else if (k == "file_order") c->file_order = value != 0;
     else if (k == "no_stride") c->no_stride = value != 0;
-    else return fail(TPS_E_ARG, "unknown debug option '%s' (event_stride, no_events, force_generic, spans_per_tile, force_pair, so_order, wpg, stamps, file_order, no_stride)", key);
+    else if (k == "no_inline_rows") c->no_inline_rows = value != 0;
+    else return fail(TPS_E_ARG, "unknown debug option '%s' (event_stride, no_events, force_generic, spans_per_tile, force_pair, so_order, wpg, stamps, file_order, no_stride, no_inline_rows)", key);
     for (auto& sl : c->slots) sl.planned = false;
     return TPS_OK;
 }

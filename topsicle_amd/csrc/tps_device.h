@@ -312,6 +312,8 @@ struct ScanArgs {
     const int64_t* win_off16;    // n+1
     uint8_t* raw;                // or nullptr
     uint64_t* stamps;            // diagnostics: 16 clock stamps per read, or nullptr
+    int32_t raw_m;               // 0, or 2 (strided scans, tps_plan.h: stride_base): the per-pattern tiles store only every 2nd window's raw row, straight into the
+    const int64_t* raw_win_off;  //    layout of the requested slide -- raw = that scan's buffer, raw_win_off = its window layout (tables without self-overlap, clean batches)
     const int32_t* order;        // n, or nullptr: the read wave slot i of the launch takes (plan_dispatch_order: reads in classes of equal work, longest first;
                                  // nullptr = file order, also whenever every read of the batch is in one class)
     int64_t n_reads;
@@ -2822,7 +2824,43 @@ TPS_DEV bool tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
     }
     TPS_SYNC();                                   // every END word has been read: both halves of END are free
     TPS_PP_STAMP(7);
-    if (staged) {
+    bool rows_done = false;
+    if constexpr (D == 0 && CD == 0) {
+        if (staged && a.raw_m == 2) {
+            // Strided scans (round 5): this scan runs at HALF the requested slide and only the even windows are wanted -- tiles start at
+            // even windows, so a lane keeps its rows 0, 2, 4, 6: 4 P contiguous bytes per lane in the requested slide's layout, all 64
+            // lanes in ONE pass through the (free) END area, copied out in 16-byte pieces like the full rows below.
+            rows_done = true;
+            const int pd = pat.P >> 2;            // dwords per row: 1, 2 or 3
+            uint32_t* buf = l.XPC;
+            uint32_t* gout = (uint32_t*)(a.raw + (a.raw_win_off[tc.rd] + (w0 >> 1)) * (int64_t)pat.P);
+            TPS_PHASE {
+                uint32_t* dst = buf + tid * 4 * pd;
+#ifdef TPS_EMU
+                for (int j = 0; j < B; ++j) for (int i = 0; i < 3; ++i) rows[j][i] = rows_keep[tid][j][i];
+#endif
+                TPS_UNROLL
+                for (int j = 0; j < 4; ++j) {
+                    TPS_UNROLL
+                    for (int i = 0; i < 3; ++i)
+                        if (i < pd) dst[j * pd + i] = rows[2 * j][i];
+                }
+            }
+            TPS_SYNC();
+            TPS_PHASE {
+                const int nvalid = ((nw_tile + 1) >> 1) * pd;       // dwords of the tile's even windows
+                const int npass = (nvalid + 4 * NT - 1) / (4 * NT);  // uniform
+                TPS_NOVEC
+                for (int it = 0; it < npass; ++it) {
+                    const int cdw = 4 * tid + it * 4 * NT;
+                    g_store16_clamped(gout, nvalid, cdw, *(const u32x4*)(buf + cdw));
+                }
+            }
+            TPS_SYNC();
+        }
+    }
+    if (rows_done) {
+    } else if (staged) {
         // Raw rows leave through LDS: a lane's 8 rows are 8 P contiguous bytes in HBM, LPP lanes per pass mirror a
         // contiguous stretch of the output in the (now free) END / totals area, and all 64 lanes copy it out in
         // 16-byte pieces -- full cache lines instead of 64 scattered 12-byte writes per store instruction.
@@ -3875,6 +3913,7 @@ struct StrideArgs {
     int64_t n_reads;
     int32_t m, P, n_patterns, jump, min_size, binseg;
     int32_t s16_dw;                        // LDS words per wave for the compacted S_w as 16-bit values (0 = none)
+                                           // (raw == nullptr with raw rows wanted: the base scan stored every m-th row itself, ScanArgs::raw_m)
 };
 // `s16`: this wave's LDS copy of the compacted series (host: StrideArgs::s16_dw words per wave, 0 = the series is too long for LDS and
 // the change point reads it back from HBM -- the lane-contiguous chunks of binseg_wg are 20 dependent-latency loads per pass there)

@@ -228,7 +228,7 @@ class HipScanner:
 
     def debug_option(self, key: str, value: int = 1):
         """tps_ctx_debug_option: diagnostics / tests (event_stride, no_events, force_generic, spans_per_tile, force_pair, so_order,
-        stamps, file_order, no_stride).  Applies to this context and to the helper contexts it makes afterwards."""
+        stamps, file_order, no_stride, no_inline_rows).  Applies to this context and to the helper contexts it makes afterwards."""
         self._check(self.lib.tps_ctx_debug_option(self._h, key.encode(), int(value)))
         self._debug = getattr(self, "_debug", {})
         self._debug[key] = int(value)
