@@ -2825,7 +2825,10 @@ TPS_DEV bool tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
     TPS_SYNC();                                   // every END word has been read: both halves of END are free
     TPS_PP_STAMP(7);
     bool rows_done = false;
-    if constexpr (D == 0 && CD == 0) {
+#ifndef TPS_RAW_M
+#define TPS_RAW_M 1           // 0: A/B builds without the every-second-row store of the strided scans
+#endif
+    if constexpr (D == 0 && CD == 0 && TPS_RAW_M != 0) {
         if (staged && a.raw_m == 2) {
             // Strided scans (round 5): this scan runs at HALF the requested slide and only the even windows are wanted -- tiles start at
             // even windows, so a lane keeps its rows 0, 2, 4, 6: 4 P contiguous bytes per lane in the requested slide's layout, all 64
