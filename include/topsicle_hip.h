@@ -243,8 +243,10 @@ int  tps_ctx_debug_option(tps_ctx* ctx, const char* key, int64_t value);
 int  tps_debug_stamps_get(tps_ctx* ctx, int32_t slot, uint64_t* out, int64_t n_reads);
 /* Name of the device and a few properties, as a NUL-terminated string. */
 int  tps_device_info(tps_ctx* ctx, char* buf, int32_t buf_len);
-/* What the last tps_batch_scan of `slot` launched: "<kernel name> lds=<bytes per workgroup> wgs_per_cu=<n>"
- * (the kernel family is chosen per scan from slide, table and LDS plan; profiles and bench.py name it). */
+/* What the last tps_batch_scan of `slot` launched: "<kernel name> lds=<bytes per workgroup> wgs_per_cu=<n> waves_per_wg=<n>"
+ * (the kernel family is chosen per scan from slide, table and LDS plan; profiles and bench.py name it).  A scan whose slide is a
+ * multiple of a fused kernel's slide reports "<that kernel> every 2nd window" (3rd, 4th ...): it ran that kernel at the base slide
+ * and kept every m-th window (tps_stride_kernel; outputs in the layout of the requested slide). */
 int  tps_batch_kernel_info(tps_ctx* ctx, int32_t slot, char* buf, int32_t buf_len);
 
 #ifdef __cplusplus
