@@ -871,6 +871,26 @@ TPS_DEV void trc_count_packed(const ScanArgs& a, const Lds& l, const Stage& st_s
                     tr &= below(npos - 16 * c - 2 * d);
                     if (pat.n_periods == 1) qd &= below(npos - 16 * c - 2 * d); else qd &= below(npos - 16 * c - d);
                 }
+#ifndef TPS_TRC_PAIRWALK
+#define TPS_TRC_PAIRWALK 1        // 0: A/B builds with round 4's walk over all 16 positions of a chunk that holds a pair
+#endif
+#if TPS_TRC_PAIRWALK != 0 && !defined(TPS_EMU_OLD_PAIRWALK)
+                // a pair starts in this chunk (or the bases are periodic without a pattern): its pattern is looked up again, pair by pair --
+                // a lane holds one or two (a deleted base inside the telomere), where walking all 16 positions of the chunk with three masks
+                // each cost 160 instructions per pass whenever ANY lane of the wave had one: always, on telomeric heads at ONT error rates
+                {
+                    uint32_t m = pr;
+                    while (m != 0u) {
+                        const uint32_t j2 = (uint32_t)ffs0(m);              // = 2 j
+                        m &= m - 1u;
+                        const uint32_t hj = M16 ? lut16_at(l.lut, alignbit(w1, w0, j2), amask) : lut_at(l.lut, alignbit(w1, w0, j2), amask);
+                        const uint32_t f = fieldsq(hj);
+                        pe += f & 0x33333333u; po += (f >> 2) & 0x33333333u;
+                        if ((tr >> j2) & 1u) { te += f & 0x33333333u; to += (f >> 2) & 0x33333333u; }
+                        if ((qd >> j2) & 1u) cf |= hj;
+                    }
+                }
+#else
                 if (pr != 0u) {                        // a pair starts in this chunk (or the bases are periodic without a pattern)
                     uint32_t xp[2] = {0u, 0u}, xt[2] = {0u, 0u};
                     TPS_UNROLL
@@ -887,6 +907,7 @@ TPS_DEV void trc_count_packed(const ScanArgs& a, const Lds& l, const Stage& st_s
                         te += xt[half] & 0x33333333u; to += (xt[half] >> 2) & 0x33333333u;
                     }
                 }
+#endif
             }
         }
     }
