@@ -382,7 +382,7 @@ int do_scan_strided(tps_ctx* c, Slot& sl, const tps_params& prm, int base, hipEv
     if (!sb.args.variant) return fail(TPS_E_STATE, "strided scan: the base slide %d did not plan a fused kernel", base);
     const int64_t n = sl.n;
     tps::StrideArgs a{};
-    a.base_results = sb.h_results;
+    a.base_results = (const tps_read_result*)sb.results.p;
     a.base_sums16 = (const uint16_t*)sb.sums.p;
     a.base_win_off16 = (const int64_t*)sb.win_off16.p;
     a.base_raw = ((prm.flags & TPS_F_STORE_RAW) && !sb.rows_inline) ? (const uint8_t*)sb.raw.p : nullptr;
@@ -493,6 +493,10 @@ int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm, bool inner, hipEvent_t 
     a.pair_img = a.lut + (a.pair16 ? c->lut_cur->off_p16 : (a.lut_fields && a.pair_n) ? c->lut_cur->off_pfld : (size_t)a.lut_n);      // (the 32-bit pair table follows the 4^k masks)
     a.lut_img = a.lut + ((a.lut16 && a.lut_fields) ? c->lut_cur->off_f16 : a.lut16 ? c->lut_cur->off_m16 : a.lut_fields ? c->lut_cur->off_fld : c->lut_cur->off_e32);
     a.results = sl.h_results;                      // (written by the kernel straight into mapped pinned host memory)
+    if (inner) {                                   // a base-slide scan: its results are read by tps_stride_kernel, not by the host -- they stay in HBM
+        if ((rc = sl.results.ensure((size_t)std::max<int64_t>(n, 1) * sizeof(tps_read_result)))) return rc;
+        a.results = (tps_read_result*)sl.results.p;
+    }
     a.c_start = a.c_end = nullptr;
     if ((prm.flags & TPS_F_STEP1) && !sl.stride_base) {       // (a strided scan borrows the base scan's counts)
         if ((rc = sl.c_start.ensure((size_t)std::max<int64_t>(n * P, 1) * 4))) return rc;
