@@ -542,11 +542,13 @@ def test_emulation_results_do_not_depend_on_the_dispatch_order():
         assert np.array_equal(out["sums"][out["win_off"][i]:out["win_off"][i + 1]], one["sums"])
 
 
-@pytest.mark.parametrize("motif,k,slide", [("CCCTAA", 4, 6), ("CCCTAA", 4, 5), ("TTAGGG", 4, 7), ("TTAGGC", 4, 6)])
+@pytest.mark.parametrize("motif,k,slide", [("CCCTAA", 4, 6), ("CCCTAA", 4, 5), ("TTAGGG", 4, 7), ("TTAGGC", 4, 6), ("CCCTAA", 5, 6), ("CCCTAA", 6, 6), ("CCCTAA", 6, 5),
+                                           ("TTAGGG", 5, 7)])
 def test_emulation_per_pattern_tiles_store_every_second_row(motif, k, slide):
-    """Strided scans at twice a base slide (round 5): the per-pattern tiles of a table without self-overlap store the even windows' raw
-    rows themselves, packed per read in the layout of slide 2 s (ScanArgs::raw_m = 2) -- against the oracle AT slide 2 s, reads of one,
-    several and partly filled tiles; the sums stay those of the base slide."""
+    """Strided scans at twice a base slide (round 5): the per-pattern tiles store the even windows' raw rows themselves, packed per read in
+    the layout of slide 2 s (ScanArgs::raw_m = 2) -- tables without self-overlap and, with the repairs of chained windows mapped the same
+    way, with one (k = 5, 6 of a 6-mer motif: ONT-like errors make chains) -- against the oracle AT slide 2 s, reads of one, several and
+    partly filled tiles; the sums stay those of the base slide."""
     pats = orc.kmer_table(motif, k)
     P = len(pats)
     if P % 4:

@@ -679,7 +679,9 @@ def test_dispatch_order_changes_no_result(sc, k, raw):
     ("CCCTAA", 4, 15, True, "tps_scan_kernel_s5r every 3rd window"), ("CCCTAA", 6, 10, False, "tps_scan_kernel_s5so every 2nd window"),
     ("CCCTAA", 6, 12, True, "tps_scan_kernel_s6sorh every 2nd window"), ("CCCTAA", 5, 14, True, "tps_scan_kernel_s7sor every 2nd window"),
     ("CCCTAA", 4, 20, False, "tps_scan_kernel_s10p every 2nd window"), ("AAACCCT", 5, 28, False, "tps_scan_kernel_s7q every 4th window"),
-    ("TTTTAGGG", 6, 16, False, "tps_scan_kernel_s8so every 2nd window")])
+    ("TTTTAGGG", 6, 16, False, "tps_scan_kernel_s8so every 2nd window"),
+    ("CCCTAA", 4, 10, "clean", "tps_scan_kernel_s5r every 2nd window"), ("CCCTAA", 6, 12, "clean", "tps_scan_kernel_s6sorh every 2nd window"),
+    ("CCCTAA", 5, 10, "clean", "tps_scan_kernel_s5sor every 2nd window")])
 def test_strided_scans_keep_every_mth_window_of_a_fused_kernel(sc, motif, k, slide, raw, kernel):
     """Round 5: `--slide 10 --rawcountpattern`, `--slide 10 --telophrase 6` and the like have no fused kernel of their
     own; their windows are every m-th window of a slide that has (tps::stride_base): the launch shape is asserted, every window sum
@@ -688,7 +690,8 @@ def test_strided_scans_keep_every_mth_window_of_a_fused_kernel(sc, motif, k, sli
     pats = orc.kmer_table(motif, k)
     P = len(pats)
     # (sixteen patterns with a self-overlap take the fused tiles on clean batches only: no N for that table)
-    bases, offsets, _ = synth.make_ragged_reads(600, motif, 700 + slide + k, n_frac=0.0 if P == 16 else 0.0002, len_mu=9.5, len_sigma=0.5, max_len=26000)
+    # raw == "clean": no N in the batch -- at twice the base slide the tiles then store every second raw row themselves (ScanArgs::raw_m)
+    bases, offsets, _ = synth.make_ragged_reads(600, motif, 700 + slide + k, n_frac=0.0 if (P == 16 or raw == "clean") else 0.0002, len_mu=9.5, len_sigma=0.5, max_len=26000)
     prm = hiplib.make_params(min_len=9000, min_count=allsteps.min_count_for_cutoff(0.7, 1000 / len(motif), 1000), slide=slide,
                              flags=hiplib.F_STEP1 | hiplib.F_WINDOWS | hiplib.F_BINSEG | hiplib.F_STORE_SUMS | (hiplib.F_STORE_RAW if raw else 0))
     got = {}

@@ -527,10 +527,10 @@ int do_scan(tps_ctx* c, Slot& sl, const tps_params& prm, bool inner, hipEvent_t 
     a.raw_win_off = nullptr;
     sl.rows_inline = false;
     if (prm.flags & TPS_F_STORE_RAW) {
-        // a base-slide scan at half the requested slide: the per-pattern tiles of a table without self-overlap store the even windows' rows
-        // straight into the requesting scan's layout (rows of whole dwords; a clean batch -- the fallback tile of a batch with
-        // non-ACGT letters writes whole rows by address)
-        if (inner && sl.ext_raw && a.variant && a.pp_d == 0 && c->pat.so_mask == 0 && (P & 3) == 0 && !sl.any_invalid) {
+        // a base-slide scan at half the requested slide: the per-pattern tiles store the even windows' rows straight into the requesting
+        // scan's layout (rows of whole dwords; a clean batch -- the fallback tile of a batch with non-ACGT letters writes whole rows by
+        // address; the self-overlap tiles' repairs follow the same mapping)
+        if (inner && sl.ext_raw && a.variant && a.pp_d >= 0 && (c->pat.so_mask == 0 ? a.pp_d == 0 : a.pp_d > 0) && (P & 3) == 0 && !sl.any_invalid) {
             a.raw = (uint8_t*)sl.ext_raw;
             a.raw_m = 2;
             a.raw_win_off = sl.ext_raw_win_off;

@@ -1300,6 +1300,9 @@ TPS_DEV TileConst tile_const(const ScanArgs& a, int64_t r) {
     return t;
 }
 
+#ifndef TPS_RAW_M
+#define TPS_RAW_M 1           // 0: A/B builds without the every-second-row store of the strided scans (ScanArgs::raw_m)
+#endif
 template <int S>
 struct Geo {
     static constexpr int B = 8;                   // blocks (= windows) per lane
@@ -2846,10 +2849,7 @@ TPS_DEV bool tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
     TPS_SYNC();                                   // every END word has been read: both halves of END are free
     TPS_PP_STAMP(7);
     bool rows_done = false;
-#ifndef TPS_RAW_M
-#define TPS_RAW_M 1           // 0: A/B builds without the every-second-row store of the strided scans
-#endif
-    if constexpr (D == 0 && CD == 0 && TPS_RAW_M != 0) {
+    if constexpr (TPS_RAW_M != 0) {
         if (staged && a.raw_m == 2) {
             // Strided scans (round 5): this scan runs at HALF the requested slide and only the even windows are wanted -- tiles start at
             // even windows, so a lane keeps its rows 0, 2, 4, 6: 4 P contiguous bytes per lane in the requested slide's layout, all 64
@@ -3022,6 +3022,8 @@ TPS_DEV bool tile_pp_s(const ScanArgs& a, const TileConst& tc, const Lds& l, int
                 const int j = bit & 7, wl = lane * B + j;
                 if (wl >= nw_tile) continue;
                 uint8_t* raw_row = a.raw ? a.raw + (out_base + w0 + wl) * (int64_t)pat.P : nullptr;
+                if (TPS_RAW_M != 0 && a.raw && a.raw_m == 2)      // strided scans: only the even windows have a row, in the requested slide's layout
+                    raw_row = ((w0 + wl) & 1) ? nullptr : a.raw + (a.raw_win_off[tc.rd] + ((w0 + wl) >> 1)) * (int64_t)pat.P;
                 uint32_t sw = l.row[lane * (B + 1) + j];
                 if (bit < 8) {
 #ifdef TPS_EMU
